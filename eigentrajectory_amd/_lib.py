@@ -1,0 +1,107 @@
+"""ctypes binding of libetamd.so (C ABI: include/eigentraj.h).
+
+PyTorch is used here only for device memory and streams: every call passes raw
+device pointers (``tensor.data_ptr()``) and the current HIP stream across the C
+ABI.  There is no CPU fallback: if the shared library is missing, or no HIP
+device is present, the operations raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libetamd.so")
+
+ET_OK = 0
+MODE_STATIC, MODE_MOVING, MODE_SPLIT, MODE_IDENTITY = 0, 1, 2, 3
+MAX_T, MAX_K, KMEANS_MAX_D, KMEANS_MAX_CLUSTERS = 32, 32, 32, 255
+
+#: every symbol include/eigentraj.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "et_abi_version", "et_status_string", "et_compiled_arch",
+    "et_norm_params", "et_norm_params_from_nrm", "et_normalize", "et_denormalize",
+    "et_norm_project", "et_anchor_reconstruct_fwd", "et_anchor_reconstruct_bwd",
+    "et_fit_gram_workspace_bytes", "et_fit_gram", "et_eigh_topk",
+    "et_euc_sim", "et_kmeans_partials_len", "et_kmeans_workspace_bytes", "et_kmeans_scan", "et_kmeans_begin",
+    "et_kmeans_init_step", "et_kmeans_init_set", "et_kmeans_gather_point", "et_kmeans_init_farthest",
+    "et_kmeans_assign_accumulate", "et_kmeans_update", "et_kmeans_labels_i64", "et_kmeans_fit", "et_kmeans_predict",
+]
+
+
+class KMeansState(C.Structure):
+    """Mirror of ``et_kmeans_state`` (include/eigentraj.h)."""
+    _fields_ = [("max_abs_x", C.c_double), ("max_abs_c", C.c_double), ("n_total", C.c_int64), ("frac", C.c_int64),
+                ("sim_frac", C.c_int64), ("iter", C.c_int64), ("done", C.c_int64), ("bad_input", C.c_int64),
+                ("error", C.c_double), ("inertia", C.c_double)]
+
+
+STATE_BYTES = C.sizeof(KMeansState)
+_lib = None
+
+
+class ETLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libetamd.so (built in-tree by ``__graft_entry__.build()`` / ``make -C eigentrajectory_amd/csrc``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ETLibraryError(
+                f"{LIB_PATH} is missing: build the HIP kernels first (python -c 'import __graft_entry__ as g; "
+                "g.build()' or make -C eigentrajectory_amd/csrc).  eigentrajectory_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        l.et_status_string.restype = C.c_char_p
+        l.et_compiled_arch.restype = C.c_char_p
+        for name in ("et_fit_gram_workspace_bytes", "et_kmeans_partials_len", "et_kmeans_workspace_bytes"):
+            getattr(l, name).restype = C.c_size_t
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != ET_OK:
+        msg = lib().et_status_string(rc).decode()
+        if rc == 1:
+            raise ValueError(f"{what}: {msg}")
+        raise ETLibraryError(f"{what}: {msg} (status {rc})")
+
+
+def require_device(*tensors):
+    """Return the HIP device the call runs on; raise when there is none (no CPU path)."""
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            return t.device
+    if not torch.cuda.is_available():
+        raise ETLibraryError("eigentrajectory_amd needs a HIP device (MI355X); no CPU fallback is provided")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def on_device(t, device, dtype=torch.float32):
+    """Contiguous ``dtype`` copy/view of ``t`` on ``device`` (None passes through)."""
+    if t is None:
+        return None
+    t = t.detach()
+    if t.device != device or t.dtype != dtype:
+        t = t.to(device=device, dtype=dtype)
+    return t.contiguous()
+
+
+def ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def i64(v):
+    return C.c_int64(int(v))
+
+
+def f32(v):
+    return C.c_float(float(v))

@@ -1,0 +1,529 @@
+// et_descriptor.hip -- projection and (anchor +) reconstruction kernels for gfx950.
+//
+// Reference semantics (paths relative to the reference repository):
+//   projection      EigenTrajectory/descriptor.py:144-160 (+ normalizer.py:17-51)
+//   reconstruction  EigenTrajectory/anchor.py:76-88 + descriptor.py:162-176 (+ normalizer.py:53-62)
+//   routing         EigenTrajectory/model.py:73-105 (moving / static descriptor per row)
+//
+// All three kernels are HBM-bound scans (208 / 136 / 136 B per
+// trajectory against ~500 flop), so the design goal is full-width coalesced
+// traffic: 16-byte-per-lane global accesses on the AoS trajectory rows, staged
+// through LDS so that each lane can then own one trajectory (or one
+// (trajectory, sample) pair) for the tiny k<=6 contraction.  MFMA is not used:
+// the contraction depth is k=6 / 2T=16..24 and the kernels sit far below the
+// VALU roof.
+#include "et_common.h"
+
+namespace et {
+
+constexpr int kTile = 256;  // trajectories (or pairs) per workgroup = threads per workgroup
+
+// ------------------------------------------------------------------------------------------
+// Projection, specialised: one workgroup = 256 trajectories.
+//   phase 1  coalesced float4 loads of the obs / pred row blocks -> LDS (row pitch padded
+//            by 16 B so that the per-lane row reads below are bank-conflict free)
+//   phase 2  lane = trajectory: normaliser state, normalise, U^T x (U from LDS), k-major stores
+// ------------------------------------------------------------------------------------------
+template <int TO, int TP, int K>
+__global__ __launch_bounds__(kTile) void project_tile_kernel(
+    const float *__restrict__ obs, const float *__restrict__ pred, int64_t N,
+    const float *__restrict__ U_obs_m, const float *__restrict__ U_pred_m,
+    const float *__restrict__ U_obs_s, const float *__restrict__ U_pred_s,
+    int mode, float static_dist,
+    float *__restrict__ C_obs, float *__restrict__ C_pred, float *__restrict__ nrm, uint8_t *__restrict__ flag) {
+    constexpr int DO = 2 * TO, DP = 2 * TP;
+    constexpr int QO = DO / 4, QP = DP / 4;        // float4 per row
+    constexpr int PO = QO + 1, PP = QP + 1;        // padded row pitch in float4 (odd -> conflict free)
+    constexpr int UN = (DO + DP) * K;              // floats of U per descriptor
+    static_assert(DO % 4 == 0 && DP % 4 == 0, "rows must be float4 multiples");
+    static_assert(PO % 2 == 1 && PP % 2 == 1, "padded pitch must be odd in float4 units");
+
+    __shared__ float4 sObs[kTile * PO];
+    __shared__ float4 sPred[kTile * PP];
+    __shared__ float sU[2 * UN];  // [descriptor: 0 static, 1 moving][obs rows | pred rows][K]
+
+    const int tid = threadIdx.x;
+    const int64_t n0 = (int64_t)blockIdx.x * kTile;
+    const int rows = (int)min((int64_t)kTile, N - n0);
+    const bool has_pred = pred != nullptr && C_pred != nullptr;
+
+    // ---- phase 1: stage rows (all loads issued before the first LDS write)
+    {
+        const float4 *g = reinterpret_cast<const float4 *>(obs + n0 * DO);
+        float4 v[QO];
+#pragma unroll
+        for (int j = 0; j < QO; ++j) {
+            const int q = tid + j * kTile;
+            v[j] = (q < rows * QO) ? g[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 w[QP];
+        if (has_pred) {
+            const float4 *gp = reinterpret_cast<const float4 *>(pred + n0 * DP);
+#pragma unroll
+            for (int j = 0; j < QP; ++j) {
+                const int q = tid + j * kTile;
+                w[j] = (q < rows * QP) ? gp[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        for (int i = tid; i < 2 * UN; i += kTile) {
+            const int desc = i / UN, r = i - desc * UN;
+            const float *src;
+            int off;
+            if (r < DO * K) {
+                src = desc ? U_obs_m : U_obs_s;
+                off = r;
+            } else {
+                src = desc ? U_pred_m : U_pred_s;
+                off = r - DO * K;
+            }
+            sU[i] = src ? src[off] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < QO; ++j) {
+            const int q = tid + j * kTile;
+            sObs[(q / QO) * PO + (q % QO)] = v[j];
+        }
+        if (has_pred) {
+#pragma unroll
+            for (int j = 0; j < QP; ++j) {
+                const int q = tid + j * kTile;
+                sPred[(q / QP) * PP + (q % QP)] = w[j];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid >= rows) return;
+
+    // ---- phase 2: one lane = one trajectory
+    const int64_t n = n0 + tid;
+    float xo[DO];
+#pragma unroll
+    for (int j = 0; j < QO; ++j) {
+        const float4 v = sObs[tid * PO + j];
+        xo[4 * j] = v.x;
+        xo[4 * j + 1] = v.y;
+        xo[4 * j + 2] = v.z;
+        xo[4 * j + 3] = v.w;
+    }
+    const float ox = xo[DO - 2], oy = xo[DO - 1];
+    const float dx = ox - xo[DO - 6], dy = oy - xo[DO - 5];
+    const RowNorm p = row_norm(ox, oy, dx, dy, mode, static_dist);
+    if (nrm) {
+        nrm[n] = ox;
+        nrm[N + n] = oy;
+        nrm[2 * N + n] = dx;
+        nrm[3 * N + n] = dy;
+    }
+    if (flag) flag[n] = (uint8_t)p.mv;
+
+    const float *u = sU + p.mv * UN;
+    if (C_obs) {
+        float acc[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < TO; ++t) {
+            float a, b;
+            normalize_point(p, xo[2 * t], xo[2 * t + 1], a, b);
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc[j] = fmaf(u[(2 * t) * K + j], a, acc[j]);
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc[j] = fmaf(u[(2 * t + 1) * K + j], b, acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) C_obs[(int64_t)j * N + n] = acc[j];
+    }
+    if (has_pred) {
+        const float *up = u + DO * K;
+        float acc[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+            const float4 v = sPred[tid * PP + q];
+            float a, b;
+            normalize_point(p, v.x, v.y, a, b);
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc[j] = fmaf(up[(4 * q) * K + j], a, acc[j]);
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc[j] = fmaf(up[(4 * q + 1) * K + j], b, acc[j]);
+            normalize_point(p, v.z, v.w, a, b);
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc[j] = fmaf(up[(4 * q + 2) * K + j], a, acc[j]);
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc[j] = fmaf(up[(4 * q + 3) * K + j], b, acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) C_pred[(int64_t)j * N + n] = acc[j];
+    }
+}
+
+// Projection, any (T_obs, T_pred, k): one lane = one trajectory, rows read straight
+// from global memory.  Correct for every shape the ABI admits; not tuned.
+__global__ __launch_bounds__(kTile) void project_generic_kernel(
+    const float *__restrict__ obs, const float *__restrict__ pred, int64_t N, int T_obs, int T_pred, int k,
+    const float *__restrict__ U_obs_m, const float *__restrict__ U_pred_m,
+    const float *__restrict__ U_obs_s, const float *__restrict__ U_pred_s,
+    int mode, float static_dist,
+    float *__restrict__ C_obs, float *__restrict__ C_pred, float *__restrict__ nrm, uint8_t *__restrict__ flag) {
+    const int64_t n = (int64_t)blockIdx.x * kTile + threadIdx.x;
+    if (n >= N) return;
+    const float *row = obs + n * 2 * T_obs;
+    const float ox = row[2 * (T_obs - 1)], oy = row[2 * (T_obs - 1) + 1];
+    const float dx = ox - row[2 * (T_obs - 3)], dy = oy - row[2 * (T_obs - 3) + 1];
+    const RowNorm p = row_norm(ox, oy, dx, dy, mode, static_dist);
+    if (nrm) {
+        nrm[n] = ox;
+        nrm[N + n] = oy;
+        nrm[2 * N + n] = dx;
+        nrm[3 * N + n] = dy;
+    }
+    if (flag) flag[n] = (uint8_t)p.mv;
+    if (C_obs) {
+        const float *U = p.mv ? U_obs_m : U_obs_s;
+        for (int j = 0; j < k; ++j) {
+            float acc = 0.f;
+            for (int t = 0; t < T_obs; ++t) {
+                float a, b;
+                normalize_point(p, row[2 * t], row[2 * t + 1], a, b);
+                acc = fmaf(U[(2 * t) * k + j], a, acc);
+                acc = fmaf(U[(2 * t + 1) * k + j], b, acc);
+            }
+            C_obs[(int64_t)j * N + n] = acc;
+        }
+    }
+    if (pred && C_pred) {
+        const float *U = p.mv ? U_pred_m : U_pred_s;
+        const float *prow = pred + n * 2 * T_pred;
+        for (int j = 0; j < k; ++j) {
+            float acc = 0.f;
+            for (int t = 0; t < T_pred; ++t) {
+                float a, b;
+                normalize_point(p, prow[2 * t], prow[2 * t + 1], a, b);
+                acc = fmaf(U[(2 * t) * k + j], a, acc);
+                acc = fmaf(U[(2 * t + 1) * k + j], b, acc);
+            }
+            C_pred[(int64_t)j * N + n] = acc;
+        }
+    }
+}
+
+// Normaliser state of trajectory n from the cached nrm (4,N) or, failing that, from obs.
+__device__ __forceinline__ RowNorm load_row_norm(const float *__restrict__ nrm, const float *__restrict__ obs,
+                                                 int64_t N, int64_t n, int T_obs, int mode, float static_dist) {
+    float ox = 0.f, oy = 0.f, dx = 0.f, dy = 0.f;
+    if (mode == ET_MODE_IDENTITY) {
+    } else if (nrm) {
+        ox = nrm[n];
+        oy = nrm[N + n];
+        dx = nrm[2 * N + n];
+        dy = nrm[3 * N + n];
+    } else {
+        const float *row = obs + n * 2 * T_obs;
+        ox = row[2 * (T_obs - 1)];
+        oy = row[2 * (T_obs - 1) + 1];
+        dx = ox - row[2 * (T_obs - 3)];
+        dy = oy - row[2 * (T_obs - 3) + 1];
+    }
+    return row_norm(ox, oy, dx, dy, mode, static_dist);
+}
+
+constexpr int kNormStride = 8;  // floats per cached RowNorm in LDS
+
+__device__ __forceinline__ void store_row_norm(float *s, const RowNorm &p) {
+    s[0] = p.ox;
+    s[1] = p.oy;
+    s[2] = p.c;
+    s[3] = p.s;
+    s[4] = p.sca;
+    s[5] = p.inv;
+    s[6] = __int_as_float(p.mv);
+}
+
+__device__ __forceinline__ RowNorm fetch_row_norm(const float *s) {
+    RowNorm p;
+    p.ox = s[0];
+    p.oy = s[1];
+    p.c = s[2];
+    p.s = s[3];
+    p.sca = s[4];
+    p.inv = s[5];
+    p.mv = __float_as_int(s[6]);
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------
+// Anchor add + reconstruction, specialised on (T_pred, k); S is a run-time value <= 256.
+// One workgroup = TN = 256/S trajectories x S samples; lane = (trajectory, sample) pair,
+// numbered nl*S + s so that the k coefficient loads C[j][n][s] are unit-stride across lanes.
+// The (S, TN, 2T) result tile is staged in LDS and written back with coalesced float4 stores
+// (each sample plane of the (S,N,T,2) output is a contiguous run of TN rows).
+// ------------------------------------------------------------------------------------------
+template <int TP, int K>
+__global__ __launch_bounds__(kTile) void reconstruct_tile_kernel(
+    const float *__restrict__ C, int64_t N, int S, int TN, int T_obs,
+    const float *__restrict__ obs, const float *__restrict__ nrm,
+    const float *__restrict__ A_m, const float *__restrict__ A_s,
+    const float *__restrict__ U_m, const float *__restrict__ U_s,
+    int mode, float static_dist, float *__restrict__ out) {
+    constexpr int DP = 2 * TP, QP = DP / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sOut = smem;                               // rows*S*DP floats (16-B aligned)
+    float *sNorm = sOut + TN * S * DP;                // TN * kNormStride
+    float *sU = sNorm + TN * kNormStride;             // 2 * DP * K
+    float *sA = sU + 2 * DP * K;                      // 2 * K * S
+
+    const int tid = threadIdx.x;
+    const int64_t n0 = (int64_t)blockIdx.x * TN;
+    const int rows = (int)min((int64_t)TN, N - n0);
+
+    for (int i = tid; i < 2 * DP * K; i += kTile) {
+        const float *src = (i >= DP * K) ? U_m : U_s;
+        sU[i] = src ? src[i % (DP * K)] : 0.f;
+    }
+    for (int i = tid; i < 2 * K * S; i += kTile) {
+        const float *src = (i >= K * S) ? A_m : A_s;
+        sA[i] = src ? src[i % (K * S)] : 0.f;
+    }
+    if (tid < rows) store_row_norm(sNorm + tid * kNormStride, load_row_norm(nrm, obs, N, n0 + tid, T_obs, mode, static_dist));
+    __syncthreads();
+
+    const int npairs = rows * S;
+    if (tid < npairs) {
+        const int nl = tid / S, s = tid - nl * S;
+        const int64_t n = n0 + nl;
+        const RowNorm p = fetch_row_norm(sNorm + nl * kNormStride);
+        const float *u = sU + p.mv * DP * K;
+        const float *a = sA + p.mv * K * S;
+        float c[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) c[j] = a[j * S + s] + C[((int64_t)j * N + n) * S + s];  // anchor.py:87
+        float4 *dst = reinterpret_cast<float4 *>(sOut + ((size_t)s * rows + nl) * DP);
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int f = 4 * q + e;
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < K; ++j) acc = fmaf(u[f * K + j], c[j], acc);  // descriptor.py:87
+                v[e] = acc;
+            }
+            float4 o;
+            denormalize_point(p, v[0], v[1], o.x, o.y);
+            denormalize_point(p, v[2], v[3], o.z, o.w);
+            dst[q] = o;
+        }
+    }
+    __syncthreads();
+
+    // coalesced write-back: plane s holds rows*QP consecutive float4 starting at row n0
+    const float4 *src4 = reinterpret_cast<const float4 *>(sOut);
+    float4 *out4 = reinterpret_cast<float4 *>(out);
+    const int per_plane = rows * QP;
+    const int total = S * per_plane;
+    for (int q = tid; q < total; q += kTile) {
+        const int s = q / per_plane, r = q - s * per_plane;
+        out4[((int64_t)s * N + n0) * QP + r] = src4[q];
+    }
+}
+
+// Backward of the above w.r.t. C: dtraj (S,N,T,2) -> dC (k,N,S).  Mirror image: coalesced
+// float4 loads of the gradient tile into LDS, lane = pair, unit-stride dC stores.
+template <int TP, int K>
+__global__ __launch_bounds__(kTile) void reconstruct_bwd_tile_kernel(
+    const float *__restrict__ dtraj, int64_t N, int S, int TN, int T_obs,
+    const float *__restrict__ obs, const float *__restrict__ nrm,
+    const float *__restrict__ U_m, const float *__restrict__ U_s,
+    int mode, float static_dist, float *__restrict__ dC) {
+    constexpr int DP = 2 * TP, QP = DP / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sIn = smem;
+    float *sNorm = sIn + TN * S * DP;
+    float *sU = sNorm + TN * kNormStride;
+
+    const int tid = threadIdx.x;
+    const int64_t n0 = (int64_t)blockIdx.x * TN;
+    const int rows = (int)min((int64_t)TN, N - n0);
+
+    const float4 *in4 = reinterpret_cast<const float4 *>(dtraj);
+    float4 *dst4 = reinterpret_cast<float4 *>(sIn);
+    const int per_plane = rows * QP;
+    const int total = S * per_plane;
+    for (int q = tid; q < total; q += kTile) {
+        const int s = q / per_plane, r = q - s * per_plane;
+        dst4[q] = in4[((int64_t)s * N + n0) * QP + r];
+    }
+    for (int i = tid; i < 2 * DP * K; i += kTile) {
+        const float *src = (i >= DP * K) ? U_m : U_s;
+        sU[i] = src ? src[i % (DP * K)] : 0.f;
+    }
+    if (tid < rows) store_row_norm(sNorm + tid * kNormStride, load_row_norm(nrm, obs, N, n0 + tid, T_obs, mode, static_dist));
+    __syncthreads();
+
+    const int npairs = rows * S;
+    if (tid >= npairs) return;
+    const int nl = tid / S, s = tid - nl * S;
+    const int64_t n = n0 + nl;
+    const RowNorm p = fetch_row_norm(sNorm + nl * kNormStride);
+    const float *u = sU + p.mv * DP * K;
+    const float4 *src = reinterpret_cast<const float4 *>(sIn + ((size_t)s * rows + nl) * DP);
+    float acc[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+        const float4 g = src[q];
+        float a, b;
+        denormalize_point_bwd(p, g.x, g.y, a, b);
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc[j] = fmaf(u[(4 * q) * K + j], a, acc[j]);
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc[j] = fmaf(u[(4 * q + 1) * K + j], b, acc[j]);
+        denormalize_point_bwd(p, g.z, g.w, a, b);
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc[j] = fmaf(u[(4 * q + 2) * K + j], a, acc[j]);
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc[j] = fmaf(u[(4 * q + 3) * K + j], b, acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) dC[((int64_t)j * N + n) * S + s] = acc[j];
+}
+
+// Any-shape fallbacks: lane = (trajectory, sample) pair, direct global accesses.
+__global__ __launch_bounds__(kTile) void reconstruct_generic_kernel(
+    const float *__restrict__ C, int64_t N, int S, int k, int T_obs, int T_pred,
+    const float *__restrict__ obs, const float *__restrict__ nrm,
+    const float *__restrict__ A_m, const float *__restrict__ A_s,
+    const float *__restrict__ U_m, const float *__restrict__ U_s,
+    int mode, float static_dist, float *__restrict__ out) {
+    const int64_t pair = (int64_t)blockIdx.x * kTile + threadIdx.x;
+    if (pair >= N * S) return;
+    const int64_t n = pair / S;
+    const int s = (int)(pair - n * S);
+    const RowNorm p = load_row_norm(nrm, obs, N, n, T_obs, mode, static_dist);
+    const float *U = p.mv ? U_m : U_s;
+    const float *A = p.mv ? A_m : A_s;
+    float c[ET_MAX_K];
+    for (int j = 0; j < k; ++j) {
+        const float cj = C[((int64_t)j * N + n) * S + s];
+        c[j] = A ? A[j * S + s] + cj : cj;
+    }
+    float *dst = out + (((int64_t)s * N + n) * T_pred) * 2;
+    for (int t = 0; t < T_pred; ++t) {
+        float vx = 0.f, vy = 0.f;
+        for (int j = 0; j < k; ++j) vx = fmaf(U[(2 * t) * k + j], c[j], vx);
+        for (int j = 0; j < k; ++j) vy = fmaf(U[(2 * t + 1) * k + j], c[j], vy);
+        float x, y;
+        denormalize_point(p, vx, vy, x, y);
+        dst[2 * t] = x;
+        dst[2 * t + 1] = y;
+    }
+}
+
+__global__ __launch_bounds__(kTile) void reconstruct_bwd_generic_kernel(
+    const float *__restrict__ dtraj, int64_t N, int S, int k, int T_obs, int T_pred,
+    const float *__restrict__ obs, const float *__restrict__ nrm,
+    const float *__restrict__ U_m, const float *__restrict__ U_s,
+    int mode, float static_dist, float *__restrict__ dC) {
+    const int64_t pair = (int64_t)blockIdx.x * kTile + threadIdx.x;
+    if (pair >= N * S) return;
+    const int64_t n = pair / S;
+    const int s = (int)(pair - n * S);
+    const RowNorm p = load_row_norm(nrm, obs, N, n, T_obs, mode, static_dist);
+    const float *U = p.mv ? U_m : U_s;
+    const float *g = dtraj + (((int64_t)s * N + n) * T_pred) * 2;
+    for (int j = 0; j < k; ++j) {
+        float acc = 0.f;
+        for (int t = 0; t < T_pred; ++t) {
+            float a, b;
+            denormalize_point_bwd(p, g[2 * t], g[2 * t + 1], a, b);
+            acc = fmaf(U[(2 * t) * k + j], a, acc);
+            acc = fmaf(U[(2 * t + 1) * k + j], b, acc);
+        }
+        dC[((int64_t)j * N + n) * S + s] = acc;
+    }
+}
+
+static bool need_m(int mode) { return mode == ET_MODE_MOVING || mode == ET_MODE_SPLIT; }
+static bool need_s(int mode) { return mode != ET_MODE_MOVING; }
+
+static bool dims_ok(int T_obs, int T_pred, int k) {
+    return T_obs >= 3 && T_obs <= ET_MAX_T && T_pred >= 1 && T_pred <= ET_MAX_T && k >= 1 && k <= ET_MAX_K;
+}
+
+}  // namespace et
+
+using namespace et;
+
+extern "C" int et_norm_project(const float *obs, const float *pred, int64_t N, int T_obs, int T_pred, int k,
+                               const float *U_obs_m, const float *U_pred_m, const float *U_obs_s,
+                               const float *U_pred_s, int mode, float static_dist, float *C_obs, float *C_pred,
+                               float *nrm, uint8_t *flag, et_stream_t stream) {
+    if (N < 0 || !dims_ok(T_obs, T_pred, k) || mode < 0 || mode > 3) return ET_ERR_INVALID_ARG;
+    if (N == 0) return ET_OK;
+    if (!obs) return ET_ERR_INVALID_ARG;
+    if (C_obs && ((need_m(mode) && !U_obs_m) || (need_s(mode) && !U_obs_s))) return ET_ERR_INVALID_ARG;
+    if (pred && C_pred && ((need_m(mode) && !U_pred_m) || (need_s(mode) && !U_pred_s))) return ET_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)ceil_div(N, kTile);
+    const bool fast = T_obs == 8 && T_pred == 12 && k == 6 && aligned16(obs) && (!pred || aligned16(pred));
+    if (fast) {
+        hipLaunchKernelGGL((project_tile_kernel<8, 12, 6>), dim3(grid), dim3(kTile), 0, st, obs, pred, N, U_obs_m,
+                           U_pred_m, U_obs_s, U_pred_s, mode, static_dist, C_obs, C_pred, nrm, flag);
+    } else {
+        hipLaunchKernelGGL(project_generic_kernel, dim3(grid), dim3(kTile), 0, st, obs, pred, N, T_obs, T_pred, k,
+                           U_obs_m, U_pred_m, U_obs_s, U_pred_s, mode, static_dist, C_obs, C_pred, nrm, flag);
+    }
+    ET_LAUNCH_CHECK();
+    return ET_OK;
+}
+
+extern "C" int et_anchor_reconstruct_fwd(const float *C, int64_t N, int S, int k, int T_obs, int T_pred,
+                                         const float *obs, const float *nrm, const float *A_m, const float *A_s,
+                                         const float *U_pred_m, const float *U_pred_s, int mode, float static_dist,
+                                         float *out, et_stream_t stream) {
+    if (N < 0 || S < 1 || !dims_ok(T_obs, T_pred, k) || mode < 0 || mode > 3) return ET_ERR_INVALID_ARG;
+    if (N == 0) return ET_OK;
+    if (!C || !out || (!obs && !nrm && mode != ET_MODE_IDENTITY)) return ET_ERR_INVALID_ARG;
+    if ((need_m(mode) && !U_pred_m) || (need_s(mode) && !U_pred_s)) return ET_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const bool fast = T_pred == 12 && k == 6 && S <= kTile && aligned16(out);
+    if (fast) {
+        const int TN = kTile / S;
+        const size_t lds = sizeof(float) * ((size_t)TN * S * 24 + (size_t)TN * kNormStride + 2 * 24 * 6 + 2 * 6 * (size_t)S);
+        hipLaunchKernelGGL((reconstruct_tile_kernel<12, 6>), dim3((unsigned)ceil_div(N, TN)), dim3(kTile), lds, st, C, N,
+                           S, TN, T_obs, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, out);
+    } else {
+        const int64_t pairs = N * S;
+        hipLaunchKernelGGL(reconstruct_generic_kernel, dim3((unsigned)ceil_div(pairs, kTile)), dim3(kTile), 0, st, C, N,
+                           S, k, T_obs, T_pred, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, out);
+    }
+    ET_LAUNCH_CHECK();
+    return ET_OK;
+}
+
+extern "C" int et_anchor_reconstruct_bwd(const float *dtraj, int64_t N, int S, int k, int T_obs, int T_pred,
+                                         const float *obs, const float *nrm, const float *U_pred_m,
+                                         const float *U_pred_s, int mode, float static_dist, float *dC,
+                                         et_stream_t stream) {
+    if (N < 0 || S < 1 || !dims_ok(T_obs, T_pred, k) || mode < 0 || mode > 3) return ET_ERR_INVALID_ARG;
+    if (N == 0) return ET_OK;
+    if (!dtraj || !dC || (!obs && !nrm && mode != ET_MODE_IDENTITY)) return ET_ERR_INVALID_ARG;
+    if ((need_m(mode) && !U_pred_m) || (need_s(mode) && !U_pred_s)) return ET_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const bool fast = T_pred == 12 && k == 6 && S <= kTile && aligned16(dtraj);
+    if (fast) {
+        const int TN = kTile / S;
+        const size_t lds = sizeof(float) * ((size_t)TN * S * 24 + (size_t)TN * kNormStride + 2 * 24 * 6);
+        hipLaunchKernelGGL((reconstruct_bwd_tile_kernel<12, 6>), dim3((unsigned)ceil_div(N, TN)), dim3(kTile), lds, st,
+                           dtraj, N, S, TN, T_obs, obs, nrm, U_pred_m, U_pred_s, mode, static_dist, dC);
+    } else {
+        const int64_t pairs = N * S;
+        hipLaunchKernelGGL(reconstruct_bwd_generic_kernel, dim3((unsigned)ceil_div(pairs, kTile)), dim3(kTile), 0, st,
+                           dtraj, N, S, k, T_obs, T_pred, obs, nrm, U_pred_m, U_pred_s, mode, static_dist, dC);
+    }
+    ET_LAUNCH_CHECK();
+    return ET_OK;
+}

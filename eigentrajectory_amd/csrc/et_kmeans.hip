@@ -1,0 +1,663 @@
+// et_kmeans.hip -- BatchKMeans (EigenTrajectory/kmeans.py) for gfx950.
+//
+//   euc_sim            kmeans.py:59-76    y = (2 a.b - |a|^2) - |b|^2, a.b an fmaf chain
+//   kmeanspp           kmeans.py:78-112   farthest-first: running max-similarity + global arg-min
+//   get_labels         kmeans.py:143-158  arg-max (first max wins, NaN wins)
+//   compute_centroids  kmeans.py:160-198  per-cluster mean, empty cluster -> NaN
+//   fit / predict      kmeans.py:200-272
+//
+// Layout: X is (d, N) d-major, so every coordinate row is a unit-stride stream: lanes read
+// 16 B (4 consecutive points) per row.  One Lloyd step reads d*4 B per point once and keeps
+// everything else (K centroids, K*(d+1)+2 accumulators) in LDS.
+//
+// Exactness: the reference sums per-cluster coordinates in fp32 in torch's reduction order,
+// which a parallel machine cannot reproduce.  Here every coordinate is converted to a 64-bit
+// fixed-point integer (truncation, power-of-two scale => exact) and integers are summed, so the
+// result is independent of the order: the same bits for any workgroup schedule, grid size or
+// number of GPUs, and identical to the CPU oracle (oracle/et_oracle.c).
+#include "et_common.h"
+
+namespace et {
+
+constexpr int kKmThreads = 256;
+constexpr int kKmMaxBlocks = 1024;
+
+// ---- scalar helpers shared with the oracle's definitions -----------------------------------
+__device__ __forceinline__ int exponent_above(double m) {  // smallest E with m < 2^E; 0 for m == 0
+    if (!(m > 0.0)) return 0;
+    const unsigned long long b = (unsigned long long)__double_as_longlong(m);
+    return (int)((b >> 52) & 0x7ff) - 1022;
+}
+
+__device__ __forceinline__ int bits_for(int64_t n) {  // smallest b with 2^b > n
+    return n > 0 ? 64 - __clzll((long long)n) : 0;
+}
+
+// trunc(x * 2^frac) for finite x, by shifting the mantissa: bit-identical to the oracle's
+// (int64_t)ldexp((double)x, frac) and ~10 integer ops instead of an fp64 -> i64 emulation.
+__device__ __forceinline__ long long to_fixed(float x, int frac) {
+    const unsigned u = (unsigned)__float_as_int(x);
+    const int e = (int)((u >> 23) & 0xff);
+    const unsigned long long m = (u & 0x7fffffu) | (e ? 0x800000u : 0u);
+    const int sh = (e ? e : 1) - 150 + frac;  // x = m * 2^(e-150)
+    unsigned long long mag;
+    if (sh >= 0) mag = sh < 64 ? (m << sh) : 0ull;
+    else mag = sh > -64 ? (m >> (-sh)) : 0ull;
+    const long long v = (long long)mag;
+    return (u >> 31) ? -v : v;
+}
+
+__device__ __forceinline__ bool gt_nanmax(float cand, float best) {  // torch.max: NaN beats everything
+    return (cand > best) || (isnan(cand) && !isnan(best));
+}
+
+__device__ __forceinline__ unsigned orderable(float f) {  // ascending uint order; NaN -> 0 (torch.argmin)
+    if (isnan(f)) return 0u;
+    if (f == 0.f) return 0x80000000u;  // -0 and +0 tie, like a float compare
+    const unsigned u = (unsigned)__float_as_int(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// ---- centroids in LDS: row j = {c[0..d-1], |c_j|^2}, pitch = d+1 rounded up to 4 floats ------
+__device__ __forceinline__ int cpitch(int d) { return (d + 1 + 3) & ~3; }
+
+__device__ __forceinline__ void stage_centroids(const float *__restrict__ cen, int d, int K, float *sC) {
+    const int pitch = cpitch(d);
+    for (int j = threadIdx.x; j < K; j += blockDim.x) {
+        float bn = 0.f;
+        for (int i = 0; i < d; ++i) {
+            const float v = cen[i * K + j];
+            sC[j * pitch + i] = v;
+            bn = bn + v * v;  // kmeans.py:74 |b|^2: sequential sum of rounded squares
+        }
+        sC[j * pitch + d] = bn;
+    }
+}
+
+// similarity of one point to every centroid; returns the arg-max and its value.
+template <int D>
+__device__ __forceinline__ void best_centroid(const float *x, int d_rt, const float *sC, int K, int &label, float &best) {
+    const int d = D ? D : d_rt;
+    const int pitch = cpitch(d);
+    float an = 0.f;
+#pragma unroll
+    for (int i = 0; i < (D ? D : ET_KMEANS_MAX_D); ++i)
+        if (i < d) an = an + x[i] * x[i];  // kmeans.py:73 |a|^2
+    int lb = 0;
+    float bv = 0.f;
+    for (int j = 0; j < K; ++j) {
+        const float *c = sC + j * pitch;
+        float y = 0.f;
+#pragma unroll
+        for (int i = 0; i < (D ? D : ET_KMEANS_MAX_D); ++i)
+            if (i < d) y = fmaf(x[i], c[i], y);  // kmeans.py:71
+        y = y * 2.0f;                            // :72
+        y = y - an;                              // :73
+        y = y - c[d];                            // :74
+        if (j == 0 || gt_nanmax(y, bv)) {
+            bv = y;
+            lb = j;
+        }
+    }
+    label = lb;
+    best = bv;
+}
+
+// ------------------------------------------------------------------------------------------
+// scan: max |x| and a non-finite flag, straight into the state block (zeroed by the host side)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kKmThreads) void kmeans_scan_kernel(const float *__restrict__ X, int64_t count,
+                                                                 et_kmeans_state *state) {
+    float m = 0.f;
+    int bad = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const float a = fabsf(X[i]);
+        if (!(a <= 3.402823466e+38f)) bad = 1;
+        else if (a > m) m = a;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, o));
+        bad |= __shfl_xor(bad, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(reinterpret_cast<unsigned long long *>(&state->max_abs_x),
+                  (unsigned long long)__double_as_longlong((double)m));
+        if (bad) atomicMax(reinterpret_cast<unsigned long long *>(&state->bad_input), 1ull);
+    }
+}
+
+__device__ __forceinline__ double max_abs_centroid(const float *cen, int n) {  // NaN ignored
+    double m = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double a = fabs((double)cen[i]);
+        if (a > m) m = a;
+    }
+    return m;
+}
+
+__device__ __forceinline__ int sim_frac_bits(double mx, double mc, int d, int64_t n_total) {
+    const double m = mx > mc ? mx : mc;
+    return 62 - exponent_above(4.0 * d * m * m) - bits_for(n_total);
+}
+
+__global__ void kmeans_begin_kernel(et_kmeans_state *state, int64_t n_total, const float *__restrict__ cen, int d,
+                                    int K) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    state->n_total = n_total;
+    state->frac = 62 - exponent_above(state->max_abs_x) - bits_for(n_total);
+    const double mc = max_abs_centroid(cen, d * K);
+    state->max_abs_c = mc;
+    state->sim_frac = sim_frac_bits(state->max_abs_x, mc, d, n_total);
+    state->iter = 0;
+    state->done = state->bad_input ? 1 : 0;  // non-finite data: every later step is a no-op
+    state->error = 0.0;
+    state->inertia = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Lloyd half-step: labels + exact partial sums.  VEC = points per lane per pass (4 when the
+// coordinate rows are 16-B aligned, else 1).  Workgroup accumulators live in LDS (64-bit
+// integer atomics, order-free); each workgroup writes one partial block, summed afterwards.
+// ------------------------------------------------------------------------------------------
+template <int D, int VEC>
+__global__ __launch_bounds__(kKmThreads) void kmeans_assign_kernel(
+    const float *__restrict__ X, int64_t N, int d_rt, int K, const et_kmeans_state *__restrict__ state,
+    const float *__restrict__ cen, const int64_t *__restrict__ given, uint8_t *__restrict__ labels,
+    long long *__restrict__ block_partials) {
+    if (state->done) return;
+    const int d = D ? D : d_rt;
+    const int plen = d * K + K + 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    long long *sAcc = reinterpret_cast<long long *>(smem_raw);                       // plen
+    float *sC = reinterpret_cast<float *>(smem_raw + sizeof(long long) * ((plen + 1) & ~1));  // K * cpitch
+
+    const int frac = (int)state->frac, sfrac = (int)state->sim_frac;
+    for (int i = threadIdx.x; i < plen; i += kKmThreads) sAcc[i] = 0;
+    stage_centroids(cen, d, K, sC);
+    __syncthreads();
+
+    long long sim_acc = 0, nan_acc = 0;
+    const int64_t n_groups = (N + VEC - 1) / VEC;
+    const int64_t stride = (int64_t)gridDim.x * kKmThreads;
+    for (int64_t gidx = (int64_t)blockIdx.x * kKmThreads + threadIdx.x; gidx < n_groups; gidx += stride) {
+        const int64_t n = gidx * VEC;
+        float x[VEC][D ? D : ET_KMEANS_MAX_D];
+        if (VEC == 4) {
+#pragma unroll
+            for (int i = 0; i < (D ? D : ET_KMEANS_MAX_D); ++i)
+                if (i < d) {
+                    const float4 v = *reinterpret_cast<const float4 *>(X + (int64_t)i * N + n);
+                    x[0][i] = v.x;
+                    x[1 % VEC][i] = v.y;
+                    x[2 % VEC][i] = v.z;
+                    x[3 % VEC][i] = v.w;
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < (D ? D : ET_KMEANS_MAX_D); ++i)
+                if (i < d) x[0][i] = X[(int64_t)i * N + n];
+        }
+        unsigned packed = 0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            int lb;
+            float best;
+            if (given) {
+                lb = (int)given[n + v];
+                best = 0.f;
+            } else {
+                best_centroid<D>(x[v], d, sC, K, lb, best);
+            }
+            packed |= (unsigned)lb << (8 * v);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + lb]), 1ull);
+#pragma unroll
+            for (int i = 0; i < (D ? D : ET_KMEANS_MAX_D); ++i)
+                if (i < d)
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[i * K + lb]),
+                              (unsigned long long)to_fixed(x[v][i], frac));
+            if (isnan(best) || isinf(best)) nan_acc += 1;
+            else sim_acc += to_fixed(best, sfrac);
+        }
+        if (VEC == 4) *reinterpret_cast<unsigned *>(labels + n) = packed;
+        else labels[n] = (uint8_t)packed;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sim_acc += __shfl_xor(sim_acc, o);
+        nan_acc += __shfl_xor(nan_acc, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K]), (unsigned long long)sim_acc);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K + 1]), (unsigned long long)nan_acc);
+    }
+    __syncthreads();
+    long long *dst = block_partials + (size_t)blockIdx.x * plen;
+    for (int i = threadIdx.x; i < plen; i += kKmThreads) dst[i] = sAcc[i];
+}
+
+// sum the workgroup partials (integers: any order) -> partials[plen]
+__global__ __launch_bounds__(kKmThreads) void kmeans_reduce_partials_kernel(const long long *__restrict__ block_partials,
+                                                                            int n_blocks, int plen,
+                                                                            const et_kmeans_state *__restrict__ state,
+                                                                            long long *__restrict__ partials) {
+    if (state->done) return;
+    // 4 lanes per entry walk interleaved workgroup slots, then combine
+    const int e = (blockIdx.x * kKmThreads + threadIdx.x) >> 2, sub = threadIdx.x & 3;
+    long long s = 0;
+    if (e < plen)
+        for (int b = sub; b < n_blocks; b += 4) s += block_partials[(size_t)b * plen + e];
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (e < plen && sub == 0) partials[e] = s;
+}
+
+// centroid update + convergence scalars from the (all-reduced) exact sums.  One workgroup.
+__global__ __launch_bounds__(kKmThreads) void kmeans_update_kernel(et_kmeans_state *state,
+                                                                   const long long *__restrict__ partials, int d, int K,
+                                                                   float tol, float *__restrict__ cen,
+                                                                   float *__restrict__ trace) {
+    if (state->done) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *sSq = reinterpret_cast<float *>(smem_raw);  // d*K squared differences
+    float *sNew = sSq + d * K;
+    const int frac = (int)state->frac;
+    const double inv_scale = ldexp(1.0, -frac);
+    for (int e = threadIdx.x; e < d * K; e += kKmThreads) {
+        const int j = e % K;
+        const long long cnt = partials[d * K + j];
+        float c;
+        if (cnt == 0) c = __int_as_float(0x7fc00000);  // 0/0 (kmeans.py:182)
+        else c = (float)(((double)partials[e] * inv_scale) / (double)cnt);
+        const float diff = cen[e] - c;  // kmeans.py:48
+        sSq[e] = diff * diff;           // :49
+        sNew[e] = c;
+        cen[e] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double err = 0.0;
+        for (int e = 0; e < d * K; ++e) err += (double)sSq[e];  // :50, fixed order
+        const float error = (float)err;
+        const long long sim_sum = partials[d * K + K], nan_count = partials[d * K + K + 1];
+        const int64_t n_total = state->n_total;
+        float inertia;
+        if (nan_count > 0) inertia = __int_as_float(0x7fc00000);
+        else inertia = (float)(-(((double)sim_sum * ldexp(1.0, -(int)state->sim_frac)) / (double)n_total));  // :57
+        const double mc = max_abs_centroid(sNew, d * K);
+        state->max_abs_c = mc;
+        state->sim_frac = sim_frac_bits(state->max_abs_x, mc, d, n_total);
+        if (trace) {
+            trace[2 * state->iter] = error;
+            trace[2 * state->iter + 1] = inertia;
+        }
+        state->error = (double)error;
+        state->inertia = (double)inertia;
+        state->iter = state->iter + 1;
+        state->done = (error <= tol) ? 1 : 0;  // kmeans.py:239 (NaN -> keep going)
+    }
+}
+
+__global__ __launch_bounds__(kKmThreads) void kmeans_labels_i64_kernel(const uint8_t *__restrict__ lb, int64_t N,
+                                                                       int64_t *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) out[n] = (int64_t)lb[n];
+}
+
+// predict (kmeans.py:261-272): labels int64 + optional max similarity
+template <int D>
+__global__ __launch_bounds__(kKmThreads) void kmeans_predict_kernel(const float *__restrict__ X, int64_t N, int d_rt,
+                                                                    const float *__restrict__ cen, int K,
+                                                                    int64_t *__restrict__ labels,
+                                                                    float *__restrict__ maxsims) {
+    const int d = D ? D : d_rt;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *sC = reinterpret_cast<float *>(smem_raw);
+    stage_centroids(cen, d, K, sC);
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * kKmThreads;
+    for (int64_t n = (int64_t)blockIdx.x * kKmThreads + threadIdx.x; n < N; n += stride) {
+        float x[D ? D : ET_KMEANS_MAX_D];
+#pragma unroll
+        for (int i = 0; i < (D ? D : ET_KMEANS_MAX_D); ++i)
+            if (i < d) x[i] = X[(int64_t)i * N + n];
+        int lb;
+        float best;
+        best_centroid<D>(x, d, sC, K, lb, best);
+        if (labels) labels[n] = lb;
+        if (maxsims) maxsims[n] = best;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// farthest-first initialisation (kmeans.py:88-112): one pass per new centroid.
+// best[n] = max(best[n], sim(x_n, c_{i-1})); candidate = arg-min over n (first index on ties,
+// NaN first) encoded as a 64-bit key so that a plain unsigned min is the reduction.
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const float *__restrict__ X, int64_t N, int d_rt,
+                                                                      int K, int step, const float *__restrict__ C0,
+                                                                      float *__restrict__ best, int64_t index_base,
+                                                                      unsigned long long *__restrict__ block_keys) {
+    const int d = D ? D : d_rt;
+    __shared__ float sc[ET_KMEANS_MAX_D + 1];
+    __shared__ unsigned long long sKey[kKmThreads / 64];
+    if (threadIdx.x == 0) {
+        float bn = 0.f;
+        for (int i = 0; i < d; ++i) {
+            const float v = C0[i * K + (step - 1)];
+            sc[i] = v;
+            bn = bn + v * v;
+        }
+        sc[d] = bn;
+    }
+    __syncthreads();
+    float c[D ? D : ET_KMEANS_MAX_D];
+#pragma unroll
+    for (int i = 0; i < (D ? D : ET_KMEANS_MAX_D); ++i)
+        if (i < d) c[i] = sc[i];
+    const float bn = sc[d];
+    unsigned long long key = ~0ull;
+    const int64_t stride = (int64_t)gridDim.x * kKmThreads;
+    for (int64_t n = (int64_t)blockIdx.x * kKmThreads + threadIdx.x; n < N; n += stride) {
+        float an = 0.f, y = 0.f;
+#pragma unroll
+        for (int i = 0; i < (D ? D : ET_KMEANS_MAX_D); ++i)
+            if (i < d) {
+                const float v = X[(int64_t)i * N + n];
+                an = an + v * v;
+                y = fmaf(v, c[i], y);
+            }
+        y = y * 2.0f;
+        y = y - an;
+        y = y - bn;
+        float b = y;
+        if (step > 1) {
+            b = best[n];
+            if (gt_nanmax(y, b)) b = y;
+        }
+        best[n] = b;
+        const unsigned long long k = ((unsigned long long)orderable(b) << 32) | (unsigned)(index_base + n);
+        key = k < key ? k : key;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other < key ? other : key;
+    }
+    if ((threadIdx.x & 63) == 0) sKey[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kKmThreads / 64; ++w) key = sKey[w] < key ? sKey[w] : key;
+        block_keys[blockIdx.x] = key;
+    }
+}
+
+// reduce the workgroup keys; candidate record = {key, d floats of the winning local point}
+__global__ __launch_bounds__(kKmThreads) void kmeans_init_pick_kernel(const float *__restrict__ X, int64_t N, int d,
+                                                                      const unsigned long long *__restrict__ block_keys,
+                                                                      int n_blocks, int64_t index_base,
+                                                                      unsigned char *__restrict__ cand) {
+    __shared__ unsigned long long sKey[kKmThreads / 64];
+    unsigned long long key = ~0ull;
+    for (int b = threadIdx.x; b < n_blocks; b += kKmThreads) key = block_keys[b] < key ? block_keys[b] : key;
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other < key ? other : key;
+    }
+    if ((threadIdx.x & 63) == 0) sKey[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kKmThreads / 64; ++w) key = sKey[w] < key ? sKey[w] : key;
+        *reinterpret_cast<unsigned long long *>(cand) = key;
+        float *pt = reinterpret_cast<float *>(cand + 8);
+        const int64_t local = (int64_t)(unsigned)(key & 0xffffffffull) - index_base;
+        for (int i = 0; i < d; ++i)
+            pt[i] = (key != ~0ull && local >= 0 && local < N) ? X[(int64_t)i * N + local] : __int_as_float(0x7fc00000);
+    }
+}
+
+__global__ void kmeans_init_set_kernel(float *__restrict__ C0, int d, int K, int col, const float *__restrict__ point) {
+    const int i = threadIdx.x;
+    if (i < d) C0[i * K + col] = point[i];
+}
+
+__global__ void kmeans_gather_point_kernel(const float *__restrict__ X, int64_t N, int d, int64_t idx,
+                                           float *__restrict__ point) {
+    const int i = threadIdx.x;
+    if (i < d) point[i] = X[(int64_t)i * N + idx];
+}
+
+static int km_grid(int64_t work_items) {
+    const int64_t b = ceil_div(work_items, (int64_t)kKmThreads);
+    return (int)(b < 1 ? 1 : (b > kKmMaxBlocks ? kKmMaxBlocks : b));
+}
+
+static bool km_dims_ok(int d, int K) { return d >= 1 && d <= ET_KMEANS_MAX_D && K >= 1 && K <= ET_KMEANS_MAX_CLUSTERS; }
+
+static size_t km_plen(int d, int K) { return (size_t)d * K + K + 2; }
+
+// workspace carve: [block partials | block keys | cand | best (N) | labels_u8 (N) | partials | C0 scratch ...]
+struct KmWorkspace {
+    long long *block_partials;
+    unsigned long long *block_keys;
+    unsigned char *cand;
+    long long *partials;
+    et_kmeans_state *state;
+    float *best;
+    uint8_t *labels_u8;
+    size_t bytes;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static KmWorkspace km_carve(void *base, int64_t N, int d, int K) {
+    KmWorkspace w;
+    size_t off = 0;
+    unsigned char *p = (unsigned char *)base;
+    w.block_partials = (long long *)(p + off);
+    off = align_up(off + sizeof(long long) * km_plen(d, K) * kKmMaxBlocks, 256);
+    w.block_keys = (unsigned long long *)(p + off);
+    off = align_up(off + sizeof(unsigned long long) * kKmMaxBlocks, 256);
+    w.cand = p + off;
+    off = align_up(off + 8 + sizeof(float) * ET_KMEANS_MAX_D, 256);
+    w.partials = (long long *)(p + off);
+    off = align_up(off + sizeof(long long) * km_plen(d, K), 256);
+    w.state = (et_kmeans_state *)(p + off);
+    off = align_up(off + sizeof(et_kmeans_state), 256);
+    w.best = (float *)(p + off);
+    off = align_up(off + sizeof(float) * (size_t)(N > 0 ? N : 1), 256);
+    w.labels_u8 = (uint8_t *)(p + off);
+    off = align_up(off + (size_t)(N > 0 ? N : 1) + 4, 256);
+    w.bytes = off;
+    return w;
+}
+
+template <int D>
+static void launch_assign(const float *X, int64_t N, int d, int K, const et_kmeans_state *state, const float *cen,
+                          const int64_t *given, uint8_t *labels, long long *block_partials, int grid, bool vec4,
+                          hipStream_t st) {
+    const size_t plen = km_plen(d, K);
+    const size_t lds = sizeof(long long) * ((plen + 1) & ~(size_t)1) + sizeof(float) * (size_t)K * ((d + 1 + 3) & ~3);
+    if (vec4)
+        hipLaunchKernelGGL((kmeans_assign_kernel<D, 4>), dim3(grid), dim3(kKmThreads), lds, st, X, N, d, K, state, cen,
+                           given, labels, block_partials);
+    else
+        hipLaunchKernelGGL((kmeans_assign_kernel<D, 1>), dim3(grid), dim3(kKmThreads), lds, st, X, N, d, K, state, cen,
+                           given, labels, block_partials);
+}
+
+}  // namespace et
+
+using namespace et;
+
+extern "C" size_t et_kmeans_partials_len(int d, int K) { return km_plen(d, K); }
+
+extern "C" size_t et_kmeans_workspace_bytes(int64_t N, int d, int K) {
+    if (!km_dims_ok(d, K) || N < 0) return 0;
+    return km_carve(nullptr, N, d, K).bytes;
+}
+
+extern "C" int et_kmeans_scan(const float *X, int64_t N, int d, et_kmeans_state *state, et_stream_t stream) {
+    if (!state || N < 0 || d < 1 || d > ET_KMEANS_MAX_D || (N > 0 && !X)) return ET_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    ET_HIP_TRY(hipMemsetAsync(state, 0, sizeof(et_kmeans_state), st));
+    if (N == 0) return ET_OK;
+    hipLaunchKernelGGL(kmeans_scan_kernel, dim3(km_grid(N * d / 4 + 1)), dim3(kKmThreads), 0, st, X, N * d, state);
+    ET_LAUNCH_CHECK();
+    return ET_OK;
+}
+
+extern "C" int et_kmeans_begin(et_kmeans_state *state, int64_t n_total, const float *centroids, int d, int K,
+                               et_stream_t stream) {
+    if (!state || !centroids || n_total < 0 || !km_dims_ok(d, K)) return ET_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(kmeans_begin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, n_total, centroids, d, K);
+    ET_LAUNCH_CHECK();
+    return ET_OK;
+}
+
+extern "C" int et_kmeans_assign_accumulate(const float *X, int64_t N, int d, int K, const et_kmeans_state *state,
+                                           const float *centroids, const int64_t *given_labels, uint8_t *labels_u8,
+                                           int64_t *partials, void *workspace, size_t workspace_bytes,
+                                           et_stream_t stream) {
+    if (!km_dims_ok(d, K) || N < 0 || !state || !centroids || !partials || (N > 0 && (!X || !labels_u8)))
+        return ET_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < et_kmeans_workspace_bytes(N, d, K)) return ET_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const KmWorkspace w = km_carve(workspace, N, d, K);
+    const bool vec4 = (N % 4 == 0) && aligned16(X) && ((reinterpret_cast<uintptr_t>(labels_u8) & 3u) == 0);
+    const int grid = N > 0 ? km_grid(vec4 ? N / 4 : N) : 1;
+    if (d == 6) launch_assign<6>(X, N, d, K, state, centroids, given_labels, labels_u8, w.block_partials, grid, vec4, st);
+    else launch_assign<0>(X, N, d, K, state, centroids, given_labels, labels_u8, w.block_partials, grid, vec4, st);
+    ET_LAUNCH_CHECK();
+    const int plen = (int)km_plen(d, K);
+    hipLaunchKernelGGL(kmeans_reduce_partials_kernel, dim3((unsigned)ceil_div((int64_t)plen * 4, kKmThreads)),
+                       dim3(kKmThreads), 0, st, w.block_partials, grid, plen, state, (long long *)partials);
+    ET_LAUNCH_CHECK();
+    return ET_OK;
+}
+
+extern "C" int et_kmeans_update(et_kmeans_state *state, const int64_t *partials, int d, int K, float tol,
+                                float *centroids, float *trace, et_stream_t stream) {
+    if (!state || !partials || !centroids || !km_dims_ok(d, K)) return ET_ERR_INVALID_ARG;
+    const size_t lds = sizeof(float) * 2 * (size_t)d * K;
+    if (lds > 48 * 1024)
+        ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kmeans_update_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kmeans_update_kernel, dim3(1), dim3(kKmThreads), lds, (hipStream_t)stream, state,
+                       (const long long *)partials, d, K, tol, centroids, trace);
+    ET_LAUNCH_CHECK();
+    return ET_OK;
+}
+
+extern "C" int et_kmeans_labels_i64(const uint8_t *labels_u8, int64_t N, int64_t *labels, et_stream_t stream) {
+    if (N < 0 || (N > 0 && (!labels_u8 || !labels))) return ET_ERR_INVALID_ARG;
+    if (N == 0) return ET_OK;
+    hipLaunchKernelGGL(kmeans_labels_i64_kernel, dim3(km_grid(N)), dim3(kKmThreads), 0, (hipStream_t)stream, labels_u8,
+                       N, labels);
+    ET_LAUNCH_CHECK();
+    return ET_OK;
+}
+
+extern "C" int et_kmeans_predict(const float *X, int64_t N, int d, const float *centroids, int K, int64_t *labels,
+                                 float *maxsims, et_stream_t stream) {
+    if (!km_dims_ok(d, K) || N < 0 || !centroids || (N > 0 && !X)) return ET_ERR_INVALID_ARG;
+    if (N == 0) return ET_OK;
+    const size_t lds = sizeof(float) * (size_t)K * ((d + 1 + 3) & ~3);
+    hipStream_t st = (hipStream_t)stream;
+    if (d == 6)
+        hipLaunchKernelGGL((kmeans_predict_kernel<6>), dim3(km_grid(N)), dim3(kKmThreads), lds, st, X, N, d, centroids, K,
+                           labels, maxsims);
+    else
+        hipLaunchKernelGGL((kmeans_predict_kernel<0>), dim3(km_grid(N)), dim3(kKmThreads), lds, st, X, N, d, centroids, K,
+                           labels, maxsims);
+    ET_LAUNCH_CHECK();
+    return ET_OK;
+}
+
+extern "C" int et_kmeans_init_step(const float *X, int64_t N, int d, int K, int i, const float *C0, float *best,
+                                   int64_t index_base, void *cand, void *workspace, size_t workspace_bytes,
+                                   et_stream_t stream) {
+    if (!km_dims_ok(d, K) || N < 0 || i < 1 || i >= K || !C0 || !cand || index_base < 0 ||
+        index_base + N > 0xffffffffll || (N > 0 && (!X || !best)))
+        return ET_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < et_kmeans_workspace_bytes(N, d, K)) return ET_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const KmWorkspace w = km_carve(workspace, N, d, K);
+    const int grid = km_grid(N);
+    if (d == 6)
+        hipLaunchKernelGGL((kmeans_init_step_kernel<6>), dim3(grid), dim3(kKmThreads), 0, st, X, N, d, K, i, C0, best,
+                           index_base, w.block_keys);
+    else
+        hipLaunchKernelGGL((kmeans_init_step_kernel<0>), dim3(grid), dim3(kKmThreads), 0, st, X, N, d, K, i, C0, best,
+                           index_base, w.block_keys);
+    ET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(kmeans_init_pick_kernel, dim3(1), dim3(kKmThreads), 0, st, X, N, d, w.block_keys, grid,
+                       index_base, (unsigned char *)cand);
+    ET_LAUNCH_CHECK();
+    return ET_OK;
+}
+
+extern "C" int et_kmeans_init_set(float *C0, int d, int K, int col, const float *point, et_stream_t stream) {
+    if (!C0 || !point || !km_dims_ok(d, K) || col < 0 || col >= K) return ET_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(kmeans_init_set_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, C0, d, K, col, point);
+    ET_LAUNCH_CHECK();
+    return ET_OK;
+}
+
+extern "C" int et_kmeans_gather_point(const float *X, int64_t N, int d, int64_t local_index, float *point,
+                                      et_stream_t stream) {
+    if (!X || !point || d < 1 || d > ET_KMEANS_MAX_D || local_index < 0 || local_index >= N) return ET_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(kmeans_gather_point_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, X, N, d, local_index,
+                       point);
+    ET_LAUNCH_CHECK();
+    return ET_OK;
+}
+
+extern "C" int et_kmeans_init_farthest(const float *X, int64_t N, int d, int K, int64_t first_index, float *C0,
+                                       void *workspace, size_t workspace_bytes, et_stream_t stream) {
+    if (!km_dims_ok(d, K) || N < 1 || !X || !C0 || first_index < 0 || first_index >= N || N > 0xffffffffll)
+        return ET_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < et_kmeans_workspace_bytes(N, d, K)) return ET_ERR_WORKSPACE;
+    const KmWorkspace w = km_carve(workspace, N, d, K);
+    float *pt = reinterpret_cast<float *>(w.cand + 8);
+    int rc = et_kmeans_gather_point(X, N, d, first_index, pt, stream);
+    if (rc) return rc;
+    rc = et_kmeans_init_set(C0, d, K, 0, pt, stream);
+    for (int i = 1; i < K && !rc; ++i) {
+        rc = et_kmeans_init_step(X, N, d, K, i, C0, w.best, 0, w.cand, workspace, workspace_bytes, stream);
+        if (!rc) rc = et_kmeans_init_set(C0, d, K, i, pt, stream);
+    }
+    return rc;
+}
+
+extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_iter, float tol, float *centroids,
+                             int64_t *labels, float *trace, et_kmeans_state *state_host, void *workspace,
+                             size_t workspace_bytes, et_stream_t stream) {
+    if (!km_dims_ok(d, K) || N < 1 || !X || !centroids || !labels || !state_host || max_iter < 1)
+        return ET_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < et_kmeans_workspace_bytes(N, d, K)) return ET_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const KmWorkspace w = km_carve(workspace, N, d, K);
+    int rc = et_kmeans_scan(X, N, d, w.state, stream);
+    if (!rc) rc = et_kmeans_begin(w.state, N, centroids, d, K, stream);
+    if (rc) return rc;
+    // The reference synchronises every iteration (error <= tol on the host, kmeans.py:239).
+    // Here convergence lives on the device: once state->done is set the remaining launches are
+    // no-ops, and the host only looks at the flag every few iterations.
+    const int check_every = 8;
+    for (int it = 0; it < max_iter; ++it) {
+        rc = et_kmeans_assign_accumulate(X, N, d, K, w.state, centroids, nullptr, w.labels_u8, (int64_t *)w.partials,
+                                         workspace, workspace_bytes, stream);
+        if (!rc) rc = et_kmeans_update(w.state, (const int64_t *)w.partials, d, K, tol, centroids, trace, stream);
+        if (rc) return rc;
+        if ((it + 1) % check_every == 0 || it + 1 == max_iter) {
+            ET_HIP_TRY(hipMemcpyAsync(state_host, w.state, sizeof(et_kmeans_state), hipMemcpyDeviceToHost, st));
+            ET_HIP_TRY(hipStreamSynchronize(st));
+            if (state_host->done) break;
+        }
+    }
+    rc = et_kmeans_labels_i64(w.labels_u8, N, labels, stream);
+    if (rc) return rc;
+    ET_HIP_TRY(hipMemcpyAsync(state_host, w.state, sizeof(et_kmeans_state), hipMemcpyDeviceToHost, st));
+    ET_HIP_TRY(hipStreamSynchronize(st));
+    return state_host->bad_input ? ET_ERR_BAD_DATA : ET_OK;
+}

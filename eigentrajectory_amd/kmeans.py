@@ -1,0 +1,187 @@
+"""BatchKMeans -- the reference's EigenTrajectory/kmeans.py interface on HIP kernels.
+
+Reference: EigenTrajectory/kmeans.py:7-272.  Same constructor, ``fit`` /
+``predict`` / ``centroids`` buffer and helper methods; data is (..., d_vector,
+n_data) d-major like the reference's.  Differences that a caller can observe:
+
+* per-cluster sums are exact (64-bit fixed point), so results do not depend on
+  the launch geometry or the number of GPUs; the reference's fp32 sums carry
+  ~1e-7 relative noise, which Lloyd iterations on unstructured data can amplify
+  into a different local optimum (tests/test_oracle_golden.py, G7);
+* the convergence test runs on the device; the host looks at it every 8
+  iterations instead of synchronising every iteration (kmeans.py:239);
+* non-finite input raises instead of propagating.
+The only randomness is ``np.random.randint`` / ``np.random.choice`` on numpy's global
+RNG, drawn exactly where the reference draws it (kmeans.py:92,126).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class BatchKMeans(nn.Module):
+    r"""Run multiple independent K-means algorithms in parallel.
+
+    Args:
+        n_clusters (int): Number of clusters
+        max_iter (int): Maximum number of iterations (default: 100)
+        tol (float): Tolerance (default: 0.0001)
+        n_redo (int): Number of time k-means will be run with differently initialized centroids.
+            the centroids with the lowest inertia will be selected as a final result. (default: 1)
+        init_mode (str): Initialization method.
+            'random': randomly chose initial centroids from input data.
+            'kmeans++': use k-means++ algorithm to initialize centroids. (default: 'kmeans++')
+    """
+
+    def __init__(self, n_clusters, n_redo=1, max_iter=100, tol=1e-4, init_mode="kmeans++", verbose=False):
+        super(BatchKMeans, self).__init__()
+        self.n_redo = n_redo
+        self.n_clusters = n_clusters
+        self.max_iter = max_iter
+        self.tol = tol
+        self.init_mode = init_mode
+        self.verbose = verbose
+        self.inertia_ = None
+        self.n_iter_ = None
+
+        self.register_buffer("centroids", None)
+
+    def load_state_dict(self, state_dict, **kwargs):
+        r"""Override the default load_state_dict() to load custom buffers (kmeans.py:32-43)."""
+        for k, v in state_dict.items():
+            if "." not in k:
+                assert hasattr(self, k), f"attribute {k} does not exist"
+                delattr(self, k)
+                self.register_buffer(k, v)
+        for name, module in self.named_children():
+            sd = {k.replace(name + ".", ""): v for k, v in state_dict.items() if k.startswith(name + ".")}
+            module.load_state_dict(sd)
+
+    @staticmethod
+    def calculate_error(a, b):
+        r"""Compute L2 error between a and b (kmeans.py:45-51)"""
+        diff = a - b
+        diff.pow_(2)
+        return diff.sum()
+
+    @staticmethod
+    def calculate_inertia(a):
+        r"""Compute inertia of a (kmeans.py:53-57)"""
+        return (-a).mean()
+
+    @staticmethod
+    def _batched(x):
+        """(..., d, n) -> (B, d, n) contiguous, plus the leading shape."""
+        lead = x.shape[:-2]
+        return x.reshape((-1,) + tuple(x.shape[-2:])).contiguous(), lead
+
+    @staticmethod
+    def euc_sim(a, b):
+        r"""Batched negative squared Euclidean distance (kmeans.py:59-76): (..., d, m), (..., d, n) -> (..., m, n)"""
+        a3, lead = BatchKMeans._batched(a)
+        b3, _ = BatchKMeans._batched(b)
+        out = torch.stack([ops.euc_sim(a3[i], b3[i]) for i in range(a3.shape[0])], dim=0)
+        return out.reshape(tuple(lead) + tuple(out.shape[-2:]))
+
+    def kmeanspp(self, data):
+        r"""Farthest-first initialisation (kmeans.py:78-112): (..., d, n) -> (..., d, n_clusters)"""
+        d3, lead = self._batched(data)
+        n_data = d3.shape[-1]
+        first = np.random.randint(n_data)  # one draw for the whole batch, like kmeans.py:92
+        cen = torch.stack([ops.kmeans_init_farthest(d3[i], self.n_clusters, first) for i in range(d3.shape[0])], dim=0)
+        return cen.reshape(tuple(lead) + tuple(cen.shape[-2:]))
+
+    def initialize_centroids(self, data):
+        r"""Initialize centroids with init_method specified in __init__ (kmeans.py:114-141)"""
+        n_data = data.size(-1)
+        if self.init_mode == "random":
+            random_index = np.random.choice(n_data, size=[self.n_clusters], replace=False)
+            centroids = data[:, :, random_index].clone()
+            if self.verbose:
+                print("centroids are randomly initialized.")
+        elif self.init_mode == "kmeans++":
+            centroids = self.kmeanspp(data).clone()
+            if self.verbose:
+                print("centroids are initialized with kmeans++.")
+        else:
+            raise NotImplementedError
+        return centroids
+
+    def get_labels(self, data, centroids):
+        r"""maxsims (..., n), labels (..., n) int64 (kmeans.py:143-158)"""
+        d3, lead = self._batched(data)
+        c3, _ = self._batched(centroids)
+        outs = [ops.kmeans_predict(d3[i], c3[i]) for i in range(d3.shape[0])]
+        labels = torch.stack([o[0] for o in outs], dim=0).reshape(tuple(lead) + (d3.shape[-1],))
+        maxsims = torch.stack([o[1] for o in outs], dim=0).reshape(tuple(lead) + (d3.shape[-1],))
+        return maxsims, labels
+
+    def compute_centroids(self, data, labels):
+        r"""Per-cluster means (kmeans.py:160-198); an empty cluster gives NaN like the reference's 0/0."""
+        d3, lead = self._batched(data)
+        l2 = labels.reshape(d3.shape[0], -1)
+        cens = []
+        for i in range(d3.shape[0]):
+            sh = ops.KMeansShard(d3[i], self.n_clusters)
+            cen = torch.zeros((sh.d, self.n_clusters), device=sh.dev)
+            sh.scan()
+            sh.begin(sh.n, cen)
+            part = sh.assign(cen, given_labels=l2[i].to(device=sh.dev, dtype=torch.int64).contiguous())
+            sh.update(part, cen, 0.0)
+            cens.append(cen)
+        out = torch.stack(cens, dim=0)
+        return out.reshape(tuple(lead) + tuple(out.shape[-2:]))
+
+    def compute_centroids_loop(self, data, labels):
+        return self.compute_centroids(data, labels)
+
+    def fit(self, data, centroids=None):
+        r"""Perform K-means clustering, and return final labels (kmeans.py:200-259)
+
+        Args:
+            data (torch.Tensor): data to be clustered, shape (l, d_vector, n_data)
+            centroids (torch.Tensor): initial centroids, shape (l, d_vector, n_clusters)
+
+        Returns:
+            best_labels (torch.Tensor): final labels, shape (l, n_data)
+        """
+        assert data.is_contiguous(), "use .contiguous()"
+        assert data.dim() == 3, "fit() takes (l, d_vector, n_data) like the reference"
+
+        best_centroids = None
+        best_labels = None
+        best_inertia = 1e32
+        best_iters = None
+
+        for i in range(self.n_redo):
+            if centroids is None:
+                centroids = self.initialize_centroids(data)
+            runs = [ops.kmeans_fit(data[b], centroids[b], self.max_iter, self.tol) for b in range(data.shape[0])]
+            new_centroids = torch.stack([r["centroids"] for r in runs], dim=0)
+            labels = torch.stack([r["labels"] for r in runs], dim=0)
+            # the reference's inertia is one mean over the whole batch (kmeans.py:234)
+            inertia = float(np.mean([r["inertia"] for r in runs]))
+            if self.verbose:
+                for b, r in enumerate(runs):
+                    for j, (e, ine) in enumerate(r["trace"].cpu().tolist()):
+                        print(f"----iteration {j} of {i}th redo, error={e}, inertia={ine}")
+            if inertia < best_inertia:  # NaN (empty cluster) never wins, like kmeans.py:242
+                best_centroids = new_centroids
+                best_labels = labels
+                best_inertia = inertia
+                best_iters = [r["n_iter"] for r in runs]
+            centroids = None
+
+        self.register_buffer("centroids", best_centroids)
+        self.inertia_ = best_inertia if best_centroids is not None else float("nan")
+        self.n_iter_ = best_iters
+        return best_labels
+
+    def predict(self, query):
+        r"""Predict the closest cluster center each sample in query belongs to (kmeans.py:261-272)."""
+        _, labels = self.get_labels(query, self.centroids)
+        return labels

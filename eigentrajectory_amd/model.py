@@ -1,0 +1,131 @@
+"""EigenTrajectory -- the reference's wrapper (EigenTrajectory/model.py) on fused HIP kernels.
+
+Reference: EigenTrajectory/model.py:7-125.  Drop-in: same constructor, the same
+sub-module names (``ET_m_descriptor``, ``ET_s_descriptor``, ``ET_m_anchor``,
+``ET_s_anchor``, ``baseline_model``) and therefore the same ``state_dict`` keys, the
+same three-hook predictor protocol (model.py:93-95) and the same output dict.
+
+What changes is how the descriptor path runs.  The reference physically splits
+the batch into moving / static pedestrians with boolean masks (each mask is a
+nonzero + gather + host sync: model.py:73-77, 82-83, 86-90, 98-99, 104-105,
+110-115) and runs two descriptors.  Here every kernel takes the whole scene and
+routes each row to its descriptor by the same test (model.py:73), so a forward
+is: 1 projection kernel -> predictor -> 1 reconstruction kernel, no host syncs.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .anchor import ETAnchor
+from .descriptor import ETDescriptor
+
+
+class EigenTrajectory(nn.Module):
+    r"""The EigenTrajectory model
+
+    Args:
+        baseline_model (nn.Module): The baseline model
+        hook_func (dict): The bridge functions for the baseline model
+        hyper_params (DotDict): The hyper-parameters
+    """
+
+    def __init__(self, baseline_model, hook_func, hyper_params):
+        super().__init__()
+
+        self.baseline_model = baseline_model
+        self.hook_func = hook_func
+        self.hyper_params = hyper_params
+        self.t_obs, self.t_pred = hyper_params.obs_len, hyper_params.pred_len
+        self.obs_svd, self.pred_svd = hyper_params.obs_svd, hyper_params.pred_svd
+        self.k = hyper_params.k
+        self.s = hyper_params.num_samples
+        self.dim = hyper_params.traj_dim
+        self.static_dist = hyper_params.static_dist
+
+        self.ET_m_descriptor = ETDescriptor(hyper_params=hyper_params, norm_sca=True)
+        self.ET_s_descriptor = ETDescriptor(hyper_params=hyper_params, norm_sca=False)
+        self.ET_m_anchor = ETAnchor(hyper_params=hyper_params)
+        self.ET_s_anchor = ETAnchor(hyper_params=hyper_params)
+
+    def _U(self):
+        return (self.ET_m_descriptor.U_obs_trunc.detach(), self.ET_m_descriptor.U_pred_trunc.detach(),
+                self.ET_s_descriptor.U_obs_trunc.detach(), self.ET_s_descriptor.U_pred_trunc.detach())
+
+    def calculate_parameters(self, obs_traj, pred_traj):
+        r"""Calculate the ET descriptors of the EigenTrajectory model (model.py:34-56)
+
+        Args:
+            obs_traj (torch.Tensor): The observed trajectory
+            pred_traj (torch.Tensor): The predicted trajectory
+
+        Note:
+            This function should be called once before training the model.
+        """
+        sd = self.static_dist
+        # Descriptor initialization: one pass over ALL rows per descriptor; the kernel masks out the
+        # rows of the other one (model.py:46-52 splits the tensors instead).
+        for which, desc in ((1, self.ET_m_descriptor), (0, self.ET_s_descriptor)):
+            g_obs, g_pred, _ = ops.fit_gram(obs_traj, pred_traj, ops.MODE_SPLIT, sd, which)
+            U_obs, _ = ops.eigh_topk(g_obs, self.k)
+            U_pred, _ = ops.eigh_topk(g_pred, self.k)
+            desc.U_obs_trunc = nn.Parameter(U_obs.to(desc.U_obs_trunc.device))
+            desc.U_pred_trunc = nn.Parameter(U_pred.to(desc.U_pred_trunc.device))
+
+        # Anchor generation (model.py:55-56) on the coefficients of each descriptor's own rows
+        _, _, U_pred_m, U_pred_s = self._U()
+        _, C_pred, _, flag = ops.norm_project(obs_traj, pred_traj, None, U_pred_m, None, U_pred_s, ops.MODE_SPLIT, sd,
+                                              want_nrm=False, want_obs=False)
+        moving = flag.bool()
+        self.ET_m_anchor.generate_from_coefficients(C_pred[:, moving].contiguous())
+        self.ET_s_anchor.generate_from_coefficients(C_pred[:, ~moving].contiguous())
+
+    def forward(self, obs_traj, pred_traj=None, addl_info=None):
+        r"""The forward function of the EigenTrajectory model (model.py:58-125)
+
+        Args:
+            obs_traj (torch.Tensor): The observed trajectory
+            pred_traj (torch.Tensor): The predicted trajectory (optional, for training only)
+            addl_info (dict): The additional information (optional, if baseline model requires)
+
+        Returns:
+            output (dict): The output of the model (recon_traj, loss, etc.)
+        """
+        sd = self.static_dist
+        U_obs_m, U_pred_m, U_obs_s, U_pred_s = self._U()
+        A_m, A_s = self.ET_m_anchor.C_anchor.detach(), self.ET_s_anchor.C_anchor.detach()
+
+        # Projection of every pedestrian with its own descriptor (model.py:73-83) + the cached
+        # normaliser state; nrm[:2] is the absolute last observed position (model.py:86-88)
+        C_obs, C_pred_gt, nrm, flag = ops.norm_project(
+            obs_traj, pred_traj, U_obs_m, U_pred_m if pred_traj is not None else None,
+            U_obs_s, U_pred_s if pred_traj is not None else None, ops.MODE_SPLIT, sd, want_flag=pred_traj is not None)
+        obs_ori = nrm[:2] - nrm[:2].mean(dim=1, keepdim=True)  # move scene to origin (model.py:89)
+
+        # Trajectory prediction (model.py:93-95)
+        input_data = self.hook_func.model_forward_pre_hook(C_obs, obs_ori, addl_info)
+        output_data = self.hook_func.model_forward(input_data, self.baseline_model)
+        C_pred_refine = self.hook_func.model_forward_post_hook(output_data, addl_info)
+
+        # Anchor refinement + reconstruction in one kernel (model.py:98-105)
+        pred_traj_recon = ops.anchor_reconstruct(C_pred_refine, A_m, A_s, U_pred_m, U_pred_s, ops.MODE_SPLIT, sd,
+                                                 nrm=nrm, t_obs=obs_traj.shape[1])
+        pred_traj_recon = pred_traj_recon.to(obs_traj.device)
+
+        output = {"recon_traj": pred_traj_recon}
+
+        if pred_traj is not None:
+            moving = flag.bool()[None, :, None]
+            C_pred = torch.where(moving, A_m[:, None, :], A_s[:, None, :]) + C_pred_refine.to(A_m.device)
+            C_pred_gt = C_pred_gt.detach()  # low-rank approximation of the gt trajectory (model.py:113-116)
+            gt = pred_traj.to(pred_traj_recon.device)
+
+            # Loss calculation (model.py:119-123)
+            error_coefficient = (C_pred - C_pred_gt.unsqueeze(dim=-1)).norm(p=2, dim=0)
+            error_displacement = (pred_traj_recon - gt.unsqueeze(dim=0)).norm(p=2, dim=-1)
+            output["loss_eigentraj"] = error_coefficient.min(dim=-1)[0].mean()
+            output["loss_euclidean_ade"] = error_displacement.mean(dim=-1).min(dim=0)[0].mean()
+            output["loss_euclidean_fde"] = error_displacement[:, :, -1].min(dim=0)[0].mean()
+
+        return output

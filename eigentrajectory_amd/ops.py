@@ -1,0 +1,310 @@
+"""Functional front-end of the HIP kernels (thin: argument marshalling + autograd glue).
+
+Each function enqueues one or two kernels of libetamd.so on the current HIP
+stream and returns device tensors; none of them synchronises except
+``kmeans_fit`` (the reference synchronises every iteration there,
+EigenTrajectory/kmeans.py:239).  Inputs on the CPU are moved to the current HIP
+device first; without a HIP device every function raises (no CPU fallback).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import MODE_IDENTITY, MODE_MOVING, MODE_SPLIT, MODE_STATIC  # noqa: F401  (re-exported)
+
+
+def _dev_args(device, *tensors):
+    return [L.on_device(t, device) for t in tensors]
+
+
+# ------------------------------------------------------------------------------- TrajNorm
+def norm_params(obs, want_ori=True, want_rot=True, want_sca=True):
+    """normalizer.py:17-29 -> traj_ori (N,1,2), traj_rot (N,2,2), traj_sca (N,1,1) (None where not wanted)."""
+    dev = L.require_device(obs)
+    (obs,) = _dev_args(dev, obs)
+    n, t, _ = obs.shape
+    ori = torch.empty((n, 1, 2), device=dev) if want_ori else None
+    rot = torch.empty((n, 2, 2), device=dev) if want_rot else None
+    sca = torch.empty((n, 1, 1), device=dev) if want_sca else None
+    L.check(L.lib().et_norm_params(L.ptr(obs), L.i64(n), t, L.ptr(ori), L.ptr(rot), L.ptr(sca), L.stream(dev)),
+            "et_norm_params")
+    return ori, rot, sca
+
+
+def norm_params_from_nrm(nrm, want_ori=True, want_rot=True, want_sca=True):
+    """Same tensors from the compact state nrm (4,N) cached by :func:`norm_project`."""
+    dev = L.require_device(nrm)
+    (nrm,) = _dev_args(dev, nrm)
+    n = nrm.shape[1]
+    ori = torch.empty((n, 1, 2), device=dev) if want_ori else None
+    rot = torch.empty((n, 2, 2), device=dev) if want_rot else None
+    sca = torch.empty((n, 1, 1), device=dev) if want_sca else None
+    L.check(L.lib().et_norm_params_from_nrm(L.ptr(nrm), L.i64(n), L.ptr(ori), L.ptr(rot), L.ptr(sca), L.stream(dev)),
+            "et_norm_params_from_nrm")
+    return ori, rot, sca
+
+
+def _traj_transform(fn, name, traj, ori, rot, sca):
+    dev = L.require_device(traj, ori, rot, sca)
+    traj, ori, rot, sca = _dev_args(dev, traj, ori, rot, sca)
+    n, t, _ = traj.shape
+    out = torch.empty_like(traj)
+    L.check(fn(L.ptr(traj), L.i64(n), t, L.ptr(ori), L.ptr(rot), L.ptr(sca), L.ptr(out), L.stream(dev)), name)
+    return out
+
+
+def normalize(traj, ori=None, rot=None, sca=None):
+    """normalizer.py:42-51 with explicit parameter tensors (None = that step is off)."""
+    return _traj_transform(L.lib().et_normalize, "et_normalize", traj, ori, rot, sca)
+
+
+def denormalize(traj, ori=None, rot=None, sca=None):
+    """normalizer.py:53-62"""
+    return _traj_transform(L.lib().et_denormalize, "et_denormalize", traj, ori, rot, sca)
+
+
+# ---------------------------------------------------------------------------- projection
+def norm_project(obs, pred, U_obs_m, U_pred_m, U_obs_s, U_pred_s, mode, static_dist=0.0,
+                 want_nrm=True, want_flag=True, want_obs=True):
+    """descriptor.py:144-160 fused with model.py:73-90.
+
+    Returns (C_obs (k,N) | None, C_pred (k,N) | None, nrm (4,N) | None, flag (N,) uint8 | None).
+    """
+    dev = L.require_device(obs)
+    obs, pred, U_obs_m, U_pred_m, U_obs_s, U_pred_s = _dev_args(dev, obs, pred, U_obs_m, U_pred_m, U_obs_s, U_pred_s)
+    n, t_obs, _ = obs.shape
+    us_obs = U_obs_m if U_obs_m is not None else U_obs_s
+    us_pred = U_pred_m if U_pred_m is not None else U_pred_s
+    k = (us_obs if us_obs is not None else us_pred).shape[1]
+    t_pred = pred.shape[1] if pred is not None else (us_pred.shape[0] // 2 if us_pred is not None else 1)
+    c_obs = torch.empty((k, n), device=dev) if (want_obs and us_obs is not None) else None
+    c_pred = torch.empty((k, n), device=dev) if pred is not None else None
+    nrm = torch.empty((4, n), device=dev) if want_nrm else None
+    flag = torch.empty((n,), device=dev, dtype=torch.uint8) if want_flag else None
+    L.check(L.lib().et_norm_project(L.ptr(obs), L.ptr(pred), L.i64(n), t_obs, t_pred, k, L.ptr(U_obs_m),
+                                    L.ptr(U_pred_m), L.ptr(U_obs_s), L.ptr(U_pred_s), int(mode), L.f32(static_dist),
+                                    L.ptr(c_obs), L.ptr(c_pred), L.ptr(nrm), L.ptr(flag), L.stream(dev)),
+            "et_norm_project")
+    return c_obs, c_pred, nrm, flag
+
+
+# ------------------------------------------------------------------------- reconstruction
+def _reconstruct_fwd(Cc, obs, nrm, A_m, A_s, U_m, U_s, mode, static_dist, t_obs):
+    dev = Cc.device
+    k, n, s = Cc.shape
+    u = U_m if U_m is not None else U_s
+    t_pred = u.shape[0] // 2
+    out = torch.empty((s, n, t_pred, 2), device=dev)
+    L.check(L.lib().et_anchor_reconstruct_fwd(L.ptr(Cc), L.i64(n), s, k, t_obs, t_pred, L.ptr(obs), L.ptr(nrm),
+                                              L.ptr(A_m), L.ptr(A_s), L.ptr(U_m), L.ptr(U_s), int(mode),
+                                              L.f32(static_dist), L.ptr(out), L.stream(dev)),
+            "et_anchor_reconstruct_fwd")
+    return out
+
+
+def _reconstruct_bwd(dtraj, obs, nrm, U_m, U_s, mode, static_dist, t_obs):
+    dev = dtraj.device
+    s, n, t_pred, _ = dtraj.shape
+    u = U_m if U_m is not None else U_s
+    k = u.shape[1]
+    dC = torch.empty((k, n, s), device=dev)
+    L.check(L.lib().et_anchor_reconstruct_bwd(L.ptr(dtraj), L.i64(n), s, k, t_obs, t_pred, L.ptr(obs), L.ptr(nrm),
+                                              L.ptr(U_m), L.ptr(U_s), int(mode), L.f32(static_dist), L.ptr(dC),
+                                              L.stream(dev)), "et_anchor_reconstruct_bwd")
+    return dC
+
+
+class _AnchorReconstruct(torch.autograd.Function):
+    """Differentiable w.r.t. C only: U, anchors and the normaliser state are detached in the
+    reference too (descriptor.py:72,87; anchor.py:87)."""
+
+    @staticmethod
+    def forward(ctx, Cc, obs, nrm, A_m, A_s, U_m, U_s, mode, static_dist, t_obs):
+        ctx.saved = (obs, nrm, U_m, U_s, mode, static_dist, t_obs)
+        return _reconstruct_fwd(Cc, obs, nrm, A_m, A_s, U_m, U_s, mode, static_dist, t_obs)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        obs, nrm, U_m, U_s, mode, static_dist, t_obs = ctx.saved
+        dC = _reconstruct_bwd(grad_out.contiguous().float(), obs, nrm, U_m, U_s, mode, static_dist, t_obs)
+        return (dC,) + (None,) * 9
+
+
+def anchor_reconstruct(Cc, A_m, A_s, U_m, U_s, mode, static_dist=0.0, *, obs=None, nrm=None, t_obs=8):
+    """anchor.py:76-88 + descriptor.py:162-176: C (k,N,S) -> (S,N,T_pred,2); autograd w.r.t. C.
+
+    The normaliser state comes from ``nrm`` (4,N) (as returned by :func:`norm_project`) or is
+    recomputed from ``obs`` (N,T_obs,2).
+    """
+    dev = L.require_device(Cc)
+    if Cc.device != dev or Cc.dtype != torch.float32 or not Cc.is_contiguous():
+        Cc = Cc.to(device=dev, dtype=torch.float32).contiguous()  # differentiable
+    obs, nrm, A_m, A_s, U_m, U_s = _dev_args(dev, obs, nrm, A_m, A_s, U_m, U_s)
+    if obs is not None:
+        t_obs = obs.shape[1]
+    return _AnchorReconstruct.apply(Cc, obs, nrm, A_m, A_s, U_m, U_s, int(mode), float(static_dist), int(t_obs))
+
+
+# ------------------------------------------------------------------------------------ fit
+def fit_gram(obs, pred, mode, static_dist=0.0, which=1):
+    """Gram matrices (fp64) of the normalised rows routed to descriptor ``which`` + their count (int64, device)."""
+    dev = L.require_device(obs)
+    obs, pred = _dev_args(dev, obs, pred)
+    n, t_obs, _ = obs.shape
+    t_pred = pred.shape[1]
+    g_obs = torch.empty((2 * t_obs, 2 * t_obs), device=dev, dtype=torch.float64)
+    g_pred = torch.empty((2 * t_pred, 2 * t_pred), device=dev, dtype=torch.float64)
+    count = torch.zeros((1,), device=dev, dtype=torch.int64)
+    ws_bytes = L.lib().et_fit_gram_workspace_bytes(L.i64(n), t_obs, t_pred)
+    ws = torch.empty((max(ws_bytes, 8),), device=dev, dtype=torch.uint8)
+    L.check(L.lib().et_fit_gram(L.ptr(obs), L.ptr(pred), L.i64(n), t_obs, t_pred, int(mode), L.f32(static_dist),
+                                int(which), L.ptr(g_obs), L.ptr(g_pred), L.ptr(count), L.ptr(ws),
+                                C.c_size_t(ws.numel()), L.stream(dev)), "et_fit_gram")
+    return g_obs, g_pred, count
+
+
+def eigh_topk(G, k):
+    """Top-k eigenvectors (n,k) fp32 and sigma (k,) = sqrt(eigenvalues) of a symmetric fp64 matrix."""
+    dev = L.require_device(G)
+    G = L.on_device(G, dev, torch.float64)
+    n = G.shape[0]
+    U = torch.empty((n, k), device=dev)
+    sigma = torch.empty((k,), device=dev)
+    L.check(L.lib().et_eigh_topk(L.ptr(G), n, int(k), L.ptr(U), L.ptr(sigma), L.stream(dev)), "et_eigh_topk")
+    return U, sigma
+
+
+# -------------------------------------------------------------------------------- k-means
+def euc_sim(a, b):
+    """kmeans.py:59-76 for 2-D operands a (d,m), b (d,n) -> (m,n)."""
+    dev = L.require_device(a, b)
+    a, b = _dev_args(dev, a, b)
+    d, m = a.shape
+    n = b.shape[1]
+    y = torch.empty((m, n), device=dev)
+    L.check(L.lib().et_euc_sim(L.ptr(a), L.ptr(b), d, L.i64(m), L.i64(n), L.ptr(y), L.stream(dev)), "et_euc_sim")
+    return y
+
+
+def kmeans_workspace(n, d, K, device):
+    nbytes = L.lib().et_kmeans_workspace_bytes(L.i64(n), int(d), int(K))
+    if nbytes == 0:
+        raise ValueError(f"k-means dimensions out of range: d={d} (<= {L.KMEANS_MAX_D}), K={K} (<= {L.KMEANS_MAX_CLUSTERS})")
+    return torch.empty((nbytes,), device=device, dtype=torch.uint8)
+
+
+def kmeans_init_farthest(X, K, first_index, workspace=None):
+    """kmeans.py:78-112 for one batch element: X (d,N) -> C0 (d,K)."""
+    dev = L.require_device(X)
+    (X,) = _dev_args(dev, X)
+    d, n = X.shape
+    ws = workspace if workspace is not None else kmeans_workspace(n, d, K, dev)
+    c0 = torch.empty((d, K), device=dev)
+    L.check(L.lib().et_kmeans_init_farthest(L.ptr(X), L.i64(n), d, int(K), L.i64(first_index), L.ptr(c0), L.ptr(ws),
+                                            C.c_size_t(ws.numel()), L.stream(dev)), "et_kmeans_init_farthest")
+    return c0
+
+
+def kmeans_fit(X, centroids, max_iter=100, tol=1e-4, workspace=None):
+    """kmeans.py:228-240 for one batch element from given initial centroids.
+
+    Returns dict(centroids (d,K), labels (N,) int64, n_iter, error, inertia, trace (n_iter,2), done).
+    """
+    dev = L.require_device(X)
+    X, centroids = _dev_args(dev, X, centroids)
+    d, n = X.shape
+    K = centroids.shape[1]
+    ws = workspace if workspace is not None else kmeans_workspace(n, d, K, dev)
+    cen = centroids.clone()
+    labels = torch.empty((n,), device=dev, dtype=torch.int64)
+    trace = torch.zeros((max_iter, 2), device=dev)
+    st = L.KMeansState()
+    L.check(L.lib().et_kmeans_fit(L.ptr(X), L.i64(n), d, K, int(max_iter), L.f32(tol), L.ptr(cen), L.ptr(labels),
+                                  L.ptr(trace), C.byref(st), L.ptr(ws), C.c_size_t(ws.numel()), L.stream(dev)),
+            "et_kmeans_fit")
+    return dict(centroids=cen, labels=labels, n_iter=int(st.iter), error=float(st.error), inertia=float(st.inertia),
+                trace=trace[:int(st.iter)], done=bool(st.done))
+
+
+def kmeans_predict(X, centroids, want_maxsims=True):
+    """kmeans.py:143-158 / 261-272: labels (N,) int64 and max similarity (N,)."""
+    dev = L.require_device(X)
+    X, centroids = _dev_args(dev, X, centroids)
+    d, n = X.shape
+    labels = torch.empty((n,), device=dev, dtype=torch.int64)
+    maxsims = torch.empty((n,), device=dev) if want_maxsims else None
+    L.check(L.lib().et_kmeans_predict(L.ptr(X), L.i64(n), d, L.ptr(centroids), centroids.shape[1], L.ptr(labels),
+                                      L.ptr(maxsims), L.stream(dev)), "et_kmeans_predict")
+    return labels, maxsims
+
+
+class KMeansShard:
+    """Step-wise Lloyd iteration on one shard of the points (the sharded / multi-GPU form).
+
+    ``scan`` -> [all-reduce MAX of ``state_f64[0]`` and ``state_i64[7]``] -> ``begin`` ->
+    repeat { ``assign`` -> [all-reduce SUM of the int64 partials] -> ``update`` } -> ``labels``.
+    Everything stays on the device; ``state`` is read back only when the caller asks.
+    """
+
+    def __init__(self, X, K):
+        self.dev = L.require_device(X)
+        self.X = L.on_device(X, self.dev)
+        self.d, self.n = self.X.shape
+        self.K = int(K)
+        self.ws = kmeans_workspace(self.n, self.d, self.K, self.dev)
+        self.state = torch.zeros((L.STATE_BYTES // 8,), device=self.dev, dtype=torch.int64)
+        self.partials = torch.zeros((L.lib().et_kmeans_partials_len(self.d, self.K),), device=self.dev,
+                                    dtype=torch.int64)
+        self.labels_u8 = torch.zeros((max(self.n, 1) + 3,), device=self.dev, dtype=torch.uint8)
+        self.best = torch.empty((max(self.n, 1),), device=self.dev)
+        self.cand = torch.zeros((8 + 4 * L.KMEANS_MAX_D,), device=self.dev, dtype=torch.uint8)
+
+    @property
+    def state_f64(self):
+        return self.state.view(torch.float64)
+
+    def scan(self):
+        L.check(L.lib().et_kmeans_scan(L.ptr(self.X), L.i64(self.n), self.d, L.ptr(self.state), L.stream(self.dev)),
+                "et_kmeans_scan")
+
+    def begin(self, n_total, centroids):
+        L.check(L.lib().et_kmeans_begin(L.ptr(self.state), L.i64(n_total), L.ptr(centroids), self.d, self.K,
+                                        L.stream(self.dev)), "et_kmeans_begin")
+
+    def init_step(self, i, C0, index_base):
+        """candidate record of farthest-first step i: uint8 tensor {key u64, d floats}."""
+        L.check(L.lib().et_kmeans_init_step(L.ptr(self.X), L.i64(self.n), self.d, self.K, int(i), L.ptr(C0),
+                                            L.ptr(self.best), L.i64(index_base), L.ptr(self.cand), L.ptr(self.ws),
+                                            C.c_size_t(self.ws.numel()), L.stream(self.dev)), "et_kmeans_init_step")
+        return self.cand
+
+    def gather_point(self, local_index):
+        pt = torch.empty((self.d,), device=self.dev)
+        L.check(L.lib().et_kmeans_gather_point(L.ptr(self.X), L.i64(self.n), self.d, L.i64(local_index), L.ptr(pt),
+                                               L.stream(self.dev)), "et_kmeans_gather_point")
+        return pt
+
+    def assign(self, centroids, given_labels=None):
+        L.check(L.lib().et_kmeans_assign_accumulate(L.ptr(self.X), L.i64(self.n), self.d, self.K, L.ptr(self.state),
+                                                    L.ptr(centroids), L.ptr(given_labels), L.ptr(self.labels_u8),
+                                                    L.ptr(self.partials), L.ptr(self.ws), C.c_size_t(self.ws.numel()),
+                                                    L.stream(self.dev)), "et_kmeans_assign_accumulate")
+        return self.partials
+
+    def update(self, partials, centroids, tol, trace=None):
+        L.check(L.lib().et_kmeans_update(L.ptr(self.state), L.ptr(partials), self.d, self.K, L.f32(tol),
+                                         L.ptr(centroids), L.ptr(trace), L.stream(self.dev)), "et_kmeans_update")
+
+    def labels(self):
+        out = torch.empty((self.n,), device=self.dev, dtype=torch.int64)
+        L.check(L.lib().et_kmeans_labels_i64(L.ptr(self.labels_u8), L.i64(self.n), L.ptr(out), L.stream(self.dev)),
+                "et_kmeans_labels_i64")
+        return out
+
+    def read_state(self):
+        """Blocking read-back of the state block -> _lib.KMeansState."""
+        host = self.state.cpu().numpy().tobytes()
+        return L.KMeansState.from_buffer_copy(host)

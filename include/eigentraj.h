@@ -1,0 +1,216 @@
+/*
+ * eigentraj.h -- C ABI of libetamd.so, the MI355X (gfx950) implementation of the
+ * EigenTrajectory SVD-descriptor hot path.
+ *
+ * The reference (InhwanBae/EigenTrajectory) is pure Python/PyTorch and has no FFI
+ * of its own; the entry points below are what a binding for
+ * this path has to cover, one per reference call site:
+ *
+ *   et_norm_project            EigenTrajectory/descriptor.py:144-160 (projection)
+ *                              + normalizer.py:17-51, fused with the moving/static
+ *                              routing of EigenTrajectory/model.py:73-90
+ *   et_anchor_reconstruct_fwd  EigenTrajectory/anchor.py:76-88 + descriptor.py:162-176
+ *                              + normalizer.py:53-62, routed like model.py:98-105
+ *   et_anchor_reconstruct_bwd  autograd of the above w.r.t. C_pred (training)
+ *   et_fit_gram, et_eigh_topk  descriptor.py:91-114 truncated_SVD via the 2T x 2T Gram
+ *                              matrix (parameter_initialization, descriptor.py:116-142)
+ *   et_kmeans_*                EigenTrajectory/kmeans.py:59-272 (BatchKMeans); used for
+ *                              anchor generation (anchor.py:54-74)
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *  - tensors are contiguous fp32; obs (N,T_obs,2), pred (N,T_pred,2) row-major "NTC";
+ *    coefficients are k-major: C (k,N) and C (k,N,S); labels are int64;
+ *  - the caller owns every buffer; the library never allocates user-visible memory.
+ *    Scratch is passed in as a workspace whose size comes from *_workspace_bytes();
+ *  - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work and
+ *    never synchronise unless documented;
+ *  - return value: ET_OK or an ET_ERR_* code; no exceptions cross this boundary;
+ *    N == 0 is valid and a no-op; NaN/Inf in the data propagate like in the reference
+ *    (normalizer.py:28-29) and are not errors, except in k-means (see below).
+ *
+ * mode (which descriptor a row uses; the reference keeps two ETDescriptor objects,
+ * model.py:29-30):
+ *   ET_MODE_STATIC 0  every row: norm_sca=False descriptor (U_*_s, A_s)
+ *   ET_MODE_MOVING 1  every row: norm_sca=True  descriptor (U_*_m, A_m)
+ *   ET_MODE_SPLIT  2  per row: moving iff ||(obs[-1]-obs[-3])/2|| > static_dist (model.py:46,73)
+ *   ET_MODE_IDENTITY 3 rows are used as they are (already normalised input / normalised output)
+ */
+#ifndef EIGENTRAJ_H
+#define EIGENTRAJ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ET_ABI_VERSION 1
+
+#define ET_OK 0
+#define ET_ERR_INVALID_ARG 1  /* bad shape / null pointer / misaligned buffer */
+#define ET_ERR_HIP 2          /* a HIP runtime call or launch failed */
+#define ET_ERR_UNSUPPORTED 3  /* dimensions outside the compiled range */
+#define ET_ERR_WORKSPACE 4    /* workspace too small */
+#define ET_ERR_BAD_DATA 5     /* k-means input contains NaN/Inf */
+
+#define ET_MODE_STATIC 0
+#define ET_MODE_MOVING 1
+#define ET_MODE_SPLIT 2
+#define ET_MODE_IDENTITY 3 /* no normalisation at all: bare to_ET_space / to_Euclidean_space
+                              (descriptor.py:59-89) with the U_*_s / A_s operands */
+
+#define ET_MAX_T 32  /* max T_obs, T_pred (2T <= 64 rows for the one-wavefront eigensolver) */
+#define ET_MAX_K 32  /* max descriptor rank k */
+#define ET_KMEANS_MAX_D 32
+#define ET_KMEANS_MAX_CLUSTERS 255
+
+typedef void *et_stream_t;
+
+int et_abi_version(void);
+const char *et_status_string(int status);
+/* name of the GPU arch the kernels were compiled for ("gfx950") */
+const char *et_compiled_arch(void);
+
+/* ---- TrajNorm (EigenTrajectory/normalizer.py) -------------------------------------------
+ * et_norm_params   normalizer.py:17-29: ori (N,1,2), rot (N,2,2) = [[c,-s],[s,c]], sca (N,1,1)
+ *                  = 2/||obs[-1]-obs[-3]||; any output may be NULL (flag off).
+ * et_normalize     normalizer.py:42-51: ((traj - ori) @ rot) * sca, each step skipped when its
+ *                  pointer is NULL.  traj/out (N,T,2); in-place allowed.
+ * et_denormalize   normalizer.py:53-62: (traj / sca) @ rot^T + ori. */
+int et_norm_params(const float *obs, int64_t N, int T, float *ori, float *rot, float *sca, et_stream_t stream);
+/* the same tensors from the compact state nrm (4,N) = ox, oy, dx, dy cached by et_norm_project */
+int et_norm_params_from_nrm(const float *nrm, int64_t N, float *ori, float *rot, float *sca, et_stream_t stream);
+int et_normalize(const float *traj, int64_t N, int T, const float *ori, const float *rot, const float *sca,
+                 float *out, et_stream_t stream);
+int et_denormalize(const float *traj, int64_t N, int T, const float *ori, const float *rot, const float *sca,
+                   float *out, et_stream_t stream);
+
+/* ---- projection -------------------------------------------------------------------
+ * C_obs[j][n]  = sum_f U_obs[f][j]  * normalize(obs[n])[f]      (k,N)
+ * C_pred[j][n] = sum_f U_pred[f][j] * normalize(pred[n])[f]     (k,N), if pred != NULL
+ * nrm (4,N)    = ox, oy, dx, dy with (ox,oy)=obs[n,-1], (dx,dy)=obs[n,-1]-obs[n,-3]: the
+ *                state TrajNorm caches between projection and reconstruction
+ *                (normalizer.py:15,20-28); rows 0-1 are model.py:86-87's obs_ori.
+ * flag (N)     = 1 for rows routed to the moving descriptor.
+ * U_* are (2T,k) row-major like the reference's nn.Parameter (descriptor.py:26-27);
+ * the pair a mode does not use may be NULL.  C_pred, nrm, flag may be NULL. */
+int et_norm_project(const float *obs, const float *pred, int64_t N, int T_obs, int T_pred, int k,
+                    const float *U_obs_m, const float *U_pred_m, const float *U_obs_s, const float *U_pred_s,
+                    int mode, float static_dist,
+                    float *C_obs, float *C_pred, float *nrm, uint8_t *flag, et_stream_t stream);
+
+/* ---- anchor refinement + reconstruction -------------------------------------------
+ * out[s][n] = denormalize( reshape( U_pred . (C[:,n,s] + A[:,s]) ) )      (S,N,T_pred,2)
+ * C (k,N,S); A_m/A_s (k,S) or NULL (no anchor add); normaliser state comes from `nrm`
+ * (4,N) as written by et_norm_project, or, when nrm == NULL, is recomputed from obs. */
+int et_anchor_reconstruct_fwd(const float *C, int64_t N, int S, int k, int T_obs, int T_pred,
+                              const float *obs, const float *nrm,
+                              const float *A_m, const float *A_s, const float *U_pred_m, const float *U_pred_s,
+                              int mode, float static_dist, float *out, et_stream_t stream);
+
+/* dC[j][n][s] = sum_f U_pred[f][j] * ((dtraj[s][n] @ R_n) / sca_n)[f]          (k,N,S) */
+int et_anchor_reconstruct_bwd(const float *dtraj, int64_t N, int S, int k, int T_obs, int T_pred,
+                              const float *obs, const float *nrm,
+                              const float *U_pred_m, const float *U_pred_s,
+                              int mode, float static_dist, float *dC, et_stream_t stream);
+
+/* ---- fit ----------------------------------------------------------------------------
+ * Gram matrices of the normalised trajectories routed to descriptor `which`
+ * (1 moving / 0 static) under `mode`:  G_obs (2T_obs,2T_obs), G_pred (2T_pred,2T_pred)
+ * fp64, full symmetric; *count = rows used (int64, device).  A data-sharded fit sums
+ * G_obs, G_pred and count over ranks (RCCL all-reduce) before et_eigh_topk. */
+size_t et_fit_gram_workspace_bytes(int64_t N, int T_obs, int T_pred);
+int et_fit_gram(const float *obs, const float *pred, int64_t N, int T_obs, int T_pred,
+                int mode, float static_dist, int which,
+                double *G_obs, double *G_pred, int64_t *count,
+                void *workspace, size_t workspace_bytes, et_stream_t stream);
+
+/* Top-k eigenpairs of a symmetric n x n fp64 matrix (n <= 64), cyclic Jacobi on one
+ * wavefront: U (n,k) fp32 = eigenvectors by descending eigenvalue, each signed so its
+ * largest-|.| component is positive; sigma[k] = sqrt(max(lambda,0)) -- U[:, :k], S[:k]
+ * of torch.linalg.svd at descriptor.py:110-113 up to sign. */
+int et_eigh_topk(const double *G, int n, int k, float *U, float *sigma, et_stream_t stream);
+
+/* ---- BatchKMeans ----------------------------------------------------------------------
+ * X (d,N) d-major points (= C_pred (k,N)); centroids (d,K); labels int64 (N).
+ * Similarity is kmeans.py:71-74 in the reference's operation order; the argmax takes
+ * the first maximum and lets NaN win (torch.max).  Per-cluster sums are exact 64-bit
+ * fixed-point integers (state.frac fractional bits), hence identical for any
+ * partition of the points over workgroups or GPUs. */
+typedef struct et_kmeans_state {
+    double max_abs_x;   /* max |x| over ALL shards (all-reduce MAX before et_kmeans_begin) */
+    double max_abs_c;   /* max |centroid| of the current centroids (NaN ignored)           */
+    int64_t n_total;    /* number of points over all shards                                */
+    int64_t frac;       /* fractional bits of the coordinate accumulators                   */
+    int64_t sim_frac;   /* fractional bits of the similarity (inertia) accumulator          */
+    int64_t iter;       /* Lloyd iterations executed                                       */
+    int64_t done;       /* 1 once error <= tol (kmeans.py:239); later steps are no-ops     */
+    int64_t bad_input;  /* 1 if X holds NaN/Inf (all-reduce MAX)                           */
+    double error;       /* kmeans.py:45-51 of the last update                              */
+    double inertia;     /* kmeans.py:53-57 of the last assignment                          */
+} et_kmeans_state;
+
+/* kmeans.py:59-76 euc_sim for one batch element: a (d,m), b (d,n) -> y (m,n) */
+int et_euc_sim(const float *a, const float *b, int d, int64_t m, int64_t n, float *y, et_stream_t stream);
+
+/* number of int64 in a partials block: d*K sums (d-major), K counts, sim_sum, nan_count */
+size_t et_kmeans_partials_len(int d, int K);
+size_t et_kmeans_workspace_bytes(int64_t N, int d, int K);
+
+/* max |x| and non-finite flag of this shard -> state->max_abs_x, state->bad_input
+ * (the rest of *state is zeroed). */
+int et_kmeans_scan(const float *X, int64_t N, int d, et_kmeans_state *state, et_stream_t stream);
+/* fix frac / sim_frac from the (all-reduced) max_abs_x, n_total and the initial centroids
+ * (d,K); reset iter/done (done = 1 straight away when bad_input is set). */
+int et_kmeans_begin(et_kmeans_state *state, int64_t n_total, const float *centroids, int d, int K,
+                    et_stream_t stream);
+
+/* farthest-first initialisation (kmeans.py:78-112).  best (N) fp32 scratch.
+ *   step i (1 <= i < K): similarity of every local point to centroid column i-1 of C0,
+ *   running max into best, local arg-min -> cand: {uint64 key, d floats} where
+ *   key = orderable(best) << 32 | (index_base + local index); smaller key wins and a
+ *   sharded run picks the minimum key over ranks.  cand must hold 8 + 4*d bytes.
+ * et_kmeans_init_set copies a point (device, d floats) into column `col` of C0 (d,K). */
+int et_kmeans_init_step(const float *X, int64_t N, int d, int K, int i, const float *C0, float *best,
+                        int64_t index_base, void *cand, void *workspace, size_t workspace_bytes,
+                        et_stream_t stream);
+int et_kmeans_init_set(float *C0, int d, int K, int col, const float *point, et_stream_t stream);
+/* gather X[:, local_index] -> point (d floats, device) */
+int et_kmeans_gather_point(const float *X, int64_t N, int d, int64_t local_index, float *point,
+                           et_stream_t stream);
+/* single-GPU convenience: the whole initialisation, first centroid = X[:, first_index] */
+int et_kmeans_init_farthest(const float *X, int64_t N, int d, int K, int64_t first_index, float *C0,
+                            void *workspace, size_t workspace_bytes, et_stream_t stream);
+
+/* one Lloyd half-step on a shard (kmeans.py:230 + the sums of :231, :234): labels_u8 (N)
+ * and this shard's exact partials; no-op when state->done.  With given_labels != NULL
+ * (int64, N) the labels are taken as they are instead of computed (compute_centroids,
+ * kmeans.py:160-198, as a public method). */
+int et_kmeans_assign_accumulate(const float *X, int64_t N, int d, int K, const et_kmeans_state *state,
+                                const float *centroids, const int64_t *given_labels, uint8_t *labels_u8,
+                                int64_t *partials, void *workspace, size_t workspace_bytes, et_stream_t stream);
+/* centroid update + error/inertia/convergence from (all-reduced) partials
+ * (kmeans.py:180-182, 45-57, 239).  centroids updated in place; trace (max_iter,2) fp32
+ * receives (error, inertia) at row state->iter when not NULL. */
+int et_kmeans_update(et_kmeans_state *state, const int64_t *partials, int d, int K, float tol,
+                     float *centroids, float *trace, et_stream_t stream);
+/* widen the uint8 labels of the last assignment to the reference's int64 */
+int et_kmeans_labels_i64(const uint8_t *labels_u8, int64_t N, int64_t *labels, et_stream_t stream);
+
+/* single-GPU fit of one batch element from given initial centroids (kmeans.py:228-240):
+ * centroids (d,K) in/out, labels int64 (N) out, *state_host receives the final state.
+ * Synchronises the stream (the reference syncs every iteration at kmeans.py:239). */
+int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_iter, float tol, float *centroids,
+                  int64_t *labels, float *trace, et_kmeans_state *state_host,
+                  void *workspace, size_t workspace_bytes, et_stream_t stream);
+
+/* kmeans.py:261-272 predict: labels int64 (N); maxsims (N) optional */
+int et_kmeans_predict(const float *X, int64_t N, int d, const float *centroids, int K, int64_t *labels,
+                      float *maxsims, et_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EIGENTRAJ_H */

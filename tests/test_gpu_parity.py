@@ -1,0 +1,505 @@
+"""HIP path (through the C ABI, via eigentrajectory_amd.ops) vs the CPU oracle and the golden
+vectors.  Needs a real MI355X: run with ``pytest -m gpu``."""
+import numpy as np
+import pytest
+import torch
+
+from . import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+FP = dict(rtol=2e-5, atol=2e-5)  # north-star tolerance for the floating-point path: 1e-5 on ADE/FDE
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from eigentrajectory_amd import ops as o
+    return o
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N_(t):
+    return t.detach().cpu().numpy()
+
+
+def eth_params():
+    g2 = G.load("g2_fit_all_scenes.npz")
+    return {k: g2[f"eth.{k}"] for k in
+            ["ET_m_descriptor.U_obs_trunc", "ET_m_descriptor.U_pred_trunc", "ET_s_descriptor.U_obs_trunc",
+             "ET_s_descriptor.U_pred_trunc", "ET_m_anchor.C_anchor", "ET_s_anchor.C_anchor"]}
+
+
+def synth(n, seed=0, min_disp=0.0):
+    from eigentrajectory_amd.synth import synthetic_trajectories_np
+    return synthetic_trajectories_np(n, seed=seed, min_disp=min_disp)
+
+
+# --------------------------------------------------------------------------------- TrajNorm
+@pytest.mark.parametrize("sca", [True, False])
+def test_trajnorm_vs_oracle_and_golden(ops, oracle, dev, sca):
+    from eigentrajectory_amd import TrajNorm
+    g1 = G.load("g1_trajnorm_eth_test.npz")
+    obs, pred, _ = G.dataset("eth", "test")
+    tn = TrajNorm(ori=True, rot=True, sca=sca)
+    tn.calculate_params(T(obs, dev))
+    t = "sca1" if sca else "sca0"
+    assert np.array_equal(N_(tn.traj_ori), g1[t + "_ori"])
+    np.testing.assert_allclose(N_(tn.traj_rot), g1[t + "_rot"], atol=5e-7)
+    fin = np.isfinite(g1[t + "_pred_norm"]).all(axis=(1, 2))
+    pn = tn.normalize(T(pred, dev))
+    np.testing.assert_allclose(N_(pn)[fin], g1[t + "_pred_norm"][fin], **FP)
+    np.testing.assert_allclose(N_(pn)[fin], oracle.normalize(obs, pred, sca)[fin], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(N_(tn.denormalize(pn))[fin], pred[fin], rtol=1e-5, atol=1e-5)
+    if sca:
+        assert np.array_equal(np.isfinite(N_(tn.traj_sca)), np.isfinite(g1[t + "_sca"]))
+    # flag subsets (normalizer.py:20-28 are independent switches)
+    tn2 = TrajNorm(ori=True, rot=False, sca=False)
+    tn2.calculate_params(T(obs, dev))
+    assert tn2.traj_rot is None and tn2.traj_sca is None
+    np.testing.assert_array_equal(N_(tn2.normalize(T(pred, dev))), pred - obs[:, -1:, :])
+
+
+# ------------------------------------------------------------------------------- projection
+@pytest.mark.parametrize("n", [0, 1, 255, 256, 257, 1000, 70001])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_project_fast_path_vs_oracle(ops, oracle, dev, n, mode):
+    p = eth_params()
+    obs, pred = synth(max(n, 1), seed=3, min_disp=1e-3 if mode == 1 else 0.0)
+    obs, pred = obs[:n], pred[:n]
+    us = [p["ET_m_descriptor.U_obs_trunc"], p["ET_m_descriptor.U_pred_trunc"], p["ET_s_descriptor.U_obs_trunc"],
+          p["ET_s_descriptor.U_pred_trunc"]]
+    c_obs, c_pred, nrm, flag = ops.norm_project(T(obs, dev), T(pred, dev), *(T(u, dev) for u in us), mode, 0.3)
+    assert c_obs.shape == (6, n) and c_pred.shape == (6, n) and nrm.shape == (4, n)
+    if n == 0:
+        return
+    r_obs, r_pred, r_nrm, r_flag = oracle.norm_project(obs, pred, *us, mode, 0.3)
+    assert np.array_equal(N_(flag), r_flag) and np.array_equal(N_(nrm), r_nrm)
+    np.testing.assert_allclose(N_(c_obs), r_obs, **FP)
+    np.testing.assert_allclose(N_(c_pred), r_pred, **FP)
+    # obs-only (inference) form
+    c_obs2, c_none, _, _ = ops.norm_project(T(obs, dev), None, T(us[0], dev), None, T(us[2], dev), None, mode, 0.3)
+    assert c_none is None and torch.equal(c_obs2, c_obs)
+
+
+@pytest.mark.parametrize("k,t_obs,t_pred", [(1, 8, 12), (4, 8, 12), (12, 8, 12), (3, 5, 7), (16, 8, 12), (6, 3, 1)])
+def test_project_reconstruct_generic_dims_vs_oracle(ops, oracle, dev, k, t_obs, t_pred):
+    from eigentrajectory_amd.synth import synthetic_trajectories_np
+    rng = np.random.default_rng(k * 100 + t_obs)
+    obs, pred = synthetic_trajectories_np(777, seed=5, obs_len=t_obs, pred_len=t_pred, min_disp=1e-3)
+    us = [rng.standard_normal((2 * t, k)).astype(np.float32) for t in (t_obs, t_pred, t_obs, t_pred)]
+    for mode in (0, 1, 2):
+        c_obs, c_pred, nrm, flag = ops.norm_project(T(obs, dev), T(pred, dev), *(T(u, dev) for u in us), mode, 0.3)
+        r_obs, r_pred, r_nrm, r_flag = oracle.norm_project(obs, pred, *us, mode, 0.3)
+        assert np.array_equal(N_(flag), r_flag)
+        np.testing.assert_allclose(N_(c_obs), r_obs, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(N_(c_pred), r_pred, rtol=1e-4, atol=1e-4)
+        s = 3
+        cr = rng.standard_normal((k, 777, s)).astype(np.float32)
+        a_m, a_s = rng.standard_normal((k, s)).astype(np.float32), rng.standard_normal((k, s)).astype(np.float32)
+        rec = ops.anchor_reconstruct(T(cr, dev), T(a_m, dev), T(a_s, dev), T(us[1], dev), T(us[3], dev), mode, 0.3,
+                                     obs=T(obs, dev))
+        ref = oracle.anchor_reconstruct(cr, obs, a_m, a_s, us[1], us[3], mode, 0.3)
+        np.testing.assert_allclose(N_(rec), ref, rtol=1e-4, atol=2e-4)
+        dt = rng.standard_normal(ref.shape).astype(np.float32)
+        from eigentrajectory_amd.ops import _reconstruct_bwd
+        dC = _reconstruct_bwd(T(dt, dev), T(obs, dev), None, T(us[1], dev), T(us[3], dev), mode, 0.3, t_obs)
+        np.testing.assert_allclose(N_(dC), oracle.anchor_reconstruct_bwd(dt, obs, us[1], us[3], mode, 0.3), rtol=1e-4,
+                                   atol=2e-4)
+
+
+def test_projection_golden_g4(ops, dev):
+    z = G.load("g45_project_reconstruct_eth_test.npz")
+    p = eth_params()
+    obs, pred, _ = G.dataset("eth", "test")
+    for tag, mode in (("m", 1), ("s", 0)):
+        rows = z[f"{tag}.rows"]
+        uo, up = p[f"ET_{tag}_descriptor.U_obs_trunc"], p[f"ET_{tag}_descriptor.U_pred_trunc"]
+        c_obs, c_pred, _, _ = ops.norm_project(T(obs[rows], dev), T(pred[rows], dev), T(uo, dev), T(up, dev), T(uo, dev),
+                                               T(up, dev), mode)
+        np.testing.assert_allclose(N_(c_obs), z[f"{tag}.C_obs"], **FP)
+        np.testing.assert_allclose(N_(c_pred), z[f"{tag}.C_pred"], **FP)
+
+
+# --------------------------------------------------------------------------- reconstruction
+@pytest.mark.parametrize("s", [1, 2, 20, 37, 256, 300])
+@pytest.mark.parametrize("n", [1, 13, 256, 1001])
+def test_reconstruct_fwd_bwd_vs_oracle(ops, oracle, dev, s, n):
+    p = eth_params()
+    rng = np.random.default_rng(s * 1000 + n)
+    obs, _ = synth(n, seed=9)
+    um, us_ = p["ET_m_descriptor.U_pred_trunc"], p["ET_s_descriptor.U_pred_trunc"]
+    a_m = rng.standard_normal((6, s)).astype(np.float32)
+    a_s = rng.standard_normal((6, s)).astype(np.float32)
+    c = rng.standard_normal((6, n, s)).astype(np.float32)
+    _, _, nrm, _ = ops.norm_project(T(obs, dev), None, T(p["ET_m_descriptor.U_obs_trunc"], dev), None,
+                                    T(p["ET_s_descriptor.U_obs_trunc"], dev), None, 2, 0.3)
+    ct = T(c, dev).requires_grad_(True)
+    rec = ops.anchor_reconstruct(ct, T(a_m, dev), T(a_s, dev), T(um, dev), T(us_, dev), 2, 0.3, nrm=nrm)
+    ref = oracle.anchor_reconstruct(c, obs, a_m, a_s, um, us_, 2, 0.3)
+    assert rec.shape == (s, n, 12, 2)
+    np.testing.assert_allclose(N_(rec), ref, rtol=2e-5, atol=5e-5)
+    rec_obs = ops.anchor_reconstruct(T(c, dev), T(a_m, dev), T(a_s, dev), T(um, dev), T(us_, dev), 2, 0.3, obs=T(obs, dev))
+    assert torch.equal(rec_obs, rec.detach())  # cached nrm and obs give the same normaliser state
+    dt = rng.standard_normal(ref.shape).astype(np.float32)
+    (rec * T(dt, dev)).sum().backward()
+    np.testing.assert_allclose(N_(ct.grad), oracle.anchor_reconstruct_bwd(dt, obs, um, us_, 2, 0.3), rtol=2e-5,
+                               atol=5e-5)
+
+
+def test_reconstruction_golden_g5(ops, dev):
+    z = G.load("g45_project_reconstruct_eth_test.npz")
+    p = eth_params()
+    obs, _, _ = G.dataset("eth", "test")
+    for tag, mode in (("m", 1), ("s", 0)):
+        rows = z[f"{tag}.rows"]
+        up, a = p[f"ET_{tag}_descriptor.U_pred_trunc"], p[f"ET_{tag}_anchor.C_anchor"]
+        ct = T(z[f"{tag}.C_refine"], dev).requires_grad_(True)
+        rec = ops.anchor_reconstruct(ct, T(a, dev), T(a, dev), T(up, dev), T(up, dev), mode, obs=T(obs[rows], dev))
+        np.testing.assert_allclose(N_(rec), z[f"{tag}.recon"], rtol=1e-5, atol=3e-5)
+        (rec * T(z[f"{tag}.dtraj"], dev)).sum().backward()
+        np.testing.assert_allclose(N_(ct.grad), z[f"{tag}.dC"], rtol=1e-5, atol=3e-5)
+
+
+# -------------------------------------------------------------------------------------- fit
+def test_fit_gram_and_eigh_vs_oracle_and_golden_g2(ops, oracle, dev):
+    g2 = G.load("g2_fit_all_scenes.npz")
+    obs, pred = G.eth_fit_input()
+    sd = G.static_dist("eth")
+    for which, tag in ((1, "m"), (0, "s")):
+        g_obs, g_pred, cnt = ops.fit_gram(T(obs, dev), T(pred, dev), 2, sd, which)
+        r_obs, r_pred, r_cnt = oracle.fit_gram(obs, pred, 2, sd, which)
+        assert int(cnt.item()) == r_cnt == int(g2[f"eth.n_{'moving' if which else 'static'}"])
+        # fp64 sums of exact products in another order: 1e-12 relative to the matrix scale
+        for g, r in ((g_obs, r_obs), (g_pred, r_pred)):
+            g = N_(g)
+            assert np.array_equal(g, g.T)
+            np.testing.assert_allclose(g, r, rtol=0, atol=1e-11 * np.abs(r).max())
+        for name, g, key in (("obs", g_obs, "U_obs_trunc"), ("pred", g_pred, "U_pred_trunc")):
+            U, sigma = ops.eigh_topk(g, 6)
+            Ur, sr = oracle.eigh_topk(N_(g), 6)  # same matrix in -> the Jacobi kernel must reproduce the oracle
+            np.testing.assert_allclose(N_(U), Ur, rtol=0, atol=1e-6)
+            np.testing.assert_allclose(N_(sigma), sr, rtol=1e-6)
+            U_ref = g2[f"eth.ET_{tag}_descriptor.{key}"]
+            np.testing.assert_allclose(G.sign_align(N_(U), U_ref), U_ref, atol=2e-5)
+            np.testing.assert_allclose(N_(sigma), g2[f"eth.sigma_{name}_{tag}"][:6], rtol=1e-5)
+
+
+def test_eigh_bit_exact_vs_oracle(ops, oracle, dev):
+    rng = np.random.default_rng(1)
+    exact = 0
+    for n in (1, 2, 5, 16, 24, 33, 64):
+        a = rng.standard_normal((n, n + 2))
+        g = a @ a.T
+        k = max(1, n // 2)
+        U, s = ops.eigh_topk(T(g, dev), k)
+        Ur, sr = oracle.eigh_topk(g, k)
+        np.testing.assert_allclose(N_(U), Ur, atol=1e-6)
+        np.testing.assert_allclose(N_(s), sr, rtol=1e-6)
+        exact += int(np.array_equal(N_(U), Ur) and np.array_equal(N_(s), sr))
+    assert exact == 7, f"Jacobi kernel bit-exact vs oracle on {exact}/7 matrices"
+
+
+def test_fit_generic_dims_and_truncated_svd(ops, oracle, dev):
+    from eigentrajectory_amd import ETDescriptor
+    from eigentrajectory_amd.synth import synthetic_trajectories_np
+    from eigentrajectory_amd.utils import default_hyper_params
+    obs, pred = synthetic_trajectories_np(3000, seed=2, obs_len=5, pred_len=7, min_disp=1e-3)
+    for which in (1, 0):
+        g_obs, g_pred, cnt = ops.fit_gram(T(obs, dev), T(pred, dev), 2, 0.3, which)
+        r_obs, r_pred, r_cnt = oracle.fit_gram(obs, pred, 2, 0.3, which)
+        assert int(cnt.item()) == r_cnt
+        np.testing.assert_allclose(N_(g_obs), r_obs, rtol=0, atol=1e-11 * np.abs(r_obs).max())
+        np.testing.assert_allclose(N_(g_pred), r_pred, rtol=0, atol=1e-11 * np.abs(r_pred).max())
+    # truncated_SVD API (descriptor.py:91-114) against torch's SVD
+    d = ETDescriptor(default_hyper_params(obs_len=5, pred_len=7, k=4))
+    xn = torch.from_numpy(oracle.normalize(obs, pred, True))
+    U, S, V = d.truncated_SVD(xn.to(dev))
+    Ur, Sr, Vtr = torch.linalg.svd(xn.reshape(-1, 14).T.double(), full_matrices=False)
+    np.testing.assert_allclose(N_(S), Sr[:4].numpy(), rtol=1e-5)
+    np.testing.assert_allclose(G.sign_align(N_(U), Ur[:, :4].numpy()), Ur[:, :4].numpy(), atol=2e-5)
+    M = xn.reshape(-1, 14).T.numpy()
+    np.testing.assert_allclose((N_(U) * N_(S)) @ N_(V).T, Ur[:, :4].numpy() * Sr[:4].numpy() @ Vtr[:4].numpy(), atol=2e-3)
+    assert M.shape == (14, 3000)
+
+
+# ---------------------------------------------------------------------------------- k-means
+def km_points(tag, z):
+    from eigentrajectory_amd.synth import gaussian_points_np
+    if tag == "ethm":
+        return z["ethm.x"]
+    n = int(tag.replace("gauss", "").replace("blobs", ""))
+    return gaussian_points_np(6, n, seed=11, n_blobs=int(z[f"{tag}.blobs"]))
+
+
+@pytest.mark.parametrize("tag", ["gauss1000", "gauss10000", "blobs10000", "gauss100000", "ethm"])
+def test_kmeans_bit_exact_vs_oracle_and_golden_g7(ops, oracle, dev, tag):
+    z = G.load("g7_batchkmeans.npz")
+    x = km_points(tag, z)
+    first = int(z[f"{tag}.first_index"])
+    c0 = ops.kmeans_init_farthest(T(x, dev), 20, first)
+    assert np.array_equal(N_(c0), z[f"{tag}.c0"])  # the reference's 20 farthest-first picks, bit for bit
+    res = ops.kmeans_fit(T(x, dev), c0, 100, 1e-4)
+    ref = oracle.kmeans_fit(x, z[f"{tag}.c0"], 100, 1e-4)
+    assert res["n_iter"] == ref["n_iter"]
+    assert np.array_equal(N_(res["labels"]), ref["labels"])            # bit-exact assignments
+    assert np.array_equal(N_(res["centroids"]), ref["centroids"])      # bit-exact centroids
+    assert np.array_equal(N_(res["trace"]), ref["trace"])
+    if tag != "gauss10000":  # whole-run equality with the reference is ill-conditioned there (see G7 notes)
+        assert np.array_equal(N_(res["labels"]), z[f"{tag}.labels"].astype(np.int64))
+        assert res["n_iter"] == len(z[f"{tag}.trace"])
+    # step-wise parity with the reference from ITS centroids (teacher forcing), first/last iterations
+    hist = z[f"{tag}.history"]
+    for i in (0, 1, len(hist) - 2):
+        lb, _ = ops.kmeans_predict(T(x, dev), T(hist[i], dev))
+        rl, _ = oracle.kmeans_assign(x, hist[i])
+        assert np.array_equal(N_(lb), rl)
+    assert np.array_equal(N_(lb), z[f"{tag}.labels"].astype(np.int64))
+
+
+@pytest.mark.parametrize("n,d,K", [(1, 6, 1), (37, 6, 20), (1001, 6, 20), (4099, 3, 7), (5000, 2, 255), (2048, 16, 33),
+                                   (999, 32, 5)])
+def test_kmeans_shapes_vs_oracle(ops, oracle, dev, n, d, K):
+    from eigentrajectory_amd.synth import gaussian_points_np
+    K = min(K, n)
+    x = gaussian_points_np(d, n, seed=n + d, n_blobs=5)
+    c0 = ops.kmeans_init_farthest(T(x, dev), K, n // 2)
+    r0, idx = oracle.kmeans_init_farthest(x, K, n // 2)
+    assert np.array_equal(N_(c0), r0)
+    res = ops.kmeans_fit(T(x, dev), c0, 30, 1e-4)
+    ref = oracle.kmeans_fit(x, r0, 30, 1e-4)
+    assert res["n_iter"] == ref["n_iter"]
+    assert np.array_equal(N_(res["labels"]), ref["labels"])
+    assert np.array_equal(N_(res["centroids"]), ref["centroids"], equal_nan=True)
+    np.testing.assert_array_equal(N_(res["trace"]), ref["trace"])
+    lb, ms = ops.kmeans_predict(T(x, dev), res["centroids"])
+    rl, rm = oracle.kmeans_assign(x, ref["centroids"])
+    assert np.array_equal(N_(lb), rl) and np.array_equal(N_(ms), rm, equal_nan=True)
+    np.testing.assert_array_equal(N_(ops.euc_sim(T(x[:, :50], dev), res["centroids"])),
+                                  oracle.euc_sim(x[:, :50], ref["centroids"]))
+
+
+def test_kmeans_duplicates_nan_propagation_g7(ops, oracle, dev):
+    from eigentrajectory_amd import BatchKMeans
+    z = G.load("g7_batchkmeans.npz")
+    x = z["dup.x"]
+    c0 = z["dup.c0"]
+    lb0, _ = ops.kmeans_predict(T(x, dev), T(c0, dev))
+    assert np.array_equal(N_(lb0), z["dup.labels_iter0"])
+    res = ops.kmeans_fit(T(x, dev), T(c0, dev), 5, 1e-4)
+    ref = oracle.kmeans_fit(x, c0, 5, 1e-4)
+    assert res["n_iter"] == 5 and np.isnan(res["inertia"]) and np.isnan(res["error"])
+    assert np.array_equal(N_(res["centroids"]), ref["centroids"], equal_nan=True)
+    assert np.array_equal(N_(res["labels"]), ref["labels"])
+    km = BatchKMeans(n_clusters=20, max_iter=5)
+    assert km.fit(T(x, dev)[None].contiguous(), T(c0, dev)[None]) is None  # like the reference (NaN inertia never wins)
+    with pytest.raises(Exception):
+        ops.kmeans_fit(T(np.full((6, 40), np.nan, np.float32), dev), T(c0, dev), 5, 1e-4)
+
+
+def test_kmeans_sharded_steps_partition_independent(ops, oracle, dev):
+    """The step API a multi-GPU run uses: shards of any size sum to the single-shard partials, bit for bit."""
+    from eigentrajectory_amd.synth import gaussian_points_np
+    x = gaussian_points_np(6, 10007, seed=4, n_blobs=9)
+    c0, _ = oracle.kmeans_init_farthest(x, 20, 5)
+    cuts = [0, 1, 4000, 4004, 10007]
+    shards = [ops.KMeansShard(T(np.ascontiguousarray(x[:, a:b]), dev), 20) for a, b in zip(cuts[:-1], cuts[1:])]
+    whole = ops.KMeansShard(T(x, dev), 20)
+    for sh in shards + [whole]:
+        sh.scan()
+    mx = max(float(sh.state_f64[0].item()) for sh in shards)
+    assert mx == float(whole.state_f64[0].item()) == float(np.abs(x).max())
+    cen = [T(c0, dev).clone() for _ in shards]
+    cw = T(c0, dev).clone()
+    for sh, c in zip(shards, cen):
+        sh.state_f64[0] = mx  # what an all-reduce(MAX) leaves on every rank
+        sh.begin(10007, c)
+    whole.begin(10007, cw)
+    for it in range(6):
+        total = sum(sh.assign(c).clone() for sh, c in zip(shards, cen))  # the all-reduce(SUM)
+        pw = whole.assign(cw)
+        assert torch.equal(total, pw)
+        for sh, c in zip(shards, cen):
+            sh.update(total, c, 1e-4)
+        whole.update(pw, cw, 1e-4)
+        assert all(torch.equal(c, cw) for c in cen)
+    ref = oracle.kmeans_fit(x, c0, 6, 1e-4)
+    assert np.array_equal(N_(cw), ref["centroids"])
+    assert np.array_equal(np.concatenate([N_(sh.labels()) for sh in shards]), ref["labels"])
+
+
+# ---------------------------------------------------------------------------------- wrapper
+def stub_hooks():
+    from eigentrajectory_amd.utils import DotDict
+    return DotDict(
+        model_forward_pre_hook=lambda obs_data, obs_ori, addl_info=None: torch.cat([obs_data, obs_ori], dim=0),
+        model_forward=lambda input_data, baseline_model: baseline_model(input_data),
+        model_forward_post_hook=lambda output_data, addl_info=None: output_data)
+
+
+class ZeroStub(torch.nn.Module):
+    def forward(self, x):
+        return torch.zeros(6, x.size(1), 20, device=x.device)
+
+
+class LinearStub(torch.nn.Module):
+    def __init__(self, w):
+        super().__init__()
+        self.w = torch.nn.Parameter(w)
+
+    def forward(self, x):
+        return torch.einsum("skj,jn->kns", self.w, x)
+
+
+@pytest.mark.parametrize("scene", G.SCENES)
+@pytest.mark.parametrize("stub", ["zero", "linear"])
+def test_wrapper_ade_fde_parity_g6(dev, scene, stub):
+    """Same weights + same inputs => same ADE/FDE as the reference on all five ETH/UCY test splits (1e-5)."""
+    from eigentrajectory_amd import EigenTrajectory
+    from eigentrajectory_amd.utils import compute_batch_ade, compute_batch_fde, default_hyper_params
+    g2 = G.load("g2_fit_all_scenes.npz")
+    g6 = G.load("g6_wrapper_stub_predictors.npz")
+    hp = default_hyper_params(static_dist=G.static_dist(scene))
+    base = ZeroStub() if stub == "zero" else LinearStub(torch.from_numpy(g6["linear_stub_w"]))
+    model = EigenTrajectory(base, stub_hooks(), hp)
+    sd = {k[len(scene) + 1:]: torch.from_numpy(g2[k]) for k in g2.files
+          if k.startswith(scene + ".ET_")}
+    for k, v in base.state_dict().items():
+        sd["baseline_model." + k] = v
+    model.load_state_dict(sd)  # the reference's state_dict keys load unchanged
+    model = model.to(dev).eval()
+    obs, pred, sse = G.dataset(scene, "test")
+    obs_t, pred_t = T(obs, dev), T(pred, dev)
+    ades, fdes, losses = [], [], []
+    with torch.no_grad():
+        for s, e in sse:
+            out = model(obs_t[s:e], pred_t[s:e])
+            ades.append(compute_batch_ade(out["recon_traj"], pred_t[s:e]))
+            fdes.append(compute_batch_fde(out["recon_traj"], pred_t[s:e]))
+            losses.append(torch.stack([out["loss_eigentraj"], out["loss_euclidean_ade"], out["loss_euclidean_fde"]]))
+    ades, fdes = N_(torch.cat(ades)), N_(torch.cat(fdes))
+    np.testing.assert_allclose(ades, g6[f"{scene}.{stub}.ade"], atol=1e-5)
+    np.testing.assert_allclose(fdes, g6[f"{scene}.{stub}.fde"], atol=1e-5)
+    assert abs(ades.mean() - g6[f"{scene}.{stub}.ade"].mean()) < 1e-5
+    assert abs(fdes.mean() - g6[f"{scene}.{stub}.fde"].mean()) < 1e-5
+    np.testing.assert_allclose(N_(torch.stack(losses)), g6[f"{scene}.{stub}.losses"], rtol=1e-5, atol=1e-5)
+    if scene == "eth":
+        np.testing.assert_allclose(N_(out["recon_traj"]), g6[f"eth.{stub}.recon_last"], rtol=1e-5, atol=3e-5)
+
+
+def test_wrapper_training_step_gradients(dev):
+    """Gradients reach the predictor through reconstruction + anchor add (trainer.py:132-152 sums the losses)."""
+    from eigentrajectory_amd import EigenTrajectory
+    from eigentrajectory_amd.utils import default_hyper_params
+    from oracle import wrapper_ref as W
+    g2 = G.load("g2_fit_all_scenes.npz")
+    g6 = G.load("g6_wrapper_stub_predictors.npz")
+    base = LinearStub(torch.from_numpy(g6["linear_stub_w"]).clone())
+    model = EigenTrajectory(base, stub_hooks(), default_hyper_params(static_dist=G.static_dist("eth")))
+    sd = {k[4:]: torch.from_numpy(g2[k]) for k in g2.files if k.startswith("eth.ET_")}
+    sd["baseline_model.w"] = base.w.data
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    obs, pred, sse = G.dataset("eth", "test")
+    s, e = sse[-1]
+    out = model(T(obs[s:e], dev), T(pred[s:e], dev))
+    loss = out["loss_eigentraj"] + out["loss_euclidean_ade"] + out["loss_euclidean_fde"]
+    loss.backward()
+    g = N_(model.baseline_model.w.grad)
+    assert np.isfinite(g).all() and np.abs(g).max() > 0
+    for name in ("ET_m_descriptor.U_pred_trunc", "ET_m_anchor.C_anchor"):
+        assert dict(model.named_parameters())[name].grad is None  # detached like the reference
+    # finite-difference check of one weight through the oracle restatement of the wrapper
+    p = {k[4:]: g2[k] for k in g2.files if k.startswith("eth.ET_")}
+    w0 = g6["linear_stub_w"].copy()
+
+    def total(w):
+        o = W.forward(p, obs[s:e], pred[s:e], W.linear_stub(w), G.static_dist("eth"))
+        return float(o["loss_eigentraj"]) + float(o["loss_euclidean_ade"]) + float(o["loss_euclidean_fde"])
+    idx = np.unravel_index(np.abs(g).argmax(), g.shape)
+    eps = 1e-2
+    wp, wm = w0.copy(), w0.copy()
+    wp[idx] += eps
+    wm[idx] -= eps
+    fd = (total(wp) - total(wm)) / (2 * eps)
+    assert abs(fd - g[idx]) < 5e-2 * max(1.0, abs(fd))
+
+
+def test_wrapper_fit_calculate_parameters_eth(dev, oracle):
+    """calculate_parameters (model.py:34-56): U matches the reference's SVD (sign-aligned), anchors are as good."""
+    from eigentrajectory_amd import EigenTrajectory
+    from eigentrajectory_amd.utils import default_hyper_params
+    g2 = G.load("g2_fit_all_scenes.npz")
+    obs, pred = G.eth_fit_input()
+    model = EigenTrajectory(ZeroStub(), stub_hooks(), default_hyper_params(static_dist=G.static_dist("eth"))).to(dev)
+    model.calculate_parameters(T(obs, dev), T(pred, dev))
+    sd = model.state_dict()
+    for key in ("ET_m_descriptor.U_obs_trunc", "ET_m_descriptor.U_pred_trunc", "ET_s_descriptor.U_obs_trunc",
+                "ET_s_descriptor.U_pred_trunc"):
+        U, U_ref = N_(sd[key]), g2["eth." + key]
+        assert U.shape == U_ref.shape
+        np.testing.assert_allclose(G.sign_align(U, U_ref), U_ref, atol=2e-5)
+    # anchors: inertia of our anchors on the moving coefficients vs the reference's sklearn anchors
+    flag = oracle.moving_flags(obs, G.static_dist("eth"))
+    for tag, sel, mode in (("m", flag, 1), ("s", ~flag, 0)):
+        A, A_ref = N_(sd[f"ET_{tag}_anchor.C_anchor"]), g2[f"eth.ET_{tag}_anchor.C_anchor"]
+        assert A.shape == A_ref.shape == (6, 20) and np.isfinite(A).all()
+        Up = N_(sd[f"ET_{tag}_descriptor.U_pred_trunc"])
+        _, c_pred, _, _ = oracle.norm_project(obs[sel], pred[sel], Up, Up, Up, Up, mode)
+        ours = -oracle.kmeans_assign(c_pred, A)[1].mean()
+        Ur = g2[f"eth.ET_{tag}_descriptor.U_pred_trunc"]
+        _, c_ref, _, _ = oracle.norm_project(obs[sel], pred[sel], Ur, Ur, Ur, Ur, mode)
+        theirs = -oracle.kmeans_assign(c_ref, A_ref)[1].mean()
+        assert ours < 1.15 * theirs, f"anchor inertia {ours:.4f} vs sklearn n_init=10 {theirs:.4f}"
+
+
+# -------------------------------------------------------------- full-size properties (N = 1e6)
+def test_full_size_properties(ops, dev):
+    """Size-independent checks at BASELINE.json's N=1e6: P(R(P(x))) = P(x); sharding is additive; Lloyd never
+    increases the inertia; labels are the arg-max of the similarity."""
+    from eigentrajectory_amd.synth import synthetic_trajectories_torch
+    n = 1_000_000
+    obs, pred = synthetic_trajectories_torch(n, dev, seed=0)
+    sd = 0.3
+    us = {}
+    for which in (1, 0):
+        g_obs, g_pred, cnt = ops.fit_gram(obs, pred, ops.MODE_SPLIT, sd, which)
+        us[which] = (ops.eigh_topk(g_obs, 6)[0], ops.eigh_topk(g_pred, 6)[0])
+        # additivity of the Gram over two shards (what the RCCL all-reduce relies on)
+        h = n // 3
+        ga, _, ca = ops.fit_gram(obs[:h], pred[:h], ops.MODE_SPLIT, sd, which)
+        gb, _, cb = ops.fit_gram(obs[h:], pred[h:], ops.MODE_SPLIT, sd, which)
+        assert int(ca.item() + cb.item()) == int(cnt.item())
+        assert torch.allclose(ga + gb, g_obs, rtol=0, atol=1e-11 * float(g_obs.abs().max()))
+        uu = us[which][1].double()
+        assert torch.allclose(uu.T @ uu, torch.eye(6, device=dev, dtype=torch.float64), atol=1e-6)
+    c_obs, c_pred, nrm, flag = ops.norm_project(obs, pred, us[1][0], us[1][1], us[0][0], us[0][1], ops.MODE_SPLIT, sd)
+    assert torch.isfinite(c_pred).all()
+    rec = ops.anchor_reconstruct(c_pred.unsqueeze(-1).contiguous(), None, None, us[1][1], us[0][1], ops.MODE_SPLIT, sd,
+                                 nrm=nrm)[0]
+    _, c_again, _, _ = ops.norm_project(obs, rec.contiguous(), us[1][0], us[1][1], us[0][0], us[0][1], ops.MODE_SPLIT, sd)
+    scale = float(c_pred.abs().max())
+    assert float((c_again - c_pred).abs().max()) < 2e-5 * scale  # projector idempotence: U^T U = I
+    err = (rec - pred).norm(dim=-1).mean()
+    assert float(err) < 0.2  # k=6 keeps the low-rank reconstruction error small (metres)
+    x = c_pred.contiguous()
+    c0 = ops.kmeans_init_farthest(x, 20, 12345)
+    res = ops.kmeans_fit(x, c0, 25, 1e-4)
+    tr = res["trace"].cpu().numpy()
+    assert (np.diff(tr[:, 1]) <= 1e-6 * tr[0, 1]).all(), "Lloyd iterations must not increase the inertia"
+    counts = torch.bincount(res["labels"], minlength=20)
+    assert int(counts.sum()) == n and int(counts.min()) > 0
+    # the returned labels are the assignment against the centroids of the previous iteration; one more
+    # fit iteration from the final centroids must reproduce predict()
+    lb, ms = ops.kmeans_predict(x, res["centroids"])
+    res2 = ops.kmeans_fit(x, res["centroids"], 1, 1e-4)
+    assert torch.equal(res2["labels"], lb)
+    assert abs(res2["inertia"] - float((-ms.double()).mean())) < 1e-5 * abs(res2["inertia"])

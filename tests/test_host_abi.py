@@ -1,0 +1,139 @@
+"""CPU-side checks: the C-ABI library loads and exports everything include/eigentraj.h declares,
+the host mirror of the reference interface has the reference's names/shapes, and the product
+path fails loudly without a HIP device (no CPU fallback).  No kernels are launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from . import _golden as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+needs_no_gpu = pytest.mark.skipif(torch.cuda.is_available(), reason="asserts the behaviour on a box without a GPU")
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "eigentraj.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(et_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from eigentrajectory_amd import _lib
+    lib = _lib.lib()
+    declared = header_functions()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"libetamd.so does not export {name}"
+    assert sorted(_lib.SYMBOLS) == declared
+    assert lib.et_abi_version() == 1
+    assert lib.et_compiled_arch() == b"gfx950"
+    assert lib.et_status_string(0) == b"ok" and b"workspace" in lib.et_status_string(4)
+
+
+def test_state_struct_layout_matches_header():
+    from eigentrajectory_amd import _lib
+    assert _lib.STATE_BYTES == 80
+    offs = {n: getattr(_lib.KMeansState, n).offset for n, _ in _lib.KMeansState._fields_}
+    assert offs == dict(max_abs_x=0, max_abs_c=8, n_total=16, frac=24, sim_frac=32, iter=40, done=48, bad_input=56,
+                        error=64, inertia=72)
+    lib = _lib.lib()
+    assert lib.et_kmeans_partials_len(6, 20) == 6 * 20 + 20 + 2
+    assert lib.et_kmeans_workspace_bytes(ctypes.c_int64(1000), 6, 20) > 1000 * 5
+    assert lib.et_kmeans_workspace_bytes(ctypes.c_int64(1000), 33, 20) == 0  # d out of range
+    assert lib.et_fit_gram_workspace_bytes(ctypes.c_int64(10 ** 7), 8, 12) >= 512 * (256 + 576 + 1) * 8
+
+
+def test_argument_validation_without_device_work():
+    """Invalid arguments are rejected on the host side before any launch."""
+    from eigentrajectory_amd import _lib
+    lib = _lib.lib()
+    null = ctypes.c_void_p(0)
+    z = ctypes.c_int64(0)
+    assert lib.et_norm_project(null, null, ctypes.c_int64(-1), 8, 12, 6, null, null, null, null, 2,
+                               ctypes.c_float(0), null, null, null, null, null) == 1
+    assert lib.et_norm_project(null, null, z, 8, 12, 6, null, null, null, null, 2, ctypes.c_float(0), null, null, null,
+                               null, null) == 0  # N == 0 is a valid no-op
+    assert lib.et_norm_project(null, null, z, 2, 12, 6, null, null, null, null, 2, ctypes.c_float(0), null, null, null,
+                               null, null) == 1  # T_obs < 3: obs[-3] does not exist
+    assert lib.et_anchor_reconstruct_fwd(null, z, 0, 6, 8, 12, null, null, null, null, null, null, 2,
+                                         ctypes.c_float(0), null, null) == 1
+    assert lib.et_eigh_topk(null, 16, 6, null, null, null) == 1
+    assert lib.et_kmeans_predict(null, z, 6, null, 20, null, null, null) == 1
+
+
+@needs_no_gpu
+def test_product_path_fails_loudly_without_gpu():
+    from eigentrajectory_amd import TrajNorm, ops
+    from eigentrajectory_amd._lib import ETLibraryError
+    with pytest.raises(ETLibraryError):
+        TrajNorm().calculate_params(torch.zeros(4, 8, 2))
+    with pytest.raises(ETLibraryError):
+        ops.kmeans_predict(torch.zeros(6, 10), torch.zeros(6, 20))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "eigentrajectory_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "et_oracle" not in text.replace(
+                    "oracle/et_oracle.c", ""), f
+
+
+def test_wrapper_has_the_reference_interface():
+    """Sub-module names, state_dict keys and shapes of EigenTrajectory/model.py:16-32."""
+    from eigentrajectory_amd import BatchKMeans, EigenTrajectory, ETAnchor, ETDescriptor, TrajNorm
+    from eigentrajectory_amd.utils import DotDict, default_hyper_params
+    hp = default_hyper_params()
+    assert isinstance(hp, DotDict) and hp.k == 6 and hp.missing is None
+    base = torch.nn.Linear(3, 3)
+    hooks = DotDict(model_forward_pre_hook=None, model_forward=None, model_forward_post_hook=None)
+    m = EigenTrajectory(base, hooks, hp)
+    sd = m.state_dict()
+    expect = {"ET_m_descriptor.U_obs_trunc": (16, 6), "ET_m_descriptor.U_pred_trunc": (24, 6),
+              "ET_s_descriptor.U_obs_trunc": (16, 6), "ET_s_descriptor.U_pred_trunc": (24, 6),
+              "ET_m_anchor.C_anchor": (6, 20), "ET_s_anchor.C_anchor": (6, 20),
+              "baseline_model.weight": (3, 3), "baseline_model.bias": (3,)}
+    assert {k: tuple(v.shape) for k, v in sd.items()} == expect
+    g2 = G.load("g2_fit_all_scenes.npz")
+    ref_sd = {k[4:]: torch.from_numpy(g2[k]) for k in g2.files if k.startswith("eth.ET_")}
+    ref_sd.update({"baseline_model.weight": base.weight.data, "baseline_model.bias": base.bias.data})
+    m.load_state_dict(ref_sd)  # a reference checkpoint loads unchanged
+    assert torch.equal(m.ET_s_anchor.C_anchor.data, ref_sd["ET_s_anchor.C_anchor"])
+    assert m.ET_m_descriptor.traj_normalizer.sca is True and m.ET_s_descriptor.traj_normalizer.sca is False
+    for cls, names in ((TrajNorm, ["calculate_params", "get_params", "set_params", "normalize", "denormalize"]),
+                       (ETDescriptor, ["normalize_trajectory", "denormalize_trajectory", "to_ET_space",
+                                       "to_Euclidean_space", "truncated_SVD", "parameter_initialization", "projection",
+                                       "reconstruction", "forward"]),
+                       (ETAnchor, ["to_ET_space", "to_Euclidean_space", "anchor_generation", "forward"]),
+                       (BatchKMeans, ["calculate_error", "calculate_inertia", "euc_sim", "kmeanspp",
+                                      "initialize_centroids", "get_labels", "compute_centroids", "fit", "predict",
+                                      "load_state_dict"])):
+        for n in names:
+            assert callable(getattr(cls, n)), f"{cls.__name__}.{n}"
+    km = BatchKMeans(n_clusters=20)
+    assert km.centroids is None and km.max_iter == 100 and km.tol == 1e-4 and km.init_mode == "kmeans++"
+    km.load_state_dict({"centroids": torch.zeros(1, 6, 20)})
+    assert km.centroids.shape == (1, 6, 20)
+    a = ETAnchor(hp)
+    c = torch.randn(6, 5, 20)
+    assert torch.equal(a(c), c)  # zero anchors: identity (anchor.py:87)
+
+
+def test_augment_and_metrics_helpers():
+    from eigentrajectory_amd.utils import augment_trajectory, compute_batch_ade, compute_batch_fde
+    z = G.load("g9_metrics.npz")
+    np.testing.assert_allclose(compute_batch_ade(torch.from_numpy(z["pred"]), torch.from_numpy(z["gt"])).numpy(),
+                               z["ade"], rtol=1e-6)
+    np.testing.assert_allclose(compute_batch_fde(torch.from_numpy(z["pred"]), torch.from_numpy(z["gt"])).numpy(),
+                               z["fde"], rtol=1e-6)
+    o, p, _ = G.dataset("eth", "val")
+    ao, ap = augment_trajectory(torch.from_numpy(o), torch.from_numpy(p))
+    fo, fp = G.eth_fit_input()
+    assert ao.shape[0] == 2 * o.shape[0] and np.array_equal(ao[len(o):, :, 1].numpy(), -o[:, :, 1])
+    assert fo.shape == (70316, 8, 2) and fp.shape == (70316, 12, 2)
