@@ -74,7 +74,7 @@ class EigenTrajectory(nn.Module):
             desc.U_pred_trunc = nn.Parameter(U_pred.to(desc.U_pred_trunc.device))
 
         # Anchor generation (model.py:55-56) on the coefficients of each descriptor's own rows
-        _, _, U_pred_m, U_pred_s = self._U()
+        _, U_pred_m, _, U_pred_s = self._U()
         _, C_pred, _, flag = ops.norm_project(obs_traj, pred_traj, None, U_pred_m, None, U_pred_s, ops.MODE_SPLIT, sd,
                                               want_nrm=False, want_obs=False)
         moving = flag.bool()

@@ -96,7 +96,7 @@ def norm_project(obs, pred, U_obs_m, U_pred_m, U_obs_s, U_pred_s, mode, static_d
     t_pred = pred.shape[1] if pred is not None else (U_pred_m if U_pred_m is not None else U_pred_s).shape[0] // 2
     us = [None if u is None else _f32(u) for u in (U_obs_m, U_pred_m, U_obs_s, U_pred_s)]
     k = next(u for u in us if u is not None).shape[1]
-    c_obs = np.empty((k, n), np.float32)
+    c_obs = np.empty((k, n), np.float32) if (us[0] is not None or us[2] is not None) else None
     c_pred = np.empty((k, n), np.float32) if pred is not None else None
     nrm = np.empty((4, n), np.float32)
     flag = np.empty((n,), np.uint8)
