@@ -38,6 +38,11 @@ class KMeansState(C.Structure):
                 ("error", C.c_double), ("inertia", C.c_double)]
 
 
+class KMeansTiming(C.Structure):
+    """Mirror of ``et_kmeans_timing``."""
+    _fields_ = [("assign_ms", C.c_double), ("assign_launches", C.c_int64)]
+
+
 STATE_BYTES = C.sizeof(KMeansState)
 _lib = None
 

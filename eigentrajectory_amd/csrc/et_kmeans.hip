@@ -15,6 +15,8 @@
 // fixed-point integer (truncation, power-of-two scale => exact) and integers are summed, so the
 // result is independent of the order: the same bits for any workgroup schedule, grid size or
 // number of GPUs, and identical to the CPU oracle (oracle/et_oracle.c).
+#include <vector>
+
 #include "et_common.h"
 
 namespace et {
@@ -514,25 +516,34 @@ extern "C" int et_kmeans_begin(et_kmeans_state *state, int64_t n_total, const fl
     return ET_OK;
 }
 
-extern "C" int et_kmeans_assign_accumulate(const float *X, int64_t N, int d, int K, const et_kmeans_state *state,
-                                           const float *centroids, const int64_t *given_labels, uint8_t *labels_u8,
-                                           int64_t *partials, void *workspace, size_t workspace_bytes,
-                                           et_stream_t stream) {
+static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, const et_kmeans_state *state,
+                                  const float *centroids, const int64_t *given_labels, uint8_t *labels_u8,
+                                  int64_t *partials, void *workspace, size_t workspace_bytes, hipStream_t st,
+                                  hipEvent_t ev_begin, hipEvent_t ev_end) {
     if (!km_dims_ok(d, K) || N < 0 || !state || !centroids || !partials || (N > 0 && (!X || !labels_u8)))
         return ET_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < et_kmeans_workspace_bytes(N, d, K)) return ET_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
     const KmWorkspace w = km_carve(workspace, N, d, K);
     const bool vec4 = (N % 4 == 0) && aligned16(X) && ((reinterpret_cast<uintptr_t>(labels_u8) & 3u) == 0);
     const int grid = N > 0 ? km_grid(vec4 ? N / 4 : N) : 1;
+    if (ev_begin) ET_HIP_TRY(hipEventRecord(ev_begin, st));
     if (d == 6) launch_assign<6>(X, N, d, K, state, centroids, given_labels, labels_u8, w.block_partials, grid, vec4, st);
     else launch_assign<0>(X, N, d, K, state, centroids, given_labels, labels_u8, w.block_partials, grid, vec4, st);
     ET_LAUNCH_CHECK();
+    if (ev_end) ET_HIP_TRY(hipEventRecord(ev_end, st));
     const int plen = (int)km_plen(d, K);
     hipLaunchKernelGGL(kmeans_reduce_partials_kernel, dim3((unsigned)ceil_div((int64_t)plen * 4, kKmThreads)),
                        dim3(kKmThreads), 0, st, w.block_partials, grid, plen, state, (long long *)partials);
     ET_LAUNCH_CHECK();
     return ET_OK;
+}
+
+extern "C" int et_kmeans_assign_accumulate(const float *X, int64_t N, int d, int K, const et_kmeans_state *state,
+                                           const float *centroids, const int64_t *given_labels, uint8_t *labels_u8,
+                                           int64_t *partials, void *workspace, size_t workspace_bytes,
+                                           et_stream_t stream) {
+    return assign_accumulate_impl(X, N, d, K, state, centroids, given_labels, labels_u8, partials, workspace,
+                                  workspace_bytes, (hipStream_t)stream, nullptr, nullptr);
 }
 
 extern "C" int et_kmeans_update(et_kmeans_state *state, const int64_t *partials, int d, int K, float tol,
@@ -630,13 +641,22 @@ extern "C" int et_kmeans_init_farthest(const float *X, int64_t N, int d, int K, 
 }
 
 extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_iter, float tol, float *centroids,
-                             int64_t *labels, float *trace, et_kmeans_state *state_host, void *workspace,
-                             size_t workspace_bytes, et_stream_t stream) {
+                             int64_t *labels, float *trace, et_kmeans_state *state_host,
+                             et_kmeans_timing *timing_host, void *workspace, size_t workspace_bytes,
+                             et_stream_t stream) {
     if (!km_dims_ok(d, K) || N < 1 || !X || !centroids || !labels || !state_host || max_iter < 1)
         return ET_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < et_kmeans_workspace_bytes(N, d, K)) return ET_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const KmWorkspace w = km_carve(workspace, N, d, K);
+    static std::vector<hipEvent_t> events;  // reused across calls; only touched when timing is requested
+    if (timing_host) {
+        while ((int)events.size() < 2 * max_iter) {
+            hipEvent_t e;
+            ET_HIP_TRY(hipEventCreate(&e));
+            events.push_back(e);
+        }
+    }
     int rc = et_kmeans_scan(X, N, d, w.state, stream);
     if (!rc) rc = et_kmeans_begin(w.state, N, centroids, d, K, stream);
     if (rc) return rc;
@@ -644,11 +664,14 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     // Here convergence lives on the device: once state->done is set the remaining launches are
     // no-ops, and the host only looks at the flag every few iterations.
     const int check_every = 8;
+    int launched = 0;
     for (int it = 0; it < max_iter; ++it) {
-        rc = et_kmeans_assign_accumulate(X, N, d, K, w.state, centroids, nullptr, w.labels_u8, (int64_t *)w.partials,
-                                         workspace, workspace_bytes, stream);
+        rc = assign_accumulate_impl(X, N, d, K, w.state, centroids, nullptr, w.labels_u8, (int64_t *)w.partials,
+                                    workspace, workspace_bytes, st, timing_host ? events[2 * it] : nullptr,
+                                    timing_host ? events[2 * it + 1] : nullptr);
         if (!rc) rc = et_kmeans_update(w.state, (const int64_t *)w.partials, d, K, tol, centroids, trace, stream);
         if (rc) return rc;
+        launched = it + 1;
         if ((it + 1) % check_every == 0 || it + 1 == max_iter) {
             ET_HIP_TRY(hipMemcpyAsync(state_host, w.state, sizeof(et_kmeans_state), hipMemcpyDeviceToHost, st));
             ET_HIP_TRY(hipStreamSynchronize(st));
@@ -659,5 +682,17 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     if (rc) return rc;
     ET_HIP_TRY(hipMemcpyAsync(state_host, w.state, sizeof(et_kmeans_state), hipMemcpyDeviceToHost, st));
     ET_HIP_TRY(hipStreamSynchronize(st));
+    if (timing_host) {
+        // launches after convergence are no-ops (a few microseconds); count only the working ones
+        const int worked = (int)(state_host->iter < launched ? state_host->iter : launched);
+        double total = 0.0;
+        for (int it = 0; it < worked; ++it) {
+            float ms = 0.f;
+            ET_HIP_TRY(hipEventElapsedTime(&ms, events[2 * it], events[2 * it + 1]));
+            total += (double)ms;
+        }
+        timing_host->assign_ms = total;
+        timing_host->assign_launches = worked;
+    }
     return state_host->bad_input ? ET_ERR_BAD_DATA : ET_OK;
 }

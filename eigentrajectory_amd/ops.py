@@ -208,7 +208,7 @@ def kmeans_init_farthest(X, K, first_index, workspace=None):
     return c0
 
 
-def kmeans_fit(X, centroids, max_iter=100, tol=1e-4, workspace=None):
+def kmeans_fit(X, centroids, max_iter=100, tol=1e-4, workspace=None, timing=False):
     """kmeans.py:228-240 for one batch element from given initial centroids.
 
     Returns dict(centroids (d,K), labels (N,) int64, n_iter, error, inertia, trace (n_iter,2), done).
@@ -222,11 +222,15 @@ def kmeans_fit(X, centroids, max_iter=100, tol=1e-4, workspace=None):
     labels = torch.empty((n,), device=dev, dtype=torch.int64)
     trace = torch.zeros((max_iter, 2), device=dev)
     st = L.KMeansState()
+    tm = L.KMeansTiming() if timing else None
     L.check(L.lib().et_kmeans_fit(L.ptr(X), L.i64(n), d, K, int(max_iter), L.f32(tol), L.ptr(cen), L.ptr(labels),
-                                  L.ptr(trace), C.byref(st), L.ptr(ws), C.c_size_t(ws.numel()), L.stream(dev)),
-            "et_kmeans_fit")
-    return dict(centroids=cen, labels=labels, n_iter=int(st.iter), error=float(st.error), inertia=float(st.inertia),
-                trace=trace[:int(st.iter)], done=bool(st.done))
+                                  L.ptr(trace), C.byref(st), C.byref(tm) if timing else None, L.ptr(ws),
+                                  C.c_size_t(ws.numel()), L.stream(dev)), "et_kmeans_fit")
+    out = dict(centroids=cen, labels=labels, n_iter=int(st.iter), error=float(st.error), inertia=float(st.inertia),
+               trace=trace[:int(st.iter)], done=bool(st.done))
+    if timing:
+        out["assign_ms"], out["assign_launches"] = float(tm.assign_ms), int(tm.assign_launches)
+    return out
 
 
 def kmeans_predict(X, centroids, want_maxsims=True):

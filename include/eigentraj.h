@@ -199,11 +199,19 @@ int et_kmeans_update(et_kmeans_state *state, const int64_t *partials, int d, int
 /* widen the uint8 labels of the last assignment to the reference's int64 */
 int et_kmeans_labels_i64(const uint8_t *labels_u8, int64_t N, int64_t *labels, et_stream_t stream);
 
+/* optional kernel timing of et_kmeans_fit: HIP events recorded on `stream` around every launch
+ * of the assign kernel (the dominant kernel of the path); filled after the final sync. */
+typedef struct et_kmeans_timing {
+    double assign_ms;        /* sum of the assign-kernel durations */
+    int64_t assign_launches; /* number of launches that did work (state.iter) */
+} et_kmeans_timing;
+
 /* single-GPU fit of one batch element from given initial centroids (kmeans.py:228-240):
- * centroids (d,K) in/out, labels int64 (N) out, *state_host receives the final state.
- * Synchronises the stream (the reference syncs every iteration at kmeans.py:239). */
+ * centroids (d,K) in/out, labels int64 (N) out, *state_host receives the final state,
+ * *timing_host (may be NULL) the assign-kernel timing.  Synchronises the stream (the
+ * reference syncs every iteration at kmeans.py:239; here every 8th). */
 int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_iter, float tol, float *centroids,
-                  int64_t *labels, float *trace, et_kmeans_state *state_host,
+                  int64_t *labels, float *trace, et_kmeans_state *state_host, et_kmeans_timing *timing_host,
                   void *workspace, size_t workspace_bytes, et_stream_t stream);
 
 /* kmeans.py:261-272 predict: labels int64 (N); maxsims (N) optional */
