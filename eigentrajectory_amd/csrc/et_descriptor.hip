@@ -468,7 +468,7 @@ extern "C" int et_norm_project(const float *obs, const float *pred, int64_t N, i
     if (pred && C_pred && ((need_m(mode) && !U_pred_m) || (need_s(mode) && !U_pred_s))) return ET_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ceil_div(N, kTile);
-    const bool fast = T_obs == 8 && T_pred == 12 && k == 6 && aligned16(obs) && (!pred || aligned16(pred));
+    const bool fast = T_obs == 8 && (!pred || T_pred == 12) && k == 6 && aligned16(obs) && (!pred || aligned16(pred));
     if (fast) {
         hipLaunchKernelGGL((project_tile_kernel<8, 12, 6>), dim3(grid), dim3(kTile), 0, st, obs, pred, N, U_obs_m,
                            U_pred_m, U_obs_s, U_pred_s, mode, static_dist, C_obs, C_pred, nrm, flag);

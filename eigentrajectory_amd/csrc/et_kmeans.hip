@@ -105,6 +105,65 @@ __device__ __forceinline__ void best_centroid(const float *x, int d_rt, const fl
     best = bv;
 }
 
+// Fast arg-max for d = 6, four points per lane as two packed pairs (v_pk_fma_f32 / v_pk_add_f32:
+// the same IEEE operations, two points per instruction) with the next centroid row prefetched from
+// LDS while the current one is evaluated.  Only valid when no similarity can be NaN/Inf
+// (finite centroids, magnitudes < 1e18: checked once per iteration on the device, state->fast_ok),
+// so the NaN rule of torch.max (kmeans.py:156) reduces to a plain `>`; results are bit-identical
+// to best_centroid().
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void best_centroid_x4_d6(const f32x2 (&xa)[6], const f32x2 (&xb)[6], const float *sC, int K,
+                                                    int (&lb)[4], float (&bv)[4]) {
+    f32x2 ana = {0.f, 0.f}, anb = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        ana = ana + xa[i] * xa[i];  // kmeans.py:73
+        anb = anb + xb[i] * xb[i];
+    }
+    const float4 *s4 = reinterpret_cast<const float4 *>(sC);  // row j = s4[2j], s4[2j+1] = {c0..c3},{c4,c5,|c|^2,-}
+    float4 n0 = s4[0], n1 = s4[1];
+    lb[0] = lb[1] = lb[2] = lb[3] = 0;
+    for (int j = 0; j < K; ++j) {
+        const float4 p0 = n0, p1 = n1;
+        if (j + 1 < K) {
+            n0 = s4[2 * j + 2];
+            n1 = s4[2 * j + 3];
+        }
+        const float cc[6] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y};
+        f32x2 ya = {0.f, 0.f}, yb = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const f32x2 c = {cc[i], cc[i]};
+            ya = __builtin_elementwise_fma(xa[i], c, ya);  // kmeans.py:71
+            yb = __builtin_elementwise_fma(xb[i], c, yb);
+        }
+        ya = ya * 2.0f;  // :72
+        yb = yb * 2.0f;
+        ya = ya - ana;   // :73
+        yb = yb - anb;
+        const f32x2 bn = {p1.z, p1.z};
+        ya = ya - bn;    // :74
+        yb = yb - bn;
+        if (j == 0) {
+            bv[0] = ya.x;
+            bv[1] = ya.y;
+            bv[2] = yb.x;
+            bv[3] = yb.y;
+        } else {
+            const bool t0 = ya.x > bv[0], t1 = ya.y > bv[1], t2 = yb.x > bv[2], t3 = yb.y > bv[3];
+            bv[0] = t0 ? ya.x : bv[0];
+            lb[0] = t0 ? j : lb[0];
+            bv[1] = t1 ? ya.y : bv[1];
+            lb[1] = t1 ? j : lb[1];
+            bv[2] = t2 ? yb.x : bv[2];
+            lb[2] = t2 ? j : lb[2];
+            bv[3] = t3 ? yb.y : bv[3];
+            lb[3] = t3 ? j : lb[3];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // scan: max |x| and a non-finite flag, straight into the state block (zeroed by the host side)
 // ------------------------------------------------------------------------------------------
@@ -138,6 +197,14 @@ __device__ __forceinline__ double max_abs_centroid(const float *cen, int n) {  /
     return m;
 }
 
+// 1 when no similarity of the coming assignment can overflow or be NaN: every centroid finite and
+// all magnitudes below 1e18 (|2 a.b| + |a|^2 + |b|^2 <= 4 d 1e36 < FLT_MAX for d <= 32).
+__device__ __forceinline__ int64_t fast_ok_flag(const float *cen, int n, double mx, double mc) {
+    for (int i = 0; i < n; ++i)
+        if (!(fabsf(cen[i]) <= 3.402823466e+38f)) return 0;
+    return (mx < 1e18 && mc < 1e18) ? 1 : 0;
+}
+
 __device__ __forceinline__ int sim_frac_bits(double mx, double mc, int d, int64_t n_total) {
     const double m = mx > mc ? mx : mc;
     return 62 - exponent_above(4.0 * d * m * m) - bits_for(n_total);
@@ -151,6 +218,7 @@ __global__ void kmeans_begin_kernel(et_kmeans_state *state, int64_t n_total, con
     const double mc = max_abs_centroid(cen, d * K);
     state->max_abs_c = mc;
     state->sim_frac = sim_frac_bits(state->max_abs_x, mc, d, n_total);
+    state->fast_ok = fast_ok_flag(cen, d * K, state->max_abs_x, mc);
     state->iter = 0;
     state->done = state->bad_input ? 1 : 0;  // non-finite data: every later step is a no-op
     state->error = 0.0;
@@ -175,6 +243,12 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_kernel(
     float *sC = reinterpret_cast<float *>(smem_raw + sizeof(long long) * ((plen + 1) & ~1));  // K * cpitch
 
     const int frac = (int)state->frac, sfrac = (int)state->sim_frac;
+    // After the first iteration only the points whose label CHANGED touch the accumulators
+    // (-x from the old cluster, +x to the new one).  Integer sums make this exact: the running
+    // totals are bit-identical to a full re-accumulation, and once Lloyd settles the LDS atomics
+    // (the expensive part of this kernel) all but disappear.
+    const bool incremental = (state->iter > 0) && (given == nullptr);
+    const bool fast = state->fast_ok != 0;
     for (int i = threadIdx.x; i < plen; i += kKmThreads) sAcc[i] = 0;
     stage_centroids(cen, d, K, sC);
     __syncthreads();
@@ -185,6 +259,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_kernel(
     for (int64_t gidx = (int64_t)blockIdx.x * kKmThreads + threadIdx.x; gidx < n_groups; gidx += stride) {
         const int64_t n = gidx * VEC;
         float x[VEC][D ? D : ET_KMEANS_MAX_D];
+        unsigned old_packed = 0xffffffffu;
         if (VEC == 4) {
 #pragma unroll
             for (int i = 0; i < (D ? D : ET_KMEANS_MAX_D); ++i)
@@ -195,12 +270,25 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_kernel(
                     x[2 % VEC][i] = v.z;
                     x[3 % VEC][i] = v.w;
                 }
+            if (incremental) old_packed = *reinterpret_cast<const unsigned *>(labels + n);
         } else {
 #pragma unroll
             for (int i = 0; i < (D ? D : ET_KMEANS_MAX_D); ++i)
                 if (i < d) x[0][i] = X[(int64_t)i * N + n];
+            if (incremental) old_packed = labels[n];
         }
         unsigned packed = 0;
+        int lbs[4];
+        float bests[4];
+        if (D == 6 && VEC == 4 && fast && !given) {
+            f32x2 xa[6], xb[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                xa[i] = f32x2{x[0][i], x[1 % VEC][i]};
+                xb[i] = f32x2{x[2 % VEC][i], x[3 % VEC][i]};
+            }
+            best_centroid_x4_d6(xa, xb, sC, K, lbs, bests);
+        }
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             int lb;
@@ -208,21 +296,32 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_kernel(
             if (given) {
                 lb = (int)given[n + v];
                 best = 0.f;
+            } else if (D == 6 && VEC == 4 && fast) {
+                lb = lbs[v];
+                best = bests[v];
             } else {
                 best_centroid<D>(x[v], d, sC, K, lb, best);
             }
             packed |= (unsigned)lb << (8 * v);
-            atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + lb]), 1ull);
+            const int old = incremental ? (int)((old_packed >> (8 * v)) & 0xffu) : -1;
+            if (lb != old) {
+                atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + lb]), 1ull);
+                if (old >= 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + old]), ~0ull);  // -1
 #pragma unroll
-            for (int i = 0; i < (D ? D : ET_KMEANS_MAX_D); ++i)
-                if (i < d)
-                    atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[i * K + lb]),
-                              (unsigned long long)to_fixed(x[v][i], frac));
-            if (isnan(best) || isinf(best)) nan_acc += 1;
+                for (int i = 0; i < (D ? D : ET_KMEANS_MAX_D); ++i)
+                    if (i < d) {
+                        const unsigned long long f = (unsigned long long)to_fixed(x[v][i], frac);
+                        atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[i * K + lb]), f);
+                        if (old >= 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[i * K + old]), 0ull - f);
+                    }
+            }
+            if (!fast && (isnan(best) || isinf(best))) nan_acc += 1;
             else sim_acc += to_fixed(best, sfrac);
         }
-        if (VEC == 4) *reinterpret_cast<unsigned *>(labels + n) = packed;
-        else labels[n] = (uint8_t)packed;
+        if (packed != old_packed || !incremental) {
+            if (VEC == 4) *reinterpret_cast<unsigned *>(labels + n) = packed;
+            else labels[n] = (uint8_t)packed;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         sim_acc += __shfl_xor(sim_acc, o);
@@ -233,24 +332,30 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_kernel(
         atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K + 1]), (unsigned long long)nan_acc);
     }
     __syncthreads();
-    long long *dst = block_partials + (size_t)blockIdx.x * plen;
-    for (int i = threadIdx.x; i < plen; i += kKmThreads) dst[i] = sAcc[i];
+    // transposed [entry][workgroup] so that the reduction below reads unit-stride
+    for (int i = threadIdx.x; i < plen; i += kKmThreads) block_partials[(size_t)i * gridDim.x + blockIdx.x] = sAcc[i];
 }
 
-// sum the workgroup partials (integers: any order) -> partials[plen]
+// Fold the workgroup deltas into the shard's running totals: one workgroup per entry, unit-stride
+// reads.  Cluster sums / counts accumulate across iterations (deltas), the similarity sum and
+// the NaN count are per-iteration quantities and are overwritten.
 __global__ __launch_bounds__(kKmThreads) void kmeans_reduce_partials_kernel(const long long *__restrict__ block_partials,
-                                                                            int n_blocks, int plen,
+                                                                            int n_blocks, int plen, int full,
                                                                             const et_kmeans_state *__restrict__ state,
                                                                             long long *__restrict__ partials) {
     if (state->done) return;
-    // 4 lanes per entry walk interleaved workgroup slots, then combine
-    const int e = (blockIdx.x * kKmThreads + threadIdx.x) >> 2, sub = threadIdx.x & 3;
+    __shared__ long long sW[kKmThreads / 64];
+    const int e = blockIdx.x;
     long long s = 0;
-    if (e < plen)
-        for (int b = sub; b < n_blocks; b += 4) s += block_partials[(size_t)b * plen + e];
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    if (e < plen && sub == 0) partials[e] = s;
+    for (int b = threadIdx.x; b < n_blocks; b += kKmThreads) s += block_partials[(size_t)e * n_blocks + b];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sW[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kKmThreads / 64; ++w) s += sW[w];
+        const bool running = !full && state->iter > 0 && e < plen - 2;
+        partials[e] = running ? partials[e] + s : s;
+    }
 }
 
 // centroid update + convergence scalars from the (all-reduced) exact sums.  One workgroup.
@@ -288,6 +393,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_update_kernel(et_kmeans_sta
         const double mc = max_abs_centroid(sNew, d * K);
         state->max_abs_c = mc;
         state->sim_frac = sim_frac_bits(state->max_abs_x, mc, d, n_total);
+        state->fast_ok = fast_ok_flag(sNew, d * K, state->max_abs_x, mc);
         if (trace) {
             trace[2 * state->iter] = error;
             trace[2 * state->iter + 1] = inertia;
@@ -532,8 +638,8 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, const
     ET_LAUNCH_CHECK();
     if (ev_end) ET_HIP_TRY(hipEventRecord(ev_end, st));
     const int plen = (int)km_plen(d, K);
-    hipLaunchKernelGGL(kmeans_reduce_partials_kernel, dim3((unsigned)ceil_div((int64_t)plen * 4, kKmThreads)),
-                       dim3(kKmThreads), 0, st, w.block_partials, grid, plen, state, (long long *)partials);
+    hipLaunchKernelGGL(kmeans_reduce_partials_kernel, dim3(plen), dim3(kKmThreads), 0, st, w.block_partials, grid, plen,
+                       given_labels ? 1 : 0, state, (long long *)partials);
     ET_LAUNCH_CHECK();
     return ET_OK;
 }

@@ -150,6 +150,7 @@ typedef struct et_kmeans_state {
     int64_t bad_input;  /* 1 if X holds NaN/Inf (all-reduce MAX)                           */
     double error;       /* kmeans.py:45-51 of the last update                              */
     double inertia;     /* kmeans.py:53-57 of the last assignment                          */
+    int64_t fast_ok;    /* 1 when no similarity of the next assignment can be NaN/Inf      */
 } et_kmeans_state;
 
 /* kmeans.py:59-76 euc_sim for one batch element: a (d,m), b (d,n) -> y (m,n) */
@@ -185,7 +186,9 @@ int et_kmeans_init_farthest(const float *X, int64_t N, int d, int K, int64_t fir
                             void *workspace, size_t workspace_bytes, et_stream_t stream);
 
 /* one Lloyd half-step on a shard (kmeans.py:230 + the sums of :231, :234): labels_u8 (N)
- * and this shard's exact partials; no-op when state->done.  With given_labels != NULL
+ * and this shard's exact partials; no-op when state->done.  From the second iteration on only
+ * the points whose label changed update the sums (exact integer deltas), so `labels_u8` and
+ * `partials` must be the buffers of the previous iteration of the same fit, unmodified.  With given_labels != NULL
  * (int64, N) the labels are taken as they are instead of computed (compute_centroids,
  * kmeans.py:160-198, as a public method). */
 int et_kmeans_assign_accumulate(const float *X, int64_t N, int d, int K, const et_kmeans_state *state,

@@ -1,0 +1,180 @@
+"""world_size-2 gloo runs (CPU) of the sharded fit / k-means orchestration in eigentrajectory_amd.dist.
+
+The compute steps are injected: here they are backed by the CPU oracle (tests may use it; the
+product never does), so what is exercised is the exchange logic -- which tensors are reduced, in
+what order, and that every rank ends with the bit-identical result a single-shard run gives.
+"""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from . import _golden as G
+
+
+class OracleShard:
+    """ops.KMeansShard look-alike on CPU tensors, backed by oracle/et_oracle.c."""
+
+    def __init__(self, X, K):
+        from oracle import et_oracle as eo
+        self.eo = eo
+        self.X = np.ascontiguousarray(X.numpy() if isinstance(X, torch.Tensor) else X, dtype=np.float32)
+        self.d, self.n = self.X.shape
+        self.K = K
+        self.state = torch.zeros((11,), dtype=torch.int64)
+        self.partials = torch.zeros((self.d * K + K + 2,), dtype=torch.int64)
+        self._labels = np.zeros((self.n,), np.int64)
+        self.best = np.zeros((self.n,), np.float32)
+        self.cand = torch.zeros((8 + 4 * 32,), dtype=torch.uint8)
+
+    @property
+    def state_f64(self):
+        return self.state.view(torch.float64)
+
+    def scan(self):
+        self.state.zero_()
+        self.state_f64[0] = float(np.abs(self.X).max()) if self.n else 0.0
+        self.state[7] = int(not np.isfinite(self.X).all())
+
+    def begin(self, n_total, centroids):
+        mx = float(self.state_f64[0])
+        self.state[2] = n_total
+        self.state[3] = self.eo.kmeans_frac_bits(mx, n_total)
+        mc = float(np.nanmax(np.abs(centroids.numpy()))) if np.isfinite(centroids.numpy()).any() else 0.0
+        self.state_f64[1] = mc
+        self.state[4] = self.eo.kmeans_sim_frac_bits(mx, mc, self.d, n_total)
+        self.state[5] = 0
+        self.state[6] = int(self.state[7])
+
+    def gather_point(self, i):
+        return torch.from_numpy(self.X[:, i].copy())
+
+    def init_step(self, i, C0, index_base):
+        c = C0.numpy()[:, i - 1]
+        key = np.uint64(0xFFFFFFFFFFFFFFFF)
+        pt = np.full((self.d,), np.nan, np.float32)
+        if self.n:
+            y = self.eo.euc_sim(self.X, c[:, None].copy())[:, 0]
+            self.best = y if i == 1 else np.where((y > self.best) | (np.isnan(y) & ~np.isnan(self.best)), y, self.best)
+            b = self.best
+            bits = b.view(np.uint32).astype(np.uint64)
+            order = np.where(bits & np.uint64(0x80000000), (~bits) & np.uint64(0xFFFFFFFF), bits | np.uint64(0x80000000))
+            order = np.where(np.isnan(b), np.uint64(0), order)
+            order = np.where(b == 0, np.uint64(0x80000000), order)
+            keys = (order << np.uint64(32)) | (np.arange(self.n, dtype=np.uint64) + np.uint64(index_base))
+            w = int(np.argmin(keys))
+            key, pt = keys[w], self.X[:, w]
+        buf = np.zeros((8 + 4 * 32,), np.uint8)
+        buf[:8] = np.frombuffer(np.uint64(key).tobytes(), np.uint8)
+        buf[8:8 + 4 * self.d] = np.frombuffer(np.ascontiguousarray(pt, np.float32).tobytes(), np.uint8)
+        self.cand = torch.from_numpy(buf)
+        return self.cand
+
+    def assign(self, centroids, given_labels=None):
+        if int(self.state[6]):
+            return self.partials
+        if self.n:
+            lb, s, c, ss, nn = self.eo.kmeans_assign_accumulate(self.X, centroids.numpy(), int(self.state[3]),
+                                                                int(self.state[4]))
+            self._labels = lb
+            flat = np.concatenate([s.reshape(-1), c, [ss, nn]]).astype(np.int64)
+        else:
+            flat = np.zeros((self.d * self.K + self.K + 2,), np.int64)
+        self.partials = torch.from_numpy(flat)
+        return self.partials
+
+    def update(self, partials, centroids, tol, trace=None):
+        if int(self.state[6]):
+            return
+        p = partials.numpy()
+        d, K = self.d, self.K
+        n_total = int(self.state[2])
+        c_new, err, ine, done = self.eo.kmeans_update(p[:d * K].reshape(d, K), p[d * K:d * K + K], int(p[-2]), int(p[-1]),
+                                                      n_total, int(self.state[3]), int(self.state[4]), tol,
+                                                      centroids.numpy())
+        centroids.copy_(torch.from_numpy(c_new))
+        mc = float(np.nanmax(np.abs(c_new))) if np.isfinite(c_new).any() else 0.0
+        self.state_f64[1] = mc
+        self.state[4] = self.eo.kmeans_sim_frac_bits(float(self.state_f64[0]), mc, d, n_total)
+        self.state_f64[8] = err
+        self.state_f64[9] = ine
+        self.state[5] += 1
+        self.state[6] = int(done)
+
+    def labels(self):
+        return torch.from_numpy(self._labels.copy())
+
+    def read_state(self):
+        from eigentrajectory_amd import _lib
+        return _lib.KMeansState.from_buffer_copy(self.state.numpy().tobytes())
+
+
+def oracle_gram(obs, pred, mode, static_dist, which):
+    from oracle import et_oracle as eo
+    g_obs, g_pred, cnt = eo.fit_gram(obs.numpy(), pred.numpy(), mode, static_dist, which)
+    return torch.from_numpy(g_obs), torch.from_numpy(g_pred), torch.tensor([cnt], dtype=torch.int64)
+
+
+def oracle_eigh(G_, k):
+    from oracle import et_oracle as eo
+    U, s = eo.eigh_topk(G_.numpy(), k)
+    return torch.from_numpy(U), torch.from_numpy(s)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, cuts, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from eigentrajectory_amd.dist import ShardedKMeans, fit_descriptor_sharded
+        from eigentrajectory_amd.synth import gaussian_points_np, synthetic_trajectories_np
+        obs, pred = synthetic_trajectories_np(4000, seed=1)
+        lo, hi = cuts[rank], cuts[rank + 1]
+        U_obs, U_pred, s_obs, s_pred, count = fit_descriptor_sharded(
+            torch.from_numpy(obs[lo:hi]), torch.from_numpy(pred[lo:hi]), 6, 2, 0.3, 1, gram_fn=oracle_gram,
+            eigh_fn=oracle_eigh)
+        x = gaussian_points_np(6, 4000, seed=2, n_blobs=6)
+        km = ShardedKMeans(torch.from_numpy(np.ascontiguousarray(x[:, lo:hi])), 20, shard_factory=OracleShard,
+                           check_every=3)
+        c0 = km.init_farthest(first_index=1234)
+        res = km.fit(c0.clone(), max_iter=40, tol=1e-4)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), U_obs=U_obs.numpy(), U_pred=U_pred.numpy(), count=count,
+                 c0=c0.numpy(), centroids=res["centroids"].numpy(), labels=res["labels"].numpy(), n_iter=res["n_iter"],
+                 inertia=res["inertia"], n_total=km.n_total, index_base=km.index_base)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cuts", [(0, 2000, 4000), (0, 37, 4000)])
+def test_sharded_fit_and_kmeans_two_ranks_gloo(tmp_path, oracle, cuts):
+    from eigentrajectory_amd.synth import gaussian_points_np, synthetic_trajectories_np
+    mp.spawn(_worker, args=(2, _free_port(), cuts, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    # every rank holds the same fit and the same centroids
+    for key in ("U_obs", "U_pred", "count", "c0", "centroids", "n_iter", "inertia", "n_total"):
+        assert np.array_equal(r0[key], r1[key], equal_nan=True), key
+    assert int(r0["n_total"]) == 4000 and int(r1["index_base"]) == cuts[1]
+    # ... and it is what one process computes on the whole data
+    obs, pred = synthetic_trajectories_np(4000, seed=1)
+    g_obs, g_pred, cnt = oracle.fit_gram(obs, pred, 2, 0.3, 1)
+    assert int(r0["count"]) == cnt
+    U_ref, _ = oracle.eigh_topk(g_pred, 6)
+    np.testing.assert_allclose(r0["U_pred"], U_ref, atol=1e-6)  # fp64 partial sums in another order
+    x = gaussian_points_np(6, 4000, seed=2, n_blobs=6)
+    c0, _ = oracle.kmeans_init_farthest(x, 20, 1234)
+    assert np.array_equal(r0["c0"], c0)
+    ref = oracle.kmeans_fit(x, c0, 40, 1e-4)
+    assert int(r0["n_iter"]) == ref["n_iter"]
+    assert np.array_equal(r0["centroids"], ref["centroids"])          # exact integer sums: bit-identical
+    assert np.array_equal(np.concatenate([r0["labels"], r1["labels"]]), ref["labels"])

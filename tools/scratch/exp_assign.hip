@@ -1,0 +1,142 @@
+// Stand-alone experiment: cost of the k-means arg-max loop alone (no accumulation), several structures.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <cstdlib>
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} }while(0)
+
+__device__ __forceinline__ void argmax4(const f2 (&xa)[6], const f2 (&xb)[6], const float* sC, int K, unsigned& packed, float& bsum) {
+    f2 ana = {0.f, 0.f}, anb = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { ana = ana + xa[i] * xa[i]; anb = anb + xb[i] * xb[i]; }
+    const float4* s4 = reinterpret_cast<const float4*>(sC);
+    float4 c0 = s4[0], c1 = s4[1];
+    float b0, b1, b2, b3; int l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+    for (int j = 0; j < K; ++j) {
+        const float4 p0 = c0, p1 = c1;
+        if (j + 1 < K) { c0 = s4[2 * j + 2]; c1 = s4[2 * j + 3]; }
+        f2 ya = {0.f, 0.f}, yb = {0.f, 0.f};
+        const float cc[6] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { const f2 c = {cc[i], cc[i]}; ya = __builtin_elementwise_fma(xa[i], c, ya); yb = __builtin_elementwise_fma(xb[i], c, yb); }
+        ya = ya * 2.0f; yb = yb * 2.0f; ya = ya - ana; yb = yb - anb;
+        const f2 bn = {p1.z, p1.z}; ya = ya - bn; yb = yb - bn;
+        if (j == 0) { b0 = ya.x; b1 = ya.y; b2 = yb.x; b3 = yb.y; }
+        else {
+            const bool t0 = ya.x > b0, t1 = ya.y > b1, t2 = yb.x > b2, t3 = yb.y > b3;
+            b0 = t0 ? ya.x : b0; l0 = t0 ? j : l0; b1 = t1 ? ya.y : b1; l1 = t1 ? j : l1;
+            b2 = t2 ? yb.x : b2; l2 = t2 ? j : l2; b3 = t3 ? yb.y : b3; l3 = t3 ? j : l3;
+        }
+    }
+    packed = l0 | (l1 << 8) | (l2 << 16) | (l3 << 24); bsum = b0 + b1 + b2 + b3;
+}
+
+__device__ __forceinline__ void argmax4s(const float (&x)[4][6], const float* sC, int K, unsigned& packed, float& bsum) {
+    float an[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { an[v] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) an[v] = an[v] + x[v][i] * x[v][i]; }
+    const float4* s4 = reinterpret_cast<const float4*>(sC);
+    float4 c0 = s4[0], c1 = s4[1];
+    float b[4]; int l[4] = {0, 0, 0, 0};
+    for (int j = 0; j < K; ++j) {
+        const float4 p0 = c0, p1 = c1;
+        if (j + 1 < K) { c0 = s4[2 * j + 2]; c1 = s4[2 * j + 3]; }
+        const float cc[6] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            float y = 0.f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) y = fmaf(x[v][i], cc[i], y);
+            y = y * 2.0f; y = y - an[v]; y = y - p1.z;
+            if (j == 0) b[v] = y; else { const bool t = y > b[v]; b[v] = t ? y : b[v]; l[v] = t ? j : l[v]; }
+        }
+    }
+    packed = l[0] | (l[1] << 8) | (l[2] << 16) | (l[3] << 24); bsum = b[0] + b[1] + b[2] + b[3];
+}
+
+// V=0: one group per thread; V=1: grid-stride; V=2: grid-stride with next-group prefetch; V=3: like 0 but no compute (copy floor)
+template <int V>
+__global__ __launch_bounds__(256) void k(const float* __restrict__ X, long N, int K, const float* __restrict__ cen8, unsigned* __restrict__ out, float* __restrict__ acc) {
+    extern __shared__ __attribute__((aligned(16))) float sC[];
+    for (int i = threadIdx.x; i < K * 8; i += 256) sC[i] = cen8[i];
+    __syncthreads();
+    const long ngroups = N / 4;
+    const long stride = (long)gridDim.x * 256;
+    float total = 0.f;
+    long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (V == 0 || V == 3 || V == 4) {
+        if (g >= ngroups) return;
+        f2 xa[6], xb[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { const float4 v = *reinterpret_cast<const float4*>(X + (long)i * N + g * 4); xa[i] = f2{v.x, v.y}; xb[i] = f2{v.z, v.w}; }
+        unsigned p; float b;
+        if (V == 0) argmax4(xa, xb, sC, K, p, b);
+        else if (V == 4) { float xs[4][6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { xs[0][i] = xa[i].x; xs[1][i] = xa[i].y; xs[2][i] = xb[i].x; xs[3][i] = xb[i].y; }
+            argmax4s(xs, sC, K, p, b); }
+        else { p = 0; b = 0; for (int i = 0; i < 6; ++i) b += xa[i].x + xa[i].y + xb[i].x + xb[i].y; }
+        out[g] = p; total = b;
+    } else if (V == 1) {
+        for (; g < ngroups; g += stride) {
+            f2 xa[6], xb[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { const float4 v = *reinterpret_cast<const float4*>(X + (long)i * N + g * 4); xa[i] = f2{v.x, v.y}; xb[i] = f2{v.z, v.w}; }
+            unsigned p; float b; argmax4(xa, xb, sC, K, p, b); out[g] = p; total += b;
+        }
+    } else {
+        float4 nx[6];
+        if (g < ngroups) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) nx[i] = *reinterpret_cast<const float4*>(X + (long)i * N + g * 4);
+        }
+        for (; g < ngroups; g += stride) {
+            f2 xa[6], xb[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { xa[i] = f2{nx[i].x, nx[i].y}; xb[i] = f2{nx[i].z, nx[i].w}; }
+            const long gn = g + stride;
+            if (gn < ngroups) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) nx[i] = *reinterpret_cast<const float4*>(X + (long)i * N + gn * 4);
+            }
+            unsigned p; float b; argmax4(xa, xb, sC, K, p, b); out[g] = p; total += b;
+        }
+    }
+    if (total == 123.456f) acc[0] = total;
+}
+
+template <int V> float run(const float* X, long N, int K, const float* cen, unsigned* out, float* acc, int grid) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    float best = 1e9;
+    for (int r = 0; r < 6; ++r) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL((k<V>), dim3(grid), dim3(256), K * 8 * 4, 0, X, N, K, cen, out, acc);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); if (r > 0 && ms < best) best = ms;
+    }
+    return best;
+}
+
+int main(int argc, char** argv) {
+    long N = argc > 1 ? atol(argv[1]) : 10000000; int K = 20;
+    float *X, *cen, *acc; unsigned* out;
+    CK(hipMalloc(&X, N * 6 * 4)); CK(hipMalloc(&cen, K * 8 * 4)); CK(hipMalloc(&out, N)); CK(hipMalloc(&acc, 4));
+    std::vector<float> h(N * 6); for (long i = 0; i < N * 6; ++i) h[i] = (float)((i * 2654435761u) % 2001) / 100.f - 10.f;
+    CK(hipMemcpy(X, h.data(), N * 6 * 4, hipMemcpyHostToDevice));
+    std::vector<float> c(K * 8); for (int i = 0; i < K * 8; ++i) c[i] = (float)((i * 40503u) % 1999) / 100.f - 10.f;
+    CK(hipMemcpy(cen, c.data(), K * 8 * 4, hipMemcpyHostToDevice));
+    long ngroups = N / 4; int full = (int)((ngroups + 255) / 256);
+    printf("N=%ld  bytes=%.0f MB\n", N, N * 24 / 1e6);
+    float t;
+    t = run<3>(X, N, K, cen, out, acc, full); printf("V3 load-only 1grp/thread grid=%d: %.1f us  %.0f GB/s\n", full, t * 1e3, N * 24 / t / 1e6);
+    t = run<0>(X, N, K, cen, out, acc, full); printf("V0 argmax 1grp/thread grid=%d: %.1f us  %.0f GB/s\n", full, t * 1e3, N * 24 / t / 1e6);
+    t = run<4>(X, N, K, cen, out, acc, full); printf("V4 argmax scalar 1grp/thread grid=%d: %.1f us  %.0f GB/s\n", full, t * 1e3, N * 24 / t / 1e6);
+    for (int grid : {4096}) {
+        t = run<1>(X, N, K, cen, out, acc, grid); printf("V1 grid-stride grid=%d: %.1f us  %.0f GB/s\n", grid, t * 1e3, N * 24 / t / 1e6);
+        t = run<2>(X, N, K, cen, out, acc, grid); printf("V2 grid-stride+prefetch grid=%d: %.1f us  %.0f GB/s\n", grid, t * 1e3, N * 24 / t / 1e6);
+    }
+    return 0;
+}
