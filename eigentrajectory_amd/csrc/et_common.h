@@ -58,12 +58,14 @@ __device__ __forceinline__ RowNorm row_norm(float ox, float oy, float dx, float 
         mv = sqrtf(hx * hx + hy * hy) > static_dist ? 1 : 0;
     }
     p.mv = mv;
-    const float th = atan2f(dy, dx);  // normalizer.py:24
-    float sn, cs;
-    sincosf(th, &sn, &cs);            // normalizer.py:25-26
-    p.c = cs;
-    p.s = sn;
+    // normalizer.py:24-26 builds R from theta = atan2(dy, dx), cos(theta), sin(theta).  The same unit
+    // vector is (dx, dy) / ||d||, which costs one sqrt and two divisions instead of three
+    // transcendental calls per trajectory and is at least as accurate (the reference's fp32 theta
+    // already carries 6e-8 relative error); atan2(0, 0) = 0 gives the identity for motionless rows.
     const float r = sqrtf(dx * dx + dy * dy);
+    const bool still = !(r > 0.0f);
+    p.c = still ? (isnan(r) ? r : 1.0f) : dx / r;
+    p.s = still ? (isnan(r) ? r : 0.0f) : dy / r;
     p.sca = mv ? (1.0f / r) * 2.0f : 1.0f;  // normalizer.py:28
     p.inv = mv ? 1.0f / p.sca : 1.0f;
     return p;

@@ -15,6 +15,7 @@
 // fixed-point integer (truncation, power-of-two scale => exact) and integers are summed, so the
 // result is independent of the order: the same bits for any workgroup schedule, grid size or
 // number of GPUs, and identical to the CPU oracle (oracle/et_oracle.c).
+#include <cstdlib>
 #include <vector>
 
 #include "et_common.h"
@@ -170,20 +171,28 @@ __device__ __forceinline__ void best_centroid_x4_d6(const f32x2 (&xa)[6], const 
 __global__ __launch_bounds__(kKmThreads) void kmeans_scan_kernel(const float *__restrict__ X, int64_t count,
                                                                  et_kmeans_state *state) {
     float m = 0.f;
+    unsigned mn = 0x7f800000u;  // bits of the smallest non-zero |x| (positive floats order like their bits)
     int bad = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         const float a = fabsf(X[i]);
         if (!(a <= 3.402823466e+38f)) bad = 1;
-        else if (a > m) m = a;
+        else {
+            if (a > m) m = a;
+            const unsigned b = (unsigned)__float_as_int(a);
+            if (b != 0u && b < mn) mn = b;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         m = fmaxf(m, __shfl_xor(m, o));
+        const unsigned other = (unsigned)__shfl_xor((int)mn, o);
+        mn = other < mn ? other : mn;
         bad |= __shfl_xor(bad, o);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicMax(reinterpret_cast<unsigned long long *>(&state->max_abs_x),
                   (unsigned long long)__double_as_longlong((double)m));
+        atomicMin(reinterpret_cast<unsigned long long *>(&state->min_nz_x_bits), (unsigned long long)mn);
         if (bad) atomicMax(reinterpret_cast<unsigned long long *>(&state->bad_input), 1ull);
     }
 }
@@ -197,12 +206,24 @@ __device__ __forceinline__ double max_abs_centroid(const float *cen, int n) {  /
     return m;
 }
 
-// 1 when no similarity of the coming assignment can overflow or be NaN: every centroid finite and
-// all magnitudes below 1e18 (|2 a.b| + |a|^2 + |b|^2 <= 4 d 1e36 < FLT_MAX for d <= 32).
-__device__ __forceinline__ int64_t fast_ok_flag(const float *cen, int n, double mx, double mc) {
-    for (int i = 0; i < n; ++i)
-        if (!(fabsf(cen[i]) <= 3.402823466e+38f)) return 0;
-    return (mx < 1e18 && mc < 1e18) ? 1 : 0;
+// 0: similarities may be NaN/Inf -> NaN-aware scalar path.
+// 1: no similarity of the coming assignment can overflow or be NaN (every centroid finite, all
+//    magnitudes below 1e18: |2 a.b| + |a|^2 + |b|^2 <= 4 d 1e36 < FLT_MAX for d <= 32).
+// 2: additionally every non-zero |x| and |c| is >= 2^-50.  Then every partial sum of the a.b chain is
+//    a multiple of 2^-146, i.e. exactly representable even when subnormal, so scaling the chain by two
+//    commutes with every rounding: fl(2c.x) == 2 fl(c.x) bit for bit.  The matrix-core kernel relies
+//    on that to fold the reference's "y *= 2" (kmeans.py:72) into its A operand.
+__device__ __forceinline__ int64_t fast_ok_flag(const float *cen, int n, double mx, double mc, int64_t min_nz_x_bits) {
+    unsigned mn = 0x7f800000u;
+    for (int i = 0; i < n; ++i) {
+        const float a = fabsf(cen[i]);
+        if (!(a <= 3.402823466e+38f)) return 0;
+        const unsigned b = (unsigned)__float_as_int(a);
+        if (b != 0u && b < mn) mn = b;
+    }
+    if (!(mx < 1e18 && mc < 1e18)) return 0;
+    const unsigned lim = 0x26800000u;  // 2^-50
+    return (mn >= lim && (unsigned long long)min_nz_x_bits >= lim) ? 2 : 1;
 }
 
 __device__ __forceinline__ int sim_frac_bits(double mx, double mc, int d, int64_t n_total) {
@@ -218,7 +239,7 @@ __global__ void kmeans_begin_kernel(et_kmeans_state *state, int64_t n_total, con
     const double mc = max_abs_centroid(cen, d * K);
     state->max_abs_c = mc;
     state->sim_frac = sim_frac_bits(state->max_abs_x, mc, d, n_total);
-    state->fast_ok = fast_ok_flag(cen, d * K, state->max_abs_x, mc);
+    state->fast_ok = fast_ok_flag(cen, d * K, state->max_abs_x, mc, state->min_nz_x_bits);
     state->iter = 0;
     state->done = state->bad_input ? 1 : 0;  // non-finite data: every later step is a no-op
     state->error = 0.0;
@@ -231,11 +252,10 @@ __global__ void kmeans_begin_kernel(et_kmeans_state *state, int64_t n_total, con
 // integer atomics, order-free); each workgroup writes one partial block, summed afterwards.
 // ------------------------------------------------------------------------------------------
 template <int D, int VEC>
-__global__ __launch_bounds__(kKmThreads) void kmeans_assign_kernel(
+__device__ __forceinline__ void assign_body_valu(
     const float *__restrict__ X, int64_t N, int d_rt, int K, const et_kmeans_state *__restrict__ state,
     const float *__restrict__ cen, const int64_t *__restrict__ given, uint8_t *__restrict__ labels,
     long long *__restrict__ block_partials) {
-    if (state->done) return;
     const int d = D ? D : d_rt;
     const int plen = d * K + K + 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -336,6 +356,154 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_kernel(
     for (int i = threadIdx.x; i < plen; i += kKmThreads) block_partials[(size_t)i * gridDim.x + blockIdx.x] = sAcc[i];
 }
 
+template <int D, int VEC>
+__global__ __launch_bounds__(kKmThreads) void kmeans_assign_kernel(
+    const float *__restrict__ X, int64_t N, int d_rt, int K, const et_kmeans_state *__restrict__ state,
+    const float *__restrict__ cen, const int64_t *__restrict__ given, uint8_t *__restrict__ labels,
+    long long *__restrict__ block_partials) {
+    if (state->done) return;
+    assign_body_valu<D, VEC>(X, N, d_rt, K, state, cen, given, labels, block_partials);
+}
+
+// ------------------------------------------------------------------------------------------
+// Lloyd half-step on the matrix cores (d = 6, K <= 32, 16-B aligned rows, fast_ok).
+//
+// The VALU version above spends 12 op-slots per (point, cluster) pair and is compute-bound at
+// ~1.8x the time of its 24 B/point read.  v_mfma_f32_32x32x2_f32 evaluates, bit for bit, the
+// k-ordered fmaf chain  D = fma(a_k1, b_k1, fma(a_k0, b_k0, C))  -- which is exactly how the
+// reference's similarity is defined (kmeans.py:71-74) if the chain is laid out as
+//     k = 0..5 : c_i[k] * x_j[k]            three MFMAs, C = 0            (a.b, :71)
+//     VALU     : acc * 2                     exact                          (:72)
+//     k = 6    : 1 * (-|x_j|^2)              fourth MFMA, first half       (:73)
+//     k = 7    : (-|c_i|^2) * 1              fourth MFMA, second half      (:74)
+// with rows i = clusters (A operand, loop invariant) and columns j = points (B operand).
+// One wavefront handles 128 points per pass: lane (h = lane>>5, c = lane&31) loads the float4
+// of coordinate rows h, 2+h, 4+h at points 4c..4c+3; component q of every lane forms MFMA tile q
+// (32 points), so the 16-B loads feed the B operands without any shuffle.  Each lane then owns,
+// for one point, the similarities to 16 clusters (its half); 3 op-slots per pair (compare +
+// two selects) and one cross-half exchange finish the arg-max with the first-maximum rule.
+// ------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// value held by the other half-wave's lane (lane ^ 32), one VALU swap instead of an LDS permute
+__device__ __forceinline__ unsigned other_half(unsigned v, int half) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // r[0] = {lo,lo}, r[1] = {hi,hi}
+    return half ? r[0] : r[1];
+}
+
+__global__ __launch_bounds__(kKmThreads) void kmeans_assign_mfma_kernel(
+    const float *__restrict__ X, int64_t N, int K, const et_kmeans_state *__restrict__ state,
+    const float *__restrict__ cen, uint8_t *__restrict__ labels, long long *__restrict__ block_partials) {
+    if (state->done) return;
+    constexpr int d = 6;
+    if (state->fast_ok < 2) {  // NaN/Inf or sub-2^-50 magnitudes possible: the scalar path decides
+        assign_body_valu<6, 4>(X, N, d, K, state, cen, nullptr, labels, block_partials);
+        return;
+    }
+    const int plen = d * K + K + 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    long long *sAcc = reinterpret_cast<long long *>(smem_raw);
+    const int frac = (int)state->frac, sfrac = (int)state->sim_frac;
+    const bool incremental = state->iter > 0;
+    for (int i = threadIdx.x; i < plen; i += kKmThreads) sAcc[i] = 0;
+
+    const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+    // A operands (loop invariant): row i = col is a cluster, k-slot = half.  2c instead of c folds the
+    // "y *= 2" of kmeans.py:72 into the chain (exact under fast_ok == 2).
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, bn = __int_as_float(0x7f800000);  // +inf: clusters >= K never win
+    if (col < K) {
+        bn = 0.f;
+#pragma unroll
+        for (int i = 0; i < d; ++i) {
+            const float v = cen[i * K + col];
+            bn = bn + v * v;  // kmeans.py:74 |b|^2, sequential
+        }
+        a0 = 2.0f * cen[(0 + half) * K + col];
+        a1 = 2.0f * cen[(2 + half) * K + col];
+        a2 = 2.0f * cen[(4 + half) * K + col];
+    }
+    const float a3 = half ? -bn : 1.0f;
+    const int nblk = (K + 7) >> 3;  // 4-register blocks of the accumulator that hold clusters < K
+    __syncthreads();
+
+    long long sim_acc = 0;
+    const int64_t n_groups = (N + 127) / 128;
+    const int wave = threadIdx.x >> 6;
+    for (int64_t g = (int64_t)blockIdx.x * (kKmThreads / 64) + wave; g < n_groups; g += (int64_t)gridDim.x * (kKmThreads / 64)) {
+        const int64_t n = g * 128 + 4 * col;
+        const bool valid = n < N;  // N % 4 == 0: a lane's four points are all in or all out
+        float4 v[6];
+        unsigned old_packed = 0xffffffffu;
+        if (valid) {
+            // both halves read all six rows (the second half of these requests hits the lines the
+            // other half just fetched): every lane can then form |x|^2 itself
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[i] = *reinterpret_cast<const float4 *>(X + (int64_t)i * N + n);
+            if (incremental) old_packed = *reinterpret_cast<const unsigned *>(labels + n);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        unsigned packed = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) x[i] = q == 0 ? v[i].x : (q == 1 ? v[i].y : (q == 2 ? v[i].z : v[i].w));
+            float an = 0.f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) an = an + x[i] * x[i];  // kmeans.py:73 |a|^2, sequential
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, half ? x[1] : x[0], acc, 0, 0, 0);   // 2 c.x, k = 0,1
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, half ? x[3] : x[2], acc, 0, 0, 0);   //        k = 2,3
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, half ? x[5] : x[4], acc, 0, 0, 0);   //        k = 4,5
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, half ? 1.0f : -an, acc, 0, 0, 0);    // - |a|^2, - |b|^2
+            // this lane: point (col, q), clusters (r&3) + 8*(r>>2) + 4*half, ascending in r
+            float bv = __int_as_float(0xff800000);
+            int lb = 0;
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                if (blk < nblk) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = acc[4 * blk + e];
+                        const bool t = y > bv;
+                        bv = t ? y : bv;
+                        lb = t ? (e + 8 * blk + 4 * half) : lb;
+                    }
+                }
+            }
+            const float pv = __uint_as_float(other_half(__float_as_uint(bv), half));
+            const int pl = (int)other_half((unsigned)lb, half);
+            const bool tp = (pv > bv) || (pv == bv && pl < lb);  // first maximum over both halves
+            bv = tp ? pv : bv;
+            lb = tp ? pl : lb;
+            packed |= (unsigned)lb << (8 * q);
+            if (valid && (q >> 1) == half) {  // each half finishes two of the lane's four points
+                const int old = incremental ? (int)((old_packed >> (8 * q)) & 0xffu) : -1;
+                if (lb != old) {
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + lb]), 1ull);
+                    if (old >= 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + old]), ~0ull);
+#pragma unroll
+                    for (int i = 0; i < d; ++i) {
+                        const unsigned long long f = (unsigned long long)to_fixed(x[i], frac);
+                        atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[i * K + lb]), f);
+                        if (old >= 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[i * K + old]), 0ull - f);
+                    }
+                }
+                sim_acc += to_fixed(bv, sfrac);
+            }
+        }
+        if (valid && half == 0 && (packed != old_packed || !incremental)) *reinterpret_cast<unsigned *>(labels + n) = packed;
+    }
+    for (int o = 32; o > 0; o >>= 1) sim_acc += __shfl_xor(sim_acc, o);
+    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K]), (unsigned long long)sim_acc);
+    __syncthreads();
+    for (int i = threadIdx.x; i < plen; i += kKmThreads) block_partials[(size_t)i * gridDim.x + blockIdx.x] = sAcc[i];
+}
+
 // Fold the workgroup deltas into the shard's running totals: one workgroup per entry, unit-stride
 // reads.  Cluster sums / counts accumulate across iterations (deltas), the similarity sum and
 // the NaN count are per-iteration quantities and are overwritten.
@@ -393,7 +561,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_update_kernel(et_kmeans_sta
         const double mc = max_abs_centroid(sNew, d * K);
         state->max_abs_c = mc;
         state->sim_frac = sim_frac_bits(state->max_abs_x, mc, d, n_total);
-        state->fast_ok = fast_ok_flag(sNew, d * K, state->max_abs_x, mc);
+        state->fast_ok = fast_ok_flag(sNew, d * K, state->max_abs_x, mc, state->min_nz_x_bits);
         if (trace) {
             trace[2 * state->iter] = error;
             trace[2 * state->iter + 1] = inertia;
@@ -608,6 +776,7 @@ extern "C" int et_kmeans_scan(const float *X, int64_t N, int d, et_kmeans_state 
     if (!state || N < 0 || d < 1 || d > ET_KMEANS_MAX_D || (N > 0 && !X)) return ET_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     ET_HIP_TRY(hipMemsetAsync(state, 0, sizeof(et_kmeans_state), st));
+    ET_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)&state->min_nz_x_bits, 0x7f800000, 1, st));  // "+inf": no non-zero yet
     if (N == 0) return ET_OK;
     hipLaunchKernelGGL(kmeans_scan_kernel, dim3(km_grid(N * d / 4 + 1)), dim3(kKmThreads), 0, st, X, N * d, state);
     ET_LAUNCH_CHECK();
@@ -631,9 +800,23 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, const
     if (!workspace || workspace_bytes < et_kmeans_workspace_bytes(N, d, K)) return ET_ERR_WORKSPACE;
     const KmWorkspace w = km_carve(workspace, N, d, K);
     const bool vec4 = (N % 4 == 0) && aligned16(X) && ((reinterpret_cast<uintptr_t>(labels_u8) & 3u) == 0);
-    const int grid = N > 0 ? km_grid(vec4 ? N / 4 : N) : 1;
+    // The matrix-core arg-max is bit-identical but measured slower than the packed VALU kernel on MI355X
+    // (f32 MFMA runs at the VALU rate and 12 of its 32 rows are padding for K = 20), so it
+    // stays opt-in: ET_KMEANS_ARGMAX=mfma.
+    static const bool want_mfma = [] {
+        const char *e = getenv("ET_KMEANS_ARGMAX");
+        return e && e[0] == 'm';
+    }();
+    const bool use_mfma = want_mfma && vec4 && d == 6 && K <= 32 && !given_labels && N >= 128;
+    const int grid = N > 0 ? (use_mfma ? km_grid(N / 2) : km_grid(vec4 ? N / 4 : N)) : 1;
     if (ev_begin) ET_HIP_TRY(hipEventRecord(ev_begin, st));
-    if (d == 6) launch_assign<6>(X, N, d, K, state, centroids, given_labels, labels_u8, w.block_partials, grid, vec4, st);
+    if (use_mfma) {
+        // matrix-core arg-max; falls back to the NaN-aware VALU body inside the kernel when !state->fast_ok
+        const size_t plen_ = km_plen(d, K);
+        const size_t lds = sizeof(long long) * ((plen_ + 1) & ~(size_t)1) + sizeof(float) * (size_t)K * 8;
+        hipLaunchKernelGGL(kmeans_assign_mfma_kernel, dim3(grid), dim3(kKmThreads), lds, st, X, N, K, state, centroids,
+                           labels_u8, w.block_partials);
+    } else if (d == 6) launch_assign<6>(X, N, d, K, state, centroids, given_labels, labels_u8, w.block_partials, grid, vec4, st);
     else launch_assign<0>(X, N, d, K, state, centroids, given_labels, labels_u8, w.block_partials, grid, vec4, st);
     ET_LAUNCH_CHECK();
     if (ev_end) ET_HIP_TRY(hipEventRecord(ev_end, st));

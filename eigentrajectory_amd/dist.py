@@ -118,6 +118,7 @@ class ShardedKMeans:
         # global max|x| and non-finite flag
         _all_reduce(sh.state_f64[0:1], dist.ReduceOp.MAX, self.group)
         _all_reduce(sh.state[7:8], dist.ReduceOp.MAX, self.group)
+        _all_reduce(sh.state[11:12], dist.ReduceOp.MIN, self.group)  # smallest non-zero |x| (fp32 bits)
         sh.begin(self.n_total, centroids)
         reduced = torch.zeros_like(sh.partials)
         st = None

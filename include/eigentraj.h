@@ -150,7 +150,8 @@ typedef struct et_kmeans_state {
     int64_t bad_input;  /* 1 if X holds NaN/Inf (all-reduce MAX)                           */
     double error;       /* kmeans.py:45-51 of the last update                              */
     double inertia;     /* kmeans.py:53-57 of the last assignment                          */
-    int64_t fast_ok;    /* 1 when no similarity of the next assignment can be NaN/Inf      */
+    int64_t fast_ok;    /* 0/1/2: which arg-max kernel the next assignment may use          */
+    int64_t min_nz_x_bits; /* fp32 bit pattern of the smallest non-zero |x| (all-reduce MIN) */
 } et_kmeans_state;
 
 /* kmeans.py:59-76 euc_sim for one batch element: a (d,m), b (d,n) -> y (m,n) */

@@ -26,7 +26,7 @@ class OracleShard:
         self.X = np.ascontiguousarray(X.numpy() if isinstance(X, torch.Tensor) else X, dtype=np.float32)
         self.d, self.n = self.X.shape
         self.K = K
-        self.state = torch.zeros((11,), dtype=torch.int64)
+        self.state = torch.zeros((12,), dtype=torch.int64)
         self.partials = torch.zeros((self.d * K + K + 2,), dtype=torch.int64)
         self._labels = np.zeros((self.n,), np.int64)
         self.best = np.zeros((self.n,), np.float32)
@@ -40,6 +40,8 @@ class OracleShard:
         self.state.zero_()
         self.state_f64[0] = float(np.abs(self.X).max()) if self.n else 0.0
         self.state[7] = int(not np.isfinite(self.X).all())
+        nz = np.abs(self.X[self.X != 0])
+        self.state[11] = int(nz.min().view(np.uint32)) if nz.size else 0x7f800000
 
     def begin(self, n_total, centroids):
         mx = float(self.state_f64[0])

@@ -342,8 +342,11 @@ def test_kmeans_sharded_steps_partition_independent(ops, oracle, dev):
     assert mx == float(whole.state_f64[0].item()) == float(np.abs(x).max())
     cen = [T(c0, dev).clone() for _ in shards]
     cw = T(c0, dev).clone()
+    mn = min(int(sh.state[11].item()) for sh in shards)
+    assert mn == int(whole.state[11].item()) == int(np.abs(x[x != 0]).min().view(np.uint32))
     for sh, c in zip(shards, cen):
         sh.state_f64[0] = mx  # what an all-reduce(MAX) leaves on every rank
+        sh.state[11] = mn     # ... and the all-reduce(MIN) of the smallest non-zero magnitude
         sh.begin(10007, c)
     whole.begin(10007, cw)
     for it in range(6):

@@ -108,6 +108,68 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ X, long N, in
     if (total == 123.456f) acc[0] = total;
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ unsigned other_half(unsigned v, int half) { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return half ? r[0] : r[1]; }
+// M=0: full arg-max; M=1: MFMA only (sum acc); M=2: no MFMA (loads + fake argmax)
+template <int M>
+__global__ __launch_bounds__(256) void km(const float* __restrict__ X, long N, int K, const float* __restrict__ cen8, unsigned* __restrict__ out, float* __restrict__ accout) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, bn = __int_as_float(0x7f800000);
+    if (col < K) { bn = cen8[col * 8 + 6]; a0 = 2.f * cen8[col * 8 + half]; a1 = 2.f * cen8[col * 8 + 2 + half]; a2 = 2.f * cen8[col * 8 + 4 + half]; }
+    const float a3 = half ? -bn : 1.0f;
+    const int nblk = (K + 7) >> 3;
+    const long n_groups = (N + 127) / 128;
+    const int wave = threadIdx.x >> 6;
+    float total = 0.f;
+    for (long g = (long)blockIdx.x * 4 + wave; g < n_groups; g += (long)gridDim.x * 4) {
+        const long n = g * 128 + 4 * col;
+        float4 v[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] = *reinterpret_cast<const float4*>(X + (long)i * N + n);
+        unsigned packed = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) x[i] = q == 0 ? v[i].x : (q == 1 ? v[i].y : (q == 2 ? v[i].z : v[i].w));
+            float an = 0.f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) an = an + x[i] * x[i];
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if (M != 2) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, half ? x[1] : x[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, half ? x[3] : x[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, half ? x[5] : x[4], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, half ? 1.0f : -an, acc, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = x[r % 6] * a0 + an * (float)r;
+            }
+            if (M == 1) { float s = 0; for (int r = 0; r < 16; ++r) s += acc[r]; total += s; continue; }
+            float bv = __int_as_float(0xff800000); int lb = 0;
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) if (blk < nblk) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float y = acc[4 * blk + e]; const bool t = y > bv; bv = t ? y : bv; lb = t ? (e + 8 * blk + 4 * half) : lb; }
+            }
+            const float pv = __uint_as_float(other_half(__float_as_uint(bv), half));
+            const int pl = (int)other_half((unsigned)lb, half);
+            const bool tp = (pv > bv) || (pv == bv && pl < lb);
+            bv = tp ? pv : bv; lb = tp ? pl : lb;
+            packed |= (unsigned)lb << (8 * q); total += bv;
+        }
+        if (half == 0) out[g * 32 + col] = packed;
+    }
+    if (total == 123.456f) accout[0] = total;
+}
+template <int M> float runm(const float* X, long N, int K, const float* cen, unsigned* out, float* acc, int grid) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); float best = 1e9;
+    for (int r = 0; r < 6; ++r) { CK(hipEventRecord(a)); hipLaunchKernelGGL((km<M>), dim3(grid), dim3(256), 0, 0, X, N, K, cen, out, acc); CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); if (r > 0 && ms < best) best = ms; }
+    return best;
+}
+
 template <int V> float run(const float* X, long N, int K, const float* cen, unsigned* out, float* acc, int grid) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     float best = 1e9;
@@ -134,6 +196,10 @@ int main(int argc, char** argv) {
     t = run<3>(X, N, K, cen, out, acc, full); printf("V3 load-only 1grp/thread grid=%d: %.1f us  %.0f GB/s\n", full, t * 1e3, N * 24 / t / 1e6);
     t = run<0>(X, N, K, cen, out, acc, full); printf("V0 argmax 1grp/thread grid=%d: %.1f us  %.0f GB/s\n", full, t * 1e3, N * 24 / t / 1e6);
     t = run<4>(X, N, K, cen, out, acc, full); printf("V4 argmax scalar 1grp/thread grid=%d: %.1f us  %.0f GB/s\n", full, t * 1e3, N * 24 / t / 1e6);
+    for (int grid : {1024, 2048, 4096, 19532}) {
+        float t0 = runm<0>(X, N, K, cen, out, acc, grid), t1 = runm<1>(X, N, K, cen, out, acc, grid), t2 = runm<2>(X, N, K, cen, out, acc, grid);
+        printf("MFMA grid=%d: full %.1f us | mfma-only %.1f us | no-mfma %.1f us\n", grid, t0 * 1e3, t1 * 1e3, t2 * 1e3);
+    }
     for (int grid : {4096}) {
         t = run<1>(X, N, K, cen, out, acc, grid); printf("V1 grid-stride grid=%d: %.1f us  %.0f GB/s\n", grid, t * 1e3, N * 24 / t / 1e6);
         t = run<2>(X, N, K, cen, out, acc, grid); printf("V2 grid-stride+prefetch grid=%d: %.1f us  %.0f GB/s\n", grid, t * 1e3, N * 24 / t / 1e6);
