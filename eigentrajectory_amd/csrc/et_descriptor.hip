@@ -229,6 +229,10 @@ __device__ __forceinline__ RowNorm load_row_norm(const float *__restrict__ nrm, 
 }
 
 constexpr int kNormStride = 8;  // floats per cached RowNorm in LDS
+#ifndef ET_RECON_DIRECT
+#define ET_RECON_DIRECT 0
+#endif
+constexpr bool kReconDirect = ET_RECON_DIRECT != 0;  // experiment: per-lane row stores instead of the LDS-staged tile
 
 __device__ __forceinline__ void store_row_norm(float *s, const RowNorm &p) {
     s[0] = p.ox;
@@ -277,6 +281,22 @@ __global__ __launch_bounds__(kTile) void reconstruct_tile_kernel(
     const int64_t n0 = (int64_t)blockIdx.x * TN;
     const int rows = (int)min((int64_t)TN, N - n0);
 
+    // issue this lane's coefficient loads first: they are in flight while U / anchors / normaliser
+    // state are staged (one exposed HBM latency per workgroup instead of two)
+    const int npairs = rows * S;
+    const int nl = tid / S, s = tid - nl * S;
+    const int64_t n = n0 + nl;
+    float craw[K];
+    if (tid < npairs) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) craw[j] = C[((int64_t)j * N + n) * S + s];
+    }
+    RowNorm p;
+    if (S == 1) {  // lane == trajectory: the normaliser state never leaves the registers
+        if (tid < rows) p = load_row_norm(nrm, obs, N, n, T_obs, mode, static_dist);
+    } else if (tid < rows) {
+        store_row_norm(sNorm + tid * kNormStride, load_row_norm(nrm, obs, N, n0 + tid, T_obs, mode, static_dist));
+    }
     for (int i = tid; i < 2 * DP * K; i += kTile) {
         const float *src = (i >= DP * K) ? U_m : U_s;
         sU[i] = src ? src[i % (DP * K)] : 0.f;
@@ -285,20 +305,17 @@ __global__ __launch_bounds__(kTile) void reconstruct_tile_kernel(
         const float *src = (i >= K * S) ? A_m : A_s;
         sA[i] = src ? src[i % (K * S)] : 0.f;
     }
-    if (tid < rows) store_row_norm(sNorm + tid * kNormStride, load_row_norm(nrm, obs, N, n0 + tid, T_obs, mode, static_dist));
     __syncthreads();
 
-    const int npairs = rows * S;
     if (tid < npairs) {
-        const int nl = tid / S, s = tid - nl * S;
-        const int64_t n = n0 + nl;
-        const RowNorm p = fetch_row_norm(sNorm + nl * kNormStride);
+        if (S != 1) p = fetch_row_norm(sNorm + nl * kNormStride);
         const float *u = sU + p.mv * DP * K;
         const float *a = sA + p.mv * K * S;
         float c[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) c[j] = a[j * S + s] + C[((int64_t)j * N + n) * S + s];  // anchor.py:87
-        float4 *dst = reinterpret_cast<float4 *>(sOut + ((size_t)s * rows + nl) * DP);
+        for (int j = 0; j < K; ++j) c[j] = a[j * S + s] + craw[j];  // anchor.py:87
+        float4 *dst = kReconDirect ? reinterpret_cast<float4 *>(out + (((int64_t)s * N + n) * DP))
+                                   : reinterpret_cast<float4 *>(sOut + ((size_t)s * rows + nl) * DP);
 #pragma unroll
         for (int q = 0; q < QP; ++q) {
             float v[4];
@@ -316,6 +333,7 @@ __global__ __launch_bounds__(kTile) void reconstruct_tile_kernel(
             dst[q] = o;
         }
     }
+    if (kReconDirect) return;
     __syncthreads();
 
     // coalesced write-back: plane s holds rows*QP consecutive float4 starting at row n0

@@ -549,6 +549,32 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_update_kernel(et_kmeans_sta
         cen[e] = c;
     }
     __syncthreads();
+    // max |c| (NaN ignored), smallest non-zero |c| and a non-finite flag, reduced by the first wavefront
+    __shared__ float sRed[3];
+    if (threadIdx.x < 64) {
+        float mx = 0.f;
+        unsigned mn = 0x7f800000u;
+        int bad = 0;
+        for (int e = threadIdx.x; e < d * K; e += 64) {
+            const float a = fabsf(sNew[e]);
+            if (!(a <= 3.402823466e+38f)) bad = 1;
+            if (a > mx) mx = a;  // false for NaN: ignored, like the oracle
+            const unsigned b = (unsigned)__float_as_int(a);
+            if (a <= 3.402823466e+38f && b != 0u && b < mn) mn = b;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            mx = fmaxf(mx, __shfl_xor(mx, o));
+            const unsigned other = (unsigned)__shfl_xor((int)mn, o);
+            mn = other < mn ? other : mn;
+            bad |= __shfl_xor(bad, o);
+        }
+        if (threadIdx.x == 0) {
+            sRed[0] = mx;
+            sRed[1] = __int_as_float((int)mn);
+            sRed[2] = bad ? 1.f : 0.f;
+        }
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         double err = 0.0;
         for (int e = 0; e < d * K; ++e) err += (double)sSq[e];  // :50, fixed order
@@ -558,10 +584,16 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_update_kernel(et_kmeans_sta
         float inertia;
         if (nan_count > 0) inertia = __int_as_float(0x7fc00000);
         else inertia = (float)(-(((double)sim_sum * ldexp(1.0, -(int)state->sim_frac)) / (double)n_total));  // :57
-        const double mc = max_abs_centroid(sNew, d * K);
+        const double mc = (double)sRed[0];
+        const double mx = state->max_abs_x;
         state->max_abs_c = mc;
-        state->sim_frac = sim_frac_bits(state->max_abs_x, mc, d, n_total);
-        state->fast_ok = fast_ok_flag(sNew, d * K, state->max_abs_x, mc, state->min_nz_x_bits);
+        state->sim_frac = sim_frac_bits(mx, mc, d, n_total);
+        int64_t fast = 0;
+        if (sRed[2] == 0.f && mx < 1e18 && mc < 1e18) {
+            const unsigned lim = 0x26800000u;  // 2^-50, see fast_ok_flag()
+            fast = ((unsigned)__float_as_int(sRed[1]) >= lim && (unsigned long long)state->min_nz_x_bits >= lim) ? 2 : 1;
+        }
+        state->fast_ok = fast;
         if (trace) {
             trace[2 * state->iter] = error;
             trace[2 * state->iter + 1] = inertia;

@@ -294,13 +294,17 @@ int eto_fit_gram(const float *obs, const float *pred, int64_t N, int T_obs, int 
     return ETO_OK;
 }
 
-/* Cyclic Jacobi, fp64, symmetric n x n (n <= 64).  Fixed rotation order
- * (p < q row-major), fixed formulas: the HIP kernel et_eigh_topk executes the
- * same arithmetic and must agree bit for bit.  A is destroyed; on return
- * evals[i] = A[i][i], V columns = eigenvectors. */
+/* Parallel-order (round-robin) Jacobi, fp64, symmetric n x n (n <= 64).  Every round applies
+ * n/2 disjoint rotations J = J_1 (+) ... (+) J_{n/2}:  A <- J^T A J, as "all row updates, then all
+ * column updates".  The pairing is the circle method of a round-robin tournament.  The HIP
+ * kernel et_eigh_topk executes the same arithmetic element by element and must agree bit for
+ * bit.  A is destroyed; on return evals[i] = A[i][i], V columns = eigenvectors. */
 #define ETO_JACOBI_MAX_SWEEPS 30
 static void eto_jacobi(double *A, int n, double *V)
 {
+    const int m = (n + 1) & ~1; /* players, even; index n (if any) is a dummy */
+    int pp[32], qq[32], act[32];
+    double cc[32], ss[32];
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < ETO_JACOBI_MAX_SWEEPS; ++sweep) {
@@ -310,30 +314,57 @@ static void eto_jacobi(double *A, int n, double *V)
             for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
         }
         if (off <= 1e-30 * diag || off == 0.0) break;
-        for (int p = 0; p < n - 1; ++p) {
-            for (int q = p + 1; q < n; ++q) {
+        for (int r = 0; r < m - 1; ++r) {
+            for (int i = 0; i < m / 2; ++i) {
+                int a, b;
+                if (i == 0) {
+                    a = m - 1;
+                    b = r;
+                } else {
+                    a = (r + i) % (m - 1);
+                    b = (r + (m - 1) - i) % (m - 1);
+                }
+                const int p = a < b ? a : b, q = a < b ? b : a;
+                pp[i] = p;
+                qq[i] = q;
+                act[i] = 0;
+                if (q >= n) continue;
                 const double apq = A[p * n + q];
                 if (apq == 0.0) continue;
                 const double app = A[p * n + p], aqq = A[q * n + q];
                 const double theta = (aqq - app) / (2.0 * apq);
                 const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0);
-                const double s = t * c;
-                for (int j = 0; j < n; ++j) { /* rows p,q of A and of V^T */
+                cc[i] = 1.0 / sqrt(t * t + 1.0);
+                ss[i] = t * cc[i];
+                act[i] = 1;
+            }
+            for (int i = 0; i < m / 2; ++i) { /* rows p,q of every pair */
+                if (!act[i]) continue;
+                const int p = pp[i], q = qq[i];
+                const double c = cc[i], s_ = ss[i];
+                for (int j = 0; j < n; ++j) {
                     const double apj = A[p * n + j], aqj = A[q * n + j];
-                    A[p * n + j] = c * apj - s * aqj;
-                    A[q * n + j] = s * apj + c * aqj;
+                    A[p * n + j] = c * apj - s_ * aqj;
+                    A[q * n + j] = s_ * apj + c * aqj;
                 }
-                for (int j = 0; j < n; ++j) { /* columns p,q */
+            }
+            for (int i = 0; i < m / 2; ++i) { /* columns p,q of every pair, and of V */
+                if (!act[i]) continue;
+                const int p = pp[i], q = qq[i];
+                const double c = cc[i], s_ = ss[i];
+                for (int j = 0; j < n; ++j) {
                     const double ajp = A[j * n + p], ajq = A[j * n + q];
-                    A[j * n + p] = c * ajp - s * ajq;
-                    A[j * n + q] = s * ajp + c * ajq;
+                    A[j * n + p] = c * ajp - s_ * ajq;
+                    A[j * n + q] = s_ * ajp + c * ajq;
                     const double vjp = V[j * n + p], vjq = V[j * n + q];
-                    V[j * n + p] = c * vjp - s * vjq;
-                    V[j * n + q] = s * vjp + c * vjq;
+                    V[j * n + p] = c * vjp - s_ * vjq;
+                    V[j * n + q] = s_ * vjp + c * vjq;
                 }
-                A[p * n + q] = 0.0;
-                A[q * n + p] = 0.0;
+            }
+            for (int i = 0; i < m / 2; ++i) {
+                if (!act[i]) continue;
+                A[pp[i] * n + qq[i]] = 0.0;
+                A[qq[i] * n + pp[i]] = 0.0;
             }
         }
     }

@@ -11,12 +11,16 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 what = sys.argv[2] if len(sys.argv) > 2 else "all"
 obs, pred = synthetic_trajectories_torch(n, dev, seed=0, min_disp=1e-3)
 
-def timeit(fn, reps=10, warm=2):
+def timeit(fn, reps=10, warm=2, inner=4):
+    """median / min time of one call; `inner` back-to-back calls per measurement keep the GPU busy so that
+    the host-side launch latency is not counted."""
     for _ in range(warm): fn()
     ts = []
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); fn(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+        fn(); a.record()
+        for _ in range(inner): fn()
+        b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) / inner)
     return float(np.median(ts)), float(np.min(ts))
 
 g_obs, g_pred, _ = ops.fit_gram(obs, pred, 1, 0.0, 1)
