@@ -86,16 +86,43 @@ __global__ __launch_bounds__(kFitThreads) void gram_tile_kernel(
     int my_count = 0;
 
     const int64_t n_tiles = ceil_div(N, (int64_t)kFitTile);
+    // software pipeline: the raw rows of the NEXT tile are fetched into registers while the current
+    // tile is normalised and accumulated, so the HBM latency is paid once, not once per tile
+    constexpr int NLO = (kFitTile * QO + kFitThreads - 1) / kFitThreads;  // float4 of obs per thread
+    constexpr int NLP = (kFitTile * QP + kFitThreads - 1) / kFitThreads;  // float4 of pred per thread
+    float4 ro[NLO], rp[NLP];
+    auto fetch = [&](int64_t tile) {
+        const int64_t n0 = tile * kFitTile;
+        const int rows = (int)min((int64_t)kFitTile, N - n0);
+        const float4 *go = reinterpret_cast<const float4 *>(obs + n0 * DO);
+        const float4 *gp = reinterpret_cast<const float4 *>(pred + n0 * DP);
+#pragma unroll
+        for (int j = 0; j < NLO; ++j) {
+            const int q = tid + j * kFitThreads;
+            ro[j] = q < rows * QO ? go[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < NLP; ++j) {
+            const int q = tid + j * kFitThreads;
+            rp[j] = q < rows * QP ? gp[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t n0 = tile * kFitTile;
         const int rows = (int)min((int64_t)kFitTile, N - n0);
         __syncthreads();  // previous pass done with sFeat / sObs
-        {
-            const float4 *go = reinterpret_cast<const float4 *>(obs + n0 * DO);
-            const float4 *gp = reinterpret_cast<const float4 *>(pred + n0 * DP);
-            for (int q = tid; q < rows * QO; q += kFitThreads) sObs[(q / QO) * PO + (q % QO)] = go[q];
-            for (int q = tid; q < rows * QP; q += kFitThreads) sPred[(q / QP) * PP + (q % QP)] = gp[q];
+#pragma unroll
+        for (int j = 0; j < NLO; ++j) {
+            const int q = tid + j * kFitThreads;
+            if (q < kFitTile * QO) sObs[(q / QO) * PO + (q % QO)] = ro[j];
         }
+#pragma unroll
+        for (int j = 0; j < NLP; ++j) {
+            const int q = tid + j * kFitThreads;
+            if (q < kFitTile * QP) sPred[(q / QP) * PP + (q % QP)] = rp[j];
+        }
+        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
         __syncthreads();
         if (tid < kFitTile) {
             double *f = sFeat + tid * FP;
@@ -311,7 +338,7 @@ __global__ __launch_bounds__(kFitThreads) void gram_generic_finish_kernel(const 
 }
 
 // ------------------------------------------------------------------------------------------
-// Parallel-order (round-robin) Jacobi eigensolver on ONE wavefront, fp64, n <= 64, matrix in LDS.
+// Parallel-order (round-robin) Jacobi eigensolver in ONE workgroup, fp64, n <= 64, matrix in LDS.
 // A round applies n/2 disjoint rotations: lanes compute the (c, s) of one pair each, then all
 // lanes sweep the row updates of every pair, then the column updates (A and V): three barriers
 // per round instead of four per rotation.  Same pairing, same formulas and the same per-element
@@ -319,32 +346,60 @@ __global__ __launch_bounds__(kFitThreads) void gram_generic_finish_kernel(const 
 // 24 x 24 converges in ~8 sweeps (23 rounds each).
 // ------------------------------------------------------------------------------------------
 constexpr int kJacobiMaxSweeps = 30;
+constexpr int kEighThreads = 256;  // 4 wavefronts share the element updates of a round
 
-__global__ __launch_bounds__(64) void eigh_topk_kernel(const double *__restrict__ G, int n, int k,
+__global__ __launch_bounds__(kEighThreads) void eigh_topk_kernel(const double *__restrict__ G, int n, int k,
                                                        float *__restrict__ U, float *__restrict__ sigma) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *A = sm;                  // n*n
     double *V = sm + n * n;          // n*n
     double *sC = V + n * n;          // 32 cosines
     double *sS = sC + 32;            // 32 sines
-    int *sP = reinterpret_cast<int *>(sS + 32);  // 32 p, 32 q, 32 active, 64 used, 1 flag
+    int *sP = reinterpret_cast<int *>(sS + 32 + 2 * (kEighThreads / 64));  // 32 p, 32 q, 32 active, 64 used, 1 flag
     int *sQ = sP + 32, *sAct = sQ + 32, *sUsed = sAct + 32;
     int &sFlag = sUsed[64];
     const int lane = threadIdx.x;
     const int m = (n + 1) & ~1, half = m / 2;
-    for (int i = lane; i < n * n; i += 64) {
+    for (int i = lane; i < n * n; i += kEighThreads) {
         A[i] = G[i];
         V[i] = (i / n == i % n) ? 1.0 : 0.0;
     }
     __syncthreads();
+    // element slots of this thread in the row / column phases: e = lane + t*256 -> (pair i, index j)
+    constexpr int kSlots = (32 * 64 + kEighThreads - 1) / kEighThreads;
+    int slot_i[kSlots], slot_j[kSlots];
+#pragma unroll
+    for (int t = 0; t < kSlots; ++t) {
+        const int e = lane + t * kEighThreads;
+        slot_i[t] = e < half * n ? e / n : -1;
+        slot_j[t] = e < half * n ? e % n : 0;
+    }
+    double *sMax = sS + 32;  // 2 * (kEighThreads / 64) partial maxima
     for (int sweep = 0; sweep < kJacobiMaxSweeps; ++sweep) {
+        // converged when max |off-diagonal| <= 1e-15 max |diagonal| (maxima: order independent)
+        double off = 0.0, diag = 0.0;
+        for (int e = lane; e < n * n; e += kEighThreads) {
+            const int i = e / n, j = e - i * n;
+            const double a = fabs(A[e]);
+            if (i == j) diag = a > diag ? a : diag;
+            else if (j > i) off = a > off ? a : off;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const double po = __shfl_xor(off, o), pd = __shfl_xor(diag, o);
+            off = po > off ? po : off;
+            diag = pd > diag ? pd : diag;
+        }
+        if ((lane & 63) == 0) {
+            sMax[2 * (lane >> 6)] = off;
+            sMax[2 * (lane >> 6) + 1] = diag;
+        }
+        __syncthreads();
         if (lane == 0) {
-            double off = 0.0, diag = 0.0;
-            for (int i = 0; i < n; ++i) {
-                diag += A[i * n + i] * A[i * n + i];
-                for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
+            for (int w = 1; w < kEighThreads / 64; ++w) {
+                off = sMax[2 * w] > off ? sMax[2 * w] : off;
+                diag = sMax[2 * w + 1] > diag ? sMax[2 * w + 1] : diag;
             }
-            sFlag = (off <= 1e-30 * diag || off == 0.0) ? 1 : 0;
+            sFlag = (off <= 1e-15 * diag) ? 1 : 0;
         }
         __syncthreads();
         if (sFlag) break;
@@ -377,9 +432,10 @@ __global__ __launch_bounds__(64) void eigh_topk_kernel(const double *__restrict_
                 sAct[lane] = act;
             }
             __syncthreads();
-            for (int e = lane; e < half * n; e += 64) {  // rows p,q of every pair
-                const int i = e / n, j = e - i * n;
-                if (sAct[i]) {
+#pragma unroll
+            for (int t = 0; t < kSlots; ++t) {  // rows p,q of every pair
+                const int i = slot_i[t], j = slot_j[t];
+                if (i >= 0 && sAct[i]) {
                     const int p = sP[i], q = sQ[i];
                     const double c = sC[i], s = sS[i];
                     const double apj = A[p * n + j], aqj = A[q * n + j];
@@ -388,9 +444,10 @@ __global__ __launch_bounds__(64) void eigh_topk_kernel(const double *__restrict_
                 }
             }
             __syncthreads();
-            for (int e = lane; e < half * n; e += 64) {  // columns p,q of every pair, A and V
-                const int i = e / n, j = e - i * n;
-                if (sAct[i]) {
+#pragma unroll
+            for (int t = 0; t < kSlots; ++t) {  // columns p,q of every pair, A and V
+                const int i = slot_i[t], j = slot_j[t];
+                if (i >= 0 && sAct[i]) {
                     const int p = sP[i], q = sQ[i];
                     const double c = sC[i], s = sS[i];
                     const double ajp = A[j * n + p], ajq = A[j * n + q];
@@ -410,7 +467,7 @@ __global__ __launch_bounds__(64) void eigh_topk_kernel(const double *__restrict_
         }
     }
     __syncthreads();
-    sUsed[lane] = 0;
+    if (lane < 64) sUsed[lane] = 0;
     __syncthreads();
     for (int j = 0; j < k; ++j) {
         if (lane == 0) {
@@ -494,11 +551,11 @@ extern "C" int et_fit_gram(const float *obs, const float *pred, int64_t N, int T
 
 extern "C" int et_eigh_topk(const double *G, int n, int k, float *U, float *sigma, et_stream_t stream) {
     if (!G || !U || !sigma || n < 1 || n > 64 || k < 1 || k > n) return ET_ERR_INVALID_ARG;
-    const size_t lds = sizeof(double) * (2 * (size_t)n * n + 64) + sizeof(int) * (32 * 3 + 64 + 2);
+    const size_t lds = sizeof(double) * (2 * (size_t)n * n + 64 + 2 * (kEighThreads / 64)) + sizeof(int) * (32 * 3 + 64 + 2);
     if (lds > 48 * 1024)
         ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(eigh_topk_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(eigh_topk_kernel, dim3(1), dim3(64), lds, (hipStream_t)stream, G, n, k, U, sigma);
+    hipLaunchKernelGGL(eigh_topk_kernel, dim3(1), dim3(kEighThreads), lds, (hipStream_t)stream, G, n, k, U, sigma);
     ET_LAUNCH_CHECK();
     return ET_OK;
 }

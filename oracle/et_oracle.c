@@ -308,12 +308,15 @@ static void eto_jacobi(double *A, int n, double *V)
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < ETO_JACOBI_MAX_SWEEPS; ++sweep) {
+        /* converged when the largest off-diagonal magnitude is below 1e-15 of the largest diagonal one
+         * (maxima, so the test does not depend on any summation order) */
         double off = 0.0, diag = 0.0;
         for (int i = 0; i < n; ++i) {
-            diag += A[i * n + i] * A[i * n + i];
-            for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
+            if (fabs(A[i * n + i]) > diag) diag = fabs(A[i * n + i]);
+            for (int j = i + 1; j < n; ++j)
+                if (fabs(A[i * n + j]) > off) off = fabs(A[i * n + j]);
         }
-        if (off <= 1e-30 * diag || off == 0.0) break;
+        if (off <= 1e-15 * diag) break;
         for (int r = 0; r < m - 1; ++r) {
             for (int i = 0; i < m / 2; ++i) {
                 int a, b;
