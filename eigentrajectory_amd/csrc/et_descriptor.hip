@@ -347,6 +347,139 @@ __global__ __launch_bounds__(kTile) void reconstruct_tile_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused evaluation epilogue: the same anchor-add + reconstruction, but instead of
+// writing the (S,N,T,2) trajectories (1920 B per pedestrian at S=20) every pair is compared with the
+// ground truth on the spot and only best-of-S ADE / FDE per pedestrian leave the chip (8 B):
+//   ADE_n = min_s mean_t ||rec[s,n,t] - gt[n,t]||,  FDE_n = min_s ||rec[s,n,T-1] - gt[n,T-1]||
+// (utils/metrics.py:73-102, and the euclidean terms of EigenTrajectory/model.py:120-123).
+// ------------------------------------------------------------------------------------------
+template <int TP, int K>
+__global__ __launch_bounds__(kTile) void reconstruct_metrics_tile_kernel(
+    const float *__restrict__ C, int64_t N, int S, int TN, int T_obs,
+    const float *__restrict__ obs, const float *__restrict__ nrm,
+    const float *__restrict__ A_m, const float *__restrict__ A_s,
+    const float *__restrict__ U_m, const float *__restrict__ U_s,
+    int mode, float static_dist, const float *__restrict__ gt, float *__restrict__ ade, float *__restrict__ fde) {
+    constexpr int DP = 2 * TP, QP = DP / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sGt = smem;                                // TN * DP (16-B aligned)
+    float *sMet = sGt + TN * DP;                      // TN * S * 2
+    float *sNorm = sMet + TN * S * 2;                 // TN * kNormStride
+    float *sU = sNorm + TN * kNormStride;             // 2 * DP * K
+    float *sA = sU + 2 * DP * K;                      // 2 * K * S
+
+    const int tid = threadIdx.x;
+    const int64_t n0 = (int64_t)blockIdx.x * TN;
+    const int rows = (int)min((int64_t)TN, N - n0);
+    const int npairs = rows * S;
+    const int nl = tid / S, s = tid - nl * S;
+    const int64_t n = n0 + nl;
+    float craw[K];
+    if (tid < npairs) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) craw[j] = C[((int64_t)j * N + n) * S + s];
+    }
+    {
+        const float4 *g4 = reinterpret_cast<const float4 *>(gt + n0 * DP);
+        float4 *d4 = reinterpret_cast<float4 *>(sGt);
+        for (int q = tid; q < rows * QP; q += kTile) d4[q] = g4[q];
+    }
+    if (tid < rows) store_row_norm(sNorm + tid * kNormStride, load_row_norm(nrm, obs, N, n0 + tid, T_obs, mode, static_dist));
+    for (int i = tid; i < 2 * DP * K; i += kTile) {
+        const float *src = (i >= DP * K) ? U_m : U_s;
+        sU[i] = src ? src[i % (DP * K)] : 0.f;
+    }
+    for (int i = tid; i < 2 * K * S; i += kTile) {
+        const float *src = (i >= K * S) ? A_m : A_s;
+        sA[i] = src ? src[i % (K * S)] : 0.f;
+    }
+    __syncthreads();
+
+    if (tid < npairs) {
+        const RowNorm p = fetch_row_norm(sNorm + nl * kNormStride);
+        const float *u = sU + p.mv * DP * K;
+        const float *a = sA + p.mv * K * S;
+        float c[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) c[j] = a[j * S + s] + craw[j];
+        const float4 *g4 = reinterpret_cast<const float4 *>(sGt + nl * DP);
+        float sum = 0.f, last = 0.f;
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int f = 4 * q + e;
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < K; ++j) acc = fmaf(u[f * K + j], c[j], acc);
+                v[e] = acc;
+            }
+            float4 o;
+            denormalize_point(p, v[0], v[1], o.x, o.y);
+            denormalize_point(p, v[2], v[3], o.z, o.w);
+            const float4 g = g4[q];
+            const float ex = o.x - g.x, ey = o.y - g.y, fx = o.z - g.z, fy = o.w - g.w;
+            const float d0 = sqrtf(ex * ex + ey * ey), d1 = sqrtf(fx * fx + fy * fy);
+            sum = (sum + d0) + d1;
+            last = d1;
+        }
+        sMet[2 * tid] = sum / (float)TP;
+        sMet[2 * tid + 1] = last;
+    }
+    __syncthreads();
+    if (tid < rows) {
+        float best_a = sMet[2 * (tid * S)], best_f = sMet[2 * (tid * S) + 1];
+        for (int t = 1; t < S; ++t) {
+            const float va = sMet[2 * (tid * S + t)], vf = sMet[2 * (tid * S + t) + 1];
+            best_a = (va < best_a || isnan(va)) ? va : best_a;  // torch.min propagates NaN
+            best_f = (vf < best_f || isnan(vf)) ? vf : best_f;
+        }
+        ade[n0 + tid] = best_a;
+        fde[n0 + tid] = best_f;
+    }
+}
+
+// any-shape fallback: lane = pedestrian, loops over samples and steps
+__global__ __launch_bounds__(kTile) void reconstruct_metrics_generic_kernel(
+    const float *__restrict__ C, int64_t N, int S, int k, int T_obs, int T_pred,
+    const float *__restrict__ obs, const float *__restrict__ nrm,
+    const float *__restrict__ A_m, const float *__restrict__ A_s,
+    const float *__restrict__ U_m, const float *__restrict__ U_s,
+    int mode, float static_dist, const float *__restrict__ gt, float *__restrict__ ade, float *__restrict__ fde) {
+    const int64_t n = (int64_t)blockIdx.x * kTile + threadIdx.x;
+    if (n >= N) return;
+    const RowNorm p = load_row_norm(nrm, obs, N, n, T_obs, mode, static_dist);
+    const float *U = p.mv ? U_m : U_s;
+    const float *A = p.mv ? A_m : A_s;
+    const float *g = gt + n * 2 * T_pred;
+    float best_a = 0.f, best_f = 0.f;
+    for (int s = 0; s < S; ++s) {
+        float c[ET_MAX_K];
+        for (int j = 0; j < k; ++j) {
+            const float cj = C[((int64_t)j * N + n) * S + s];
+            c[j] = A ? A[j * S + s] + cj : cj;
+        }
+        float sum = 0.f, last = 0.f;
+        for (int t = 0; t < T_pred; ++t) {
+            float vx = 0.f, vy = 0.f;
+            for (int j = 0; j < k; ++j) vx = fmaf(U[(2 * t) * k + j], c[j], vx);
+            for (int j = 0; j < k; ++j) vy = fmaf(U[(2 * t + 1) * k + j], c[j], vy);
+            float x, y;
+            denormalize_point(p, vx, vy, x, y);
+            const float ex = x - g[2 * t], ey = y - g[2 * t + 1];
+            last = sqrtf(ex * ex + ey * ey);
+            sum = sum + last;
+        }
+        const float va = sum / (float)T_pred;
+        if (s == 0 || va < best_a || isnan(va)) best_a = va;
+        if (s == 0 || last < best_f || isnan(last)) best_f = last;
+    }
+    ade[n] = best_a;
+    fde[n] = best_f;
+}
+
 // Backward of the above w.r.t. C: dtraj (S,N,T,2) -> dC (k,N,S).  Mirror image: coalesced
 // float4 loads of the gradient tile into LDS, lane = pair, unit-stride dC stores.
 template <int TP, int K>
@@ -517,6 +650,31 @@ extern "C" int et_anchor_reconstruct_fwd(const float *C, int64_t N, int S, int k
         const int64_t pairs = N * S;
         hipLaunchKernelGGL(reconstruct_generic_kernel, dim3((unsigned)ceil_div(pairs, kTile)), dim3(kTile), 0, st, C, N,
                            S, k, T_obs, T_pred, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, out);
+    }
+    ET_LAUNCH_CHECK();
+    return ET_OK;
+}
+
+extern "C" int et_anchor_reconstruct_metrics(const float *C, int64_t N, int S, int k, int T_obs, int T_pred,
+                                             const float *obs, const float *nrm, const float *A_m, const float *A_s,
+                                             const float *U_pred_m, const float *U_pred_s, int mode,
+                                             float static_dist, const float *gt, float *ade, float *fde,
+                                             et_stream_t stream) {
+    if (N < 0 || S < 1 || !dims_ok(T_obs, T_pred, k) || mode < 0 || mode > 3) return ET_ERR_INVALID_ARG;
+    if (N == 0) return ET_OK;
+    if (!C || !gt || !ade || !fde || (!obs && !nrm && mode != ET_MODE_IDENTITY)) return ET_ERR_INVALID_ARG;
+    if ((need_m(mode) && !U_pred_m) || (need_s(mode) && !U_pred_s)) return ET_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const bool fast = T_pred == 12 && k == 6 && S <= kTile && aligned16(gt);
+    if (fast) {
+        const int TN = kTile / S;
+        const size_t lds = sizeof(float) * ((size_t)TN * 24 + (size_t)TN * S * 2 + (size_t)TN * kNormStride + 2 * 24 * 6 +
+                                            2 * 6 * (size_t)S);
+        hipLaunchKernelGGL((reconstruct_metrics_tile_kernel<12, 6>), dim3((unsigned)ceil_div(N, TN)), dim3(kTile), lds, st,
+                           C, N, S, TN, T_obs, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, gt, ade, fde);
+    } else {
+        hipLaunchKernelGGL(reconstruct_metrics_generic_kernel, dim3((unsigned)ceil_div(N, kTile)), dim3(kTile), 0, st, C, N,
+                           S, k, T_obs, T_pred, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, gt, ade, fde);
     }
     ET_LAUNCH_CHECK();
     return ET_OK;

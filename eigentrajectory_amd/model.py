@@ -81,6 +81,26 @@ class EigenTrajectory(nn.Module):
         self.ET_m_anchor.generate_from_coefficients(C_pred[:, moving].contiguous())
         self.ET_s_anchor.generate_from_coefficients(C_pred[:, ~moving].contiguous())
 
+    @torch.no_grad()
+    def evaluate(self, obs_traj, pred_traj, addl_info=None):
+        r"""Best-of-S ADE / FDE per pedestrian without materialising ``recon_traj`` (evaluation form of
+        :meth:`forward` + utils/metrics.py:73-102; utils/trainer.py:183-186 computes the same from the tensor).
+
+        Returns:
+            ade (torch.Tensor): (num_ped,), fde (torch.Tensor): (num_ped,)
+        """
+        sd = self.static_dist
+        U_obs_m, U_pred_m, U_obs_s, U_pred_s = self._U()
+        A_m, A_s = self.ET_m_anchor.C_anchor.detach(), self.ET_s_anchor.C_anchor.detach()
+        C_obs, _, nrm, _ = ops.norm_project(obs_traj, None, U_obs_m, None, U_obs_s, None, ops.MODE_SPLIT, sd,
+                                            want_flag=False)
+        obs_ori = nrm[:2] - nrm[:2].mean(dim=1, keepdim=True)
+        input_data = self.hook_func.model_forward_pre_hook(C_obs, obs_ori, addl_info)
+        output_data = self.hook_func.model_forward(input_data, self.baseline_model)
+        C_pred_refine = self.hook_func.model_forward_post_hook(output_data, addl_info)
+        return ops.anchor_reconstruct_metrics(C_pred_refine.contiguous(), pred_traj, A_m, A_s, U_pred_m, U_pred_s,
+                                              ops.MODE_SPLIT, sd, nrm=nrm, t_obs=obs_traj.shape[1])
+
     def forward(self, obs_traj, pred_traj=None, addl_info=None):
         r"""The forward function of the EigenTrajectory model (model.py:58-125)
 

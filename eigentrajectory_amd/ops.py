@@ -148,6 +148,24 @@ def anchor_reconstruct(Cc, A_m, A_s, U_m, U_s, mode, static_dist=0.0, *, obs=Non
     return _AnchorReconstruct.apply(Cc, obs, nrm, A_m, A_s, U_m, U_s, int(mode), float(static_dist), int(t_obs))
 
 
+def anchor_reconstruct_metrics(Cc, gt, A_m, A_s, U_m, U_s, mode, static_dist=0.0, *, obs=None, nrm=None, t_obs=8):
+    """Best-of-S ADE / FDE per pedestrian (utils/metrics.py:73-102) fused into the reconstruction:
+    C (k,N,S), gt (N,T_pred,2) -> ade (N,), fde (N,).  No autograd (evaluation form)."""
+    dev = L.require_device(Cc)
+    Cc, gt, obs, nrm, A_m, A_s, U_m, U_s = _dev_args(dev, Cc, gt, obs, nrm, A_m, A_s, U_m, U_s)
+    k, n, s = Cc.shape
+    if obs is not None:
+        t_obs = obs.shape[1]
+    t_pred = gt.shape[1]
+    ade = torch.empty((n,), device=dev)
+    fde = torch.empty((n,), device=dev)
+    L.check(L.lib().et_anchor_reconstruct_metrics(L.ptr(Cc), L.i64(n), s, k, int(t_obs), t_pred, L.ptr(obs), L.ptr(nrm),
+                                                  L.ptr(A_m), L.ptr(A_s), L.ptr(U_m), L.ptr(U_s), int(mode),
+                                                  L.f32(static_dist), L.ptr(gt), L.ptr(ade), L.ptr(fde), L.stream(dev)),
+            "et_anchor_reconstruct_metrics")
+    return ade, fde
+
+
 # ------------------------------------------------------------------------------------ fit
 def fit_gram(obs, pred, mode, static_dist=0.0, which=1):
     """Gram matrices (fp64) of the normalised rows routed to descriptor ``which`` + their count (int64, device)."""

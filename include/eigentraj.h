@@ -110,6 +110,15 @@ int et_anchor_reconstruct_fwd(const float *C, int64_t N, int S, int k, int T_obs
                               const float *A_m, const float *A_s, const float *U_pred_m, const float *U_pred_s,
                               int mode, float static_dist, float *out, et_stream_t stream);
 
+/* Fused evaluation form (no counterpart in the reference, which materialises recon_traj and calls
+ * utils/metrics.py:73-102): best-of-S displacement errors against gt (N,T_pred,2) without writing the
+ * trajectories:  ade[n] = min_s mean_t ||out[s][n][t] - gt[n][t]||,  fde[n] = min_s ||out[s][n][T-1] - gt[n][T-1]||. */
+int et_anchor_reconstruct_metrics(const float *C, int64_t N, int S, int k, int T_obs, int T_pred,
+                                  const float *obs, const float *nrm,
+                                  const float *A_m, const float *A_s, const float *U_pred_m, const float *U_pred_s,
+                                  int mode, float static_dist, const float *gt, float *ade, float *fde,
+                                  et_stream_t stream);
+
 /* dC[j][n][s] = sum_f U_pred[f][j] * ((dtraj[s][n] @ R_n) / sca_n)[f]          (k,N,S) */
 int et_anchor_reconstruct_bwd(const float *dtraj, int64_t N, int S, int k, int T_obs, int T_pred,
                               const float *obs, const float *nrm,
