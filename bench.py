@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=float, default=1e7, help="trajectories per GPU")
+    ap.add_argument("--trajectories", dest="n", type=float, default=1e7, help="trajectories per GPU")
     ap.add_argument("--max-iter", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="trajectories of the CPU-baseline sample")
@@ -151,8 +151,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("ET_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path on one GPU (testing aid)
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or (args.gpus == 1 and world == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -162,7 +166,7 @@ def main():
     K = 20
     obs, pred = synthetic_trajectories_torch(n, dev, seed=rank, min_disp=1e-3)
     km = None
-    if world > 1:
+    if world > 1 or force_dist:
         from eigentrajectory_amd.dist import ShardedKMeans
         km = ShardedKMeans
     first_index = 12345
@@ -227,7 +231,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.max_iter)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

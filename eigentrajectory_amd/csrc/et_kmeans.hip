@@ -23,7 +23,7 @@
 namespace et {
 
 constexpr int kKmThreads = 256;
-constexpr int kKmMaxBlocks = 1024;
+constexpr int kKmMaxBlocks = 4096;
 
 // ---- scalar helpers shared with the oracle's definitions -----------------------------------
 __device__ __forceinline__ int exponent_above(double m) {  // smallest E with m < 2^E; 0 for m == 0

@@ -34,7 +34,7 @@ def _world(group=None):
 
 
 def _all_reduce(t, op, group=None):
-    if _world(group)[0] > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=op, group=group)
     return t
 
@@ -96,7 +96,7 @@ class ShardedKMeans:
         rec_bytes = 8 + 4 * d
         for i in range(1, K):
             cand = self.shard.init_step(i, C0, self.index_base)[:rec_bytes].clone()
-            if self.world > 1:
+            if dist.is_available() and dist.is_initialized():
                 gathered = [torch.empty_like(cand) for _ in range(self.world)]
                 dist.all_gather(gathered, cand, group=self.group)
                 cands = torch.stack(gathered)
@@ -124,7 +124,7 @@ class ShardedKMeans:
         st = None
         for it in range(max_iter):
             part = sh.assign(centroids)
-            if self.world > 1:
+            if dist.is_available() and dist.is_initialized():
                 reduced.copy_(part)  # out of place: a finished run leaves `part` untouched
                 _all_reduce(reduced, dist.ReduceOp.SUM, self.group)  # 1.1 KB of int64
                 sh.update(reduced, centroids, tol, trace)
