@@ -739,6 +739,28 @@ static int km_grid(int64_t work_items) {
     return (int)(b < 1 ? 1 : (b > kKmMaxBlocks ? kKmMaxBlocks : b));
 }
 
+// Grid of a grid-stride kernel sized to exactly one resident wave of workgroups (CUs x workgroups
+// per CU from the occupancy query): every workgroup then gets the same number of passes (+-1) and
+// there is no sparsely filled last round (4096 workgroups at 5 resident per CU would leave the
+// chip 80 % idle for its fourth round).
+template <typename Kernel>
+static int km_resident_grid(Kernel kernel, size_t lds_bytes, int64_t work_items) {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kKmThreads, lds_bytes) != hipSuccess || per_cu < 1)
+        per_cu = 4;
+    int64_t g = (int64_t)n_cu * per_cu;
+    if (g > kKmMaxBlocks) g = kKmMaxBlocks;
+    const int64_t need = ceil_div(work_items, (int64_t)kKmThreads);
+    return (int)(need < 1 ? 1 : (need < g ? need : g));
+}
+
 static bool km_dims_ok(int d, int K) { return d >= 1 && d <= ET_KMEANS_MAX_D && K >= 1 && K <= ET_KMEANS_MAX_CLUSTERS; }
 
 static size_t km_plen(int d, int K) { return (size_t)d * K + K + 2; }
@@ -780,17 +802,21 @@ static KmWorkspace km_carve(void *base, int64_t N, int d, int K) {
 }
 
 template <int D>
-static void launch_assign(const float *X, int64_t N, int d, int K, const et_kmeans_state *state, const float *cen,
-                          const int64_t *given, uint8_t *labels, long long *block_partials, int grid, bool vec4,
-                          hipStream_t st) {
+static int launch_assign(const float *X, int64_t N, int d, int K, const et_kmeans_state *state, const float *cen,
+                         const int64_t *given, uint8_t *labels, long long *block_partials, bool vec4, hipStream_t st) {
     const size_t plen = km_plen(d, K);
     const size_t lds = sizeof(long long) * ((plen + 1) & ~(size_t)1) + sizeof(float) * (size_t)K * ((d + 1 + 3) & ~3);
-    if (vec4)
+    int grid;
+    if (vec4) {
+        grid = km_resident_grid(kmeans_assign_kernel<D, 4>, lds, N / 4);
         hipLaunchKernelGGL((kmeans_assign_kernel<D, 4>), dim3(grid), dim3(kKmThreads), lds, st, X, N, d, K, state, cen,
                            given, labels, block_partials);
-    else
+    } else {
+        grid = km_resident_grid(kmeans_assign_kernel<D, 1>, lds, N);
         hipLaunchKernelGGL((kmeans_assign_kernel<D, 1>), dim3(grid), dim3(kKmThreads), lds, st, X, N, d, K, state, cen,
                            given, labels, block_partials);
+    }
+    return grid;
 }
 
 }  // namespace et
@@ -840,16 +866,21 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, const
         return e && e[0] == 'm';
     }();
     const bool use_mfma = want_mfma && vec4 && d == 6 && K <= 32 && !given_labels && N >= 128;
-    const int grid = N > 0 ? (use_mfma ? km_grid(N / 2) : km_grid(vec4 ? N / 4 : N)) : 1;
+    int grid = 1;
     if (ev_begin) ET_HIP_TRY(hipEventRecord(ev_begin, st));
     if (use_mfma) {
         // matrix-core arg-max; falls back to the NaN-aware VALU body inside the kernel when !state->fast_ok
         const size_t plen_ = km_plen(d, K);
         const size_t lds = sizeof(long long) * ((plen_ + 1) & ~(size_t)1) + sizeof(float) * (size_t)K * 8;
+        grid = km_resident_grid(kmeans_assign_mfma_kernel, lds, N / 2);
         hipLaunchKernelGGL(kmeans_assign_mfma_kernel, dim3(grid), dim3(kKmThreads), lds, st, X, N, K, state, centroids,
                            labels_u8, w.block_partials);
-    } else if (d == 6) launch_assign<6>(X, N, d, K, state, centroids, given_labels, labels_u8, w.block_partials, grid, vec4, st);
-    else launch_assign<0>(X, N, d, K, state, centroids, given_labels, labels_u8, w.block_partials, grid, vec4, st);
+    } else if (N > 0) {
+        grid = d == 6 ? launch_assign<6>(X, N, d, K, state, centroids, given_labels, labels_u8, w.block_partials, vec4, st)
+                      : launch_assign<0>(X, N, d, K, state, centroids, given_labels, labels_u8, w.block_partials, vec4, st);
+    } else {
+        grid = launch_assign<0>(X, N, d, K, state, centroids, given_labels, labels_u8, w.block_partials, false, st);
+    }
     ET_LAUNCH_CHECK();
     if (ev_end) ET_HIP_TRY(hipEventRecord(ev_end, st));
     const int plen = (int)km_plen(d, K);

@@ -58,3 +58,36 @@ if what in ("all", "km"):
         print(f"iter {it:3d} assign+reduce {a.elapsed_time(b)*1e3:8.1f} us  update {b.elapsed_time(c)*1e3:6.1f} us  changed {ch*100:6.2f}%  -> {24*n/a.elapsed_time(b)/1e6:7.1f} GB/s")
     med, mn = timeit(lambda: ops.kmeans_predict(x, cen), reps=5, warm=1)
     print(f"{'predict (sims only)':22s} median {med*1e3:9.1f} us  {24*n/med/1e6:8.1f} GB/s (+12 B/pt written)")
+if what in ("all", "model"):
+    # model form (S=20): forward, fused metrics, backward at N = 1e6
+    m = min(n, 1_000_000)
+    S = 20
+    cr = torch.randn(6, m, S, device=dev); A = torch.randn(6, S, device=dev)
+    nr = nrm[:, :m].contiguous(); gt = pred[:m].contiguous()
+    med, mn = timeit(lambda: ops.anchor_reconstruct(cr, A, None, U_pred, None, 1, nrm=nr))
+    print(f"{'reconstruct S=20 fwd':22s} median {med*1e3:9.1f} us  {2416*m/med/1e6:8.1f} GB/s ({2416*m/med/1e6/8000*100:5.1f}% of 8 TB/s)")
+    med, mn = timeit(lambda: ops.anchor_reconstruct_metrics(cr, gt, A, None, U_pred, None, 1, nrm=nr))
+    print(f"{'fused ADE/FDE S=20':22s} median {med*1e3:9.1f} us  {(480+16+96+8)*m/med/1e6:8.1f} GB/s (600 B/traj instead of 2416 + metrics pass)")
+    from eigentrajectory_amd.ops import _reconstruct_bwd
+    dt = torch.randn(S, m, 12, 2, device=dev)
+    med, mn = timeit(lambda: _reconstruct_bwd(dt, None, nr, U_pred, None, 1, 0.0, 8))
+    print(f"{'reconstruct S=20 bwd':22s} median {med*1e3:9.1f} us  {2416*m/med/1e6:8.1f} GB/s ({2416*m/med/1e6/8000*100:5.1f}% of 8 TB/s)")
+    # scene-sized batches: launch-latency regime (ETH test scenes have <= 57 pedestrians)
+    from eigentrajectory_amd import EigenTrajectory
+    from eigentrajectory_amd.utils import DotDict, default_hyper_params
+    class Zero(torch.nn.Module):
+        def forward(self, x): return torch.zeros(6, x.size(1), 20, device=x.device)
+    hooks = DotDict(model_forward_pre_hook=lambda c, o, a=None: torch.cat([c, o], 0), model_forward=lambda i, b: b(i), model_forward_post_hook=lambda o, a=None: o)
+    model = EigenTrajectory(Zero(), hooks, default_hyper_params(static_dist=0.3)).to(dev)
+    model.calculate_parameters(obs[:100000], pred[:100000])
+    for nb in (5, 57, 128, 4096):
+        o, p = obs[:nb].contiguous(), pred[:nb].contiguous()
+        with torch.no_grad():
+            for _ in range(5): model(o, p)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(200): out = model(o, p)
+            torch.cuda.synchronize(); dt_f = (time.perf_counter() - t0) / 200
+            t0 = time.perf_counter()
+            for _ in range(200): a_, f_ = model.evaluate(o, p)
+            torch.cuda.synchronize(); dt_e = (time.perf_counter() - t0) / 200
+        print(f"wrapper forward (losses) N={nb:5d}: {dt_f*1e6:7.1f} us/scene   evaluate (fused ADE/FDE): {dt_e*1e6:7.1f} us/scene")
