@@ -13,125 +13,96 @@
 namespace et {
 
 constexpr int kFitThreads = 256;
-constexpr int kFitTile = 128;  // trajectories per workgroup pass
 
-// ------------------------------------------------------------------------------------------
-// Gram kernel, specialised on (T_obs, T_pred).
-//  1. coalesced float4 loads of kFitTile rows -> LDS (raw fp32)
-//  2. lane = trajectory: normalise, write the 2T_obs + 2T_pred features as fp64 to LDS
-//     (rows that do not belong to descriptor `which` are written as zeros)
-//  3. 8 groups of 32 lanes; lane g of a group owns one 4x4 block of the upper triangle of
-//     G_obs (10 blocks) or G_pred (21 blocks) and walks the group's trajectories:
-//     2 x 32-byte LDS reads -> 16 fp64 FMAs in registers.
-//  4. groups are summed through LDS; every workgroup writes one partial (fixed slot).
-// A grid-stride loop over tiles keeps the number of partials small.
-// ------------------------------------------------------------------------------------------
 template <int TO, int TP>
 struct GramLayout {
     static constexpr int DO = 2 * TO, DP = 2 * TP, D = DO + DP;
-    static constexpr int BO = DO / 4, BP = DP / 4;                   // 4-wide blocks per side
-    static constexpr int NBO = BO * (BO + 1) / 2, NBP = BP * (BP + 1) / 2;
-    static constexpr int NB = NBO + NBP;                             // upper-triangular 4x4 blocks
-    static constexpr int kPartial = NB * 16 + 1;                     // doubles per partial (+ row count)
+    // three 16x16 fp64 MFMA tiles cover G_obs (16x16) and the upper triangle of G_pred (24x24):
+    //   O = obs x obs,  P = pred[0:16] x pred[0:16],  Q = pred[8:24] x (pred[16:24] | pred[0:8])
+    static constexpr int kBlocks = 3;
+    static constexpr int kPartial = kBlocks * 256 + 1;               // doubles per partial (+ row count)
 };
 
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// Gram kernel, (T_obs, T_pred) = (8, 12): one workgroup pass = 256 trajectories.
+//  1. coalesced float4 loads (prefetched one pass ahead into registers) -> LDS rows (pitch + 16 B)
+//  2. lane = trajectory: normaliser state, normalise the row IN PLACE (fp32; rows that do not belong
+//     to descriptor `which` become zeros)
+//  3. fp64 matrix cores: per group of 4 trajectories three v_mfma_f64_16x16x4_f64 add the outer
+//     products to three 16x16 tiles (A[i][k] = feature i of trajectory k).  Products of fp32 values
+//     are exact in fp64 and every tile entry is one k-ordered fma chain.
+//  4. waves are summed through LDS in a fixed order; every workgroup writes one partial.
 template <int TO, int TP>
 __global__ __launch_bounds__(kFitThreads) void gram_tile_kernel(
     const float *__restrict__ obs, const float *__restrict__ pred, int64_t N, int mode, float static_dist, int which,
     double *__restrict__ partials) {
     using L = GramLayout<TO, TP>;
-    constexpr int DO = L::DO, DP = L::DP, D = L::D, NB = L::NB;
+    static_assert(TO == 8 && TP == 12, "the MFMA tiling below is laid out for 16 + 24 features");
+    constexpr int DO = L::DO, DP = L::DP;
     constexpr int QO = DO / 4, QP = DP / 4;
     constexpr int PO = QO + 1, PP = QP + 1;
-    constexpr int FP = D + 2;  // fp64 feature row pitch (doubles); +2 keeps 16-B alignment, spreads banks
-    static_assert(NB <= 32, "one 4x4 block per lane of a 32-lane group");
+    constexpr int kTileRows = kFitThreads;  // one trajectory per lane in the normalise phase
 
-    // one LDS block: [fp64 features | raw obs rows | raw pred rows]; the group partials of the
-    // final reduction reuse the feature area.
-    constexpr int kFeatDoubles = kFitTile * FP;
-    constexpr int kRedDoubles = (kFitThreads / 32) * NB * 16;
-    constexpr int kHeadDoubles = kFeatDoubles > kRedDoubles ? kFeatDoubles : kRedDoubles;
-    __shared__ __attribute__((aligned(16))) double sMem[kHeadDoubles + 2 * kFitTile * (PO + PP) + 2];
-    double *sFeat = sMem;
-    double *sRed = sMem;
-    float4 *sObs = reinterpret_cast<float4 *>(sMem + kHeadDoubles);
-    float4 *sPred = sObs + kFitTile * PO;
-    int *sCountPtr = reinterpret_cast<int *>(sPred + kFitTile * PP);
+    constexpr int kStageF4 = kTileRows * (PO + PP);
+    constexpr int kRedDoubles = (kFitThreads / 64) * L::kBlocks * 256;
+    constexpr int kLdsDoubles = (2 * kStageF4 > kRedDoubles ? 2 * kStageF4 : kRedDoubles) + 2;
+    __shared__ __attribute__((aligned(16))) double sMem[kLdsDoubles];
+    float4 *sObs = reinterpret_cast<float4 *>(sMem);
+    float4 *sPred = sObs + kTileRows * PO;
+    double *sRed = sMem;  // reused after the last pass
+    int *sCountPtr = reinterpret_cast<int *>(sMem + kLdsDoubles - 2);
 
     const int tid = threadIdx.x;
-    const int grp = tid >> 5, g = tid & 31;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int feat = lane & 15, kslot = lane >> 4;  // MFMA operand slot: feature index, trajectory within a group of 4
 
-    // block (bi,bj) owned by lane g: first the NBO blocks of G_obs, then the NBP of G_pred
-    int off_i = 0, off_j = 0;
-    bool active = g < NB;
-    {
-        int b = g, base = 0, nb = L::BO;
-        if (g >= L::NBO) {
-            b = g - L::NBO;
-            base = DO;
-            nb = L::BP;
-        }
-        int bi = 0;
-        while (active && b >= nb - bi) {
-            b -= nb - bi;
-            ++bi;
-        }
-        off_i = base + 4 * bi;
-        off_j = base + 4 * (bi + b);
-    }
-
-    double acc[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.0;
+    f64x4 accO = {0.0, 0.0, 0.0, 0.0}, accP = accO, accQ = accO;
     int my_count = 0;
 
-    const int64_t n_tiles = ceil_div(N, (int64_t)kFitTile);
-    // software pipeline: the raw rows of the NEXT tile are fetched into registers while the current
-    // tile is normalised and accumulated, so the HBM latency is paid once, not once per tile
-    constexpr int NLO = (kFitTile * QO + kFitThreads - 1) / kFitThreads;  // float4 of obs per thread
-    constexpr int NLP = (kFitTile * QP + kFitThreads - 1) / kFitThreads;  // float4 of pred per thread
-    float4 ro[NLO], rp[NLP];
+    const int64_t n_tiles = ceil_div(N, (int64_t)kTileRows);
+    float4 ro[QO], rp[QP];
     auto fetch = [&](int64_t tile) {
-        const int64_t n0 = tile * kFitTile;
-        const int rows = (int)min((int64_t)kFitTile, N - n0);
+        const int64_t n0 = tile * kTileRows;
+        const int rows = (int)min((int64_t)kTileRows, N - n0);
         const float4 *go = reinterpret_cast<const float4 *>(obs + n0 * DO);
         const float4 *gp = reinterpret_cast<const float4 *>(pred + n0 * DP);
 #pragma unroll
-        for (int j = 0; j < NLO; ++j) {
+        for (int j = 0; j < QO; ++j) {
             const int q = tid + j * kFitThreads;
             ro[j] = q < rows * QO ? go[q] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int j = 0; j < NLP; ++j) {
+        for (int j = 0; j < QP; ++j) {
             const int q = tid + j * kFitThreads;
             rp[j] = q < rows * QP ? gp[q] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t n0 = tile * kFitTile;
-        const int rows = (int)min((int64_t)kFitTile, N - n0);
-        __syncthreads();  // previous pass done with sFeat / sObs
+        const int64_t n0 = tile * kTileRows;
+        const int rows = (int)min((int64_t)kTileRows, N - n0);
+        __syncthreads();  // previous pass done with the staged rows
 #pragma unroll
-        for (int j = 0; j < NLO; ++j) {
+        for (int j = 0; j < QO; ++j) {
             const int q = tid + j * kFitThreads;
-            if (q < kFitTile * QO) sObs[(q / QO) * PO + (q % QO)] = ro[j];
+            sObs[(q / QO) * PO + (q % QO)] = ro[j];
         }
 #pragma unroll
-        for (int j = 0; j < NLP; ++j) {
+        for (int j = 0; j < QP; ++j) {
             const int q = tid + j * kFitThreads;
-            if (q < kFitTile * QP) sPred[(q / QP) * PP + (q % QP)] = rp[j];
+            sPred[(q / QP) * PP + (q % QP)] = rp[j];
         }
-        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
+        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);  // in flight during the rest of this pass
         __syncthreads();
-        if (tid < kFitTile) {
-            double *f = sFeat + tid * FP;
+        {
+            float4 *orow = sObs + tid * PO, *prow = sPred + tid * PP;
             bool use = false;
             if (tid < rows) {
                 float xo[DO];
 #pragma unroll
                 for (int j = 0; j < QO; ++j) {
-                    const float4 v = sObs[tid * PO + j];
+                    const float4 v = orow[j];
                     xo[4 * j] = v.x;
                     xo[4 * j + 1] = v.y;
                     xo[4 * j + 2] = v.z;
@@ -142,67 +113,68 @@ __global__ __launch_bounds__(kFitThreads) void gram_tile_kernel(
                 use = p.mv == which;
                 if (use) {
 #pragma unroll
-                    for (int t = 0; t < TO; ++t) {
-                        float a, b;
-                        normalize_point(p, xo[2 * t], xo[2 * t + 1], a, b);
-                        f[2 * t] = (double)a;
-                        f[2 * t + 1] = (double)b;
+                    for (int j = 0; j < QO; ++j) {
+                        float4 o;
+                        normalize_point(p, xo[4 * j], xo[4 * j + 1], o.x, o.y);
+                        normalize_point(p, xo[4 * j + 2], xo[4 * j + 3], o.z, o.w);
+                        orow[j] = o;
                     }
 #pragma unroll
                     for (int q = 0; q < QP; ++q) {
-                        const float4 v = sPred[tid * PP + q];
-                        float a, b;
-                        normalize_point(p, v.x, v.y, a, b);
-                        f[DO + 4 * q] = (double)a;
-                        f[DO + 4 * q + 1] = (double)b;
-                        normalize_point(p, v.z, v.w, a, b);
-                        f[DO + 4 * q + 2] = (double)a;
-                        f[DO + 4 * q + 3] = (double)b;
+                        const float4 v = prow[q];
+                        float4 o;
+                        normalize_point(p, v.x, v.y, o.x, o.y);
+                        normalize_point(p, v.z, v.w, o.z, o.w);
+                        prow[q] = o;
                     }
                     ++my_count;
                 }
             }
             if (!use) {
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int e = 0; e < D; ++e) f[e] = 0.0;
+                for (int j = 0; j < QO; ++j) orow[j] = z;
+#pragma unroll
+                for (int q = 0; q < QP; ++q) prow[q] = z;
             }
         }
         __syncthreads();
-        if (active) {
-            // group grp walks trajectories grp, grp+8, ... of the tile
-            for (int r = grp; r < kFitTile; r += kFitThreads / 32) {
-                const double *f = sFeat + r * FP;
-                double xi[4], xj[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    xi[e] = f[off_i + e];
-                    xj[e] = f[off_j + e];
-                }
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) acc[a * 4 + b] = fma(xi[a], xj[b], acc[a * 4 + b]);
-            }
+        const float *fo = reinterpret_cast<const float *>(sObs);
+        const float *fp = reinterpret_cast<const float *>(sPred);
+        for (int grp = wave; grp < kTileRows / 4; grp += kFitThreads / 64) {
+            const int r = 4 * grp + kslot;
+            const double vo = (double)fo[r * (4 * PO) + feat];
+            const float *pr = fp + r * (4 * PP);
+            const double vp = (double)pr[feat];
+            const double va = (double)pr[8 + feat];
+            const double vb = (double)pr[feat < 8 ? 16 + feat : feat - 8];
+            accO = __builtin_amdgcn_mfma_f64_16x16x4f64(vo, vo, accO, 0, 0, 0);
+            accP = __builtin_amdgcn_mfma_f64_16x16x4f64(vp, vp, accP, 0, 0, 0);
+            accQ = __builtin_amdgcn_mfma_f64_16x16x4f64(va, vb, accQ, 0, 0, 0);
         }
     }
 
-    // ---- combine the 8 groups (fixed order), one partial per workgroup
-    __syncthreads();  // all groups finished reading sFeat (aliased by sRed)
+    // ---- combine the 4 waves (fixed order), one partial per workgroup
+    __syncthreads();  // all waves finished reading the staged rows (aliased by sRed)
     if (tid == 0) *sCountPtr = 0;
     __syncthreads();
-    if (active) {
+    // f64 16x16x4 result layout: lane l holds D[row = (l>>4) + 4*r][col = l&15] in register r
 #pragma unroll
-        for (int e = 0; e < 16; ++e) sRed[(grp * NB + g) * 16 + e] = acc[e];
+    for (int r = 0; r < 4; ++r) {
+        const int e = ((kslot + 4 * r) * 16 + feat);
+        sRed[(wave * L::kBlocks + 0) * 256 + e] = accO[r];
+        sRed[(wave * L::kBlocks + 1) * 256 + e] = accP[r];
+        sRed[(wave * L::kBlocks + 2) * 256 + e] = accQ[r];
     }
     if (my_count) atomicAdd(sCountPtr, my_count);
     __syncthreads();
     double *dst = partials + (size_t)blockIdx.x * L::kPartial;
-    for (int i = tid; i < NB * 16; i += kFitThreads) {
-        double s = 0.0;
-        for (int gr = 0; gr < kFitThreads / 32; ++gr) s += sRed[gr * NB * 16 + i];
-        dst[i] = s;
+    for (int i = tid; i < L::kBlocks * 256; i += kFitThreads) {
+        double sum = 0.0;
+        for (int w = 0; w < kFitThreads / 64; ++w) sum += sRed[w * L::kBlocks * 256 + i];
+        dst[i] = sum;
     }
-    if (tid == 0) dst[NB * 16] = (double)*sCountPtr;
+    if (tid == 0) dst[L::kBlocks * 256] = (double)*sCountPtr;
 }
 
 // Sum the workgroup partials of one entry: one wavefront per entry, a fixed strided + butterfly
@@ -216,45 +188,34 @@ __global__ __launch_bounds__(64) void gram_reduce_kernel(const double *__restric
     if (threadIdx.x == 0) sums[e] = s;
 }
 
-// Expand the summed 4x4 upper-triangular blocks into the two full symmetric matrices.  One workgroup.
+// Assemble the two full symmetric matrices from the three summed 16x16 tiles.  Every entry of the
+// upper triangle is taken from exactly one tile and mirrored, so the output is exactly symmetric.
 template <int TO, int TP>
 __global__ __launch_bounds__(kFitThreads) void gram_finish_kernel(const double *__restrict__ sSum,
                                                                   double *__restrict__ G_obs,
                                                                   double *__restrict__ G_pred,
                                                                   int64_t *__restrict__ count) {
     using L = GramLayout<TO, TP>;
-    constexpr int DO = L::DO, DP = L::DP, NB = L::NB;
-    for (int b = threadIdx.x; b < NB; b += kFitThreads) {
-        int bb = b, nb = L::BO, dim = DO;
-        double *G = G_obs;
-        if (b >= L::NBO) {
-            bb = b - L::NBO;
-            nb = L::BP;
-            dim = DP;
-            G = G_pred;
-        }
-        int bi = 0;
-        while (bb >= nb - bi) {
-            bb -= nb - bi;
-            ++bi;
-        }
-        const int bj = bi + bb;
-        for (int a = 0; a < 4; ++a)
-            for (int c = 0; c < 4; ++c) {
-                const double v = sSum[b * 16 + a * 4 + c];
-                const int i = 4 * bi + a, j = 4 * bj + c;
-                if (bi == bj) {
-                    if (j >= i) {  // mirror the upper triangle of a diagonal block: exactly symmetric output
-                        G[i * dim + j] = v;
-                        G[j * dim + i] = v;
-                    }
-                } else {
-                    G[i * dim + j] = v;
-                    G[j * dim + i] = v;
-                }
-            }
+    constexpr int DO = L::DO, DP = L::DP;
+    const double *O = sSum, *P = sSum + 256, *Q = sSum + 512;
+    for (int e = threadIdx.x; e < DO * DO; e += kFitThreads) {
+        const int i = e / DO, j = e % DO;
+        G_obs[e] = i <= j ? O[i * 16 + j] : O[j * 16 + i];
     }
-    if (threadIdx.x == 0) *count = (int64_t)sSum[NB * 16];
+    for (int e = threadIdx.x; e < DP * DP; e += kFitThreads) {
+        int i = e / DP, j = e % DP;
+        if (i > j) {
+            const int t = i;
+            i = j;
+            j = t;
+        }
+        double v;
+        if (j < 16) v = P[i * 16 + j];                       // pred[0:16] x pred[0:16]
+        else if (i >= 8) v = Q[(i - 8) * 16 + (j - 16)];     // pred[8:24] x pred[16:24]
+        else v = Q[(j - 8) * 16 + (8 + i)];                  // transpose of pred[16:24] x pred[0:8]
+        G_pred[e] = v;
+    }
+    if (threadIdx.x == 0) *count = (int64_t)sSum[L::kBlocks * 256];
 }
 
 // Any-shape Gram: one workgroup per chunk of trajectories, thread = matrix entries.
@@ -491,9 +452,10 @@ __global__ __launch_bounds__(kEighThreads) void eigh_topk_kernel(const double *_
 }
 
 static int fit_grid(int64_t N) {
-    // enough workgroups to fill 256 CUs twice, few enough that the partial reduction stays trivial
-    const int64_t tiles = ceil_div(N, (int64_t)kFitTile);
-    return (int)(tiles < 512 ? (tiles > 0 ? tiles : 1) : 512);
+    // one resident round of workgroups (3 per CU at 48 KB of LDS), few enough that the partial
+    // reduction stays trivial
+    const int64_t tiles = ceil_div(N, (int64_t)kFitThreads);
+    return (int)(tiles < 768 ? (tiles > 0 ? tiles : 1) : 768);
 }
 
 }  // namespace et
