@@ -581,3 +581,49 @@ def test_full_size_properties(ops, dev):
     res2 = ops.kmeans_fit(x, res["centroids"], 1, 1e-4)
     assert torch.equal(res2["labels"], lb)
     assert abs(res2["inertia"] - float((-ms.double()).mean())) < 1e-5 * abs(res2["inertia"])
+
+
+# ------------------------------------------------------------------ training harness
+class TinyPredictor(torch.nn.Module):
+    """(k+2, N) -> (k, N, S): a per-pedestrian MLP, standing in for the reference's predictor networks."""
+
+    def __init__(self, k=6, s=20):
+        super().__init__()
+        self.k, self.s = k, s
+        self.net = torch.nn.Sequential(torch.nn.Linear(k + 2, 64), torch.nn.ReLU(), torch.nn.Linear(64, k * s))
+        for p in self.net[2].parameters():
+            torch.nn.init.normal_(p, std=1e-2)
+
+    def forward(self, x):
+        return self.net(x.T).view(-1, self.k, self.s).permute(1, 0, 2).contiguous()
+
+
+@pytest.mark.parametrize("mode", ["collated", "sequenced"])
+def test_trainer_harness_learns_and_roundtrips_checkpoint(dev, mode):
+    import os
+    from eigentrajectory_amd import EigenTrajectory
+    from eigentrajectory_amd.data import TrajectoryData
+    from eigentrajectory_amd.trainer import ETTrainer
+    from eigentrajectory_amd.utils import default_hyper_params
+    raw = os.path.join(G.GOLDEN, "raw")
+    val = TrajectoryData(os.path.join(raw, "eth_val"))
+    test = TrajectoryData(os.path.join(raw, "eth_test"))
+    hp = default_hyper_params(batch_size=128, lr=3e-3, weight_decay=1e-4, clip_grad=10, lr_schd=True, lr_schd_step=64,
+                              lr_schd_gamma=0.5)
+    torch.manual_seed(0)
+    model = EigenTrajectory(TinyPredictor(), stub_hooks(), hp)
+    tr = ETTrainer(model, hp, train_data=val, val_data=val, test_data=test, mode=mode, device=dev)
+    tr.init_descriptor()
+    before = tr.test()
+    v0 = tr.valid()
+    state = tr.fit(epochs=2 if mode == "sequenced" else 4)
+    assert tr.log["val_loss"][-1] < v0, (v0, tr.log)
+    after = tr.test()
+    assert np.isfinite([after["ADE"], after["FDE"]]).all() and after["ADE"] <= before["ADE"] + 0.02
+    # the checkpoint carries the reference's key names and reloads into a fresh wrapper
+    assert {"ET_m_descriptor.U_obs_trunc", "ET_s_anchor.C_anchor", "baseline_model.net.0.weight"} <= set(state)
+    fresh = EigenTrajectory(TinyPredictor(), stub_hooks(), hp)
+    fresh.load_state_dict(state)
+    tr2 = ETTrainer(fresh, hp, val, val, test, mode=mode, device=dev)
+    best = tr2.test()
+    assert np.isfinite(best["ADE"]) and best["ADE"] < before["ADE"] + 0.02

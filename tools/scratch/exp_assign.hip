@@ -57,6 +57,62 @@ __device__ __forceinline__ void argmax4s(const float (&x)[4][6], const float* sC
     packed = l[0] | (l[1] << 8) | (l[2] << 16) | (l[3] << 24); bsum = b[0] + b[1] + b[2] + b[3];
 }
 
+// fully unrolled K (compile time), no manual prefetch: the scheduler places the LDS reads
+template <int KK>
+__device__ __forceinline__ void argmax4u(const f2 (&xa)[6], const f2 (&xb)[6], const float* sC, unsigned& packed, float& bsum) {
+    f2 ana = {0.f, 0.f}, anb = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { ana = ana + xa[i] * xa[i]; anb = anb + xb[i] * xb[i]; }
+    const float4* s4 = reinterpret_cast<const float4*>(sC);
+    float b0, b1, b2, b3; int l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+#pragma unroll
+    for (int j = 0; j < KK; ++j) {
+        const float4 p0 = s4[2 * j], p1 = s4[2 * j + 1];
+        f2 ya = {0.f, 0.f}, yb = {0.f, 0.f};
+        const float cc[6] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { const f2 c = {cc[i], cc[i]}; ya = __builtin_elementwise_fma(xa[i], c, ya); yb = __builtin_elementwise_fma(xb[i], c, yb); }
+        ya = ya * 2.0f; yb = yb * 2.0f; ya = ya - ana; yb = yb - anb;
+        const f2 bn = {p1.z, p1.z}; ya = ya - bn; yb = yb - bn;
+        if (j == 0) { b0 = ya.x; b1 = ya.y; b2 = yb.x; b3 = yb.y; }
+        else {
+            const bool t0 = ya.x > b0, t1 = ya.y > b1, t2 = yb.x > b2, t3 = yb.y > b3;
+            b0 = t0 ? ya.x : b0; l0 = t0 ? j : l0; b1 = t1 ? ya.y : b1; l1 = t1 ? j : l1;
+            b2 = t2 ? yb.x : b2; l2 = t2 ? j : l2; b3 = t3 ? yb.y : b3; l3 = t3 ? j : l3;
+        }
+    }
+    packed = l0 | (l1 << 8) | (l2 << 16) | (l3 << 24); bsum = b0 + b1 + b2 + b3;
+}
+
+// 8 points per lane (4 packed pairs): more independent chains per wave
+__device__ __forceinline__ void argmax8(const f2 (&x)[4][6], const float* sC, int K, unsigned (&packed)[2], float& bsum) {
+    f2 an[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { an[p] = f2{0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) an[p] = an[p] + x[p][i] * x[p][i]; }
+    const float4* s4 = reinterpret_cast<const float4*>(sC);
+    float4 c0 = s4[0], c1 = s4[1];
+    f2 b[4]; int l[8] = {0,0,0,0,0,0,0,0};
+    for (int j = 0; j < K; ++j) {
+        const float4 p0 = c0, p1 = c1;
+        if (j + 1 < K) { c0 = s4[2 * j + 2]; c1 = s4[2 * j + 3]; }
+        const float cc[6] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y};
+        const f2 bn = {p1.z, p1.z};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            f2 y = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { const f2 c = {cc[i], cc[i]}; y = __builtin_elementwise_fma(x[p][i], c, y); }
+            y = y * 2.0f; y = y - an[p]; y = y - bn;
+            if (j == 0) b[p] = y;
+            else { const bool t0 = y.x > b[p].x, t1 = y.y > b[p].y; b[p].x = t0 ? y.x : b[p].x; l[2*p] = t0 ? j : l[2*p]; b[p].y = t1 ? y.y : b[p].y; l[2*p+1] = t1 ? j : l[2*p+1]; }
+        }
+    }
+    packed[0] = l[0] | (l[1] << 8) | (l[2] << 16) | (l[3] << 24); packed[1] = l[4] | (l[5] << 8) | (l[6] << 16) | (l[7] << 24);
+    bsum = b[0].x + b[0].y + b[1].x + b[1].y + b[2].x + b[2].y + b[3].x + b[3].y;
+}
+
 // V=0: one group per thread; V=1: grid-stride; V=2: grid-stride with next-group prefetch; V=3: like 0 but no compute (copy floor)
 template <int V>
 __global__ __launch_bounds__(256) void k(const float* __restrict__ X, long N, int K, const float* __restrict__ cen8, unsigned* __restrict__ out, float* __restrict__ acc) {
@@ -67,13 +123,14 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ X, long N, in
     const long stride = (long)gridDim.x * 256;
     float total = 0.f;
     long g = (long)blockIdx.x * 256 + threadIdx.x;
-    if (V == 0 || V == 3 || V == 4) {
+    if (V == 0 || V == 3 || V == 4 || V == 5) {
         if (g >= ngroups) return;
         f2 xa[6], xb[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) { const float4 v = *reinterpret_cast<const float4*>(X + (long)i * N + g * 4); xa[i] = f2{v.x, v.y}; xb[i] = f2{v.z, v.w}; }
         unsigned p; float b;
         if (V == 0) argmax4(xa, xb, sC, K, p, b);
+        else if (V == 5) argmax4u<20>(xa, xb, sC, p, b);
         else if (V == 4) { float xs[4][6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) { xs[0][i] = xa[i].x; xs[1][i] = xa[i].y; xs[2][i] = xb[i].x; xs[3][i] = xb[i].y; }
@@ -170,6 +227,24 @@ template <int M> float runm(const float* X, long N, int K, const float* cen, uns
     return best;
 }
 
+__global__ __launch_bounds__(256) void k8(const float* __restrict__ X, long N, int K, const float* __restrict__ cen8, unsigned* __restrict__ out, float* __restrict__ acc) {
+    extern __shared__ __attribute__((aligned(16))) float sC[];
+    for (int i = threadIdx.x; i < K * 8; i += 256) sC[i] = cen8[i];
+    __syncthreads();
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;  // group of 8 points
+    if (g * 8 >= N) return;
+    f2 x[4][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(X + (long)i * N + g * 8);
+        const float4 w = *reinterpret_cast<const float4*>(X + (long)i * N + g * 8 + 4);
+        x[0][i] = f2{v.x, v.y}; x[1][i] = f2{v.z, v.w}; x[2][i] = f2{w.x, w.y}; x[3][i] = f2{w.z, w.w};
+    }
+    unsigned p[2]; float b; argmax8(x, sC, K, p, b);
+    out[2 * g] = p[0]; out[2 * g + 1] = p[1];
+    if (b == 123.456f) acc[0] = b;
+}
+
 template <int V> float run(const float* X, long N, int K, const float* cen, unsigned* out, float* acc, int grid) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     float best = 1e9;
@@ -195,8 +270,12 @@ int main(int argc, char** argv) {
     float t;
     t = run<3>(X, N, K, cen, out, acc, full); printf("V3 load-only 1grp/thread grid=%d: %.1f us  %.0f GB/s\n", full, t * 1e3, N * 24 / t / 1e6);
     t = run<0>(X, N, K, cen, out, acc, full); printf("V0 argmax 1grp/thread grid=%d: %.1f us  %.0f GB/s\n", full, t * 1e3, N * 24 / t / 1e6);
+    { hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); float best = 1e9; int grid8 = (int)((N / 8 + 255) / 256);
+      for (int r = 0; r < 6; ++r) { CK(hipEventRecord(a)); hipLaunchKernelGGL(k8, dim3(grid8), dim3(256), K * 8 * 4, 0, X, N, K, cen, out, acc); CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); if (r > 0 && ms < best) best = ms; }
+      printf("V8 argmax 8pts/lane packed grid=%d: %.1f us  %.0f GB/s\n", grid8, best * 1e3, N * 24 / best / 1e6); }
+    t = run<5>(X, N, K, cen, out, acc, full); printf("V5 argmax K=20 unrolled grid=%d: %.1f us  %.0f GB/s\n", full, t * 1e3, N * 24 / t / 1e6);
     t = run<4>(X, N, K, cen, out, acc, full); printf("V4 argmax scalar 1grp/thread grid=%d: %.1f us  %.0f GB/s\n", full, t * 1e3, N * 24 / t / 1e6);
-    for (int grid : {1024, 2048, 4096, 19532}) {
+    for (int grid : {4096}) {
         float t0 = runm<0>(X, N, K, cen, out, acc, grid), t1 = runm<1>(X, N, K, cen, out, acc, grid), t2 = runm<2>(X, N, K, cen, out, acc, grid);
         printf("MFMA grid=%d: full %.1f us | mfma-only %.1f us | no-mfma %.1f us\n", grid, t0 * 1e3, t1 * 1e3, t2 * 1e3);
     }
