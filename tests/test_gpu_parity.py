@@ -627,3 +627,96 @@ def test_trainer_harness_learns_and_roundtrips_checkpoint(dev, mode):
     tr2 = ETTrainer(fresh, hp, val, val, test, mode=mode, device=dev)
     best = tr2.test()
     assert np.isfinite(best["ADE"]) and best["ADE"] < before["ADE"] + 0.02
+
+
+# ------------------------------------------------------------------------------------ edge cases
+def _loaded_wrapper(dev, scene="eth", stub=None):
+    from eigentrajectory_amd import EigenTrajectory
+    from eigentrajectory_amd.utils import default_hyper_params
+    g2 = G.load("g2_fit_all_scenes.npz")
+    base = stub or ZeroStub()
+    model = EigenTrajectory(base, stub_hooks(), default_hyper_params(static_dist=G.static_dist(scene)))
+    sd = {k[len(scene) + 1:]: torch.from_numpy(g2[k]) for k in g2.files if k.startswith(scene + ".ET_")}
+    for k, v in base.state_dict().items():
+        sd["baseline_model." + k] = v
+    model.load_state_dict(sd)
+    return model.to(dev).eval()
+
+
+def test_wrapper_edge_batches(dev, oracle):
+    """Empty scenes, all-static / all-moving batches (empty moving or static subset), CPU and
+    non-contiguous / fp64 inputs."""
+    from oracle import wrapper_ref as W
+    model = _loaded_wrapper(dev)
+    g2 = G.load("g2_fit_all_scenes.npz")
+    p = {k[4:]: g2[k] for k in g2.files if k.startswith("eth.ET_")}
+    obs, pred, _ = G.dataset("eth", "test")
+    flag = oracle.moving_flags(obs, G.static_dist("eth"))
+    with torch.no_grad():
+        out = model(torch.zeros(0, 8, 2, device=dev), torch.zeros(0, 12, 2, device=dev))
+        assert out["recon_traj"].shape == (20, 0, 12, 2)
+        for sel in (flag, ~flag):  # one of the two descriptors sees an empty subset
+            o, q = obs[sel][:9], pred[sel][:9]
+            out = model(T(o, dev), T(q, dev))
+            ref = W.forward(p, o, q, W.zero_stub(6, 20), G.static_dist("eth"))
+            close(N_(out["recon_traj"]), ref["recon_traj"])
+            np.testing.assert_allclose(float(out["loss_euclidean_ade"]), ref["loss_euclidean_ade"], rtol=1e-5)
+        # CPU tensors in -> CPU tensors out; fp64 / non-contiguous views are accepted
+        o, q = torch.from_numpy(obs[:7]), torch.from_numpy(pred[:7])
+        a = model(o, q)["recon_traj"]
+        assert a.device.type == "cpu"
+        b = model(torch.from_numpy(obs[:14:2].astype(np.float64)).to(dev), T(pred[:14:2], dev))["recon_traj"]
+        c = model(T(np.ascontiguousarray(obs[:14:2]), dev), T(np.ascontiguousarray(pred[:14:2]), dev))["recon_traj"]
+        assert torch.equal(b, c)
+        wide = torch.from_numpy(np.concatenate([obs[:7], obs[:7]], axis=2)).to(dev)  # (7,8,4): strided view below
+        assert torch.equal(model(wide[:, :, :2], T(pred[:7], dev))["recon_traj"].cpu(), a)
+
+
+def test_nan_and_motionless_rows_propagate_like_the_reference(ops, oracle, dev):
+    """normalizer.py:28-29: a motionless pedestrian gives sca = inf under the moving descriptor and the
+    reference lets inf/NaN propagate; NaN input rows stay confined to their own outputs."""
+    p = eth_params()
+    obs, pred = synth(64, seed=12)
+    obs[3, -3:] = obs[3, -1]            # motionless over the last three steps -> ||d|| = 0
+    obs[10, 2, 0] = np.nan              # a NaN that does not touch the normaliser state
+    us = [p["ET_m_descriptor.U_obs_trunc"], p["ET_m_descriptor.U_pred_trunc"], p["ET_s_descriptor.U_obs_trunc"],
+          p["ET_s_descriptor.U_pred_trunc"]]
+    c_obs, c_pred, nrm, flag = ops.norm_project(T(obs, dev), T(pred, dev), *(T(u, dev) for u in us), 1)
+    r_obs, r_pred, _, _ = oracle.norm_project(obs, pred, *us, 1)
+    assert np.array_equal(np.isfinite(N_(c_obs)), np.isfinite(r_obs)) and np.array_equal(np.isfinite(N_(c_pred)), np.isfinite(r_pred))
+    assert not np.isfinite(N_(c_pred)[:, 3]).any() and np.isnan(N_(c_obs)[:, 10]).all()
+    ok = np.isfinite(r_pred).all(axis=0)
+    close(N_(c_pred)[:, ok], r_pred[:, ok])
+    # the split mode routes the motionless row to the static descriptor: everything finite again
+    c_obs2, c_pred2, _, flag2 = ops.norm_project(T(obs, dev), T(pred, dev), *(T(u, dev) for u in us), 2, 0.3)
+    assert int(N_(flag2)[3]) == 0 and np.isfinite(N_(c_pred2)[:, 3]).all()
+
+
+def test_descriptor_and_anchor_modules_standalone(dev, oracle):
+    """ETDescriptor / ETAnchor used directly, the way script/*.py and other callers do (descriptor.py:116-181)."""
+    from eigentrajectory_amd import ETAnchor, ETDescriptor
+    from eigentrajectory_amd.utils import default_hyper_params
+    hp = default_hyper_params()
+    obs, pred = synth(5000, seed=21, min_disp=1e-3)
+    d = ETDescriptor(hp, norm_sca=True).to(dev)
+    pred_norm, U_pred = d.parameter_initialization(T(obs, dev), T(pred, dev))
+    assert d.U_obs_trunc.shape == (16, 6) and d.U_pred_trunc.device.type == "cuda"
+    np.testing.assert_allclose(N_(pred_norm), oracle.normalize(obs, pred, True), rtol=1e-5, atol=1e-5)
+    g_obs, g_pred, _ = oracle.fit_gram(obs, pred, 1, 0.0, 1)
+    close(G.sign_align(N_(U_pred), oracle.eigh_topk(g_pred, 6)[0]), oracle.eigh_topk(g_pred, 6)[0], tol=2e-5)
+    C_obs, C_pred = d.projection(T(obs, dev), T(pred, dev))
+    assert torch.equal(d.traj_normalizer.traj_ori[:, 0], T(obs, dev)[:, -1])  # the state model.py:86 reads
+    rec = d.reconstruction(C_pred.unsqueeze(-1).repeat(1, 1, 20))
+    assert rec.shape == (20, 5000, 12, 2)
+    assert float((rec[0] - T(pred, dev)).norm(dim=-1).mean()) < 0.2
+    a = ETAnchor(hp).to(dev)
+    a.anchor_generation(pred_norm, U_pred)
+    A = N_(a.C_anchor)
+    assert A.shape == (6, 20) and np.isfinite(A).all() and len({tuple(c) for c in A.T}) == 20
+    ref = oracle.kmeans_fit(N_(C_pred), oracle.kmeans_init_farthest(N_(C_pred), 20, np.random.RandomState(0).randint(5000))[0],
+                            100, 1e-4)
+    assert np.array_equal(A, ref["centroids"])  # same seeding draw as the reference's kmeans.py:92
+    # bare to_ET_space / to_Euclidean_space (descriptor.py:59-89) are inverse on the span of U
+    back = d.to_Euclidean_space(d.to_ET_space(pred_norm, U_pred), U_pred)
+    again = d.to_ET_space(back, U_pred)
+    close(N_(again), N_(d.to_ET_space(pred_norm, U_pred)), tol=3e-6)
