@@ -51,7 +51,7 @@ if what in ("all", "km"):
     prev = None
     for it in range(int(sys.argv[3]) if len(sys.argv) > 3 else 24):
         a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        a.record(); part = sh.assign(cen); b.record(); sh.update(part, cen, 1e-4); c.record(); torch.cuda.synchronize()
+        a.record(); part = sh.assign(cen, iteration=it); b.record(); sh.update(part, cen, 1e-4); c.record(); torch.cuda.synchronize()
         lab = sh.labels_u8[:n].clone()
         ch = float((lab != prev).float().mean()) if prev is not None else 1.0
         prev = lab
