@@ -505,6 +505,275 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_mfma_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Lloyd half-step for iterations >= 1: matrix-core FILTER + exact certification (d = 6, K <= 32).
+//
+// The exact arg-max above costs ~12 VALU slots per (point, cluster) pair and that, not the 24 B/point
+// read, is what the kernel waits for (SQ counters: 941 VALU instructions per 256 points, VALU busy 85 %).
+// From the second iteration on almost every point keeps its label, and PROVING that is much cheaper
+// than recomputing it:
+//
+//  1. f16 MFMA (v_mfma_f32_32x32x16_f16, ~16x the fp32 rate) evaluates t'_j ~ G_j = 2 x.c_j - |c_j|^2 for
+//     all clusters: x and 2c, scaled by a power of two sg so that every magnitude is below 32, are split
+//     into f16 (hi, lo) pairs (round toward zero: 2^-20 relative, 2^-24 absolute on the denormal grid);
+//     the four partial products per coordinate and the split -|c|^2 occupy 26 of the 32 k-slots of two
+//     MFMAs, accumulation is fp32 (<= 28 additions, order unknown: 2^-18.2 of the sum of magnitudes).
+//     In scaled units, r = sg ||x||, C_j = sg ||c_j||:
+//         |t'_j - G_j|            <= E2 = 2^-17.5 (r + C_j)^2 + 2^-21.7 (r + C_j) + 2^-34
+//         |(Y_j + |x|^2) - G_j|   <= E1 = 2^-21 (r + C_j)^2           (fp32 chain of kmeans.py:71-74)
+//     so with eps_j = 2^-16 (r + C_j)^2 + 2^-20 (r + C_j) + 2^-32 (> 2 (E1 + E2)):  Y_j + |x|^2 <= t'_j + eps_j.
+//     eps_j = eps(r) + r (2^-15 C_j) + (2^-16 C_j^2 + 2^-20 C_j): the cluster-dependent part is linear in
+//     (r, 1) and occupies two more k-slots, i.e. the MFMA delivers the UPPER BOUNDS u_j = t'_j + eps_j - eps(r)
+//     (r and the coefficients rounded up).  A far-away centroid has a large error but an even more
+//     negative u_j, so outliers do not loosen the test for ordinary points.
+//  2. per point only the SECOND largest u is needed (no index): top-2 with v_max3/v_med3, 1.4 VALU
+//     slots per pair.
+//  3. the similarity Y_l of the point's OLD label l is evaluated exactly (one fmaf chain, needed for
+//     the inertia anyway).  If  w = Y_l + |x|^2  exceeds  second + eps(r)  (+ the rounding of w), then
+//     every cluster whose u is not the largest loses to l strictly, and l itself cannot be among them
+//     (w <= u_l + eps(r)): l owns the largest u and is the reference's arg-max, strictly, no tie.  The
+//     label is unchanged, nothing is accumulated (the sums are incremental), Y_l goes into the inertia.
+//  4. every other point (label may change, or too close to call) is pushed on a per-wavefront LDS queue
+//     and later gets the full exact scan, 64 queued points at a time, one per lane: label, exact
+//     deltas, inertia -- exactly what kmeans_assign_kernel computes.
+//
+// The filter can only say "unchanged" when that is provably what the reference computes, so labels,
+// sums and inertia stay bit-identical; its cost is ~430 VALU instructions per 256 points.
+//
+// MFMA layout: rows = clusters (A, loop invariant), columns = points (B).  A wavefront takes 256
+// points per pass, lane (half, col) owning points 4 col..4 col+3 of its 128-point half.  Both halves
+// of a column must feed the SAME point, so the owner's packed f16 dwords are broadcast across the
+// halves with v_permlane32_swap (one VALU op yields both "lower half's value" and "upper half's
+// value"); two tiles (lower points, upper points) per component q, and one more swap brings each
+// half-wave the two partial (max, second) pairs of its own points.
+// ------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// (a, b) -> packed f16 {hi(a), hi(b)} and {lo(a), lo(b)} with a ~ hi + lo, round toward zero
+__device__ __forceinline__ void split_f16(float a, float b, unsigned &hi, unsigned &lo) {
+    const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const float ra = a - (float)h[0], rb = b - (float)h[1];  // exact
+    const auto l = __builtin_amdgcn_cvt_pkrtz(ra, rb);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+// max / min as v_med3_f32 against +-inf: fmaxf on a raw MFMA result would first be "canonicalised" by a
+// v_max x,x (the compiler cannot prove it quiet), one extra VALU op per value.  (Inline asm is not an option:
+// the compiler does not insert the MFMA -> VALU wait states in front of instructions it cannot see.)
+__device__ __forceinline__ float vmax(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
+__device__ __forceinline__ float vmin(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -__builtin_inff()); }
+__device__ __forceinline__ float vmed3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+
+// largest and second largest (as a multiset) of acc[0..NREGS)
+template <int NREGS>
+__device__ __forceinline__ void top2(const f32x16 &acc, float &b, float &s) {
+    b = vmax(acc[0], acc[1]);
+    s = vmin(acc[0], acc[1]);
+    int r = 2;
+#pragma unroll
+    for (; r + 2 < NREGS; r += 3) {  // triples: (max, median), then merge two (max, second) pairs
+        const float gs = vmed3(acc[r], acc[r + 1], acc[r + 2]);  // second of the triple
+        const float gm = vmax(vmax(acc[r], acc[r + 1]), acc[r + 2]);
+        s = vmed3(b, gm, vmax(s, gs));
+        b = vmax(b, gm);
+    }
+#pragma unroll
+    for (; r < NREGS; ++r) {
+        s = vmed3(b, s, acc[r]);
+        b = vmax(b, acc[r]);
+    }
+}
+
+constexpr int kFilterQueue = 64 + 256;  // entries per wavefront: < 64 carried over + one pass
+
+// full exact scan of `cnt` (<= 64) queued points, one per lane
+__device__ __forceinline__ void filter_drain(const unsigned *q, int cnt, const float *__restrict__ X, int64_t N, int K,
+                                             const float *sC, uint8_t *__restrict__ labels, long long *sAcc, int frac,
+                                             int sfrac, int lane, long long &sim_acc) {
+    constexpr int d = 6;
+    if (lane >= cnt) return;
+    const int64_t n = (int64_t)q[lane];
+    float x[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = X[(int64_t)i * N + n];
+    const int old = (int)labels[n];
+    int lb;
+    float best;
+    best_centroid<6>(x, d, sC, K, lb, best);
+    if (lb != old) {
+        labels[n] = (uint8_t)lb;
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + lb]), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + old]), ~0ull);
+#pragma unroll
+        for (int i = 0; i < d; ++i) {
+            const unsigned long long f = (unsigned long long)to_fixed(x[i], frac);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[i * K + lb]), f);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[i * K + old]), 0ull - f);
+        }
+    }
+    sim_acc += to_fixed(best, sfrac);
+}
+
+template <int NREGS>
+__global__ __launch_bounds__(kKmThreads) void kmeans_assign_filter_kernel(
+    const float *__restrict__ X, int64_t N, int K, const et_kmeans_state *__restrict__ state,
+    const float *__restrict__ cen, uint8_t *__restrict__ labels, long long *__restrict__ block_partials) {
+    if (state->done) return;
+    constexpr int d = 6;
+    // power-of-two scale: every |x| sg, |c| sg < 32, so that |2c x| sg^2 < 6 * 2^11 and |c|^2 sg^2 < 6 * 2^10 fit
+    // f16 and stay far above the -60000 that pads the rows of clusters >= K
+    const int e_max = exponent_above(fmax(state->max_abs_x, state->max_abs_c));
+    // first iteration (no labels yet), possible NaN/Inf, or a scale whose square leaves the fp32 range:
+    // the exact kernel decides
+    if (state->iter <= 0 || !state->fast_ok || e_max < -40 || e_max > 60) {
+        assign_body_valu<6, 4>(X, N, d, K, state, cen, nullptr, labels, block_partials);
+        return;
+    }
+    const int plen = d * K + K + 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    long long *sAcc = reinterpret_cast<long long *>(smem_raw);                                 // plen
+    float *sC = reinterpret_cast<float *>(smem_raw + sizeof(long long) * ((plen + 1) & ~1));  // K * 8
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+    unsigned *queue = reinterpret_cast<unsigned *>(sC + K * 8) + wave * kFilterQueue;
+    const int frac = (int)state->frac, sfrac = (int)state->sim_frac;
+    for (int i = threadIdx.x; i < plen; i += kKmThreads) sAcc[i] = 0;
+    stage_centroids(cen, d, K, sC);
+    __syncthreads();
+
+    const float sg = ldexpf(1.0f, 5 - e_max), sg2 = sg * sg;
+    // threshold polynomial in rr, already multiplied by sg^2 (the MFMA works on scaled operands)
+    constexpr float kUp = 1.001953125f, kTiny = 1.1920928955078125e-7f;  // (1 + 2^-9) v + 2^-23 survives the rtz to f16
+
+    // A operands: this lane feeds accumulator row m = col, k-half = half.  Row m is read back by lanes
+    // of half (m >> 2) & 1 in register 4 (m >> 3) + (m & 3); cluster j sits in register j >> 1 of half j & 1,
+    // so both halves reduce over registers 0 .. ceil(K / 2) - 1 <= NREGS - 1 (rows of clusters >= K: -60000).
+    u32x4 a1 = {0u, 0u, 0u, 0u}, a2 = {0u, 0u, 0u, 0u};
+    {
+        const int j = 2 * (4 * (col >> 3) + (col & 3)) + ((col >> 2) & 1);
+        unsigned ch[3] = {0u, 0u, 0u}, cl[3] = {0u, 0u, 0u};
+        float nb = -60000.0f;
+        if (j < K) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                split_f16(2.0f * sg * sC[j * 8 + 2 * p], 2.0f * sg * sC[j * 8 + 2 * p + 1], ch[p], cl[p]);
+            nb = -sC[j * 8 + 6] * sg2;
+        }
+        // -|c|^2 = hi + lo; lo is carried as lo * 2^10 against a 2^-10 on the point side (finer f16 grid)
+        const auto nh = __builtin_amdgcn_cvt_pkrtz(nb, 0.f);
+        const unsigned bnd = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(nb, (nb - (float)nh[0]) * 1024.0f));
+        // the cluster-dependent part of the error bound, eps_j - eps(r) = r (2^-15 C_j) + (2^-16 C_j^2 + 2^-20 C_j)
+        // with C_j = sg ||c_j|| rounded up, rides along as two more k-slots against (r, 1)
+        unsigned ebd = 0u;
+        if (j < K) {
+            const float cj = sqrtf(sC[j * 8 + 6]) * sg * 1.001f;
+            ebd = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(fmaf(3.0517578125e-5f * cj, kUp, kTiny),
+                                                                           fmaf(fmaf(cj, 1.52587890625e-5f, 9.5367431640625e-7f) * cj, kUp, kTiny)));
+        }
+        if (half == 0) {
+            a1 = u32x4{ch[0], ch[1], ch[2], ch[0]};
+            a2 = u32x4{ch[1], ch[2], bnd, ebd};
+        } else {
+            a1 = u32x4{cl[0], cl[1], cl[2], cl[0]};
+            a2 = u32x4{cl[1], cl[2], 0u, 0u};
+        }
+    }
+    const f16x8 A1 = __builtin_bit_cast(f16x8, a1), A2 = __builtin_bit_cast(f16x8, a2);
+    const float4 *s4 = reinterpret_cast<const float4 *>(sC);
+
+    long long sim_acc = 0;
+    int qn = 0;  // wave-uniform number of queued points
+    const int64_t n_groups = (N + 255) / 256;
+    for (int64_t g = (int64_t)blockIdx.x * (kKmThreads / 64) + wave; g < n_groups; g += (int64_t)gridDim.x * (kKmThreads / 64)) {
+        const int64_t n = g * 256 + 128 * half + 4 * col;
+        const bool valid = n < N;  // N % 4 == 0
+        float4 v[6];
+        unsigned old_packed = 0;
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[i] = *reinterpret_cast<const float4 *>(X + (int64_t)i * N + n);
+            old_packed = *reinterpret_cast<const unsigned *>(labels + n);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) x[i] = q == 0 ? v[i].x : (q == 1 ? v[i].y : (q == 2 ? v[i].z : v[i].w));
+            float an = 0.f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) an = an + x[i] * x[i];  // kmeans.py:73
+            const float rs = fmaf(__builtin_amdgcn_sqrtf(an) * sg, kUp, kTiny);  // >= sg ||x||
+            unsigned w[7];  // {xh01, xh23, xh45, xl01, xl23, xl45, (r, 1)}
+#pragma unroll
+            for (int p = 0; p < 3; ++p) split_f16(x[2 * p] * sg, x[2 * p + 1] * sg, w[p], w[3 + p]);
+            w[6] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(fmaf(rs, kUp, kTiny), 1.0f));
+            unsigned lo[7], up[7];  // the same dwords of the lower / upper half-wave's point of this column
+#pragma unroll
+            for (int p = 0; p < 7; ++p) {
+                const auto r = __builtin_amdgcn_permlane32_swap(w[p], w[p], false, false);
+                lo[p] = r[0];
+                up[p] = r[1];
+            }
+            const unsigned ones = 0x14003c00u;  // {1, 2^-10}: partners of {hi, lo * 2^10} of -|c|^2
+            f32x16 accL, accU;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accL[r] = accU[r] = 0.f;
+            accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, __builtin_bit_cast(f16x8, u32x4{lo[0], lo[1], lo[2], lo[3]}), accL, 0, 0, 0);
+            accU = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, __builtin_bit_cast(f16x8, u32x4{up[0], up[1], up[2], up[3]}), accU, 0, 0, 0);
+            accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, __builtin_bit_cast(f16x8, u32x4{lo[4], lo[5], ones, lo[6]}), accL, 0, 0, 0);
+            accU = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, __builtin_bit_cast(f16x8, u32x4{up[4], up[5], ones, up[6]}), accU, 0, 0, 0);
+            float bL, sL, bU, sU;
+            top2<NREGS>(accL, bL, sL);
+            top2<NREGS>(accU, bU, sU);
+            // lower half-wave: both partials of its own points (tile L); upper half-wave: those of tile U
+            const auto rb = __builtin_amdgcn_permlane32_swap(__float_as_uint(bL), __float_as_uint(bU), false, false);
+            const auto rq = __builtin_amdgcn_permlane32_swap(__float_as_uint(sL), __float_as_uint(sU), false, false);
+            const float b0 = __uint_as_float(rb[0]), b1 = __uint_as_float(rb[1]);
+            const float s0 = __uint_as_float(rq[0]), s1 = __uint_as_float(rq[1]);
+            const float second = vmed3(b0, b1, vmax(s0, s1));  // second largest upper bound u_j
+            // exact similarity to the old label's (updated) centroid, kmeans.py:71-74
+            const int ol = (int)((old_packed >> (8 * q)) & 0xffu);
+            const float4 r0 = s4[2 * ol], r1 = s4[2 * ol + 1];
+            float y = 0.f;
+            y = fmaf(x[0], r0.x, y);
+            y = fmaf(x[1], r0.y, y);
+            y = fmaf(x[2], r0.z, y);
+            y = fmaf(x[3], r0.w, y);
+            y = fmaf(x[4], r1.x, y);
+            y = fmaf(x[5], r1.y, y);
+            y = y * 2.0f;
+            y = y - an;
+            y = y - r1.z;
+            // keep <=> (Y_l + |x|^2) sg^2 exceeds every other cluster's upper bound: w - second > eps(r) + rounding of w
+            const float wv = (y + an) * sg2;
+            const float th = fmaf(fabsf(wv), 2.384185791015625e-7f, fmaf(rs, fmaf(rs, 1.52587890625e-5f, 9.5367431640625e-7f), 2.3283064365386963e-10f));
+            const bool keep = wv - second > th;
+            if (valid && keep) sim_acc += to_fixed(y, sfrac);
+            const unsigned long long m = __ballot(valid && !keep);
+            if (m) {
+                if (valid && !keep) queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)(n + q);
+                qn += __popcll(m);
+#ifdef ET_FILTER_DEBUG
+                if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K + 1]), (unsigned long long)__popcll(m));
+#endif
+            }
+        }
+        while (qn >= 64) {
+            qn -= 64;
+            filter_drain(queue + qn, 64, X, N, K, sC, labels, sAcc, frac, sfrac, lane, sim_acc);
+        }
+    }
+    if (qn) filter_drain(queue, qn, X, N, K, sC, labels, sAcc, frac, sfrac, lane, sim_acc);
+    for (int o = 32; o > 0; o >>= 1) sim_acc += __shfl_xor(sim_acc, o);
+    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K]), (unsigned long long)sim_acc);
+    __syncthreads();
+    for (int i = threadIdx.x; i < plen; i += kKmThreads) block_partials[(size_t)i * gridDim.x + blockIdx.x] = sAcc[i];
+}
+
+// ------------------------------------------------------------------------------------------
 // Label-sorted layout + wave-level exact pruning (d = 6, rows 16-B aligned, fast_ok).
 //
 // The arg-max over K centroids is VALU-bound (above).  After the first Lloyd iteration the points are
@@ -1191,7 +1460,7 @@ extern "C" int et_kmeans_begin(et_kmeans_state *state, int64_t n_total, const fl
 static bool km_prune_enabled() {
     static const bool on = [] {
         const char *e = getenv("ET_KMEANS_PRUNE");
-        return !(e && e[0] == '0');
+        return e && e[0] == '1';
     }();
     return on;
 }
@@ -1209,13 +1478,17 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_km
     // The matrix-core arg-max is bit-identical but measured slower than the packed VALU kernel on MI355X
     // (f32 MFMA runs at the VALU rate and 12 of its 32 rows are padding for K = 20), so it
     // stays opt-in: ET_KMEANS_ARGMAX=mfma.
-    static const bool want_mfma = [] {
+    static const char argmax_mode = [] {
         const char *e = getenv("ET_KMEANS_ARGMAX");
-        return e && e[0] == 'm';
+        return e ? e[0] : 'f';
     }();
+    const bool want_mfma = argmax_mode == 'm';
+    // iterations >= 1: matrix-core filter + exact certification (default; ET_KMEANS_ARGMAX=valu disables it)
+    const bool use_filter = argmax_mode == 'f' && vec4 && d == 6 && K >= 2 && K <= 32 && !given_labels && N >= 1024 &&
+                            N <= 0xffffffffll && iteration >= 1;
     const bool use_mfma = want_mfma && vec4 && d == 6 && K <= 32 && !given_labels && N >= 128;
     // label-sorted layout + wave-level exact pruning from the second iteration on
-    const bool prune = km_prune_enabled() && !use_mfma && vec4 && d == 6 && K <= 64 && !given_labels && N >= 1024 &&
+    const bool prune = km_prune_enabled() && !use_mfma && !use_filter && vec4 && d == 6 && K <= 64 && !given_labels && N >= 1024 &&
                        N <= 0xffffffffll && iteration >= 1;
     int grid = 1;
     if (prune && iteration == 1) {
@@ -1233,7 +1506,20 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_km
         ET_LAUNCH_CHECK();
     }
     if (ev_begin) ET_HIP_TRY(hipEventRecord(ev_begin, st));
-    if (prune) {
+    if (use_filter) {
+        const size_t plen_ = km_plen(d, K);
+        const size_t lds = sizeof(long long) * ((plen_ + 1) & ~(size_t)1) + sizeof(float) * (size_t)K * 8 +
+                           sizeof(unsigned) * kFilterQueue * (kKmThreads / 64);
+        if (K <= 20) {
+            grid = km_resident_grid(kmeans_assign_filter_kernel<10>, lds, N / 4);
+            hipLaunchKernelGGL(kmeans_assign_filter_kernel<10>, dim3(grid), dim3(kKmThreads), lds, st, X, N, K, state,
+                               centroids, labels_u8, w.block_partials);
+        } else {
+            grid = km_resident_grid(kmeans_assign_filter_kernel<16>, lds, N / 4);
+            hipLaunchKernelGGL(kmeans_assign_filter_kernel<16>, dim3(grid), dim3(kKmThreads), lds, st, X, N, K, state,
+                               centroids, labels_u8, w.block_partials);
+        }
+    } else if (prune) {
         const size_t plen_ = km_plen(d, K);
         const size_t lds = sizeof(long long) * ((plen_ + 1) & ~(size_t)1) + sizeof(float) * ((size_t)K * 8 + (size_t)K * K) +
                            sizeof(ChangedPoint) * 256 * (kKmThreads / 64);

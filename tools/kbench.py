@@ -51,11 +51,15 @@ if what in ("all", "km"):
     prev = None
     for it in range(int(sys.argv[3]) if len(sys.argv) > 3 else 24):
         a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        a.record(); part = sh.assign(cen, iteration=it); b.record(); sh.update(part, cen, 1e-4); c.record(); torch.cuda.synchronize()
+        a.record(); part = sh.assign(cen, iteration=it); b.record()
+        queued = None
+        if os.environ.get("ET_FILTER_DEBUG") and it > 0:  # library built with -DET_FILTER_DEBUG: queued points in the NaN slot
+            queued = int(part[-1]); part[-1] = 0
+        sh.update(part, cen, 1e-4); c.record(); torch.cuda.synchronize()
         lab = sh.labels_u8[:n].clone()
         ch = float((lab != prev).float().mean()) if prev is not None else 1.0
         prev = lab
-        print(f"iter {it:3d} assign+reduce {a.elapsed_time(b)*1e3:8.1f} us  update {b.elapsed_time(c)*1e3:6.1f} us  changed {ch*100:6.2f}%  -> {24*n/a.elapsed_time(b)/1e6:7.1f} GB/s")
+        print(f"iter {it:3d} assign+reduce {a.elapsed_time(b)*1e3:8.1f} us  update {b.elapsed_time(c)*1e3:6.1f} us  changed {ch*100:6.2f}%  -> {24*n/a.elapsed_time(b)/1e6:7.1f} GB/s" + (f"  queued {queued/n*100:.3f}%" if queued is not None else ""))
     med, mn = timeit(lambda: ops.kmeans_predict(x, cen), reps=5, warm=1)
     print(f"{'predict (sims only)':22s} median {med*1e3:9.1f} us  {24*n/med/1e6:8.1f} GB/s (+12 B/pt written)")
 if what in ("all", "model"):
