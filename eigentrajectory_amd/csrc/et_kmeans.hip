@@ -549,10 +549,11 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_mfma_kernel(
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// (a, b) -> packed f16 {hi(a), hi(b)} and {lo(a), lo(b)} with a ~ hi + lo, round toward zero
-__device__ __forceinline__ void split_f16(float a, float b, unsigned &hi, unsigned &lo) {
-    const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);
-    const float ra = a - (float)h[0], rb = b - (float)h[1];  // exact
+// (a, b) * sg (a power of two) -> packed f16 {hi(a), hi(b)} and {lo(a), lo(b)} with sg a ~ hi + lo, round toward
+// zero.  The residual is a single fma (v_fma_mix_f32 reads the f16 halves directly) and exact.
+__device__ __forceinline__ void split_f16(float a, float b, float sg, unsigned &hi, unsigned &lo) {
+    const auto h = __builtin_amdgcn_cvt_pkrtz(a * sg, b * sg);
+    const float ra = __builtin_fmaf(a, sg, -(float)h[0]), rb = __builtin_fmaf(b, sg, -(float)h[1]);
     const auto l = __builtin_amdgcn_cvt_pkrtz(ra, rb);
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
@@ -565,18 +566,19 @@ __device__ __forceinline__ float vmax(float a, float b) { return __builtin_amdgc
 __device__ __forceinline__ float vmin(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -__builtin_inff()); }
 __device__ __forceinline__ float vmed3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 
-// largest and second largest (as a multiset) of acc[0..NREGS)
+// largest and second largest (as a multiset) of acc[0..NREGS), NREGS >= 3: (max3, med3) per triple, two ops to
+// merge the maxima and one more for the seconds
 template <int NREGS>
 __device__ __forceinline__ void top2(const f32x16 &acc, float &b, float &s) {
-    b = vmax(acc[0], acc[1]);
-    s = vmin(acc[0], acc[1]);
-    int r = 2;
+    b = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
+    s = vmed3(acc[0], acc[1], acc[2]);
+    int r = 3;
 #pragma unroll
-    for (; r + 2 < NREGS; r += 3) {  // triples: (max, median), then merge two (max, second) pairs
+    for (; r + 2 < NREGS; r += 3) {
         const float gs = vmed3(acc[r], acc[r + 1], acc[r + 2]);  // second of the triple
-        const float gm = vmax(vmax(acc[r], acc[r + 1]), acc[r + 2]);
-        s = vmed3(b, gm, vmax(s, gs));
-        b = vmax(b, gm);
+        const float gm = __builtin_fmaxf(__builtin_fmaxf(acc[r], acc[r + 1]), acc[r + 2]);
+        s = vmed3(b, gm, __builtin_fmaxf(s, gs));
+        b = __builtin_fmaxf(b, gm);
     }
 #pragma unroll
     for (; r < NREGS; ++r) {
@@ -656,7 +658,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_filter_kernel(
         if (j < K) {
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                split_f16(2.0f * sg * sC[j * 8 + 2 * p], 2.0f * sg * sC[j * 8 + 2 * p + 1], ch[p], cl[p]);
+                split_f16(sC[j * 8 + 2 * p], sC[j * 8 + 2 * p + 1], 2.0f * sg, ch[p], cl[p]);
             nb = -sC[j * 8 + 6] * sg2;
         }
         // -|c|^2 = hi + lo; lo is carried as lo * 2^10 against a 2^-10 on the point side (finer f16 grid)
@@ -670,18 +672,22 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_filter_kernel(
             ebd = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(fmaf(3.0517578125e-5f * cj, kUp, kTiny),
                                                                            fmaf(fmaf(cj, 1.52587890625e-5f, 9.5367431640625e-7f) * cj, kUp, kTiny)));
         }
-        if (half == 0) {
-            a1 = u32x4{ch[0], ch[1], ch[2], ch[0]};
-            a2 = u32x4{ch[1], ch[2], bnd, ebd};
-        } else {
-            a1 = u32x4{cl[0], cl[1], cl[2], cl[0]};
-            a2 = u32x4{cl[1], cl[2], 0u, 0u};
-        }
+        // k-slots: the lower half-wave's lanes meet the points' hi parts (and the {1, 2^-10} of -|c|^2), the upper
+        // half-wave's lanes the lo parts (and (r, 1)); the first MFMA multiplies both by hi(2c), the second by lo(2c)
+        a1 = u32x4{ch[0], ch[1], ch[2], half == 0 ? bnd : ebd};
+        a2 = u32x4{cl[0], cl[1], cl[2], 0u};
     }
     const f16x8 A1 = __builtin_bit_cast(f16x8, a1), A2 = __builtin_bit_cast(f16x8, a2);
     const float4 *s4 = reinterpret_cast<const float4 *>(sC);
 
+    // Inertia: trunc(Y 2^sim_frac) is an integer below 2^(62 - bits(n_total)); a lane may add 2^(bits - 9) of them
+    // in fp64 without leaving the exactly representable integers (< 2^53), four fp64 ops per point instead of
+    // the ~25 of the integer conversion.  Flushed into the 64-bit accumulator before that limit.
     long long sim_acc = 0;
+    double dsum = 0.0;
+    const double sim_scale = ldexp(1.0, sfrac);
+    const int term_limit = 1 << min(max(bits_for(state->n_total) - 9, 2), 30);
+    int terms = 0;
     int qn = 0;  // wave-uniform number of queued points
     const int64_t n_groups = (N + 255) / 256;
     for (int64_t g = (int64_t)blockIdx.x * (kKmThreads / 64) + wave; g < n_groups; g += (int64_t)gridDim.x * (kKmThreads / 64)) {
@@ -708,23 +714,29 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_filter_kernel(
             const float rs = fmaf(__builtin_amdgcn_sqrtf(an) * sg, kUp, kTiny);  // >= sg ||x||
             unsigned w[7];  // {xh01, xh23, xh45, xl01, xl23, xl45, (r, 1)}
 #pragma unroll
-            for (int p = 0; p < 3; ++p) split_f16(x[2 * p] * sg, x[2 * p + 1] * sg, w[p], w[3 + p]);
+            for (int p = 0; p < 3; ++p) split_f16(x[2 * p], x[2 * p + 1], sg, w[p], w[3 + p]);
             w[6] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(fmaf(rs, kUp, kTiny), 1.0f));
-            unsigned lo[7], up[7];  // the same dwords of the lower / upper half-wave's point of this column
-#pragma unroll
-            for (int p = 0; p < 7; ++p) {
-                const auto r = __builtin_amdgcn_permlane32_swap(w[p], w[p], false, false);
-                lo[p] = r[0];
-                up[p] = r[1];
-            }
+            // One v_permlane32_swap of (hi, lo) dwords yields the B dword of both tiles: r[0] = {lower lanes: own hi,
+            // upper lanes: the lower partner's lo} feeds tile L (points of the lower half-wave), r[1] = {lower lanes:
+            // the upper partner's hi, upper lanes: own lo} feeds tile U -- no copies, and the same four dwords serve
+            // both MFMAs (the second one multiplies the fourth by zero).
             const unsigned ones = 0x14003c00u;  // {1, 2^-10}: partners of {hi, lo * 2^10} of -|c|^2
+            u32x4 bLo, bUp;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const auto r = p < 3 ? __builtin_amdgcn_permlane32_swap(w[p], w[3 + p], false, false)
+                                     : __builtin_amdgcn_permlane32_swap(ones, w[6], false, false);
+                bLo[p] = r[0];
+                bUp[p] = r[1];
+            }
+            const f16x8 BL = __builtin_bit_cast(f16x8, bLo), BU = __builtin_bit_cast(f16x8, bUp);
             f32x16 accL, accU;
 #pragma unroll
             for (int r = 0; r < 16; ++r) accL[r] = accU[r] = 0.f;
-            accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, __builtin_bit_cast(f16x8, u32x4{lo[0], lo[1], lo[2], lo[3]}), accL, 0, 0, 0);
-            accU = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, __builtin_bit_cast(f16x8, u32x4{up[0], up[1], up[2], up[3]}), accU, 0, 0, 0);
-            accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, __builtin_bit_cast(f16x8, u32x4{lo[4], lo[5], ones, lo[6]}), accL, 0, 0, 0);
-            accU = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, __builtin_bit_cast(f16x8, u32x4{up[4], up[5], ones, up[6]}), accU, 0, 0, 0);
+            accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, BL, accL, 0, 0, 0);
+            accU = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, BU, accU, 0, 0, 0);
+            accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, BL, accL, 0, 0, 0);
+            accU = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, BU, accU, 0, 0, 0);
             float bL, sL, bU, sU;
             top2<NREGS>(accL, bL, sL);
             top2<NREGS>(accU, bU, sU);
@@ -751,7 +763,8 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_filter_kernel(
             const float wv = (y + an) * sg2;
             const float th = fmaf(fabsf(wv), 2.384185791015625e-7f, fmaf(rs, fmaf(rs, 1.52587890625e-5f, 9.5367431640625e-7f), 2.3283064365386963e-10f));
             const bool keep = wv - second > th;
-            if (valid && keep) sim_acc += to_fixed(y, sfrac);
+            const double term = trunc((double)y * sim_scale);
+            dsum += (valid && keep) ? term : 0.0;
             const unsigned long long m = __ballot(valid && !keep);
             if (m) {
                 if (valid && !keep) queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)(n + q);
@@ -761,11 +774,18 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_filter_kernel(
 #endif
             }
         }
+        terms += 4;
+        if (terms + 4 > term_limit) {
+            sim_acc += (long long)dsum;
+            dsum = 0.0;
+            terms = 0;
+        }
         while (qn >= 64) {
             qn -= 64;
             filter_drain(queue + qn, 64, X, N, K, sC, labels, sAcc, frac, sfrac, lane, sim_acc);
         }
     }
+    sim_acc += (long long)dsum;
     if (qn) filter_drain(queue, qn, X, N, K, sC, labels, sAcc, frac, sfrac, lane, sim_acc);
     for (int o = 32; o > 0; o >>= 1) sim_acc += __shfl_xor(sim_acc, o);
     if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K]), (unsigned long long)sim_acc);
