@@ -36,12 +36,12 @@ class KMeansState(C.Structure):
     _fields_ = [("max_abs_x", C.c_double), ("max_abs_c", C.c_double), ("n_total", C.c_int64), ("frac", C.c_int64),
                 ("sim_frac", C.c_int64), ("iter", C.c_int64), ("done", C.c_int64), ("bad_input", C.c_int64),
                 ("error", C.c_double), ("inertia", C.c_double), ("fast_ok", C.c_int64),
-                ("min_nz_x_bits", C.c_int64), ("sorted", C.c_int64)]
+                ("min_nz_x_bits", C.c_int64)]
 
 
 class KMeansTiming(C.Structure):
     """Mirror of ``et_kmeans_timing``."""
-    _fields_ = [("assign_ms", C.c_double), ("assign_launches", C.c_int64)]
+    _fields_ = [("assign_ms", C.c_double), ("assign_launches", C.c_int64), ("first_assign_ms", C.c_double)]
 
 
 STATE_BYTES = C.sizeof(KMeansState)

@@ -123,7 +123,7 @@ class ShardedKMeans:
         reduced = torch.zeros_like(sh.partials)
         st = None
         for it in range(max_iter):
-            part = sh.assign(centroids, iteration=it)
+            part = sh.assign(centroids)
             if dist.is_available() and dist.is_initialized():
                 reduced.copy_(part)  # out of place: a finished run leaves `part` untouched
                 _all_reduce(reduced, dist.ReduceOp.SUM, self.group)  # 1.1 KB of int64

@@ -248,6 +248,7 @@ def kmeans_fit(X, centroids, max_iter=100, tol=1e-4, workspace=None, timing=Fals
                trace=trace[:int(st.iter)], done=bool(st.done))
     if timing:
         out["assign_ms"], out["assign_launches"] = float(tm.assign_ms), int(tm.assign_launches)
+        out["first_assign_ms"] = float(tm.first_assign_ms)
     return out
 
 
@@ -309,13 +310,11 @@ class KMeansShard:
                                                L.stream(self.dev)), "et_kmeans_gather_point")
         return pt
 
-    def assign(self, centroids, given_labels=None, iteration=0):
-        """One assignment; ``iteration`` is the Lloyd loop index (the library regroups the points at 1)."""
+    def assign(self, centroids, given_labels=None):
         L.check(L.lib().et_kmeans_assign_accumulate(L.ptr(self.X), L.i64(self.n), self.d, self.K, L.ptr(self.state),
                                                     L.ptr(centroids), L.ptr(given_labels), L.ptr(self.labels_u8),
-                                                    L.ptr(self.partials), int(iteration), L.ptr(self.ws),
-                                                    C.c_size_t(self.ws.numel()), L.stream(self.dev)),
-                "et_kmeans_assign_accumulate")
+                                                    L.ptr(self.partials), L.ptr(self.ws), C.c_size_t(self.ws.numel()),
+                                                    L.stream(self.dev)), "et_kmeans_assign_accumulate")
         return self.partials
 
     def update(self, partials, centroids, tol, trace=None):
@@ -324,8 +323,7 @@ class KMeansShard:
 
     def labels(self):
         out = torch.empty((self.n,), device=self.dev, dtype=torch.int64)
-        L.check(L.lib().et_kmeans_labels_i64(L.ptr(self.labels_u8), L.i64(self.n), self.d, self.K, L.ptr(self.state),
-                                             L.ptr(out), L.ptr(self.ws), C.c_size_t(self.ws.numel()), L.stream(self.dev)),
+        L.check(L.lib().et_kmeans_labels_i64(L.ptr(self.labels_u8), L.i64(self.n), L.ptr(out), L.stream(self.dev)),
                 "et_kmeans_labels_i64")
         return out
 

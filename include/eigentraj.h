@@ -161,8 +161,6 @@ typedef struct et_kmeans_state {
     double inertia;     /* kmeans.py:53-57 of the last assignment                          */
     int64_t fast_ok;    /* 0/1/2: which arg-max kernel the next assignment may use          */
     int64_t min_nz_x_bits; /* fp32 bit pattern of the smallest non-zero |x| (all-reduce MIN) */
-    int64_t sorted;     /* 1 once the shard's points were regrouped by label in the workspace:   */
-                        /* labels_u8 is then in that order until et_kmeans_labels_i64 undoes it  */
 } et_kmeans_state;
 
 /* kmeans.py:59-76 euc_sim for one batch element: a (d,m), b (d,n) -> y (m,n) */
@@ -197,41 +195,39 @@ int et_kmeans_gather_point(const float *X, int64_t N, int d, int64_t local_index
 int et_kmeans_init_farthest(const float *X, int64_t N, int d, int K, int64_t first_index, float *C0,
                             void *workspace, size_t workspace_bytes, et_stream_t stream);
 
-/* one Lloyd half-step on a shard (kmeans.py:230 + the sums of :231, :234): labels_u8 (N) and this
- * shard's exact partials; no-op when state->done.  `iteration` is the caller's loop index (0, 1, ...).
- * From the second iteration on only the points whose label changed update the sums (exact integer
- * deltas), and for d = 6 the library regroups the points by label in its workspace at iteration 1
- * and prunes, per wavefront, the centroids that provably cannot win (bit-identical results).  Hence
- * `labels_u8`, `partials` and `workspace` must be the buffers of the previous iteration of the same
- * fit, unmodified, and labels_u8 must be read back through et_kmeans_labels_i64.  With
- * given_labels != NULL (int64, N) the labels are taken as they are instead of computed
- * (compute_centroids, kmeans.py:160-198, as a public method). */
-int et_kmeans_assign_accumulate(const float *X, int64_t N, int d, int K, et_kmeans_state *state,
+/* one Lloyd half-step on a shard (kmeans.py:230 + the sums of :231, :234): labels_u8 (N)
+ * and this shard's exact partials; no-op when state->done.  From the second iteration on only
+ * the points whose label changed update the sums (exact integer deltas) -- for d = 6, K <= 32 a
+ * matrix-core filter first proves, per point, that the label cannot change (bit-identical results) --
+ * so `labels_u8` and `partials` must be the buffers of the previous iteration of the same fit,
+ * unmodified.  With given_labels != NULL (int64, N) the labels are taken as they are instead of
+ * computed (compute_centroids, kmeans.py:160-198, as a public method). */
+int et_kmeans_assign_accumulate(const float *X, int64_t N, int d, int K, const et_kmeans_state *state,
                                 const float *centroids, const int64_t *given_labels, uint8_t *labels_u8,
-                                int64_t *partials, int iteration, void *workspace, size_t workspace_bytes,
-                                et_stream_t stream);
+                                int64_t *partials, void *workspace, size_t workspace_bytes, et_stream_t stream);
 /* centroid update + error/inertia/convergence from (all-reduced) partials
  * (kmeans.py:180-182, 45-57, 239).  centroids updated in place; trace (max_iter,2) fp32
  * receives (error, inertia) at row state->iter when not NULL. */
 int et_kmeans_update(et_kmeans_state *state, const int64_t *partials, int d, int K, float tol,
                      float *centroids, float *trace, et_stream_t stream);
-/* widen the uint8 labels of the last assignment to the reference's int64, in the original point
- * order (undoing the workspace's label-sorted order when state->sorted).  workspace may be NULL for
- * labels that never went through a fit (then d, K, state are ignored). */
-int et_kmeans_labels_i64(const uint8_t *labels_u8, int64_t N, int d, int K, const et_kmeans_state *state,
-                         int64_t *labels, void *workspace, size_t workspace_bytes, et_stream_t stream);
+/* widen the uint8 labels of the last assignment to the reference's int64 */
+int et_kmeans_labels_i64(const uint8_t *labels_u8, int64_t N, int64_t *labels, et_stream_t stream);
 
-/* optional kernel timing of et_kmeans_fit: HIP events recorded on `stream` around every launch
- * of the assign kernel (the dominant kernel of the path); filled after the final sync. */
+/* optional kernel timing of et_kmeans_fit: HIP events recorded on `stream` around a sample of the
+ * launches of the assign kernel (the dominant kernel of the path) -- the first launch and every 8th
+ * of the others; timing every launch would put a dispatch gap around each of them.  Filled after
+ * the final sync. */
 typedef struct et_kmeans_timing {
-    double assign_ms;        /* sum of the assign-kernel durations */
-    int64_t assign_launches; /* number of launches that did work (state.iter) */
+    double assign_ms;        /* sum of the sampled durations of launches 1, 9, 17, ... (the filter kernel for d = 6) */
+    int64_t assign_launches; /* number of samples in assign_ms (only launches that did work count)               */
+    double first_assign_ms;  /* launch 0: plain exact scan + full accumulation                                    */
 } et_kmeans_timing;
 
 /* single-GPU fit of one batch element from given initial centroids (kmeans.py:228-240):
  * centroids (d,K) in/out, labels int64 (N) out, *state_host receives the final state,
- * *timing_host (may be NULL) the assign-kernel timing.  Synchronises the stream (the
- * reference syncs every iteration at kmeans.py:239; here every 8th). */
+ * *timing_host (may be NULL) the assign-kernel timing.  Synchronises the stream once, at the
+ * end (the reference syncs every iteration at kmeans.py:239; here the convergence flag is polled
+ * without blocking, a few iterations behind the launches). */
 int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_iter, float tol, float *centroids,
                   int64_t *labels, float *trace, et_kmeans_state *state_host, et_kmeans_timing *timing_host,
                   void *workspace, size_t workspace_bytes, et_stream_t stream);

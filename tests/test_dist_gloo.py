@@ -26,7 +26,7 @@ class OracleShard:
         self.X = np.ascontiguousarray(X.numpy() if isinstance(X, torch.Tensor) else X, dtype=np.float32)
         self.d, self.n = self.X.shape
         self.K = K
-        self.state = torch.zeros((13,), dtype=torch.int64)
+        self.state = torch.zeros((12,), dtype=torch.int64)
         self.partials = torch.zeros((self.d * K + K + 2,), dtype=torch.int64)
         self._labels = np.zeros((self.n,), np.int64)
         self.best = np.zeros((self.n,), np.float32)
@@ -77,7 +77,7 @@ class OracleShard:
         self.cand = torch.from_numpy(buf)
         return self.cand
 
-    def assign(self, centroids, given_labels=None, iteration=0):
+    def assign(self, centroids, given_labels=None):
         if int(self.state[6]):
             return self.partials
         if self.n:

@@ -365,8 +365,8 @@ def test_kmeans_sharded_steps_partition_independent(ops, oracle, dev):
         sh.begin(10007, c)
     whole.begin(10007, cw)
     for it in range(6):
-        total = sum(sh.assign(c, iteration=it).clone() for sh, c in zip(shards, cen))  # the all-reduce(SUM)
-        pw = whole.assign(cw, iteration=it)
+        total = sum(sh.assign(c).clone() for sh, c in zip(shards, cen))  # the all-reduce(SUM)
+        pw = whole.assign(cw)
         assert torch.equal(total, pw)
         for sh, c in zip(shards, cen):
             sh.update(total, c, 1e-4)

@@ -36,13 +36,13 @@ def test_library_exports_every_declared_symbol():
 
 def test_state_struct_layout_matches_header():
     from eigentrajectory_amd import _lib
-    assert _lib.STATE_BYTES == 104
+    assert _lib.STATE_BYTES == 96
     offs = {n: getattr(_lib.KMeansState, n).offset for n, _ in _lib.KMeansState._fields_}
     assert offs == dict(max_abs_x=0, max_abs_c=8, n_total=16, frac=24, sim_frac=32, iter=40, done=48, bad_input=56,
-                        error=64, inertia=72, fast_ok=80, min_nz_x_bits=88, sorted=96)
+                        error=64, inertia=72, fast_ok=80, min_nz_x_bits=88)
     lib = _lib.lib()
     assert lib.et_kmeans_partials_len(6, 20) == 6 * 20 + 20 + 2
-    assert lib.et_kmeans_workspace_bytes(ctypes.c_int64(1000), 6, 20) > 1000 * (5 + 28)
+    assert lib.et_kmeans_workspace_bytes(ctypes.c_int64(1000), 6, 20) > 1000 * 5
     assert lib.et_kmeans_workspace_bytes(ctypes.c_int64(1000), 33, 20) == 0  # d out of range
     assert lib.et_fit_gram_workspace_bytes(ctypes.c_int64(10 ** 7), 8, 12) >= 512 * (256 + 576 + 1) * 8
 

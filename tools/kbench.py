@@ -51,7 +51,7 @@ if what in ("all", "km"):
     prev = None
     for it in range(int(sys.argv[3]) if len(sys.argv) > 3 else 24):
         a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        a.record(); part = sh.assign(cen, iteration=it); b.record()
+        a.record(); part = sh.assign(cen); b.record()
         queued = None
         if os.environ.get("ET_FILTER_DEBUG") and it > 0:  # library built with -DET_FILTER_DEBUG: queued points in the NaN slot
             queued = int(part[-1]); part[-1] = 0
