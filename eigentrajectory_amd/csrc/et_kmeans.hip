@@ -365,144 +365,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_kernel(
     assign_body_valu<D, VEC>(X, N, d_rt, K, state, cen, given, labels, block_partials);
 }
 
-// ------------------------------------------------------------------------------------------
-// Lloyd half-step on the matrix cores (d = 6, K <= 32, 16-B aligned rows, fast_ok).
-//
-// The VALU version above spends 12 op-slots per (point, cluster) pair and is compute-bound at
-// ~1.8x the time of its 24 B/point read.  v_mfma_f32_32x32x2_f32 evaluates, bit for bit, the
-// k-ordered fmaf chain  D = fma(a_k1, b_k1, fma(a_k0, b_k0, C))  -- which is exactly how the
-// reference's similarity is defined (kmeans.py:71-74) if the chain is laid out as
-//     k = 0..5 : c_i[k] * x_j[k]            three MFMAs, C = 0            (a.b, :71)
-//     VALU     : acc * 2                     exact                          (:72)
-//     k = 6    : 1 * (-|x_j|^2)              fourth MFMA, first half       (:73)
-//     k = 7    : (-|c_i|^2) * 1              fourth MFMA, second half      (:74)
-// with rows i = clusters (A operand, loop invariant) and columns j = points (B operand).
-// One wavefront handles 128 points per pass: lane (h = lane>>5, c = lane&31) loads the float4
-// of coordinate rows h, 2+h, 4+h at points 4c..4c+3; component q of every lane forms MFMA tile q
-// (32 points), so the 16-B loads feed the B operands without any shuffle.  Each lane then owns,
-// for one point, the similarities to 16 clusters (its half); 3 op-slots per pair (compare +
-// two selects) and one cross-half exchange finish the arg-max with the first-maximum rule.
-// ------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// value held by the other half-wave's lane (lane ^ 32), one VALU swap instead of an LDS permute
-__device__ __forceinline__ unsigned other_half(unsigned v, int half) {
-    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // r[0] = {lo,lo}, r[1] = {hi,hi}
-    return half ? r[0] : r[1];
-}
-
-__global__ __launch_bounds__(kKmThreads) void kmeans_assign_mfma_kernel(
-    const float *__restrict__ X, int64_t N, int K, const et_kmeans_state *__restrict__ state,
-    const float *__restrict__ cen, uint8_t *__restrict__ labels, long long *__restrict__ block_partials) {
-    if (state->done) return;
-    constexpr int d = 6;
-    if (state->fast_ok < 2) {  // NaN/Inf or sub-2^-50 magnitudes possible: the scalar path decides
-        assign_body_valu<6, 4>(X, N, d, K, state, cen, nullptr, labels, block_partials);
-        return;
-    }
-    const int plen = d * K + K + 2;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    long long *sAcc = reinterpret_cast<long long *>(smem_raw);
-    const int frac = (int)state->frac, sfrac = (int)state->sim_frac;
-    const bool incremental = state->iter > 0;
-    for (int i = threadIdx.x; i < plen; i += kKmThreads) sAcc[i] = 0;
-
-    const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
-    // A operands (loop invariant): row i = col is a cluster, k-slot = half.  2c instead of c folds the
-    // "y *= 2" of kmeans.py:72 into the chain (exact under fast_ok == 2).
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, bn = __int_as_float(0x7f800000);  // +inf: clusters >= K never win
-    if (col < K) {
-        bn = 0.f;
-#pragma unroll
-        for (int i = 0; i < d; ++i) {
-            const float v = cen[i * K + col];
-            bn = bn + v * v;  // kmeans.py:74 |b|^2, sequential
-        }
-        a0 = 2.0f * cen[(0 + half) * K + col];
-        a1 = 2.0f * cen[(2 + half) * K + col];
-        a2 = 2.0f * cen[(4 + half) * K + col];
-    }
-    const float a3 = half ? -bn : 1.0f;
-    const int nblk = (K + 7) >> 3;  // 4-register blocks of the accumulator that hold clusters < K
-    __syncthreads();
-
-    long long sim_acc = 0;
-    const int64_t n_groups = (N + 127) / 128;
-    const int wave = threadIdx.x >> 6;
-    for (int64_t g = (int64_t)blockIdx.x * (kKmThreads / 64) + wave; g < n_groups; g += (int64_t)gridDim.x * (kKmThreads / 64)) {
-        const int64_t n = g * 128 + 4 * col;
-        const bool valid = n < N;  // N % 4 == 0: a lane's four points are all in or all out
-        float4 v[6];
-        unsigned old_packed = 0xffffffffu;
-        if (valid) {
-            // both halves read all six rows (the second half of these requests hits the lines the
-            // other half just fetched): every lane can then form |x|^2 itself
-#pragma unroll
-            for (int i = 0; i < 6; ++i) v[i] = *reinterpret_cast<const float4 *>(X + (int64_t)i * N + n);
-            if (incremental) old_packed = *reinterpret_cast<const unsigned *>(labels + n);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        unsigned packed = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float x[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) x[i] = q == 0 ? v[i].x : (q == 1 ? v[i].y : (q == 2 ? v[i].z : v[i].w));
-            float an = 0.f;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) an = an + x[i] * x[i];  // kmeans.py:73 |a|^2, sequential
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, half ? x[1] : x[0], acc, 0, 0, 0);   // 2 c.x, k = 0,1
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, half ? x[3] : x[2], acc, 0, 0, 0);   //        k = 2,3
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, half ? x[5] : x[4], acc, 0, 0, 0);   //        k = 4,5
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, half ? 1.0f : -an, acc, 0, 0, 0);    // - |a|^2, - |b|^2
-            // this lane: point (col, q), clusters (r&3) + 8*(r>>2) + 4*half, ascending in r
-            float bv = __int_as_float(0xff800000);
-            int lb = 0;
-#pragma unroll
-            for (int blk = 0; blk < 4; ++blk) {
-                if (blk < nblk) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float y = acc[4 * blk + e];
-                        const bool t = y > bv;
-                        bv = t ? y : bv;
-                        lb = t ? (e + 8 * blk + 4 * half) : lb;
-                    }
-                }
-            }
-            const float pv = __uint_as_float(other_half(__float_as_uint(bv), half));
-            const int pl = (int)other_half((unsigned)lb, half);
-            const bool tp = (pv > bv) || (pv == bv && pl < lb);  // first maximum over both halves
-            bv = tp ? pv : bv;
-            lb = tp ? pl : lb;
-            packed |= (unsigned)lb << (8 * q);
-            if (valid && (q >> 1) == half) {  // each half finishes two of the lane's four points
-                const int old = incremental ? (int)((old_packed >> (8 * q)) & 0xffu) : -1;
-                if (lb != old) {
-                    atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + lb]), 1ull);
-                    if (old >= 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + old]), ~0ull);
-#pragma unroll
-                    for (int i = 0; i < d; ++i) {
-                        const unsigned long long f = (unsigned long long)to_fixed(x[i], frac);
-                        atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[i * K + lb]), f);
-                        if (old >= 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[i * K + old]), 0ull - f);
-                    }
-                }
-                sim_acc += to_fixed(bv, sfrac);
-            }
-        }
-        if (valid && half == 0 && (packed != old_packed || !incremental)) *reinterpret_cast<unsigned *>(labels + n) = packed;
-    }
-    for (int o = 32; o > 0; o >>= 1) sim_acc += __shfl_xor(sim_acc, o);
-    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K]), (unsigned long long)sim_acc);
-    __syncthreads();
-    for (int i = threadIdx.x; i < plen; i += kKmThreads) block_partials[(size_t)i * gridDim.x + blockIdx.x] = sAcc[i];
-}
 
 // ------------------------------------------------------------------------------------------
 // Lloyd half-step for iterations >= 1: matrix-core FILTER + exact certification (d = 6, K <= 32).
@@ -562,8 +425,13 @@ __device__ __forceinline__ void split_f16(float a, float b, float sg, unsigned &
 // max / min as v_med3_f32 against +-inf: fmaxf on a raw MFMA result would first be "canonicalised" by a
 // v_max x,x (the compiler cannot prove it quiet), one extra VALU op per value.  (Inline asm is not an option:
 // the compiler does not insert the MFMA -> VALU wait states in front of instructions it cannot see.)
-__device__ __forceinline__ float vmax(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
-__device__ __forceinline__ float vmin(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -__builtin_inff()); }
+__device__ __forceinline__ float opaque_inf() {  // +inf the optimiser cannot see through (no instruction is emitted)
+    unsigned u = 0x7f800000u;
+    asm volatile("" : "+s"(u));
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ float vmax(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, opaque_inf()); }
+__device__ __forceinline__ float vmin(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -opaque_inf()); }
 __device__ __forceinline__ float vmed3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 
 // largest and second largest (as a multiset) of acc[0..NREGS), NREGS >= 3: (max3, med3) per triple, two ops to
@@ -577,8 +445,8 @@ __device__ __forceinline__ void top2(const f32x16 &acc, float &b, float &s) {
     for (; r + 2 < NREGS; r += 3) {
         const float gs = vmed3(acc[r], acc[r + 1], acc[r + 2]);  // second of the triple
         const float gm = __builtin_fmaxf(__builtin_fmaxf(acc[r], acc[r + 1]), acc[r + 2]);
-        s = vmed3(b, gm, __builtin_fmaxf(s, gs));
-        b = __builtin_fmaxf(b, gm);
+        s = vmed3(b, gm, vmax(s, gs));
+        b = vmax(b, gm);
     }
 #pragma unroll
     for (; r < NREGS; ++r) {
@@ -703,6 +571,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_filter_kernel(
 #pragma unroll
             for (int i = 0; i < 6; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        unsigned undecided = 0u;  // bit q: point q of this lane goes to the queue
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float x[6];
@@ -765,9 +634,14 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_filter_kernel(
             const bool keep = wv - second > th;
             const double term = trunc((double)y * sim_scale);
             dsum += (valid && keep) ? term : 0.0;
-            const unsigned long long m = __ballot(valid && !keep);
-            if (m) {
-                if (valid && !keep) queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)(n + q);
+            undecided |= (valid && !keep) ? (1u << q) : 0u;
+        }
+        if (__ballot(undecided != 0u)) {  // rare once Lloyd settles: queue the points that need the full scan
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool push = (undecided >> q) & 1u;
+                const unsigned long long m = __ballot(push);
+                if (push) queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)(n + q);
                 qn += __popcll(m);
 #ifdef ET_FILTER_DEBUG
                 if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K + 1]), (unsigned long long)__popcll(m));
@@ -1193,19 +1067,14 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_km
     if (!workspace || workspace_bytes < et_kmeans_workspace_bytes(N, d, K)) return ET_ERR_WORKSPACE;
     const KmWorkspace w = km_carve(workspace, N, d, K);
     const bool vec4 = (N % 4 == 0) && aligned16(X) && ((reinterpret_cast<uintptr_t>(labels_u8) & 3u) == 0);
-    // The matrix-core arg-max is bit-identical but measured slower than the packed VALU kernel on MI355X
-    // (f32 MFMA runs at the VALU rate and 12 of its 32 rows are padding for K = 20), so it
-    // stays opt-in: ET_KMEANS_ARGMAX=mfma.
     static const char argmax_mode = [] {
         const char *e = getenv("ET_KMEANS_ARGMAX");
         return e ? e[0] : 'f';
     }();
-    const bool want_mfma = argmax_mode == 'm';
     // matrix-core filter + exact certification (default; ET_KMEANS_ARGMAX=valu disables it).  The kernel itself
     // runs the plain exact scan for the first iteration of a fit (state->iter == 0: no labels to confirm yet).
     const bool use_filter = argmax_mode == 'f' && vec4 && d == 6 && K >= 3 && K <= 32 && !given_labels && N >= 1024 &&
                             N <= 0xffffffffll;
-    const bool use_mfma = want_mfma && vec4 && d == 6 && K <= 32 && !given_labels && N >= 128;
     int grid = 1;
     if (ev_begin) ET_HIP_TRY(hipEventRecord(ev_begin, st));
     if (use_filter) {
@@ -1221,12 +1090,6 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_km
             hipLaunchKernelGGL(kmeans_assign_filter_kernel<16>, dim3(grid), dim3(kKmThreads), lds, st, X, N, K, state,
                                centroids, labels_u8, w.block_partials);
         }
-    } else if (use_mfma) {
-        const size_t plen_ = km_plen(d, K);
-        const size_t lds = sizeof(long long) * ((plen_ + 1) & ~(size_t)1) + sizeof(float) * (size_t)K * 8;
-        grid = km_resident_grid(kmeans_assign_mfma_kernel, lds, N / 2);
-        hipLaunchKernelGGL(kmeans_assign_mfma_kernel, dim3(grid), dim3(kKmThreads), lds, st, X, N, K, state, centroids,
-                           labels_u8, w.block_partials);
     } else if (N > 0) {
         grid = d == 6 ? launch_assign<6>(X, N, d, K, state, centroids, given_labels, labels_u8, w.block_partials, vec4, st)
                       : launch_assign<0>(X, N, d, K, state, centroids, given_labels, labels_u8, w.block_partials, vec4, st);
