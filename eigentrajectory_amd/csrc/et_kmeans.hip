@@ -455,19 +455,22 @@ __device__ __forceinline__ void top2(const f32x16 &acc, float &b, float &s) {
     }
 }
 
-constexpr int kFilterQueue = 64 + 256;  // entries per wavefront: < 64 carried over + one pass
+// per-wavefront queue of undecided points: 8 rows (x[0..5], point index, old label) of kFilterSlots entries;
+// < 64 entries are carried over and one component q of a pass adds at most 64
+constexpr int kFilterSlots = 128;
+constexpr int kFilterQueue = 8 * kFilterSlots;  // 32-bit words per wavefront
 
 // full exact scan of `cnt` (<= 64) queued points, one per lane
-__device__ __forceinline__ void filter_drain(const unsigned *q, int cnt, const float *__restrict__ X, int64_t N, int K,
-                                             const float *sC, uint8_t *__restrict__ labels, long long *sAcc, int frac,
-                                             int sfrac, int lane, long long &sim_acc) {
+__device__ __forceinline__ void filter_drain(const unsigned *q, int cnt, int K, const float *sC,
+                                             uint8_t *__restrict__ labels, long long *sAcc, int frac, int sfrac, int lane,
+                                             long long &sim_acc) {
     constexpr int d = 6;
     if (lane >= cnt) return;
-    const int64_t n = (int64_t)q[lane];
+    const int64_t n = (int64_t)q[6 * kFilterSlots + lane];
     float x[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) x[i] = X[(int64_t)i * N + n];
-    const int old = (int)labels[n];
+    for (int i = 0; i < 6; ++i) x[i] = __uint_as_float(q[i * kFilterSlots + lane]);
+    const int old = (int)q[7 * kFilterSlots + lane];
     int lb;
     float best;
     best_centroid<6>(x, d, sC, K, lb, best);
@@ -641,11 +644,22 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_filter_kernel(
             for (int q = 0; q < 4; ++q) {
                 const bool push = (undecided >> q) & 1u;
                 const unsigned long long m = __ballot(push);
-                if (push) queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)(n + q);
+                if (push) {  // the coordinates travel with the entry: no second trip to HBM for them
+                    unsigned *e = queue + qn + __popcll(m & ((1ull << lane) - 1ull));
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+                        e[i * kFilterSlots] = __float_as_uint(q == 0 ? v[i].x : (q == 1 ? v[i].y : (q == 2 ? v[i].z : v[i].w)));
+                    e[6 * kFilterSlots] = (unsigned)(n + q);
+                    e[7 * kFilterSlots] = (old_packed >> (8 * q)) & 0xffu;
+                }
                 qn += __popcll(m);
 #ifdef ET_FILTER_DEBUG
                 if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K + 1]), (unsigned long long)__popcll(m));
 #endif
+                if (qn >= 64) {
+                    qn -= 64;
+                    filter_drain(queue + qn, 64, K, sC, labels, sAcc, frac, sfrac, lane, sim_acc);
+                }
             }
         }
         terms += 4;
@@ -654,13 +668,9 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_filter_kernel(
             dsum = 0.0;
             terms = 0;
         }
-        while (qn >= 64) {
-            qn -= 64;
-            filter_drain(queue + qn, 64, X, N, K, sC, labels, sAcc, frac, sfrac, lane, sim_acc);
-        }
     }
     sim_acc += (long long)dsum;
-    if (qn) filter_drain(queue, qn, X, N, K, sC, labels, sAcc, frac, sfrac, lane, sim_acc);
+    if (qn) filter_drain(queue, qn, K, sC, labels, sAcc, frac, sfrac, lane, sim_acc);
     for (int o = 32; o > 0; o >>= 1) sim_acc += __shfl_xor(sim_acc, o);
     if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K]), (unsigned long long)sim_acc);
     __syncthreads();
