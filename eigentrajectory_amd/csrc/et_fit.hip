@@ -309,8 +309,8 @@ __global__ __launch_bounds__(kFitThreads) void gram_generic_finish_kernel(const 
 constexpr int kJacobiMaxSweeps = 30;
 constexpr int kEighThreads = 256;  // 4 wavefronts share the element updates of a round
 
-__global__ __launch_bounds__(kEighThreads) void eigh_topk_kernel(const double *__restrict__ G, int n, int k,
-                                                       float *__restrict__ U, float *__restrict__ sigma) {
+__device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int n, int k, float *__restrict__ U,
+                                               float *__restrict__ sigma) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *A = sm;                  // n*n
     double *V = sm + n * n;          // n*n
@@ -451,6 +451,26 @@ __global__ __launch_bounds__(kEighThreads) void eigh_topk_kernel(const double *_
     }
 }
 
+__global__ __launch_bounds__(kEighThreads) void eigh_topk_kernel(const double *__restrict__ G, int n, int k,
+                                                                  float *__restrict__ U, float *__restrict__ sigma) {
+    eigh_topk_body(G, n, k, U, sigma);
+}
+
+// several independent matrices in one launch, one workgroup each (the obs / pred, moving / static Gram
+// matrices of a fit are solved side by side instead of one after the other)
+struct EighBatch {
+    const double *G[ET_EIGH_MAX_BATCH];
+    float *U[ET_EIGH_MAX_BATCH];
+    float *sigma[ET_EIGH_MAX_BATCH];
+    int n[ET_EIGH_MAX_BATCH];
+    int k[ET_EIGH_MAX_BATCH];
+};
+
+__global__ __launch_bounds__(kEighThreads) void eigh_topk_batch_kernel(const EighBatch b) {
+    const int i = blockIdx.x;
+    eigh_topk_body(b.G[i], b.n[i], b.k[i], b.U[i], b.sigma[i]);
+}
+
 static int fit_grid(int64_t N) {
     // one resident round of workgroups (3 per CU at 48 KB of LDS), few enough that the partial
     // reduction stays trivial
@@ -511,9 +531,37 @@ extern "C" int et_fit_gram(const float *obs, const float *pred, int64_t N, int T
     return ET_OK;
 }
 
+static size_t eigh_lds_bytes(int n) {
+    return sizeof(double) * (2 * (size_t)n * n + 64 + 2 * (kEighThreads / 64)) + sizeof(int) * (32 * 3 + 64 + 2);
+}
+
+extern "C" int et_eigh_topk_batch(int batch, const double *const *G, const int *n, const int *k, float *const *U,
+                                  float *const *sigma, et_stream_t stream) {
+    if (batch < 0 || batch > ET_EIGH_MAX_BATCH || (batch > 0 && (!G || !n || !k || !U || !sigma))) return ET_ERR_INVALID_ARG;
+    if (batch == 0) return ET_OK;
+    EighBatch b;
+    size_t lds = 0;
+    for (int i = 0; i < batch; ++i) {
+        if (!G[i] || !U[i] || !sigma[i] || n[i] < 1 || n[i] > 64 || k[i] < 1 || k[i] > n[i]) return ET_ERR_INVALID_ARG;
+        b.G[i] = G[i];
+        b.U[i] = U[i];
+        b.sigma[i] = sigma[i];
+        b.n[i] = n[i];
+        b.k[i] = k[i];
+        const size_t need = eigh_lds_bytes(n[i]);
+        lds = need > lds ? need : lds;
+    }
+    if (lds > 48 * 1024)
+        ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(eigh_topk_batch_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(eigh_topk_batch_kernel, dim3(batch), dim3(kEighThreads), lds, (hipStream_t)stream, b);
+    ET_LAUNCH_CHECK();
+    return ET_OK;
+}
+
 extern "C" int et_eigh_topk(const double *G, int n, int k, float *U, float *sigma, et_stream_t stream) {
     if (!G || !U || !sigma || n < 1 || n > 64 || k < 1 || k > n) return ET_ERR_INVALID_ARG;
-    const size_t lds = sizeof(double) * (2 * (size_t)n * n + 64 + 2 * (kEighThreads / 64)) + sizeof(int) * (32 * 3 + 64 + 2);
+    const size_t lds = eigh_lds_bytes(n);
     if (lds > 48 * 1024)
         ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(eigh_topk_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

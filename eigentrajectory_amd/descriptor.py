@@ -100,8 +100,7 @@ class ETDescriptor(nn.Module):
         r"""Initialize the ET descriptor parameters (descriptor.py:116-142; call once before training)"""
         if self._fused:
             g_obs, g_pred, _ = ops.fit_gram(obs_traj, pred_traj, self._mode, which=self._mode)
-            U_obs_trunc, _ = ops.eigh_topk(g_obs, self.k)
-            U_pred_trunc, _ = ops.eigh_topk(g_pred, self.k)
+            (U_obs_trunc, _), (U_pred_trunc, _) = ops.eigh_topk_batch([g_obs, g_pred], self.k)  # one launch
             self.traj_normalizer.calculate_params(obs_traj)
             pred_traj_norm = self.traj_normalizer.normalize(pred_traj)
         else:

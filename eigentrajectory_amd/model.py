@@ -66,10 +66,13 @@ class EigenTrajectory(nn.Module):
         sd = self.static_dist
         # Descriptor initialization: one pass over ALL rows per descriptor; the kernel masks out the
         # rows of the other one (model.py:46-52 splits the tensors instead).
-        for which, desc in ((1, self.ET_m_descriptor), (0, self.ET_s_descriptor)):
+        grams = []
+        for which in (1, 0):
             g_obs, g_pred, _ = ops.fit_gram(obs_traj, pred_traj, ops.MODE_SPLIT, sd, which)
-            U_obs, _ = ops.eigh_topk(g_obs, self.k)
-            U_pred, _ = ops.eigh_topk(g_pred, self.k)
+            grams += [g_obs, g_pred]
+        bases = ops.eigh_topk_batch(grams, self.k)  # the four eigenproblems side by side, one launch
+        for i, desc in enumerate((self.ET_m_descriptor, self.ET_s_descriptor)):
+            U_obs, U_pred = bases[2 * i][0], bases[2 * i + 1][0]
             desc.U_obs_trunc = nn.Parameter(U_obs.to(desc.U_obs_trunc.device))
             desc.U_pred_trunc = nn.Parameter(U_pred.to(desc.U_pred_trunc.device))
 

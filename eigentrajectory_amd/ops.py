@@ -195,6 +195,25 @@ def eigh_topk(G, k):
     return U, sigma
 
 
+def eigh_topk_batch(mats, k):
+    """``eigh_topk`` of several symmetric fp64 matrices in one launch (one workgroup each, side by side).
+
+    mats: sequence of (n_i, n_i) tensors; k: int or sequence of ints.  -> list of (U_i, sigma_i)."""
+    mats = list(mats)
+    if not mats:
+        return []
+    ks = [int(k)] * len(mats) if isinstance(k, int) else [int(x) for x in k]
+    dev = L.require_device(mats[0])
+    mats = [L.on_device(G, dev, torch.float64) for G in mats]
+    outs = [(torch.empty((G.shape[0], kk), device=dev), torch.empty((kk,), device=dev)) for G, kk in zip(mats, ks)]
+    b = len(mats)
+    PD, PF, PI = C.c_void_p * b, C.c_void_p * b, C.c_int * b
+    L.check(L.lib().et_eigh_topk_batch(b, PD(*[G.data_ptr() for G in mats]), PI(*[G.shape[0] for G in mats]), PI(*ks),
+                                       PF(*[U.data_ptr() for U, _ in outs]), PF(*[s.data_ptr() for _, s in outs]),
+                                       L.stream(dev)), "et_eigh_topk_batch")
+    return outs
+
+
 # -------------------------------------------------------------------------------- k-means
 def euc_sim(a, b):
     """kmeans.py:59-76 for 2-D operands a (d,m), b (d,n) -> (m,n)."""

@@ -142,6 +142,15 @@ int et_fit_gram(const float *obs, const float *pred, int64_t N, int T_obs, int T
  * of torch.linalg.svd at descriptor.py:110-113 up to sign. */
 int et_eigh_topk(const double *G, int n, int k, float *U, float *sigma, et_stream_t stream);
 
+/* The same for `batch` (<= ET_EIGH_MAX_BATCH) independent matrices in ONE launch, one workgroup each:
+ * G[i] (n[i] x n[i]) -> U[i] (n[i], k[i]), sigma[i] (k[i]).  The arrays themselves are host memory, the
+ * matrices and outputs device memory.  A fit solves its obs / pred (x moving / static) Gram matrices
+ * side by side this way (the reference runs its torch.linalg.svd calls one after the other,
+ * model.py:50-52). */
+#define ET_EIGH_MAX_BATCH 8
+int et_eigh_topk_batch(int batch, const double *const *G, const int *n, const int *k, float *const *U,
+                       float *const *sigma, et_stream_t stream);
+
 /* ---- BatchKMeans ----------------------------------------------------------------------
  * X (d,N) d-major points (= C_pred (k,N)); centroids (d,K); labels int64 (N).
  * Similarity is kmeans.py:71-74 in the reference's operation order; the argmax takes

@@ -24,8 +24,7 @@ def svd_table(obs, pred, ks=range(1, 13)):
     g_obs, g_pred, _ = ops.fit_gram(obs, pred, ops.MODE_STATIC, which=0)
     out = []
     for k in ks:
-        U_obs, _ = ops.eigh_topk(g_obs, k)
-        U_pred, _ = ops.eigh_topk(g_pred, k)
+        (U_obs, _), (U_pred, _) = ops.eigh_topk_batch([g_obs, g_pred], k)
         c_obs, c_pred, nrm, _ = ops.norm_project(obs, pred, None, None, U_obs, U_pred, ops.MODE_STATIC, want_flag=False)
         r_obs = ops.anchor_reconstruct(c_obs.unsqueeze(-1), None, None, None, U_obs, ops.MODE_STATIC, nrm=nrm)[0]
         r_pred = ops.anchor_reconstruct(c_pred.unsqueeze(-1), None, None, None, U_pred, ops.MODE_STATIC, nrm=nrm)[0]

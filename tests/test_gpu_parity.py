@@ -225,6 +225,9 @@ def test_eigh_bit_exact_vs_oracle(ops, oracle, dev):
         k = max(1, n // 2)
         U, s = ops.eigh_topk(T(g, dev), k)
         Ur, sr = oracle.eigh_topk(g, k)
+        (Ub, sb), (Ub2, _) = ops.eigh_topk_batch([T(g, dev), T(g[:8, :8].copy(), dev)], [k, min(k, 8)])  # one launch
+        assert torch.equal(Ub, U) and torch.equal(sb, s)
+        assert np.array_equal(N_(Ub2), oracle.eigh_topk(np.ascontiguousarray(g[:8, :8]), min(k, 8))[0])
         np.testing.assert_allclose(N_(U), Ur, atol=1e-6)
         np.testing.assert_allclose(N_(s), sr, rtol=1e-6)
         exact += int(np.array_equal(N_(U), Ur) and np.array_equal(N_(s), sr))

@@ -62,6 +62,9 @@ def test_argument_validation_without_device_work():
     assert lib.et_anchor_reconstruct_fwd(null, z, 0, 6, 8, 12, null, null, null, null, null, null, 2,
                                          ctypes.c_float(0), null, null) == 1
     assert lib.et_eigh_topk(null, 16, 6, null, null, null) == 1
+    assert lib.et_eigh_topk_batch(1, null, null, null, null, null, null) == 1
+    assert lib.et_eigh_topk_batch(9, null, null, null, null, null, null) == 1  # more than ET_EIGH_MAX_BATCH
+    assert lib.et_eigh_topk_batch(0, null, null, null, null, null, null) == 0  # empty batch: no-op
     assert lib.et_kmeans_predict(null, z, 6, null, 20, null, null, null) == 1
 
 
