@@ -23,6 +23,10 @@
 namespace et {
 
 constexpr int kKmThreads = 256;
+// The filter kernel runs as ONE 16-wavefront workgroup per CU: same occupancy as four 256-thread ones, but a
+// quarter of the workgroup partials, so that a single workgroup can fold them and update the centroids in one
+// short launch (kmeans_reduce_update_kernel) without any inter-workgroup hand-off.
+constexpr int kFilterThreads = 1024;
 constexpr int kKmMaxBlocks = 4096;
 
 // ---- scalar helpers shared with the oracle's definitions -----------------------------------
@@ -269,14 +273,15 @@ __device__ __forceinline__ void assign_body_valu(
     // (the expensive part of this kernel) all but disappear.
     const bool incremental = (state->iter > 0) && (given == nullptr);
     const bool fast = state->fast_ok != 0;
-    for (int i = threadIdx.x; i < plen; i += kKmThreads) sAcc[i] = 0;
+    const int n_threads = (int)blockDim.x;  // 256, or kFilterThreads when called from the filter kernel
+    for (int i = threadIdx.x; i < plen; i += n_threads) sAcc[i] = 0;
     stage_centroids(cen, d, K, sC);
     __syncthreads();
 
     long long sim_acc = 0, nan_acc = 0;
     const int64_t n_groups = (N + VEC - 1) / VEC;
-    const int64_t stride = (int64_t)gridDim.x * kKmThreads;
-    for (int64_t gidx = (int64_t)blockIdx.x * kKmThreads + threadIdx.x; gidx < n_groups; gidx += stride) {
+    const int64_t stride = (int64_t)gridDim.x * n_threads;
+    for (int64_t gidx = (int64_t)blockIdx.x * n_threads + threadIdx.x; gidx < n_groups; gidx += stride) {
         const int64_t n = gidx * VEC;
         float x[VEC][D ? D : ET_KMEANS_MAX_D];
         unsigned old_packed = 0xffffffffu;
@@ -353,7 +358,7 @@ __device__ __forceinline__ void assign_body_valu(
     }
     __syncthreads();
     // transposed [entry][workgroup] so that the reduction below reads unit-stride
-    for (int i = threadIdx.x; i < plen; i += kKmThreads) block_partials[(size_t)i * gridDim.x + blockIdx.x] = sAcc[i];
+    for (int i = threadIdx.x; i < plen; i += n_threads) block_partials[(size_t)i * gridDim.x + blockIdx.x] = sAcc[i];
 }
 
 template <int D, int VEC>
@@ -489,7 +494,7 @@ __device__ __forceinline__ void filter_drain(const unsigned *q, int cnt, int K, 
 }
 
 template <int NREGS>
-__global__ __launch_bounds__(kKmThreads) void kmeans_assign_filter_kernel(
+__global__ __launch_bounds__(kFilterThreads) void kmeans_assign_filter_kernel(
     const float *__restrict__ X, int64_t N, int K, const et_kmeans_state *__restrict__ state,
     const float *__restrict__ cen, uint8_t *__restrict__ labels, long long *__restrict__ block_partials) {
     if (state->done) return;
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_filter_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
     unsigned *queue = reinterpret_cast<unsigned *>(sC + K * 8) + wave * kFilterQueue;
     const int frac = (int)state->frac, sfrac = (int)state->sim_frac;
-    for (int i = threadIdx.x; i < plen; i += kKmThreads) sAcc[i] = 0;
+    for (int i = threadIdx.x; i < plen; i += kFilterThreads) sAcc[i] = 0;
     stage_centroids(cen, d, K, sC);
     __syncthreads();
 
@@ -561,7 +566,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_filter_kernel(
     int terms = 0;
     int qn = 0;  // wave-uniform number of queued points
     const int64_t n_groups = (N + 255) / 256;
-    for (int64_t g = (int64_t)blockIdx.x * (kKmThreads / 64) + wave; g < n_groups; g += (int64_t)gridDim.x * (kKmThreads / 64)) {
+    for (int64_t g = (int64_t)blockIdx.x * (kFilterThreads / 64) + wave; g < n_groups; g += (int64_t)gridDim.x * (kFilterThreads / 64)) {
         const int64_t n = g * 256 + 128 * half + 4 * col;
         const bool valid = n < N;  // N % 4 == 0
         float4 v[6];
@@ -674,7 +679,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_assign_filter_kernel(
     for (int o = 32; o > 0; o >>= 1) sim_acc += __shfl_xor(sim_acc, o);
     if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K]), (unsigned long long)sim_acc);
     __syncthreads();
-    for (int i = threadIdx.x; i < plen; i += kKmThreads) block_partials[(size_t)i * gridDim.x + blockIdx.x] = sAcc[i];
+    for (int i = threadIdx.x; i < plen; i += kFilterThreads) block_partials[(size_t)i * gridDim.x + blockIdx.x] = sAcc[i];
 }
 
 // Fold the workgroup deltas into the shard's running totals: one workgroup per entry, unit-stride
@@ -710,7 +715,7 @@ __device__ __forceinline__ void update_body(et_kmeans_state *state, const long l
     const long long sim_sum = partials[d * K + K], nan_count = partials[d * K + K + 1];
     const int frac = (int)st.frac;
     const double inv_scale = ldexp(1.0, -frac);
-    for (int e = threadIdx.x; e < d * K; e += kKmThreads) {
+    for (int e = threadIdx.x; e < d * K; e += (int)blockDim.x) {
         const int j = e % K;
         const long long cnt = partials[d * K + j];
         float c;
@@ -785,28 +790,26 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_update_kernel(et_kmeans_sta
     update_body(state, partials, d, K, tol, cen, trace);
 }
 
-// Single-GPU fit: the reduction above and the update in ONE launch.  Workgroup e sums entry e; the workgroup
-// that arrives last at the ticket (release fence -> device-scope atomic -> acquire fence, so the other
-// workgroups' totals are visible to it) runs the update.  One launch (and one dispatch gap) less per
-// Lloyd iteration.
+// Single-GPU fit: the reduction above and the update in ONE launch.  One entry per WAVEFRONT (the filter kernel
+// runs one fat workgroup per CU, so an entry has only a few hundred workgroup partials); the workgroup that
+// arrives last at the ticket (release fence -> device-scope atomic -> acquire fence, so the other workgroups'
+// totals are visible to it) runs the update.  Few workgroups => few arrivals: they serialise at ~12-25 ns each.
 __global__ __launch_bounds__(kKmThreads) void kmeans_reduce_update_kernel(const long long *__restrict__ block_partials,
                                                                           int n_blocks, int plen, et_kmeans_state *state,
                                                                           long long *partials, unsigned *ticket, int d,
                                                                           int K, float tol, float *cen, float *trace) {
     if (state->done) return;
-    __shared__ long long sW[kKmThreads / 64];
     __shared__ int sLast;
-    const int e = blockIdx.x;
-    const bool running = state->iter > 0 && e < plen - 2;
-    const long long before = partials[e];  // fetched while the reduction runs
-    long long s = 0;
-    for (int b = threadIdx.x; b < n_blocks; b += kKmThreads) s += block_partials[(size_t)e * n_blocks + b];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0) sW[threadIdx.x >> 6] = s;
+    const int lane = threadIdx.x & 63, e = blockIdx.x * (kKmThreads / 64) + (threadIdx.x >> 6);
+    if (e < plen) {
+        const long long before = (lane == 0 && state->iter > 0 && e < plen - 2) ? partials[e] : 0;
+        long long s = 0;
+        for (int b = lane; b < n_blocks; b += 64) s += block_partials[(size_t)e * n_blocks + b];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) partials[e] = before + s;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < kKmThreads / 64; ++w) s += sW[w];
-        partials[e] = running ? before + s : s;
         __threadfence();
         const unsigned arrived = atomicAdd(ticket, 1u);
         sLast = arrived == gridDim.x - 1;
@@ -959,7 +962,7 @@ static int km_grid(int64_t work_items) {
 // there is no sparsely filled last round (4096 workgroups at 5 resident per CU would leave the
 // chip 80 % idle for its fourth round).
 template <typename Kernel>
-static int km_resident_grid(Kernel kernel, size_t lds_bytes, int64_t work_items) {
+static int km_resident_grid(Kernel kernel, size_t lds_bytes, int64_t work_items, int threads = kKmThreads) {
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -968,11 +971,11 @@ static int km_resident_grid(Kernel kernel, size_t lds_bytes, int64_t work_items)
         if (n_cu <= 0) n_cu = 256;
     }
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kKmThreads, lds_bytes) != hipSuccess || per_cu < 1)
-        per_cu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds_bytes) != hipSuccess || per_cu < 1)
+        per_cu = threads > 256 ? 1 : 4;
     int64_t g = (int64_t)n_cu * per_cu;
     if (g > kKmMaxBlocks) g = kKmMaxBlocks;
-    const int64_t need = ceil_div(work_items, (int64_t)kKmThreads);
+    const int64_t need = ceil_div(work_items, (int64_t)threads);
     return (int)(need < 1 ? 1 : (need < g ? need : g));
 }
 
@@ -1090,14 +1093,22 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_km
     if (use_filter) {
         const size_t plen_ = km_plen(d, K);
         const size_t lds = sizeof(long long) * ((plen_ + 1) & ~(size_t)1) + sizeof(float) * (size_t)K * 8 +
-                           sizeof(unsigned) * kFilterQueue * (kKmThreads / 64);
+                           sizeof(unsigned) * kFilterQueue * (kFilterThreads / 64);
+        static bool lds_ok = false;  // 66 KB of dynamic LDS: above the default 64 KB window
+        if (!lds_ok) {
+            ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kmeans_assign_filter_kernel<10>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kmeans_assign_filter_kernel<16>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            lds_ok = true;
+        }
         if (K <= 20) {
-            grid = km_resident_grid(kmeans_assign_filter_kernel<10>, lds, N / 4);
-            hipLaunchKernelGGL(kmeans_assign_filter_kernel<10>, dim3(grid), dim3(kKmThreads), lds, st, X, N, K, state,
+            grid = km_resident_grid(kmeans_assign_filter_kernel<10>, lds, N / 4, kFilterThreads);
+            hipLaunchKernelGGL(kmeans_assign_filter_kernel<10>, dim3(grid), dim3(kFilterThreads), lds, st, X, N, K, state,
                                centroids, labels_u8, w.block_partials);
         } else {
-            grid = km_resident_grid(kmeans_assign_filter_kernel<16>, lds, N / 4);
-            hipLaunchKernelGGL(kmeans_assign_filter_kernel<16>, dim3(grid), dim3(kKmThreads), lds, st, X, N, K, state,
+            grid = km_resident_grid(kmeans_assign_filter_kernel<16>, lds, N / 4, kFilterThreads);
+            hipLaunchKernelGGL(kmeans_assign_filter_kernel<16>, dim3(grid), dim3(kFilterThreads), lds, st, X, N, K, state,
                                centroids, labels_u8, w.block_partials);
         }
     } else if (N > 0) {
@@ -1114,8 +1125,9 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_km
         if (lds > 48 * 1024)
             ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kmeans_reduce_update_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kmeans_reduce_update_kernel, dim3(plen), dim3(kKmThreads), lds, st, w.block_partials, grid, plen,
-                           state, (long long *)partials, w.ticket, d, K, tol, const_cast<float *>(centroids), trace);
+        hipLaunchKernelGGL(kmeans_reduce_update_kernel, dim3((plen + kKmThreads / 64 - 1) / (kKmThreads / 64)),
+                           dim3(kKmThreads), lds, st, w.block_partials, grid, plen, state, (long long *)partials, w.ticket, d,
+                           K, tol, const_cast<float *>(centroids), trace);
     } else {
         hipLaunchKernelGGL(kmeans_reduce_partials_kernel, dim3(plen), dim3(kKmThreads), 0, st, w.block_partials, grid,
                            plen, given_labels ? 1 : 0, state, (long long *)partials);
