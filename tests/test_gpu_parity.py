@@ -328,6 +328,46 @@ def test_kmeans_shapes_vs_oracle(ops, oracle, dev, n, d, K):
                                   oracle.euc_sim(x[:, :50], ref["centroids"]))
 
 
+def _filter_case(kind, n, seed):
+    """Point clouds chosen to stress the matrix-core filter of the Lloyd assignment (d = 6, N % 4 == 0, N >= 1024)."""
+    from eigentrajectory_amd.synth import gaussian_points_np
+    rng = np.random.default_rng(seed)
+    x = gaussian_points_np(6, n, seed=seed, n_blobs=7)
+    if kind == "tiny":            # magnitudes far below the f16 range: everything rides on the power-of-two scale
+        x = x * np.float32(1e-12)
+    elif kind == "huge":
+        x = x * np.float32(3e11)
+    elif kind == "outliers":      # a few points 1000x further out (what a 2/|d| normalisation does to slow walkers)
+        idx = rng.choice(n, n // 100, replace=False)
+        x[:, idx] *= np.float32(1000.0)
+    elif kind == "lattice":       # integer coordinates: many exact ties and duplicates, arg-max = first maximum
+        x = rng.integers(0, 3, size=(6, n)).astype(np.float32)
+    elif kind == "subnormal_mix":  # ordinary points plus coordinates that are exactly 0 or fp32-denormal
+        x[:, ::7] = 0.0
+        x[2, ::5] = np.float32(1e-40)
+    elif kind == "line":          # nearly collinear data: centroids very close to each other, small margins
+        t = rng.standard_normal(n).astype(np.float32)
+        x = (np.outer(np.arange(1, 7, dtype=np.float32), t) + 1e-3 * rng.standard_normal((6, n))).astype(np.float32)
+    return np.ascontiguousarray(x.astype(np.float32))
+
+
+@pytest.mark.parametrize("kind,n,K", [("blobs", 1024, 20), ("blobs", 4100, 3), ("blobs", 12288, 19), ("blobs", 8192, 21),
+                                      ("blobs", 5000, 32), ("tiny", 4096, 20), ("huge", 4096, 20), ("outliers", 20000, 20),
+                                      ("lattice", 6000, 20), ("lattice", 4096, 31), ("subnormal_mix", 7000, 20),
+                                      ("line", 10000, 20)])
+def test_kmeans_filter_kernel_bit_exact_on_adversarial_data(ops, oracle, dev, kind, n, K):
+    """Iterations >= 1 run the filter kernel (f16 MFMA upper bounds + exact certification): it may only ever say
+    "label unchanged" when that is what the exact scan computes, whatever the data look like."""
+    x = _filter_case(kind, n, seed=n + K)
+    c0, _ = oracle.kmeans_init_farthest(x, K, n // 3)
+    res = ops.kmeans_fit(T(x, dev), T(c0, dev), 25, 1e-4)
+    ref = oracle.kmeans_fit(x, c0, 25, 1e-4)
+    assert res["n_iter"] == ref["n_iter"]
+    assert np.array_equal(N_(res["labels"]), ref["labels"])
+    assert np.array_equal(N_(res["centroids"]), ref["centroids"], equal_nan=True)
+    np.testing.assert_array_equal(N_(res["trace"]), ref["trace"])
+
+
 def test_kmeans_duplicates_nan_propagation_g7(ops, oracle, dev):
     from eigentrajectory_amd import BatchKMeans
     z = G.load("g7_batchkmeans.npz")
