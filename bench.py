@@ -235,9 +235,18 @@ def main():
                    roofline=roofline, stages=stages)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.max_iter)
-        print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line goes out last: anything the runtime libraries still hold in C stdio buffers (RCCL prints
+        # a version banner) is flushed first
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -26,7 +26,7 @@ SYMBOLS = [
     "et_norm_project", "et_anchor_reconstruct_fwd", "et_anchor_reconstruct_bwd", "et_anchor_reconstruct_metrics",
     "et_fit_gram_workspace_bytes", "et_fit_gram", "et_eigh_topk", "et_eigh_topk_batch",
     "et_euc_sim", "et_kmeans_partials_len", "et_kmeans_workspace_bytes", "et_kmeans_scan", "et_kmeans_begin",
-    "et_kmeans_init_step", "et_kmeans_init_set", "et_kmeans_gather_point", "et_kmeans_init_farthest",
+    "et_kmeans_init_step", "et_kmeans_init_set", "et_kmeans_init_select", "et_kmeans_gather_point", "et_kmeans_init_farthest",
     "et_kmeans_assign_accumulate", "et_kmeans_update", "et_kmeans_labels_i64", "et_kmeans_fit", "et_kmeans_predict",
 ]
 

@@ -688,7 +688,7 @@ __global__ __launch_bounds__(kFilterThreads) void kmeans_assign_filter_kernel(
 __global__ __launch_bounds__(kKmThreads) void kmeans_reduce_partials_kernel(const long long *__restrict__ block_partials,
                                                                             int n_blocks, int plen, int full,
                                                                             const et_kmeans_state *__restrict__ state,
-                                                                            long long *__restrict__ partials) {
+                                                                            long long *totals, long long *partials) {
     if (state->done) return;
     __shared__ long long sW[kKmThreads / 64];
     const int e = blockIdx.x;
@@ -699,8 +699,12 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_reduce_partials_kernel(cons
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < kKmThreads / 64; ++w) s += sW[w];
+        // the running totals stay in the workspace; the caller's buffer receives a copy it may overwrite (all-reduce
+        // in place)
         const bool running = !full && state->iter > 0 && e < plen - 2;
-        partials[e] = running ? partials[e] + s : s;
+        const long long tot = running ? totals[e] + s : s;
+        totals[e] = tot;
+        partials[e] = tot;
     }
 }
 
@@ -941,6 +945,31 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_pick_kernel(const floa
     }
 }
 
+// sharded farthest-first step: the smallest 64-bit key among the ranks' candidate records (value first, then global
+// index: the same winner on every rank) becomes centroid `col`.  One wavefront; replaces a handful of tensor ops.
+__global__ void kmeans_init_select_kernel(const unsigned char *__restrict__ cands, int n_cands, int stride, int d, int K,
+                                          int col, float *__restrict__ C0) {
+    const int lane = threadIdx.x;
+    unsigned long long key = ~0ull;
+    int who = 0;
+    for (int r = lane; r < n_cands; r += 64) {
+        const unsigned long long k = *reinterpret_cast<const unsigned long long *>(cands + (size_t)r * stride);
+        if (k < key) {
+            key = k;
+            who = r;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ok = __shfl_xor(key, o);
+        const int ow = __shfl_xor(who, o);
+        if (ok < key || (ok == key && ow < who)) {
+            key = ok;
+            who = ow;
+        }
+    }
+    if (lane < d) C0[lane * K + col] = *reinterpret_cast<const float *>(cands + (size_t)who * stride + 8 + 4 * lane);
+}
+
 __global__ void kmeans_init_set_kernel(float *__restrict__ C0, int d, int K, int col, const float *__restrict__ point) {
     const int i = threadIdx.x;
     if (i < d) C0[i * K + col] = point[i];
@@ -1130,7 +1159,7 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_km
                            K, tol, const_cast<float *>(centroids), trace);
     } else {
         hipLaunchKernelGGL(kmeans_reduce_partials_kernel, dim3(plen), dim3(kKmThreads), 0, st, w.block_partials, grid,
-                           plen, given_labels ? 1 : 0, state, (long long *)partials);
+                           plen, given_labels ? 1 : 0, state, w.partials, (long long *)partials);
     }
     ET_LAUNCH_CHECK();
     return ET_OK;
@@ -1201,6 +1230,17 @@ extern "C" int et_kmeans_init_step(const float *X, int64_t N, int d, int K, int 
     ET_LAUNCH_CHECK();
     hipLaunchKernelGGL(kmeans_init_pick_kernel, dim3(1), dim3(kKmThreads), 0, st, X, N, d, w.block_keys, grid,
                        index_base, (unsigned char *)cand);
+    ET_LAUNCH_CHECK();
+    return ET_OK;
+}
+
+extern "C" int et_kmeans_init_select(const void *cands, int n_cands, int stride_bytes, int d, int K, int col, float *C0,
+                                     et_stream_t stream) {
+    if (!cands || !C0 || !km_dims_ok(d, K) || col < 0 || col >= K || n_cands < 1 || stride_bytes < 8 + 4 * d ||
+        (stride_bytes & 7) || (reinterpret_cast<uintptr_t>(cands) & 7u))
+        return ET_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(kmeans_init_select_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                       (const unsigned char *)cands, n_cands, stride_bytes, d, K, col, C0);
     ET_LAUNCH_CHECK();
     return ET_OK;
 }

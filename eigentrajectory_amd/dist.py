@@ -43,7 +43,6 @@ def _all_reduce(t, op, group=None):
 def fit_descriptor_sharded(obs, pred, k, mode, static_dist=0.0, which=1, group=None, gram_fn=None, eigh_fn=None):
     """U_obs (2T_obs,k), U_pred (2T_pred,k), sigma_obs, sigma_pred, count for descriptor ``which`` over ALL ranks' rows."""
     gram_fn = gram_fn or ops.fit_gram
-    eigh_fn = eigh_fn or ops.eigh_topk
     g_obs, g_pred, cnt = gram_fn(obs, pred, mode, static_dist, which)
     packed = torch.cat([g_obs.reshape(-1), g_pred.reshape(-1), cnt.reshape(-1).to(g_obs.dtype)])
     _all_reduce(packed, dist.ReduceOp.SUM, group)  # one 6.7 KB message
@@ -51,8 +50,11 @@ def fit_descriptor_sharded(obs, pred, k, mode, static_dist=0.0, which=1, group=N
     g_obs = packed[:no].reshape(g_obs.shape).contiguous()
     g_pred = packed[no:no + npd].reshape(g_pred.shape).contiguous()
     count = int(round(float(packed[-1].item())))
-    U_obs, s_obs = eigh_fn(g_obs, k)
-    U_pred, s_pred = eigh_fn(g_pred, k)
+    if eigh_fn is None:
+        (U_obs, s_obs), (U_pred, s_pred) = ops.eigh_topk_batch([g_obs, g_pred], k)  # both matrices in one launch
+    else:
+        U_obs, s_obs = eigh_fn(g_obs, k)
+        U_pred, s_pred = eigh_fn(g_pred, k)
     return U_obs, U_pred, s_obs, s_pred, count
 
 
@@ -65,7 +67,7 @@ class ShardedKMeans:
     ``state``, ``state_f64`` tensors).  Every rank must call the same methods in the same order.
     """
 
-    def __init__(self, X_local, n_clusters, group=None, shard_factory=None, check_every=8):
+    def __init__(self, X_local, n_clusters, group=None, shard_factory=None, check_every=4):
         self.group = group
         self.world, self.rank = _world(group)
         self.K = int(n_clusters)
@@ -93,19 +95,16 @@ class ShardedKMeans:
             first = self.shard.gather_point(local).to(torch.float32)
         _all_reduce(first, dist.ReduceOp.SUM, self.group)  # only the owner contributes non-zeros
         C0[:, 0] = first
-        rec_bytes = 8 + 4 * d
+        rec_bytes = (8 + 4 * d + 7) // 8 * 8
+        gathered = torch.zeros((self.world * rec_bytes,), dtype=torch.uint8, device=self.dev)
         for i in range(1, K):
-            cand = self.shard.init_step(i, C0, self.index_base)[:rec_bytes].clone()
+            cand = self.shard.init_step(i, C0, self.index_base)[:rec_bytes]
             if dist.is_available() and dist.is_initialized():
-                gathered = [torch.empty_like(cand) for _ in range(self.world)]
-                dist.all_gather(gathered, cand, group=self.group)
-                cands = torch.stack(gathered)
+                dist.all_gather_into_tensor(gathered, cand, group=self.group)  # 32 B per rank
             else:
-                cands = cand[None]
-            # smallest 64-bit key wins (value first, then global index): identical on every rank
-            keys = cands[:, :8].contiguous().view(torch.int64).reshape(-1)
-            win = torch.argmin(keys ^ torch.iinfo(torch.int64).min)  # unsigned order, no host round trip
-            C0[:, i] = cands[win, 8:rec_bytes].contiguous().view(torch.float32)
+                gathered.copy_(cand)
+            # smallest 64-bit key wins (value first, then global index): identical on every rank, one tiny kernel
+            self.shard.init_select(gathered, self.world, rec_bytes, i, C0)
         return C0
 
     def fit(self, centroids, max_iter=100, tol=1e-4, trace=None):
@@ -120,21 +119,22 @@ class ShardedKMeans:
         _all_reduce(sh.state[7:8], dist.ReduceOp.MAX, self.group)
         _all_reduce(sh.state[11:12], dist.ReduceOp.MIN, self.group)  # smallest non-zero |x| (fp32 bits)
         sh.begin(self.n_total, centroids)
-        reduced = torch.zeros_like(sh.partials)
+        # Convergence is decided on the device from identical bits on every rank.  The host looks at the state block
+        # `check_every` iterations LATE (an asynchronous copy posted then, long since arrived): no pipeline drain,
+        # and every rank takes the same decision at the same iteration.  Launches after convergence are no-ops.
+        pending = []
         st = None
         for it in range(max_iter):
-            part = sh.assign(centroids)
-            if dist.is_available() and dist.is_initialized():
-                reduced.copy_(part)  # out of place: a finished run leaves `part` untouched
-                _all_reduce(reduced, dist.ReduceOp.SUM, self.group)  # 1.1 KB of int64
-                sh.update(reduced, centroids, tol, trace)
-            else:
-                sh.update(part, centroids, tol, trace)
-            if (it + 1) % self.check_every == 0 or it + 1 == max_iter:
-                st = sh.read_state()  # the same bits on every rank -> the same decision
-                if st.done:
-                    break
-        st = st or sh.read_state()
+            part = sh.assign(centroids)  # the shard keeps its running totals; `part` is a copy we may overwrite
+            _all_reduce(part, dist.ReduceOp.SUM, self.group)  # 1.1 KB of int64, in place
+            sh.update(part, centroids, tol, trace)
+            if (it + 1) % self.check_every == 0:
+                pending.append(sh.post_state())
+                if len(pending) > 1:
+                    st = sh.wait_state(pending.pop(0))
+                    if st.done:
+                        break
+        st = sh.read_state()
         if st.bad_input:
             raise ValueError("k-means input contains NaN/Inf")
         return dict(centroids=centroids, labels=sh.labels(), n_iter=int(st.iter), error=float(st.error),

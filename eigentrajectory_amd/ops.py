@@ -323,6 +323,27 @@ class KMeansShard:
                                             C.c_size_t(self.ws.numel()), L.stream(self.dev)), "et_kmeans_init_step")
         return self.cand
 
+    def init_select(self, cands, n_cands, stride, col, C0):
+        """Column ``col`` of C0 <- the candidate record with the smallest key among ``n_cands`` gathered records."""
+        L.check(L.lib().et_kmeans_init_select(L.ptr(cands), int(n_cands), int(stride), self.d, self.K, int(col), L.ptr(C0),
+                                              L.stream(self.dev)), "et_kmeans_init_select")
+
+    def post_state(self):
+        """Start an asynchronous copy of the state block to pinned host memory; -> handle for ``wait_state``."""
+        if not hasattr(self, "_pins"):
+            self._pins, self._pin_i = [torch.empty((L.STATE_BYTES // 8,), dtype=torch.int64).pin_memory() for _ in range(4)], 0
+        host = self._pins[self._pin_i % 4]
+        self._pin_i += 1
+        host.copy_(self.state, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        return host, ev
+
+    def wait_state(self, handle):
+        host, ev = handle
+        ev.synchronize()
+        return L.KMeansState.from_buffer_copy(host.numpy().tobytes())
+
     def gather_point(self, local_index):
         pt = torch.empty((self.d,), device=self.dev)
         L.check(L.lib().et_kmeans_gather_point(L.ptr(self.X), L.i64(self.n), self.d, L.i64(local_index), L.ptr(pt),

@@ -197,6 +197,10 @@ int et_kmeans_init_step(const float *X, int64_t N, int d, int K, int i, const fl
                         int64_t index_base, void *cand, void *workspace, size_t workspace_bytes,
                         et_stream_t stream);
 int et_kmeans_init_set(float *C0, int d, int K, int col, const float *point, et_stream_t stream);
+/* sharded step, after the all-gather of the ranks' candidate records (n_cands records, stride_bytes apart,
+ * 8-byte aligned): the record with the smallest key becomes column `col` of C0 -- the same on every rank. */
+int et_kmeans_init_select(const void *cands, int n_cands, int stride_bytes, int d, int K, int col, float *C0,
+                          et_stream_t stream);
 /* gather X[:, local_index] -> point (d floats, device) */
 int et_kmeans_gather_point(const float *X, int64_t N, int d, int64_t local_index, float *point,
                            et_stream_t stream);
@@ -208,8 +212,9 @@ int et_kmeans_init_farthest(const float *X, int64_t N, int d, int K, int64_t fir
  * and this shard's exact partials; no-op when state->done.  From the second iteration on only
  * the points whose label changed update the sums (exact integer deltas) -- for d = 6, K <= 32 a
  * matrix-core filter first proves, per point, that the label cannot change (bit-identical results) --
- * so `labels_u8` and `partials` must be the buffers of the previous iteration of the same fit,
- * unmodified.  With given_labels != NULL (int64, N) the labels are taken as they are instead of
+ * so `labels_u8` and `workspace` (which holds the running totals) must be the buffers of the previous
+ * iteration of the same fit, unmodified; `partials` receives a copy of the totals and is the caller's to
+ * overwrite (e.g. all-reduce in place).  With given_labels != NULL (int64, N) the labels are taken as they are instead of
  * computed (compute_centroids, kmeans.py:160-198, as a public method). */
 int et_kmeans_assign_accumulate(const float *X, int64_t N, int d, int K, const et_kmeans_state *state,
                                 const float *centroids, const int64_t *given_labels, uint8_t *labels_u8,

@@ -77,6 +77,18 @@ class OracleShard:
         self.cand = torch.from_numpy(buf)
         return self.cand
 
+    def init_select(self, cands, n_cands, stride, col, C0):
+        recs = cands.numpy().reshape(n_cands, stride)
+        keys = recs[:, :8].copy().view(np.uint64).reshape(-1)
+        w = int(np.argmin(keys))
+        C0[:, col] = torch.from_numpy(recs[w, 8:8 + 4 * self.d].copy().view(np.float32))
+
+    def post_state(self):
+        return self.read_state()
+
+    def wait_state(self, handle):
+        return handle
+
     def assign(self, centroids, given_labels=None):
         if int(self.state[6]):
             return self.partials
