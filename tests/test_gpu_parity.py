@@ -582,6 +582,42 @@ def test_wrapper_fit_calculate_parameters_eth(dev, oracle):
         assert ours < 1.15 * theirs, f"anchor inertia {ours:.4f} vs sklearn n_init=10 {theirs:.4f}"
 
 
+def test_anchor_generation_sklearn_recipe_eth(dev, oracle):
+    """anchor.py:65-71 restated on the device (`anchor_init="sklearn"`): the k-means++ seeds follow sklearn's own
+    RandomState(0) stream, and the anchors are as good as the ones the reference's sklearn call produced (G2)."""
+    from eigentrajectory_amd import EigenTrajectory
+    from eigentrajectory_amd.anchor import greedy_kmeanspp, sklearn_style_kmeans
+    from eigentrajectory_amd.utils import default_hyper_params
+    g2 = G.load("g2_fit_all_scenes.npz")
+    obs, pred = G.eth_fit_input()
+    flag = oracle.moving_flags(obs, G.static_dist("eth"))
+    Ur = g2["eth.ET_m_descriptor.U_pred_trunc"]
+    _, c_ref, _, _ = oracle.norm_project(obs[flag], pred[flag], Ur, Ur, Ur, Ur, 1)  # (6, N_moving) coefficients
+    # 1. seeding: same indices as sklearn.cluster.kmeans_plusplus fed with the same stream (when sklearn is there)
+    X = T(c_ref - c_ref.mean(axis=1, keepdims=True), dev)
+    idx, c0 = greedy_kmeanspp(X, 20, np.random.RandomState(0))
+    assert len(set(idx)) == 20 and c0.shape == (6, 20)
+    try:
+        from sklearn.cluster import kmeans_plusplus
+        _, sk_idx = kmeans_plusplus(np.ascontiguousarray(N_(X).T), 20, random_state=np.random.RandomState(0))
+        same = sum(int(a == b) for a, b in zip(idx, sk_idx))
+        assert same >= 18, f"k-means++ indices agree with sklearn on {same}/20 picks: {idx} vs {list(sk_idx)}"
+    except ImportError:
+        pass
+    # 2. the full recipe: ten initialisations, best inertia -> not worse than the reference's sklearn anchors
+    A, inertia, seeds = sklearn_style_kmeans(T(c_ref, dev), 20)
+    assert A.shape == (6, 20) and torch.isfinite(A).all() and len(seeds) == 10
+    ours = -oracle.kmeans_assign(c_ref, N_(A))[1].mean()
+    theirs = -oracle.kmeans_assign(c_ref, g2["eth.ET_m_anchor.C_anchor"])[1].mean()
+    assert ours < 1.02 * theirs, f"anchor inertia {ours:.4f} vs the reference's sklearn anchors {theirs:.4f}"
+    # 3. through the wrapper
+    hp = default_hyper_params(static_dist=G.static_dist("eth"), anchor_init="sklearn")
+    model = EigenTrajectory(ZeroStub(), stub_hooks(), hp).to(dev)
+    model.calculate_parameters(T(obs, dev), T(pred, dev))
+    assert torch.isfinite(model.ET_m_anchor.C_anchor).all() and torch.isfinite(model.ET_s_anchor.C_anchor).all()
+    assert len(model.ET_m_anchor.seed_indices_) == 10
+
+
 # -------------------------------------------------------------- full-size properties (N = 1e6)
 def test_full_size_properties(ops, dev):
     """Size-independent checks at BASELINE.json's N=1e6: P(R(P(x))) = P(x); sharding is additive; Lloyd never
