@@ -177,23 +177,52 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_scan_kernel(const float *__
     float m = 0.f;
     unsigned mn = 0x7f800000u;  // bits of the smallest non-zero |x| (positive floats order like their bits)
     int bad = 0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-        const float a = fabsf(X[i]);
+    auto take = [&](float v) {
+        const float a = fabsf(v);
         if (!(a <= 3.402823466e+38f)) bad = 1;
         else {
             if (a > m) m = a;
             const unsigned b = (unsigned)__float_as_int(a);
             if (b != 0u && b < mn) mn = b;
         }
+    };
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // 16-B loads over the aligned body, scalar loads for the (< 4 element) head and tail
+    const int64_t head = min(count, (int64_t)(((16 - (reinterpret_cast<uintptr_t>(X) & 15u)) & 15u) / 4));
+    const int64_t n4 = (count - head) / 4;
+    const float4 *X4 = reinterpret_cast<const float4 *>(X + head);
+    for (int64_t i = tid; i < n4; i += stride) {
+        const float4 v = X4[i];
+        take(v.x);
+        take(v.y);
+        take(v.z);
+        take(v.w);
     }
+    if (tid < head) take(X[tid]);
+    if (tid < count - head - 4 * n4) take(X[head + 4 * n4 + tid]);
     for (int o = 32; o > 0; o >>= 1) {
         m = fmaxf(m, __shfl_xor(m, o));
         const unsigned other = (unsigned)__shfl_xor((int)mn, o);
         mn = other < mn ? other : mn;
         bad |= __shfl_xor(bad, o);
     }
+    // one set of device-scope atomics per WORKGROUP (they serialise on their three addresses)
+    __shared__ float sM[kKmThreads / 64];
+    __shared__ unsigned sMn[kKmThreads / 64];
+    __shared__ int sBad[kKmThreads / 64];
     if ((threadIdx.x & 63) == 0) {
+        sM[threadIdx.x >> 6] = m;
+        sMn[threadIdx.x >> 6] = mn;
+        sBad[threadIdx.x >> 6] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kKmThreads / 64; ++w) {
+            m = fmaxf(m, sM[w]);
+            mn = sMn[w] < mn ? sMn[w] : mn;
+            bad |= sBad[w];
+        }
         atomicMax(reinterpret_cast<unsigned long long *>(&state->max_abs_x),
                   (unsigned long long)__double_as_longlong((double)m));
         atomicMin(reinterpret_cast<unsigned long long *>(&state->min_nz_x_bits), (unsigned long long)mn);
@@ -830,7 +859,21 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_reduce_update_kernel(const 
 __global__ __launch_bounds__(kKmThreads) void kmeans_labels_i64_kernel(const uint8_t *__restrict__ lb, int64_t N,
                                                                        int64_t *__restrict__ out) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) out[n] = (int64_t)lb[n];
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // four labels per lane: one 4-B load, two 16-B stores (both buffers come 16-B aligned from the allocator)
+    const bool vec = ((reinterpret_cast<uintptr_t>(lb) & 3u) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
+    const int64_t n4 = vec ? N / 4 : 0;
+    for (int64_t i = tid; i < n4; i += stride) {
+        const unsigned p = reinterpret_cast<const unsigned *>(lb)[i];
+        longlong2 a, b;
+        a.x = p & 0xffu;
+        a.y = (p >> 8) & 0xffu;
+        b.x = (p >> 16) & 0xffu;
+        b.y = p >> 24;
+        reinterpret_cast<longlong2 *>(out)[2 * i] = a;
+        reinterpret_cast<longlong2 *>(out)[2 * i + 1] = b;
+    }
+    for (int64_t n = 4 * n4 + tid; n < N; n += stride) out[n] = (int64_t)lb[n];
 }
 
 // predict (kmeans.py:261-272): labels int64 + optional max similarity
@@ -1086,7 +1129,9 @@ extern "C" int et_kmeans_scan(const float *X, int64_t N, int d, et_kmeans_state 
     ET_HIP_TRY(hipMemsetAsync(state, 0, sizeof(et_kmeans_state), st));
     ET_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)&state->min_nz_x_bits, 0x7f800000, 1, st));  // "+inf": no non-zero yet
     if (N == 0) return ET_OK;
-    hipLaunchKernelGGL(kmeans_scan_kernel, dim3(km_grid(N * d / 4 + 1)), dim3(kKmThreads), 0, st, X, N * d, state);
+    const int64_t scan_blocks = ceil_div(N * d / 4 + 1, (int64_t)kKmThreads);
+    hipLaunchKernelGGL(kmeans_scan_kernel, dim3((unsigned)(scan_blocks < 1024 ? scan_blocks : 1024)), dim3(kKmThreads), 0, st,
+                       X, N * d, state);
     ET_LAUNCH_CHECK();
     return ET_OK;
 }
@@ -1189,8 +1234,8 @@ extern "C" int et_kmeans_update(et_kmeans_state *state, const int64_t *partials,
 extern "C" int et_kmeans_labels_i64(const uint8_t *labels_u8, int64_t N, int64_t *labels, et_stream_t stream) {
     if (N < 0 || (N > 0 && (!labels_u8 || !labels))) return ET_ERR_INVALID_ARG;
     if (N == 0) return ET_OK;
-    hipLaunchKernelGGL(kmeans_labels_i64_kernel, dim3(km_grid(N)), dim3(kKmThreads), 0, (hipStream_t)stream, labels_u8,
-                       N, labels);
+    hipLaunchKernelGGL(kmeans_labels_i64_kernel, dim3(km_grid(N / 4 + 1)), dim3(kKmThreads), 0, (hipStream_t)stream,
+                       labels_u8, N, labels);
     ET_LAUNCH_CHECK();
     return ET_OK;
 }
@@ -1292,7 +1337,7 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     // dispatch gap on each side, so timing every launch would slow the loop it measures by ~15 %.
     constexpr int kTimeEvery = 8;
     auto timed = [&](int it) { return timing_host && (it == 0 || it % kTimeEvery == 1); };
-    static std::vector<hipEvent_t> events;  // reused across calls; only touched when timing is requested
+    static thread_local std::vector<hipEvent_t> events;  // reused across calls; only touched when timing is requested
     if (timing_host) {
         while ((int)events.size() < 2 * max_iter) {
             hipEvent_t e;
@@ -1305,8 +1350,8 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     // for it inside the loop: every few iterations the state block is copied to a pinned ring slot, and a
     // copy that has ARRIVED (event query, non-blocking) is looked at; the queue stays at most kLag iterations ahead.
     constexpr int kSlots = 4, kEvery = 4, kLag = kSlots * kEvery;
-    static et_kmeans_state *ring = nullptr;
-    static hipEvent_t ring_ev[kSlots];
+    static thread_local et_kmeans_state *ring = nullptr;  // per host thread: concurrent fits on different streams do not share it
+    static thread_local hipEvent_t ring_ev[kSlots];
     if (!ring) {
         ET_HIP_TRY(hipHostMalloc((void **)&ring, sizeof(et_kmeans_state) * kSlots, hipHostMallocDefault));
         for (int i = 0; i < kSlots; ++i) ET_HIP_TRY(hipEventCreateWithFlags(&ring_ev[i], hipEventDisableTiming));
