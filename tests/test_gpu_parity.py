@@ -328,6 +328,28 @@ def test_kmeans_shapes_vs_oracle(ops, oracle, dev, n, d, K):
                                   oracle.euc_sim(x[:, :50], ref["centroids"]))
 
 
+def test_sharded_driver_on_one_gpu_matches_oracle(ops, oracle, dev):
+    """dist.ShardedKMeans / fit_descriptor_sharded with the real device shard and no process group (world = 1): the
+    step API, the candidate-selection kernel and the lagged convergence polling give the oracle's bits."""
+    from eigentrajectory_amd.dist import ShardedKMeans, fit_descriptor_sharded
+    from eigentrajectory_amd.synth import gaussian_points_np, synthetic_trajectories_np
+    x = gaussian_points_np(6, 6000, seed=21, n_blobs=6)
+    km = ShardedKMeans(T(x, dev), 20)
+    c0 = km.init_farthest(1234)
+    r0, _ = oracle.kmeans_init_farthest(x, 20, 1234)
+    assert np.array_equal(N_(c0), r0)
+    res = km.fit(c0.clone(), 60, 1e-4)
+    ref = oracle.kmeans_fit(x, r0, 60, 1e-4)
+    assert res["n_iter"] == ref["n_iter"]
+    assert np.array_equal(N_(res["labels"]), ref["labels"])
+    assert np.array_equal(N_(res["centroids"]), ref["centroids"])
+    obs, pred = synthetic_trajectories_np(5000, seed=3)
+    U_obs, U_pred, s_obs, s_pred, count = fit_descriptor_sharded(T(obs, dev), T(pred, dev), 6, ops.MODE_MOVING, 0.0, 1)
+    g_obs, g_pred, _ = ops.fit_gram(T(obs, dev), T(pred, dev), ops.MODE_MOVING, 0.0, 1)
+    assert count == 5000
+    assert torch.equal(U_obs, ops.eigh_topk(g_obs, 6)[0]) and torch.equal(U_pred, ops.eigh_topk(g_pred, 6)[0])
+
+
 def _filter_case(kind, n, seed):
     """Point clouds chosen to stress the matrix-core filter of the Lloyd assignment (d = 6, N % 4 == 0, N >= 1024)."""
     from eigentrajectory_amd.synth import gaussian_points_np
