@@ -42,7 +42,8 @@ def parse():
     ap.add_argument("--trajectories", dest="n", type=float, default=1e7, help="trajectories per GPU")
     ap.add_argument("--max-iter", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=100_000, help="trajectories of the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=600_000,
+                    help="trajectories of the CPU-baseline sample (default: ~10 s of single-core work)")
     return ap.parse_args()
 
 

@@ -831,15 +831,18 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_reduce_update_kernel(const 
                                                                           int n_blocks, int plen, et_kmeans_state *state,
                                                                           long long *partials, unsigned *ticket, int d,
                                                                           int K, float tol, float *cen, float *trace) {
-    if (state->done) return;
     __shared__ int sLast;
     const int lane = threadIdx.x & 63, e = blockIdx.x * (kKmThreads / 64) + (threadIdx.x >> 6);
-    if (e < plen) {
-        const long long before = (lane == 0 && state->iter > 0 && e < plen - 2) ? partials[e] : 0;
-        long long s = 0;
+    // every load is issued before the first result is looked at: one memory round trip instead of three
+    const int64_t done = state->done, iter = state->iter;
+    const long long prev = (e < plen && lane == 0) ? partials[e] : 0;
+    long long s = 0;
+    if (e < plen)
         for (int b = lane; b < n_blocks; b += 64) s += block_partials[(size_t)e * n_blocks + b];
+    if (done) return;
+    if (e < plen) {
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) partials[e] = before + s;
+        if (lane == 0) partials[e] = ((iter > 0 && e < plen - 2) ? prev : 0) + s;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
