@@ -367,6 +367,9 @@ def _filter_case(kind, n, seed):
     elif kind == "subnormal_mix":  # ordinary points plus coordinates that are exactly 0 or fp32-denormal
         x[:, ::7] = 0.0
         x[2, ::5] = np.float32(1e-40)
+    elif kind == "few_distinct":  # 12 distinct points, K = 20: duplicate centroids -> empty clusters -> NaN centroids,
+        base = rng.standard_normal((6, 12)).astype(np.float32)  # which sends the later iterations through the NaN-aware scan
+        x = base[:, rng.integers(0, 12, size=n)]
     elif kind == "line":          # nearly collinear data: centroids very close to each other, small margins
         t = rng.standard_normal(n).astype(np.float32)
         x = (np.outer(np.arange(1, 7, dtype=np.float32), t) + 1e-3 * rng.standard_normal((6, n))).astype(np.float32)
@@ -376,7 +379,7 @@ def _filter_case(kind, n, seed):
 @pytest.mark.parametrize("kind,n,K", [("blobs", 1024, 20), ("blobs", 4100, 3), ("blobs", 12288, 19), ("blobs", 8192, 21),
                                       ("blobs", 5000, 32), ("tiny", 4096, 20), ("huge", 4096, 20), ("outliers", 20000, 20),
                                       ("lattice", 6000, 20), ("lattice", 4096, 31), ("subnormal_mix", 7000, 20),
-                                      ("line", 10000, 20)])
+                                      ("line", 10000, 20), ("few_distinct", 4096, 20)])
 def test_kmeans_filter_kernel_bit_exact_on_adversarial_data(ops, oracle, dev, kind, n, K):
     """Iterations >= 1 run the filter kernel (f16 MFMA upper bounds + exact certification): it may only ever say
     "label unchanged" when that is what the exact scan computes, whatever the data look like."""
