@@ -78,7 +78,7 @@ def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None)
         (U_obs, _), (U_pred, _) = ops.eigh_topk_batch([g_obs, g_pred], 6)
     else:
         from eigentrajectory_amd.dist import fit_descriptor_sharded
-        U_obs, U_pred, _, _, _ = fit_descriptor_sharded(obs, pred, 6, mode, 0.0, 1)
+        U_obs, U_pred, _, _, _ = fit_descriptor_sharded(obs, pred, 6, mode, 0.0, 1, want_count=False)
     sw.stop("fit")
     sw.start("project")
     c_obs, c_pred, nrm, _ = ops.norm_project(obs, pred, U_obs, U_pred, None, None, mode, want_flag=False)

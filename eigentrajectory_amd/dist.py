@@ -40,8 +40,12 @@ def _all_reduce(t, op, group=None):
 
 
 # ------------------------------------------------------------------------------------------ fit
-def fit_descriptor_sharded(obs, pred, k, mode, static_dist=0.0, which=1, group=None, gram_fn=None, eigh_fn=None):
-    """U_obs (2T_obs,k), U_pred (2T_pred,k), sigma_obs, sigma_pred, count for descriptor ``which`` over ALL ranks' rows."""
+def fit_descriptor_sharded(obs, pred, k, mode, static_dist=0.0, which=1, group=None, gram_fn=None, eigh_fn=None,
+                           want_count=True):
+    """U_obs (2T_obs,k), U_pred (2T_pred,k), sigma_obs, sigma_pred, count for descriptor ``which`` over ALL ranks' rows.
+
+    ``want_count=False`` skips the host read-back of the row count (the only synchronisation in here) and returns
+    it as a 0-d device tensor instead."""
     gram_fn = gram_fn or ops.fit_gram
     g_obs, g_pred, cnt = gram_fn(obs, pred, mode, static_dist, which)
     packed = torch.cat([g_obs.reshape(-1), g_pred.reshape(-1), cnt.reshape(-1).to(g_obs.dtype)])
@@ -49,7 +53,7 @@ def fit_descriptor_sharded(obs, pred, k, mode, static_dist=0.0, which=1, group=N
     no, npd = g_obs.numel(), g_pred.numel()
     g_obs = packed[:no].reshape(g_obs.shape).contiguous()
     g_pred = packed[no:no + npd].reshape(g_pred.shape).contiguous()
-    count = int(round(float(packed[-1].item())))
+    count = int(round(float(packed[-1].item()))) if want_count else packed[-1]
     if eigh_fn is None:
         (U_obs, s_obs), (U_pred, s_pred) = ops.eigh_topk_batch([g_obs, g_pred], k)  # both matrices in one launch
     else:
