@@ -12,6 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The kernels are built in-tree by __graft_entry__.build(); on a fresh checkout (no libetamd.so yet) build them
+    here so that the ABI tests have something to load (hipcc cross-compiles gfx950 without a GPU)."""
+    lib = os.path.join(ROOT, "eigentrajectory_amd", "libetamd.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.call(["make", "-C", os.path.join(ROOT, "eigentrajectory_amd", "csrc"), "-j", str(os.cpu_count() or 4)])
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import et_oracle
