@@ -412,17 +412,13 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
                     const int p = sP[i], q = sQ[i];
                     const double c = sC[i], s = sS[i];
                     const double ajp = A[j * n + p], ajq = A[j * n + q];
-                    A[j * n + p] = c * ajp - s * ajq;
-                    A[j * n + q] = s * ajp + c * ajq;
+                    // the rotated pair entries are set to exactly zero, like the oracle does after its update
+                    A[j * n + p] = j == q ? 0.0 : c * ajp - s * ajq;
+                    A[j * n + q] = j == p ? 0.0 : s * ajp + c * ajq;
                     const double vjp = V[j * n + p], vjq = V[j * n + q];
                     V[j * n + p] = c * vjp - s * vjq;
                     V[j * n + q] = s * vjp + c * vjq;
                 }
-            }
-            __syncthreads();
-            if (lane < half && sAct[lane]) {  // (the next round's pairs are different entries)
-                A[sP[lane] * n + sQ[lane]] = 0.0;
-                A[sQ[lane] * n + sP[lane]] = 0.0;
             }
             __syncthreads();
         }
