@@ -300,9 +300,9 @@ __global__ __launch_bounds__(kFitThreads) void gram_generic_finish_kernel(const 
 
 // ------------------------------------------------------------------------------------------
 // Parallel-order (round-robin) Jacobi eigensolver in ONE workgroup, fp64, n <= 64, matrix in LDS.
-// A round applies n/2 disjoint rotations: lanes compute the (c, s) of one pair each, then all
-// lanes sweep the row updates of every pair, then the column updates (A and V): three barriers
-// per round instead of four per rotation.  Same pairing, same formulas and the same per-element
+// A round applies n/2 disjoint rotations: lanes compute the (c, s) of one pair each, then every
+// 2 x 2 block (pair, pair) of A gets its row rotation followed by its column rotation from ONE lane
+// (and V its column rotation): two barriers per round instead of four per rotation.  Same pairing, same formulas and the same per-element
 // operation order as the CPU oracle (oracle/et_oracle.c: eto_jacobi) => bit-identical output.
 // 24 x 24 converges in ~8 sweeps (23 rounds each).
 // ------------------------------------------------------------------------------------------
@@ -326,14 +326,23 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
         V[i] = (i / n == i % n) ? 1.0 : 0.0;
     }
     __syncthreads();
-    // element slots of this thread in the row / column phases: e = lane + t*256 -> (pair i, index j)
+    // work items of this thread in the update phase:
+    //   V: e = lane + t*256 -> (pair i, row j): columns p_i, q_i of row j
+    //   A: b = lane + t*256 -> (pair i1, pair i2): the 2 x 2 block rows {p1, q1} x columns {p2, q2}
     constexpr int kSlots = (32 * 64 + kEighThreads - 1) / kEighThreads;
-    int slot_i[kSlots], slot_j[kSlots];
+    constexpr int kBlkSlots = (32 * 32 + kEighThreads - 1) / kEighThreads;
+    int slot_i[kSlots], slot_j[kSlots], blk_1[kBlkSlots], blk_2[kBlkSlots];
 #pragma unroll
     for (int t = 0; t < kSlots; ++t) {
         const int e = lane + t * kEighThreads;
         slot_i[t] = e < half * n ? e / n : -1;
         slot_j[t] = e < half * n ? e % n : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < kBlkSlots; ++t) {
+        const int b = lane + t * kEighThreads;
+        blk_1[t] = b < half * half ? b / half : -1;
+        blk_2[t] = b < half * half ? b % half : 0;
     }
     double *sMax = sS + 32;  // 2 * (kEighThreads / 64) partial maxima
     for (int sweep = 0; sweep < kJacobiMaxSweeps; ++sweep) {
@@ -377,14 +386,16 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
                 const int p = a < b ? a : b, q = a < b ? b : a;
                 int act = 0;
                 if (q < n) {
-                    const double apq = A[p * n + q];
+                    const double apq = A[p * n + q], app = A[p * n + p], aqq = A[q * n + q];
                     if (apq != 0.0) {
-                        const double app = A[p * n + p], aqq = A[q * n + q];
-                        const double theta = (aqq - app) / (2.0 * apq);
-                        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                        const double c = 1.0 / sqrt(t * t + 1.0);
-                        sC[lane] = c;
-                        sS[lane] = t * c;
+                        // c = D / g, s = sgn |beta| / g (see the oracle): sqrt -> sqrt -> one level of divisions
+                        const double alpha = aqq - app, beta = 2.0 * apq;
+                        const double h = sqrt(alpha * alpha + beta * beta);
+                        const double D = fabs(alpha) + h;
+                        const double g = sqrt(D * D + beta * beta);
+                        const double sgn = (alpha == 0.0 || ((alpha > 0.0) == (beta > 0.0))) ? 1.0 : -1.0;
+                        sC[lane] = D / g;
+                        sS[lane] = sgn * fabs(beta) / g;
                         act = 1;
                     }
                 }
@@ -393,31 +404,59 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
                 sAct[lane] = act;
             }
             __syncthreads();
+            // A' = J^T A J for the round's disjoint rotations, one 2 x 2 block per work item: the row rotation of pair
+            // i1 followed by the column rotation of pair i2 touches exactly these four entries, so "all row updates,
+            // then all column updates" (the oracle's order, with its intermediate roundings) needs no barrier in
+            // between.  Inactive pairs (a_pq == 0, or the padding index of an odd n) leave their side untouched.
 #pragma unroll
-            for (int t = 0; t < kSlots; ++t) {  // rows p,q of every pair
-                const int i = slot_i[t], j = slot_j[t];
-                if (i >= 0 && sAct[i]) {
-                    const int p = sP[i], q = sQ[i];
-                    const double c = sC[i], s = sS[i];
-                    const double apj = A[p * n + j], aqj = A[q * n + j];
-                    A[p * n + j] = c * apj - s * aqj;
-                    A[q * n + j] = s * apj + c * aqj;
+            for (int t = 0; t < kBlkSlots; ++t) {
+                const int i1 = blk_1[t], i2 = blk_2[t];
+                if (i1 < 0) continue;
+                // (all pair records are fetched before the first one is looked at: one LDS round trip, not three)
+                const int a1 = sAct[i1], a2 = sAct[i2];
+                const int p1 = sP[i1], q1 = sQ[i1], p2 = sP[i2], q2 = sQ[i2];
+                const double c1 = sC[i1], s1 = sS[i1], c2 = sC[i2], s2 = sS[i2];
+                if (!a1 && !a2) continue;
+                const bool hq1 = q1 < n, hq2 = q2 < n;  // an active pair always has q < n
+                double x_pp = A[p1 * n + p2], x_pq = hq2 ? A[p1 * n + q2] : 0.0;
+                double x_qp = hq1 ? A[q1 * n + p2] : 0.0, x_qq = (hq1 && hq2) ? A[q1 * n + q2] : 0.0;
+                if (a1) {  // rows p1, q1 (columns p2 and q2)
+                    const double c = c1, sn = s1;
+                    const double t_pp = c * x_pp - sn * x_qp, t_qp = sn * x_pp + c * x_qp;
+                    const double t_pq = c * x_pq - sn * x_qq, t_qq = sn * x_pq + c * x_qq;
+                    x_pp = t_pp;
+                    x_qp = t_qp;
+                    x_pq = t_pq;
+                    x_qq = t_qq;
                 }
+                if (a2) {  // columns p2, q2 (rows p1 and q1)
+                    const double c = c2, sn = s2;
+                    const double r_pp = c * x_pp - sn * x_pq, r_pq = sn * x_pp + c * x_pq;
+                    const double r_qp = c * x_qp - sn * x_qq, r_qq = sn * x_qp + c * x_qq;
+                    x_pp = r_pp;
+                    x_pq = r_pq;
+                    x_qp = r_qp;
+                    x_qq = r_qq;
+                }
+                if (i1 == i2) {  // (active) the rotated pair entries are exactly zero, like in the oracle
+                    x_pq = 0.0;
+                    x_qp = 0.0;
+                }
+                A[p1 * n + p2] = x_pp;
+                if (hq2) A[p1 * n + q2] = x_pq;
+                if (hq1) A[q1 * n + p2] = x_qp;
+                if (hq1 && hq2) A[q1 * n + q2] = x_qq;
             }
-            __syncthreads();
 #pragma unroll
-            for (int t = 0; t < kSlots; ++t) {  // columns p,q of every pair, A and V
+            for (int t = 0; t < kSlots; ++t) {  // V' = V J: columns p, q of every row
                 const int i = slot_i[t], j = slot_j[t];
-                if (i >= 0 && sAct[i]) {
-                    const int p = sP[i], q = sQ[i];
-                    const double c = sC[i], s = sS[i];
-                    const double ajp = A[j * n + p], ajq = A[j * n + q];
-                    // the rotated pair entries are set to exactly zero, like the oracle does after its update
-                    A[j * n + p] = j == q ? 0.0 : c * ajp - s * ajq;
-                    A[j * n + q] = j == p ? 0.0 : s * ajp + c * ajq;
+                if (i < 0) continue;
+                const int act = sAct[i], p = sP[i], q = sQ[i];
+                const double c = sC[i], sn = sS[i];
+                if (act) {
                     const double vjp = V[j * n + p], vjq = V[j * n + q];
-                    V[j * n + p] = c * vjp - s * vjq;
-                    V[j * n + q] = s * vjp + c * vjq;
+                    V[j * n + p] = c * vjp - sn * vjq;
+                    V[j * n + q] = sn * vjp + c * vjq;
                 }
             }
             __syncthreads();

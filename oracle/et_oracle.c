@@ -335,10 +335,17 @@ static void eto_jacobi(double *A, int n, double *V)
                 const double apq = A[p * n + q];
                 if (apq == 0.0) continue;
                 const double app = A[p * n + p], aqq = A[q * n + q];
-                const double theta = (aqq - app) / (2.0 * apq);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                cc[i] = 1.0 / sqrt(t * t + 1.0);
-                ss[i] = t * cc[i];
+                /* tan(phi) = t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written with
+                 * alpha = aqq - app, beta = 2 apq as t = sgn |beta| / D, D = |alpha| + sqrt(alpha^2 + beta^2); then
+                 * c = 1 / sqrt(1 + t^2) = D / g and s = t c = sgn |beta| / g with g = sqrt(D^2 + beta^2): two square
+                 * roots and one level of divisions on the critical path instead of three divisions and two roots */
+                const double alpha = aqq - app, beta = 2.0 * apq;
+                const double h = sqrt(alpha * alpha + beta * beta);
+                const double D = fabs(alpha) + h;
+                const double g = sqrt(D * D + beta * beta);
+                const double sgn = (alpha == 0.0 || ((alpha > 0.0) == (beta > 0.0))) ? 1.0 : -1.0;
+                cc[i] = D / g;
+                ss[i] = sgn * fabs(beta) / g;
                 act[i] = 1;
             }
             for (int i = 0; i < m / 2; ++i) { /* rows p,q of every pair */
