@@ -909,15 +909,32 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_predict_kernel(const float 
 // best[n] = max(best[n], sim(x_n, c_{i-1})); candidate = arg-min over n (first index on ties,
 // NaN first) encoded as a 64-bit key so that a plain unsigned min is the reduction.
 // ------------------------------------------------------------------------------------------
+//
+// Steps >= 2 skip the coordinate read of every point that provably keeps its running maximum (Elkan's
+// triangle inequality, made rigorous for the computed fp32 similarities): with l = nearest[n] the centroid that
+// holds best[n], Delta_l <= ||c_new - c_l|| and E >= the rounding error of any computed similarity of this shard
+// (2^-19 (R + C)^2 with R = sqrt(d) max|x| >= every local ||x|| and C = the largest centroid norm so far),
+//     ||x - c_l|| <= sqrt(E - best[n])   and   ||x - c_new|| >= Delta_l - ||x - c_l||,
+// so  Delta_l >= 2 sqrt(E - best[n])  implies  y_new <= -||x - c_new||^2 + E <= best[n]:  the strict `>` of the
+// update cannot fire and best / nearest stay as they are.  Such a point costs 5 B (best + nearest) instead of
+// 32 B; farthest-first picks are far from everything by construction, so most points qualify.  best[] is only
+// written when it changes.  max|x| is collected by step 1, which reads everything anyway.
 template <int D>
 __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const float *__restrict__ X, int64_t N, int d_rt,
                                                                       int K, int step, const float *__restrict__ C0,
-                                                                      float *__restrict__ best, int64_t index_base,
+                                                                      float *__restrict__ best,
+                                                                      uint8_t *__restrict__ nearest,
+                                                                      unsigned *__restrict__ max_abs_bits,
+                                                                      int64_t index_base,
                                                                       unsigned long long *__restrict__ block_keys) {
     const int d = D ? D : d_rt;
     __shared__ float sc[ET_KMEANS_MAX_D + 1];
+    __shared__ float sDelta[ET_KMEANS_MAX_CLUSTERS + 1];
     __shared__ unsigned long long sKey[kKmThreads / 64];
+    __shared__ unsigned sMax[kKmThreads / 64];
+    __shared__ unsigned sCmax;  // fp32 bits of the largest centroid norm among columns 0 .. step-1
     if (threadIdx.x == 0) {
+        sCmax = 0u;
         float bn = 0.f;
         for (int i = 0; i < d; ++i) {
             const float v = C0[i * K + (step - 1)];
@@ -927,43 +944,84 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
         sc[d] = bn;
     }
     __syncthreads();
+    // lower bounds of the distances from the new centroid to the earlier ones, upper bound of the centroid norms
+    for (int j = threadIdx.x; j < step; j += kKmThreads) {
+        double s2 = 0.0, n2 = 0.0;
+        for (int i = 0; i < d; ++i) {
+            const double cj = (double)C0[i * K + j];
+            const double t = (double)C0[i * K + (step - 1)] - cj;
+            s2 += t * t;
+            n2 += cj * cj;
+        }
+        sDelta[j] = (float)(sqrt(s2) * (1.0 - 1e-6)) * (1.0f - 1e-6f);
+        const float nj = (float)(sqrt(n2) * (1.0 + 1e-6)) * (1.0f + 1e-6f);
+        atomicMax(&sCmax, nj == nj ? __float_as_uint(nj) : 0x7f800000u);  // NaN centroid: +inf, nothing is skipped
+    }
+    __syncthreads();
     float c[D ? D : ET_KMEANS_MAX_D];
 #pragma unroll
     for (int i = 0; i < (D ? D : ET_KMEANS_MAX_D); ++i)
         if (i < d) c[i] = sc[i];
     const float bn = sc[d];
+    // E: bound on |computed similarity - (-||x - c||^2)| for this shard's points; +inf (never skip) if unknown
+    float E = __int_as_float(0x7f800000);
+    if (step > 1) {
+        const float R = sqrtf((float)d) * __uint_as_float(*max_abs_bits) * 1.0001f + __uint_as_float(sCmax);
+        E = R * R * 1.9073486328125e-6f;  // 2^-19 (R + C)^2
+        if (!(E <= 3.0e38f)) E = __int_as_float(0x7f800000);
+    }
     unsigned long long key = ~0ull;
+    float mabs = 0.f;
     const int64_t stride = (int64_t)gridDim.x * kKmThreads;
     for (int64_t n = (int64_t)blockIdx.x * kKmThreads + threadIdx.x; n < N; n += stride) {
-        float an = 0.f, y = 0.f;
-#pragma unroll
-        for (int i = 0; i < (D ? D : ET_KMEANS_MAX_D); ++i)
-            if (i < d) {
-                const float v = X[(int64_t)i * N + n];
-                an = an + v * v;
-                y = fmaf(v, c[i], y);
-            }
-        y = y * 2.0f;
-        y = y - an;
-        y = y - bn;
-        float b = y;
+        float b = 0.f;
+        bool skip = false;
         if (step > 1) {
             b = best[n];
-            if (gt_nanmax(y, b)) b = y;
+            const int l = (int)nearest[n];
+            // (a NaN or +inf in b, E or Delta makes the comparison false: full evaluation)
+            skip = sDelta[l] >= 2.0f * sqrtf(E - b) * 1.00001f;
         }
-        best[n] = b;
+        if (!skip) {
+            float an = 0.f, y = 0.f;
+#pragma unroll
+            for (int i = 0; i < (D ? D : ET_KMEANS_MAX_D); ++i)
+                if (i < d) {
+                    const float v = X[(int64_t)i * N + n];
+                    an = an + v * v;
+                    y = fmaf(v, c[i], y);
+                    if (step == 1) mabs = fmaxf(mabs, fabsf(v));  // NaN ignored; a NaN point never gets skipped anyway
+                }
+            y = y * 2.0f;
+            y = y - an;
+            y = y - bn;
+            if (step == 1 || gt_nanmax(y, b)) {
+                b = y;
+                best[n] = b;
+                nearest[n] = (uint8_t)(step - 1);
+            }
+        }
         const unsigned long long k = ((unsigned long long)orderable(b) << 32) | (unsigned)(index_base + n);
         key = k < key ? k : key;
     }
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned long long other = __shfl_xor(key, o);
         key = other < key ? other : key;
+        mabs = fmaxf(mabs, __shfl_xor(mabs, o));
     }
-    if ((threadIdx.x & 63) == 0) sKey[threadIdx.x >> 6] = key;
+    if ((threadIdx.x & 63) == 0) {
+        sKey[threadIdx.x >> 6] = key;
+        sMax[threadIdx.x >> 6] = __float_as_uint(mabs);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < kKmThreads / 64; ++w) key = sKey[w] < key ? sKey[w] : key;
+        unsigned mb = sMax[0];
+        for (int w = 1; w < kKmThreads / 64; ++w) {
+            key = sKey[w] < key ? sKey[w] : key;
+            mb = sMax[w] > mb ? sMax[w] : mb;
+        }
         block_keys[blockIdx.x] = key;
+        if (step == 1) atomicMax(max_abs_bits, mb);  // non-negative floats order like their bits
     }
 }
 
@@ -1068,6 +1126,7 @@ struct KmWorkspace {
     float *best;
     uint8_t *labels_u8;
     unsigned *ticket;        // arrival counter of the fused reduce + update kernel
+    unsigned *init_maxabs;   // farthest-first: fp32 bits of max|x| of this shard (collected by step 1)
     size_t bytes;
 };
 
@@ -1092,6 +1151,8 @@ static KmWorkspace km_carve(void *base, int64_t N, int d, int K) {
     w.labels_u8 = (uint8_t *)(p + off);
     off = align_up(off + (size_t)(N > 0 ? N : 1) + 4, 256);
     w.ticket = (unsigned *)(p + off);
+    off = align_up(off + sizeof(unsigned), 256);
+    w.init_maxabs = (unsigned *)(p + off);
     off = align_up(off + sizeof(unsigned), 256);
     w.bytes = off;
     return w;
@@ -1269,12 +1330,13 @@ extern "C" int et_kmeans_init_step(const float *X, int64_t N, int d, int K, int 
     hipStream_t st = (hipStream_t)stream;
     const KmWorkspace w = km_carve(workspace, N, d, K);
     const int grid = km_grid(N);
+    if (i == 1) ET_HIP_TRY(hipMemsetAsync(w.init_maxabs, 0, sizeof(unsigned), st));
     if (d == 6)
         hipLaunchKernelGGL((kmeans_init_step_kernel<6>), dim3(grid), dim3(kKmThreads), 0, st, X, N, d, K, i, C0, best,
-                           index_base, w.block_keys);
+                           w.labels_u8, w.init_maxabs, index_base, w.block_keys);
     else
         hipLaunchKernelGGL((kmeans_init_step_kernel<0>), dim3(grid), dim3(kKmThreads), 0, st, X, N, d, K, i, C0, best,
-                           index_base, w.block_keys);
+                           w.labels_u8, w.init_maxabs, index_base, w.block_keys);
     ET_LAUNCH_CHECK();
     hipLaunchKernelGGL(kmeans_init_pick_kernel, dim3(1), dim3(kKmThreads), 0, st, X, N, d, w.block_keys, grid,
                        index_base, (unsigned char *)cand);
