@@ -1029,7 +1029,8 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
 __global__ __launch_bounds__(kKmThreads) void kmeans_init_pick_kernel(const float *__restrict__ X, int64_t N, int d,
                                                                       const unsigned long long *__restrict__ block_keys,
                                                                       int n_blocks, int64_t index_base,
-                                                                      unsigned char *__restrict__ cand) {
+                                                                      unsigned char *__restrict__ cand, float *C0_out, int K,
+                                                                      int col) {
     __shared__ unsigned long long sKey[kKmThreads / 64];
     unsigned long long key = ~0ull;
     for (int b = threadIdx.x; b < n_blocks; b += kKmThreads) key = block_keys[b] < key ? block_keys[b] : key;
@@ -1044,8 +1045,10 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_pick_kernel(const floa
         *reinterpret_cast<unsigned long long *>(cand) = key;
         float *pt = reinterpret_cast<float *>(cand + 8);
         const int64_t local = (int64_t)(unsigned)(key & 0xffffffffull) - index_base;
-        for (int i = 0; i < d; ++i)
+        for (int i = 0; i < d; ++i) {
             pt[i] = (key != ~0ull && local >= 0 && local < N) ? X[(int64_t)i * N + local] : __int_as_float(0x7fc00000);
+            if (C0_out) C0_out[i * K + col] = pt[i];  // single-GPU path: the candidate IS the new centroid
+        }
     }
 }
 
@@ -1320,9 +1323,11 @@ extern "C" int et_kmeans_predict(const float *X, int64_t N, int d, const float *
     return ET_OK;
 }
 
-extern "C" int et_kmeans_init_step(const float *X, int64_t N, int d, int K, int i, const float *C0, float *best,
-                                   int64_t index_base, void *cand, void *workspace, size_t workspace_bytes,
-                                   et_stream_t stream) {
+// fused != nullptr: single-GPU path, the one-workgroup pick launch also stores the candidate as centroid i of `fused`
+// (= C0).  (Letting the last of the 4096 step workgroups do the pick was measured 3x SLOWER: 4096 device-scope
+// arrivals on one ticket serialise at ~25 ns each.)
+static int init_step_impl(const float *X, int64_t N, int d, int K, int i, const float *C0, float *best, int64_t index_base,
+                          void *cand, void *workspace, size_t workspace_bytes, et_stream_t stream, float *fused) {
     if (!km_dims_ok(d, K) || N < 0 || i < 1 || i >= K || !C0 || !cand || index_base < 0 ||
         index_base + N > 0xffffffffll || (N > 0 && (!X || !best)))
         return ET_ERR_INVALID_ARG;
@@ -1339,9 +1344,15 @@ extern "C" int et_kmeans_init_step(const float *X, int64_t N, int d, int K, int 
                            w.labels_u8, w.init_maxabs, index_base, w.block_keys);
     ET_LAUNCH_CHECK();
     hipLaunchKernelGGL(kmeans_init_pick_kernel, dim3(1), dim3(kKmThreads), 0, st, X, N, d, w.block_keys, grid,
-                       index_base, (unsigned char *)cand);
+                       index_base, (unsigned char *)cand, fused, K, i);
     ET_LAUNCH_CHECK();
     return ET_OK;
+}
+
+extern "C" int et_kmeans_init_step(const float *X, int64_t N, int d, int K, int i, const float *C0, float *best,
+                                   int64_t index_base, void *cand, void *workspace, size_t workspace_bytes,
+                                   et_stream_t stream) {
+    return init_step_impl(X, N, d, K, i, C0, best, index_base, cand, workspace, workspace_bytes, stream, nullptr);
 }
 
 extern "C" int et_kmeans_init_select(const void *cands, int n_cands, int stride_bytes, int d, int K, int col, float *C0,
@@ -1381,10 +1392,8 @@ extern "C" int et_kmeans_init_farthest(const float *X, int64_t N, int d, int K, 
     int rc = et_kmeans_gather_point(X, N, d, first_index, pt, stream);
     if (rc) return rc;
     rc = et_kmeans_init_set(C0, d, K, 0, pt, stream);
-    for (int i = 1; i < K && !rc; ++i) {
-        rc = et_kmeans_init_step(X, N, d, K, i, C0, w.best, 0, w.cand, workspace, workspace_bytes, stream);
-        if (!rc) rc = et_kmeans_init_set(C0, d, K, i, pt, stream);
-    }
+    for (int i = 1; i < K && !rc; ++i)  // two launches per new centroid: update + arg-min, then pick + set
+        rc = init_step_impl(X, N, d, K, i, C0, w.best, 0, w.cand, workspace, workspace_bytes, stream, C0);
     return rc;
 }
 
