@@ -972,16 +972,8 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
     }
     unsigned long long key = ~0ull;
     float mabs = 0.f;
-    const int64_t stride = (int64_t)gridDim.x * kKmThreads;
-    for (int64_t n = (int64_t)blockIdx.x * kKmThreads + threadIdx.x; n < N; n += stride) {
-        float b = 0.f;
-        bool skip = false;
-        if (step > 1) {
-            b = best[n];
-            const int l = (int)nearest[n];
-            // (a NaN or +inf in b, E or Delta makes the comparison false: full evaluation)
-            skip = sDelta[l] >= 2.0f * sqrtf(E - b) * 1.00001f;
-        }
+    // one point: full evaluation unless `skip`; returns the (possibly updated) running maximum
+    auto visit = [&](int64_t n, float b, bool skip) {
         if (!skip) {
             float an = 0.f, y = 0.f;
 #pragma unroll
@@ -1003,6 +995,31 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
         }
         const unsigned long long k = ((unsigned long long)orderable(b) << 32) | (unsigned)(index_base + n);
         key = k < key ? k : key;
+    };
+    const int64_t stride = (int64_t)gridDim.x * kKmThreads;
+    const int64_t tid = (int64_t)blockIdx.x * kKmThreads + threadIdx.x;
+    // steps >= 2 look at four points per lane through one 16-B load of best[] and one 4-B load of nearest[]
+    const bool vec = step > 1 && ((reinterpret_cast<uintptr_t>(best) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(nearest) & 3u) == 0);
+    const int64_t n4 = vec ? N / 4 : 0;
+    for (int64_t g = tid; g < n4; g += stride) {
+        const float4 b4 = reinterpret_cast<const float4 *>(best)[g];
+        const unsigned l4 = reinterpret_cast<const unsigned *>(nearest)[g];
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            // (a NaN or +inf in b, E or Delta makes the comparison false: full evaluation)
+            const bool skip = sDelta[(l4 >> (8 * v)) & 0xffu] >= 2.0f * sqrtf(E - bb[v]) * 1.00001f;
+            visit(4 * g + v, bb[v], skip);
+        }
+    }
+    for (int64_t n = 4 * n4 + tid; n < N; n += stride) {
+        float b = 0.f;
+        bool skip = false;
+        if (step > 1) {
+            b = best[n];
+            skip = sDelta[(int)nearest[n]] >= 2.0f * sqrtf(E - b) * 1.00001f;
+        }
+        visit(n, b, skip);
     }
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned long long other = __shfl_xor(key, o);
@@ -1334,7 +1351,7 @@ static int init_step_impl(const float *X, int64_t N, int d, int K, int i, const 
     if (!workspace || workspace_bytes < et_kmeans_workspace_bytes(N, d, K)) return ET_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const KmWorkspace w = km_carve(workspace, N, d, K);
-    const int grid = km_grid(N);
+    const int grid = i == 1 ? km_grid(N) : min(km_grid(N / 4 + 1), 1024);  // steps >= 2: four points per lane
     if (i == 1) ET_HIP_TRY(hipMemsetAsync(w.init_maxabs, 0, sizeof(unsigned), st));
     if (d == 6)
         hipLaunchKernelGGL((kmeans_init_step_kernel<6>), dim3(grid), dim3(kKmThreads), 0, st, X, N, d, K, i, C0, best,
