@@ -342,6 +342,28 @@ __device__ __forceinline__ void assign_body_valu(
                 xb[i] = f32x2{x[2 % VEC][i], x[3 % VEC][i]};
             }
             best_centroid_x4_d6(xa, xb, sC, K, lbs, bests);
+            // Full accumulation (first iteration) with every point of this wavefront pass in ONE cluster -- the
+            // usual picture right after a farthest-first initialisation on heavy-tailed data, and for any input
+            // stored cluster by cluster: sum the lane's four points, reduce over the wavefront, 7 LDS atomics
+            // instead of 7 x 256 on one address.  Integer sums: the same totals in any order.
+            if (!incremental && __ballot(1) == ~0ull) {
+                const int L0 = __builtin_amdgcn_readfirstlane(lbs[0]);
+                if (__all(lbs[0] == L0 && lbs[1] == L0 && lbs[2] == L0 && lbs[3] == L0)) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        long long f = to_fixed(x[0][i], frac) + to_fixed(x[1 % VEC][i], frac) + to_fixed(x[2 % VEC][i], frac) +
+                                      to_fixed(x[3 % VEC][i], frac);
+                        for (int o = 32; o > 0; o >>= 1) f += __shfl_xor(f, o);
+                        if ((threadIdx.x & 63) == 0)
+                            atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[i * K + L0]), (unsigned long long)f);
+                    }
+                    if ((threadIdx.x & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + L0]), 256ull);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) sim_acc += to_fixed(bests[v], sfrac);
+                    *reinterpret_cast<unsigned *>(labels + n) = (unsigned)L0 * 0x01010101u;
+                    continue;
+                }
+            }
         }
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
