@@ -16,7 +16,7 @@ sh = ops.KMeansShard(xt, 20); sh.scan()
 cen = torch.from_numpy(c0).to(dev).clone(); sh.begin(x.shape[1], cen)
 for it in range(40):
     cprev = cen.cpu().numpy().copy()
-    part = sh.assign(cen, iteration=it)
+    part = sh.assign(cen)
     lab = sh.labels().cpu().numpy()
     rl, rm = oracle.kmeans_assign(x, cprev)
     bad = np.nonzero(lab != rl)[0]
