@@ -545,10 +545,9 @@ __device__ __forceinline__ void filter_drain(const unsigned *q, int cnt, int K, 
 }
 
 template <int NREGS>
-__global__ __launch_bounds__(kFilterThreads) void kmeans_assign_filter_kernel(
-    const float *__restrict__ X, int64_t N, int K, const et_kmeans_state *__restrict__ state,
-    const float *__restrict__ cen, uint8_t *__restrict__ labels, long long *__restrict__ block_partials) {
-    if (state->done) return;
+__device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, int64_t N, int K,
+                                                   const et_kmeans_state *__restrict__ state, const float *cen,
+                                                   uint8_t *__restrict__ labels, long long *__restrict__ block_partials) {
     constexpr int d = 6;
     // power-of-two scale: every |x| sg, |c| sg < 32, so that |2c x| sg^2 < 6 * 2^11 and |c|^2 sg^2 < 6 * 2^10 fit
     // f16 and stay far above the -60000 that pads the rows of clusters >= K
@@ -733,6 +732,14 @@ __global__ __launch_bounds__(kFilterThreads) void kmeans_assign_filter_kernel(
     for (int i = threadIdx.x; i < plen; i += kFilterThreads) block_partials[(size_t)i * gridDim.x + blockIdx.x] = sAcc[i];
 }
 
+template <int NREGS>
+__global__ __launch_bounds__(kFilterThreads) void kmeans_assign_filter_kernel(
+    const float *__restrict__ X, int64_t N, int K, const et_kmeans_state *__restrict__ state,
+    const float *__restrict__ cen, uint8_t *__restrict__ labels, long long *__restrict__ block_partials) {
+    if (state->done) return;
+    filter_assign_body<NREGS>(X, N, K, state, cen, labels, block_partials);
+}
+
 // Fold the workgroup deltas into the shard's running totals: one workgroup per entry, unit-stride
 // reads.  Cluster sums / counts accumulate across iterations (deltas), the similarity sum and
 // the NaN count are per-iteration quantities and are overwritten.
@@ -844,6 +851,63 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_update_kernel(et_kmeans_sta
     if (state->done) return;
     update_body(state, partials, d, K, tol, cen, trace);
 }
+
+// Small shards (a few workgroups): the whole Lloyd iteration in ONE launch.  Every workgroup assigns its points
+// and writes its partials as above, then takes a ticket (release fence -> device-scope atomic -> acquire fence);
+// the last one to arrive folds the <= 32 partial blocks into the running totals and runs the update.  With so
+// few arrivals the ticket costs well under a microsecond, and a launch (~7 us + its dispatch gap) disappears
+// from a loop whose kernels themselves only take a few microseconds.  `cen` is read by every workgroup in its
+// prologue only, i.e. before the last arrival, so updating it in place is safe.
+constexpr int kSmallMaxBlocks = 32;
+
+template <int NREGS>
+__global__ __launch_bounds__(kFilterThreads) void kmeans_lloyd_small_kernel(
+    const float *__restrict__ X, int64_t N, int K, et_kmeans_state *state, float *cen, uint8_t *__restrict__ labels,
+    long long *block_partials, long long *partials, unsigned *ticket, float tol, float *trace) {
+    if (state->done) return;
+    constexpr int d = 6;
+    filter_assign_body<NREGS>(X, N, K, state, cen, labels, block_partials);
+    __shared__ int sLast;
+    __syncthreads();  // this workgroup's partials are written
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned arrived = atomicAdd(ticket, 1u);
+        sLast = arrived == gridDim.x - 1;
+        if (sLast) {
+            *ticket = 0u;  // ready for the next launch
+            __threadfence();
+        }
+    }
+    __syncthreads();
+    if (!sLast) return;
+    const int plen = d * K + K + 2, n_blocks = (int)gridDim.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    long long *sTot = reinterpret_cast<long long *>(smem_raw) + 512;  // past the 2 d K floats update_body uses
+    for (int i = threadIdx.x; i < plen; i += kFilterThreads) sTot[i] = 0;
+    __syncthreads();
+    // [entry][workgroup] partials: all loads first, then exact integer sums through LDS atomics
+    constexpr int kPer = ((6 * 32 + 32 + 2) * kSmallMaxBlocks + kFilterThreads - 1) / kFilterThreads;  // K <= 32
+    long long v[kPer];
+    const int total = plen * n_blocks;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int idx = threadIdx.x + k * kFilterThreads;
+        v[k] = idx < total ? block_partials[idx] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int idx = threadIdx.x + k * kFilterThreads;
+        if (idx < total && v[k] != 0)
+            atomicAdd(reinterpret_cast<unsigned long long *>(&sTot[idx / n_blocks]), (unsigned long long)v[k]);
+    }
+    __syncthreads();
+    const bool have_totals = state->iter > 0;
+    for (int e = threadIdx.x; e < plen; e += kFilterThreads)
+        partials[e] = ((have_totals && e < plen - 2) ? partials[e] : 0) + sTot[e];
+    __syncthreads();
+    update_body(state, partials, d, K, tol, cen, trace);
+}
+
 
 // Single-GPU fit: the reduction above and the update in ONE launch.  One entry per WAVEFRONT (the filter kernel
 // runs one fat workgroup per CU, so an entry has only a few hundred workgroup partials); the workgroup that
@@ -1280,7 +1344,28 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_km
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
             ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kmeans_assign_filter_kernel<16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<10>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<16>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
             lds_ok = true;
+        }
+        // small shard (N <= 131072), single-GPU fit: assignment, reduction and update in one launch (at most
+        // kSmallMaxBlocks workgroups, one pass per wavefront): 18 us instead of 11 + 7 us and a dispatch gap
+        const int64_t passes = ceil_div(N, (int64_t)256);
+        if (fused_update && passes <= kSmallMaxBlocks * (kFilterThreads / 64)) {
+            grid = (int)ceil_div(passes, (int64_t)(kFilterThreads / 64));
+            grid = grid > kSmallMaxBlocks ? kSmallMaxBlocks : grid;
+            float *cen_rw = const_cast<float *>(centroids);
+            if (K <= 20)
+                hipLaunchKernelGGL(kmeans_lloyd_small_kernel<10>, dim3(grid), dim3(kFilterThreads), lds, st, X, N, K, state,
+                                   cen_rw, labels_u8, w.block_partials, (long long *)partials, w.ticket, tol, trace);
+            else
+                hipLaunchKernelGGL(kmeans_lloyd_small_kernel<16>, dim3(grid), dim3(kFilterThreads), lds, st, X, N, K, state,
+                                   cen_rw, labels_u8, w.block_partials, (long long *)partials, w.ticket, tol, trace);
+            ET_LAUNCH_CHECK();
+            if (ev_end) ET_HIP_TRY(hipEventRecord(ev_end, st));
+            return ET_OK;
         }
         if (K <= 20) {
             grid = km_resident_grid(kmeans_assign_filter_kernel<10>, lds, N / 4, kFilterThreads);
