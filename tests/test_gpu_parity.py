@@ -393,6 +393,41 @@ def test_kmeans_filter_kernel_bit_exact_on_adversarial_data(ops, oracle, dev, ki
     np.testing.assert_array_equal(N_(res["trace"]), ref["trace"])
 
 
+def test_kmeans_fit_randomized_stress_vs_oracle(ops, oracle, dev):
+    """40 seeded random configurations (size, K, scale over 16 decades, outliers, duplicated points, dead and
+    near-collinear coordinates): farthest-first picks, labels, centroids and the error / inertia trace must be the
+    oracle's bits in every one of them -- whichever of the kernels (exact scan, matrix-core filter, small-shard
+    fused iteration, skipping farthest-first steps) the sizes select."""
+    rng = np.random.default_rng(20240607)
+    for case in range(40):
+        n = int(rng.integers(256, 6000)) * 4
+        K = int(rng.integers(3, 33))
+        x = rng.standard_normal((6, n))
+        nb = int(rng.integers(1, 12))
+        x += rng.standard_normal((6, nb))[:, rng.integers(0, nb, size=n)] * rng.uniform(0.5, 8.0)
+        if rng.random() < 0.4:   # heavy tail
+            idx = rng.choice(n, max(1, n // int(rng.integers(20, 400))), replace=False)
+            x[:, idx] *= 10.0 ** rng.uniform(1, 4)
+        if rng.random() < 0.3:   # duplicated points
+            src = rng.integers(0, n, size=n // 3)
+            x[:, rng.integers(0, n, size=n // 3)] = x[:, src]
+        if rng.random() < 0.3:   # a dead coordinate
+            x[int(rng.integers(0, 6))] = 0.0
+        if rng.random() < 0.3:   # two nearly collinear coordinates
+            x[1] = x[0] * 1.5 + 1e-4 * rng.standard_normal(n)
+        x = np.ascontiguousarray((x * 10.0 ** rng.uniform(-8, 8)).astype(np.float32))
+        first = int(rng.integers(0, n))
+        c0 = ops.kmeans_init_farthest(T(x, dev), K, first)
+        r0, _ = oracle.kmeans_init_farthest(x, K, first)
+        assert np.array_equal(N_(c0), r0, equal_nan=True), f"case {case}: farthest-first picks differ (n={n}, K={K})"
+        res = ops.kmeans_fit(T(x, dev), c0, 12, 1e-4)
+        ref = oracle.kmeans_fit(x, r0, 12, 1e-4)
+        assert res["n_iter"] == ref["n_iter"], f"case {case} (n={n}, K={K})"
+        assert np.array_equal(N_(res["labels"]), ref["labels"]), f"case {case} (n={n}, K={K})"
+        assert np.array_equal(N_(res["centroids"]), ref["centroids"], equal_nan=True), f"case {case} (n={n}, K={K})"
+        np.testing.assert_array_equal(N_(res["trace"]), ref["trace"], err_msg=f"case {case} (n={n}, K={K})")
+
+
 def test_kmeans_duplicates_nan_propagation_g7(ops, oracle, dev):
     from eigentrajectory_amd import BatchKMeans
     z = G.load("g7_batchkmeans.npz")
