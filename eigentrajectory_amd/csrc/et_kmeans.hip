@@ -284,11 +284,33 @@ __global__ void kmeans_begin_kernel(et_kmeans_state *state, int64_t n_total, con
 // coordinate rows are 16-B aligned, else 1).  Workgroup accumulators live in LDS (64-bit
 // integer atomics, order-free); each workgroup writes one partial block, summed afterwards.
 // ------------------------------------------------------------------------------------------
+// A workgroup's exact partial sums leave the kernel either as one column of the [entry][workgroup] table (folded by
+// kmeans_reduce_partials_kernel; what the sharded step API uses) or, in the single-GPU fit, as device-scope integer
+// atomics onto kAccLanes copies of the totals (lane = workgroup index mod kAccLanes): at most grid / kAccLanes
+// arrivals per address, nothing to fold afterwards except kAccLanes values per entry, and no arrivals at all for the
+// entries a workgroup did not change.
+constexpr int kAccLanes = 16;
+
+__device__ __forceinline__ void emit_partials(const long long *sAcc, int plen, int n_threads,
+                                              long long *__restrict__ block_partials, long long *__restrict__ lanes) {
+    if (lanes) {
+        for (int i = threadIdx.x; i < plen; i += n_threads) {
+            const long long v = sAcc[i];
+            if (v != 0)
+                atomicAdd(reinterpret_cast<unsigned long long *>(&lanes[i * kAccLanes + (blockIdx.x & (kAccLanes - 1))]),
+                          (unsigned long long)v);
+        }
+    } else {
+        // transposed [entry][workgroup] so that the reduction reads unit-stride
+        for (int i = threadIdx.x; i < plen; i += n_threads) block_partials[(size_t)i * gridDim.x + blockIdx.x] = sAcc[i];
+    }
+}
+
 template <int D, int VEC>
 __device__ __forceinline__ void assign_body_valu(
     const float *__restrict__ X, int64_t N, int d_rt, int K, const et_kmeans_state *__restrict__ state,
     const float *__restrict__ cen, const int64_t *__restrict__ given, uint8_t *__restrict__ labels,
-    long long *__restrict__ block_partials) {
+    long long *__restrict__ block_partials, long long *__restrict__ lanes = nullptr) {
     const int d = D ? D : d_rt;
     const int plen = d * K + K + 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -408,8 +430,7 @@ __device__ __forceinline__ void assign_body_valu(
         atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K + 1]), (unsigned long long)nan_acc);
     }
     __syncthreads();
-    // transposed [entry][workgroup] so that the reduction below reads unit-stride
-    for (int i = threadIdx.x; i < plen; i += n_threads) block_partials[(size_t)i * gridDim.x + blockIdx.x] = sAcc[i];
+    emit_partials(sAcc, plen, n_threads, block_partials, lanes);
 }
 
 template <int D, int VEC>
@@ -547,7 +568,8 @@ __device__ __forceinline__ void filter_drain(const unsigned *q, int cnt, int K, 
 template <int NREGS>
 __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, int64_t N, int K,
                                                    const et_kmeans_state *__restrict__ state, const float *cen,
-                                                   uint8_t *__restrict__ labels, long long *__restrict__ block_partials) {
+                                                   uint8_t *__restrict__ labels, long long *__restrict__ block_partials,
+                                                   long long *__restrict__ lanes = nullptr) {
     constexpr int d = 6;
     // power-of-two scale: every |x| sg, |c| sg < 32, so that |2c x| sg^2 < 6 * 2^11 and |c|^2 sg^2 < 6 * 2^10 fit
     // f16 and stay far above the -60000 that pads the rows of clusters >= K
@@ -555,7 +577,7 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
     // first iteration (no labels yet), possible NaN/Inf, or a scale whose square leaves the fp32 range:
     // the exact kernel decides
     if (state->iter <= 0 || !state->fast_ok || e_max < -40 || e_max > 60) {
-        assign_body_valu<6, 4>(X, N, d, K, state, cen, nullptr, labels, block_partials);
+        assign_body_valu<6, 4>(X, N, d, K, state, cen, nullptr, labels, block_partials, lanes);
         return;
     }
     const int plen = d * K + K + 2;
@@ -729,15 +751,16 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
     for (int o = 32; o > 0; o >>= 1) sim_acc += __shfl_xor(sim_acc, o);
     if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K]), (unsigned long long)sim_acc);
     __syncthreads();
-    for (int i = threadIdx.x; i < plen; i += kFilterThreads) block_partials[(size_t)i * gridDim.x + blockIdx.x] = sAcc[i];
+    emit_partials(sAcc, plen, kFilterThreads, block_partials, lanes);
 }
 
 template <int NREGS>
 __global__ __launch_bounds__(kFilterThreads) void kmeans_assign_filter_kernel(
     const float *__restrict__ X, int64_t N, int K, const et_kmeans_state *__restrict__ state,
-    const float *__restrict__ cen, uint8_t *__restrict__ labels, long long *__restrict__ block_partials) {
+    const float *__restrict__ cen, uint8_t *__restrict__ labels, long long *__restrict__ block_partials,
+    long long *__restrict__ lanes) {
     if (state->done) return;
-    filter_assign_body<NREGS>(X, N, K, state, cen, labels, block_partials);
+    filter_assign_body<NREGS>(X, N, K, state, cen, labels, block_partials, lanes);
 }
 
 // Fold the workgroup deltas into the shard's running totals: one workgroup per entry, unit-stride
@@ -849,6 +872,33 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_update_kernel(et_kmeans_sta
                                                                    float tol, float *__restrict__ cen,
                                                                    float *__restrict__ trace) {
     if (state->done) return;
+    update_body(state, partials, d, K, tol, cen, trace);
+}
+
+// Single-GPU fit, large shards: the assignment kernel has already added its deltas onto kAccLanes copies of every
+// total (emit_partials); one workgroup folds the 16 copies, clears them for the next iteration and updates.
+__global__ __launch_bounds__(kKmThreads) void kmeans_update_lanes_kernel(long long *lanes, int plen, et_kmeans_state *state,
+                                                                         long long *partials, int d, int K, float tol,
+                                                                         float *cen, float *trace) {
+    const int64_t done = state->done, iter = state->iter;
+    for (int e = threadIdx.x; e < plen; e += kKmThreads) {
+        longlong2 *src = reinterpret_cast<longlong2 *>(lanes + (size_t)e * kAccLanes);
+        longlong2 v[kAccLanes / 2];
+#pragma unroll
+        for (int k = 0; k < kAccLanes / 2; ++k) v[k] = src[k];  // all loads first
+        const long long prev = partials[e];
+        long long s = 0;
+#pragma unroll
+        for (int k = 0; k < kAccLanes / 2; ++k) s += v[k].x + v[k].y;
+        if (!done) {
+            partials[e] = ((iter > 0 && e < plen - 2) ? prev : 0) + s;
+            const longlong2 z = {0, 0};
+#pragma unroll
+            for (int k = 0; k < kAccLanes / 2; ++k) src[k] = z;
+        }
+    }
+    if (done) return;
+    __syncthreads();
     update_body(state, partials, d, K, tol, cen, trace);
 }
 
@@ -1233,6 +1283,7 @@ struct KmWorkspace {
     uint8_t *labels_u8;
     unsigned *ticket;        // arrival counter of the fused reduce + update kernel
     unsigned *init_maxabs;   // farthest-first: fp32 bits of max|x| of this shard (collected by step 1)
+    long long *acc_lanes;    // single-GPU fit: kAccLanes copies of every total, the assignment kernel's atomics land here
     size_t bytes;
 };
 
@@ -1260,6 +1311,8 @@ static KmWorkspace km_carve(void *base, int64_t N, int d, int K) {
     off = align_up(off + sizeof(unsigned), 256);
     w.init_maxabs = (unsigned *)(p + off);
     off = align_up(off + sizeof(unsigned), 256);
+    w.acc_lanes = (long long *)(p + off);
+    off = align_up(off + sizeof(long long) * km_plen(d, K) * 16, 256);
     w.bytes = off;
     return w;
 }
@@ -1367,14 +1420,24 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_km
             if (ev_end) ET_HIP_TRY(hipEventRecord(ev_end, st));
             return ET_OK;
         }
+        long long *lanes = fused_update ? w.acc_lanes : nullptr;
         if (K <= 20) {
             grid = km_resident_grid(kmeans_assign_filter_kernel<10>, lds, N / 4, kFilterThreads);
             hipLaunchKernelGGL(kmeans_assign_filter_kernel<10>, dim3(grid), dim3(kFilterThreads), lds, st, X, N, K, state,
-                               centroids, labels_u8, w.block_partials);
+                               centroids, labels_u8, w.block_partials, lanes);
         } else {
             grid = km_resident_grid(kmeans_assign_filter_kernel<16>, lds, N / 4, kFilterThreads);
             hipLaunchKernelGGL(kmeans_assign_filter_kernel<16>, dim3(grid), dim3(kFilterThreads), lds, st, X, N, K, state,
-                               centroids, labels_u8, w.block_partials);
+                               centroids, labels_u8, w.block_partials, lanes);
+        }
+        if (fused_update) {
+            ET_LAUNCH_CHECK();
+            if (ev_end) ET_HIP_TRY(hipEventRecord(ev_end, st));
+            const size_t ulds = sizeof(float) * 2 * (size_t)d * K;
+            hipLaunchKernelGGL(kmeans_update_lanes_kernel, dim3(1), dim3(kKmThreads), ulds, st, w.acc_lanes, (int)plen_, state,
+                               (long long *)partials, d, K, tol, const_cast<float *>(centroids), trace);
+            ET_LAUNCH_CHECK();
+            return ET_OK;
         }
     } else if (N > 0) {
         grid = d == 6 ? launch_assign<6>(X, N, d, K, state, centroids, given_labels, labels_u8, w.block_partials, vec4, st)
@@ -1558,6 +1621,7 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     if (!rc) rc = et_kmeans_begin(w.state, N, centroids, d, K, stream);
     if (rc) return rc;
     ET_HIP_TRY(hipMemsetAsync(w.ticket, 0, sizeof(unsigned), st));
+    ET_HIP_TRY(hipMemsetAsync(w.acc_lanes, 0, sizeof(long long) * km_plen(d, K) * 16, st));
     int launched = 0, posted = 0, seen = 0;
     bool done = false;
     for (int it = 0; it < max_iter && !done; ++it) {
