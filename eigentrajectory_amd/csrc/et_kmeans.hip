@@ -790,13 +790,15 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_reduce_partials_kernel(cons
 }
 
 // centroid update + convergence scalars from the (all-reduced) exact sums.  One workgroup.
+// `partials` may live in global memory or in LDS (flat addressing); `pre` = the state block if the caller has
+// already loaded it.
 __device__ __forceinline__ void update_body(et_kmeans_state *state, const long long *partials, int d, int K, float tol,
-                                            float *cen, float *trace) {
+                                            float *cen, float *trace, const et_kmeans_state *pre = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *sSq = reinterpret_cast<float *>(smem_raw);  // d*K squared differences
     float *sNew = sSq + d * K;
     // every global value the serial tail needs is fetched up front (one round trip instead of a chain of them)
-    const et_kmeans_state st = *state;
+    const et_kmeans_state st = pre ? *pre : *state;
     const long long sim_sum = partials[d * K + K], nan_count = partials[d * K + K + 1];
     const int frac = (int)st.frac;
     const double inv_scale = ldexp(1.0, -frac);
@@ -880,7 +882,9 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_update_kernel(et_kmeans_sta
 __global__ __launch_bounds__(kKmThreads) void kmeans_update_lanes_kernel(long long *lanes, int plen, et_kmeans_state *state,
                                                                          long long *partials, int d, int K, float tol,
                                                                          float *cen, float *trace) {
-    const int64_t done = state->done, iter = state->iter;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    long long *sTot = reinterpret_cast<long long *>(smem_raw) + 512;  // past the 2 d K floats update_body uses
+    const et_kmeans_state st = *state;  // one round trip for the state, the 16 copies and the running totals
     for (int e = threadIdx.x; e < plen; e += kKmThreads) {
         longlong2 *src = reinterpret_cast<longlong2 *>(lanes + (size_t)e * kAccLanes);
         longlong2 v[kAccLanes / 2];
@@ -890,16 +894,18 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_update_lanes_kernel(long lo
         long long s = 0;
 #pragma unroll
         for (int k = 0; k < kAccLanes / 2; ++k) s += v[k].x + v[k].y;
-        if (!done) {
-            partials[e] = ((iter > 0 && e < plen - 2) ? prev : 0) + s;
+        if (!st.done) {
+            const long long tot = ((st.iter > 0 && e < plen - 2) ? prev : 0) + s;
+            partials[e] = tot;
+            sTot[e] = tot;
             const longlong2 z = {0, 0};
 #pragma unroll
             for (int k = 0; k < kAccLanes / 2; ++k) src[k] = z;
         }
     }
-    if (done) return;
+    if (st.done) return;
     __syncthreads();
-    update_body(state, partials, d, K, tol, cen, trace);
+    update_body(state, sTot, d, K, tol, cen, trace, &st);
 }
 
 // Small shards (a few workgroups): the whole Lloyd iteration in ONE launch.  Every workgroup assigns its points
@@ -1433,7 +1439,7 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_km
         if (fused_update) {
             ET_LAUNCH_CHECK();
             if (ev_end) ET_HIP_TRY(hipEventRecord(ev_end, st));
-            const size_t ulds = sizeof(float) * 2 * (size_t)d * K;
+            const size_t ulds = 4096 + sizeof(long long) * plen_;  // update_body's 2 d K floats, then the folded totals
             hipLaunchKernelGGL(kmeans_update_lanes_kernel, dim3(1), dim3(kKmThreads), ulds, st, w.acc_lanes, (int)plen_, state,
                                (long long *)partials, d, K, tol, const_cast<float *>(centroids), trace);
             ET_LAUNCH_CHECK();
