@@ -48,21 +48,36 @@ def parse():
 
 
 class Stage:
-    """HIP-event stopwatch on the current stream (our kernels are launched on torch's current stream)."""
+    """HIP-event stopwatch on the current stream (our kernels are launched on torch's current stream).  Adjacent
+    stages share ONE boundary event (an event record between two kernels costs a few microseconds of dispatch gap,
+    two of them twice that)."""
 
     def __init__(self):
         self.t = {}
         self._open = {}
+        self._last = None  # (event, was it a stop?)
 
-    def start(self, name):
+    def _boundary(self, reuse):
+        if reuse and self._last is not None:
+            return self._last
         e = torch.cuda.Event(enable_timing=True)
         e.record()
+        return e
+
+    def start(self, name):
+        # a start right after a stop (nothing launched in between) reuses the stop's event
+        e = self._boundary(reuse=True)
+        self._last = None
         self._open[name] = e
 
     def stop(self, name):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
+        e = self._boundary(reuse=False)
+        self._last = e
         self.t.setdefault(name, []).append((self._open.pop(name), e))
+
+    def launched(self):
+        """Call after launching work that belongs to no stage: the next start gets its own event."""
+        self._last = None
 
     def ms(self, name):
         return [a.elapsed_time(b) for a, b in self.t.get(name, [])]
@@ -99,6 +114,7 @@ def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None)
         timing.append((res["assign_ms"], res["assign_launches"]))
     else:
         skm = km(c_pred, K)
+        sw.launched()
         sw.start("kmeans_init")
         c0 = skm.init_farthest(first_index)
         sw.stop("kmeans_init")
