@@ -1068,14 +1068,45 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
                                                                       uint8_t *__restrict__ nearest,
                                                                       unsigned *__restrict__ max_abs_bits,
                                                                       int64_t index_base,
-                                                                      unsigned long long *__restrict__ block_keys) {
+                                                                      unsigned long long *__restrict__ block_keys,
+                                                                      const unsigned long long *__restrict__ prev_keys,
+                                                                      int n_prev, float *C0_rw, unsigned char *cand) {
     const int d = D ? D : d_rt;
     __shared__ float sc[ET_KMEANS_MAX_D + 1];
     __shared__ float sDelta[ET_KMEANS_MAX_CLUSTERS + 1];
     __shared__ unsigned long long sKey[kKmThreads / 64];
     __shared__ unsigned sMax[kKmThreads / 64];
     __shared__ unsigned sCmax;  // fp32 bits of the largest centroid norm among columns 0 .. step-1
-    if (threadIdx.x == 0) {
+    if (prev_keys) {
+        // Single-GPU path: centroid step-1 has not been stored yet -- every workgroup derives it from the previous
+        // step's workgroup keys (the same minimum everywhere), workgroup 0 also stores it.  Two short round trips
+        // in the prologue instead of a pick launch between two steps.
+        unsigned long long key = ~0ull;
+        for (int b = threadIdx.x; b < n_prev; b += kKmThreads) key = prev_keys[b] < key ? prev_keys[b] : key;
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(key, o);
+            key = other < key ? other : key;
+        }
+        if ((threadIdx.x & 63) == 0) sKey[threadIdx.x >> 6] = key;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kKmThreads / 64; ++w) key = sKey[w] < key ? sKey[w] : key;
+            const int64_t local = (int64_t)(unsigned)(key & 0xffffffffull) - index_base;
+            sCmax = 0u;
+            float bn = 0.f;
+            for (int i = 0; i < d; ++i) {
+                const float v = (key != ~0ull && local >= 0 && local < N) ? X[(int64_t)i * N + local] : __int_as_float(0x7fc00000);
+                sc[i] = v;
+                bn = bn + v * v;
+                if (blockIdx.x == 0) {
+                    C0_rw[i * K + (step - 1)] = v;
+                    reinterpret_cast<float *>(cand + 8)[i] = v;
+                }
+            }
+            sc[d] = bn;
+            if (blockIdx.x == 0) *reinterpret_cast<unsigned long long *>(cand) = key;
+        }
+    } else if (threadIdx.x == 0) {
         sCmax = 0u;
         float bn = 0.f;
         for (int i = 0; i < d; ++i) {
@@ -1090,8 +1121,8 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
     for (int j = threadIdx.x; j < step; j += kKmThreads) {
         double s2 = 0.0, n2 = 0.0;
         for (int i = 0; i < d; ++i) {
-            const double cj = (double)C0[i * K + j];
-            const double t = (double)C0[i * K + (step - 1)] - cj;
+            const double cj = j == step - 1 ? (double)sc[i] : (double)C0[i * K + j];
+            const double t = (double)sc[i] - cj;
             s2 += t * t;
             n2 += cj * cj;
         }
@@ -1282,6 +1313,7 @@ static size_t km_plen(int d, int K) { return (size_t)d * K + K + 2; }
 struct KmWorkspace {
     long long *block_partials;
     unsigned long long *block_keys;
+    unsigned long long *block_keys2;  // farthest-first, single GPU: the previous step's keys (read by the next step)
     unsigned char *cand;
     long long *partials;
     et_kmeans_state *state;
@@ -1302,6 +1334,8 @@ static KmWorkspace km_carve(void *base, int64_t N, int d, int K) {
     w.block_partials = (long long *)(p + off);
     off = align_up(off + sizeof(long long) * km_plen(d, K) * kKmMaxBlocks, 256);
     w.block_keys = (unsigned long long *)(p + off);
+    off = align_up(off + sizeof(unsigned long long) * kKmMaxBlocks, 256);
+    w.block_keys2 = (unsigned long long *)(p + off);
     off = align_up(off + sizeof(unsigned long long) * kKmMaxBlocks, 256);
     w.cand = p + off;
     off = align_up(off + 8 + sizeof(float) * ET_KMEANS_MAX_D, 256);
@@ -1519,26 +1553,39 @@ extern "C" int et_kmeans_predict(const float *X, int64_t N, int d, const float *
 // fused != nullptr: single-GPU path, the one-workgroup pick launch also stores the candidate as centroid i of `fused`
 // (= C0).  (Letting the last of the 4096 step workgroups do the pick was measured 3x SLOWER: 4096 device-scope
 // arrivals on one ticket serialise at ~25 ns each.)
+static int init_step_grid(int64_t N, int i) {
+    return i == 1 ? km_grid(N) : min(km_grid(N / 4 + 1), 1024);  // steps >= 2: four points per lane
+}
+
+// fused != nullptr: single-GPU path.  Step i (>= 2) derives centroid i-1 itself from the keys step i-1 left in the other
+// key buffer, so no pick launch separates two steps; `last` adds the pick that stores centroid i of the final step.
 static int init_step_impl(const float *X, int64_t N, int d, int K, int i, const float *C0, float *best, int64_t index_base,
-                          void *cand, void *workspace, size_t workspace_bytes, et_stream_t stream, float *fused) {
+                          void *cand, void *workspace, size_t workspace_bytes, et_stream_t stream, float *fused,
+                          bool last = true) {
     if (!km_dims_ok(d, K) || N < 0 || i < 1 || i >= K || !C0 || !cand || index_base < 0 ||
         index_base + N > 0xffffffffll || (N > 0 && (!X || !best)))
         return ET_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < et_kmeans_workspace_bytes(N, d, K)) return ET_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const KmWorkspace w = km_carve(workspace, N, d, K);
-    const int grid = i == 1 ? km_grid(N) : min(km_grid(N / 4 + 1), 1024);  // steps >= 2: four points per lane
+    const int grid = init_step_grid(N, i);
     if (i == 1) ET_HIP_TRY(hipMemsetAsync(w.init_maxabs, 0, sizeof(unsigned), st));
+    // key buffers alternate in the fused path (a step reads its predecessor's keys while it writes its own)
+    unsigned long long *keys = (fused && (i & 1)) ? w.block_keys2 : w.block_keys;
+    const unsigned long long *prev = (fused && i > 1) ? ((i & 1) ? w.block_keys : w.block_keys2) : nullptr;
+    const int n_prev = i > 1 ? init_step_grid(N, i - 1) : 0;
     if (d == 6)
         hipLaunchKernelGGL((kmeans_init_step_kernel<6>), dim3(grid), dim3(kKmThreads), 0, st, X, N, d, K, i, C0, best,
-                           w.labels_u8, w.init_maxabs, index_base, w.block_keys);
+                           w.labels_u8, w.init_maxabs, index_base, keys, prev, n_prev, fused, (unsigned char *)cand);
     else
         hipLaunchKernelGGL((kmeans_init_step_kernel<0>), dim3(grid), dim3(kKmThreads), 0, st, X, N, d, K, i, C0, best,
-                           w.labels_u8, w.init_maxabs, index_base, w.block_keys);
+                           w.labels_u8, w.init_maxabs, index_base, keys, prev, n_prev, fused, (unsigned char *)cand);
     ET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(kmeans_init_pick_kernel, dim3(1), dim3(kKmThreads), 0, st, X, N, d, w.block_keys, grid,
-                       index_base, (unsigned char *)cand, fused, K, i);
-    ET_LAUNCH_CHECK();
+    if (!fused || last) {
+        hipLaunchKernelGGL(kmeans_init_pick_kernel, dim3(1), dim3(kKmThreads), 0, st, X, N, d, keys, grid, index_base,
+                           (unsigned char *)cand, fused, K, i);
+        ET_LAUNCH_CHECK();
+    }
     return ET_OK;
 }
 
@@ -1585,8 +1632,8 @@ extern "C" int et_kmeans_init_farthest(const float *X, int64_t N, int d, int K, 
     int rc = et_kmeans_gather_point(X, N, d, first_index, pt, stream);
     if (rc) return rc;
     rc = et_kmeans_init_set(C0, d, K, 0, pt, stream);
-    for (int i = 1; i < K && !rc; ++i)  // two launches per new centroid: update + arg-min, then pick + set
-        rc = init_step_impl(X, N, d, K, i, C0, w.best, 0, w.cand, workspace, workspace_bytes, stream, C0);
+    for (int i = 1; i < K && !rc; ++i)  // one launch per new centroid (+ one pick for the last)
+        rc = init_step_impl(X, N, d, K, i, C0, w.best, 0, w.cand, workspace, workspace_bytes, stream, C0, i == K - 1);
     return rc;
 }
 
