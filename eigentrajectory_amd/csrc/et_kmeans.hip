@@ -1651,7 +1651,18 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     // dispatch gap on each side, so timing every launch would slow the loop it measures by ~15 %.
     constexpr int kTimeEvery = 8;
     auto timed = [&](int it) { return timing_host && (it == 0 || it % kTimeEvery == 1); };
-    static thread_local std::vector<hipEvent_t> events;  // reused across calls; only touched when timing is requested
+    // events belong to the device that is current when they are created: one cached set per (host thread, device)
+    int dev_id = 0;
+    ET_HIP_TRY(hipGetDevice(&dev_id));
+    struct PerDevice {
+        std::vector<hipEvent_t> events;  // timing; only touched when timing is requested
+        hipEvent_t ring_ev[4];
+        bool ring_ready = false;
+    };
+    static thread_local std::vector<PerDevice> per_device;
+    if ((int)per_device.size() <= dev_id) per_device.resize(dev_id + 1);
+    PerDevice &pd = per_device[dev_id];
+    std::vector<hipEvent_t> &events = pd.events;
     if (timing_host) {
         while ((int)events.size() < 2 * max_iter) {
             hipEvent_t e;
@@ -1664,11 +1675,13 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     // for it inside the loop: every few iterations the state block is copied to a pinned ring slot, and a
     // copy that has ARRIVED (event query, non-blocking) is looked at; the queue stays at most kLag iterations ahead.
     constexpr int kSlots = 4, kEvery = 4, kLag = kSlots * kEvery;
+    static_assert(kSlots == 4, "PerDevice::ring_ev");
     static thread_local et_kmeans_state *ring = nullptr;  // per host thread: concurrent fits on different streams do not share it
-    static thread_local hipEvent_t ring_ev[kSlots];
-    if (!ring) {
-        ET_HIP_TRY(hipHostMalloc((void **)&ring, sizeof(et_kmeans_state) * kSlots, hipHostMallocDefault));
+    if (!ring) ET_HIP_TRY(hipHostMalloc((void **)&ring, sizeof(et_kmeans_state) * kSlots, hipHostMallocDefault));
+    hipEvent_t *ring_ev = pd.ring_ev;
+    if (!pd.ring_ready) {
         for (int i = 0; i < kSlots; ++i) ET_HIP_TRY(hipEventCreateWithFlags(&ring_ev[i], hipEventDisableTiming));
+        pd.ring_ready = true;
     }
     int rc = et_kmeans_scan(X, N, d, w.state, stream);
     if (!rc) rc = et_kmeans_begin(w.state, N, centroids, d, K, stream);
