@@ -1431,7 +1431,11 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_km
         const size_t plen_ = km_plen(d, K);
         const size_t lds = sizeof(long long) * ((plen_ + 1) & ~(size_t)1) + sizeof(float) * (size_t)K * 8 +
                            sizeof(unsigned) * kFilterQueue * (kFilterThreads / 64);
-        static bool lds_ok = false;  // 66 KB of dynamic LDS: above the default 64 KB window
+        // 66 KB of dynamic LDS: above the default 64 KB window (the attribute is per device)
+        static bool lds_set[64] = {};
+        int dev_id = 0;
+        ET_HIP_TRY(hipGetDevice(&dev_id));
+        bool &lds_ok = lds_set[dev_id & 63];
         if (!lds_ok) {
             ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kmeans_assign_filter_kernel<10>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
