@@ -350,6 +350,62 @@ def test_sharded_driver_on_one_gpu_matches_oracle(ops, oracle, dev):
     assert torch.equal(U_obs, ops.eigh_topk(g_obs, 6)[0]) and torch.equal(U_pred, ops.eigh_topk(g_pred, 6)[0])
 
 
+def _two_rank_gpu_worker(rank, world, port, cuts, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share cuda:0; gloo moves the few bytes
+    try:
+        from eigentrajectory_amd import ops
+        from eigentrajectory_amd.dist import ShardedKMeans, fit_descriptor_sharded
+        from eigentrajectory_amd.synth import gaussian_points_np, synthetic_trajectories_np
+        dev = torch.device("cuda:0")
+        obs, pred = synthetic_trajectories_np(6000, seed=5)
+        lo, hi = cuts[rank], cuts[rank + 1]
+        U_obs, U_pred, _, _, count = fit_descriptor_sharded(torch.from_numpy(obs[lo:hi]).to(dev),
+                                                            torch.from_numpy(pred[lo:hi]).to(dev), 6, ops.MODE_SPLIT, 0.3, 1)
+        x = gaussian_points_np(6, 24000, seed=6, n_blobs=7)
+        x[:, ::97] *= 300.0  # heavy tail: farthest-first picks that most points can skip
+        c = cuts[1] * 4 if rank == 0 else None
+        xs = x[:, :cuts[1] * 4] if rank == 0 else x[:, cuts[1] * 4:]
+        km = ShardedKMeans(torch.from_numpy(np.ascontiguousarray(xs)).to(dev), 20, check_every=3)
+        c0 = km.init_farthest(first_index=4321)
+        res = km.fit(c0.clone(), max_iter=30, tol=1e-4)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), U_pred=U_pred.cpu().numpy(), count=count, c0=c0.cpu().numpy(),
+                 centroids=res["centroids"].cpu().numpy(), labels=res["labels"].cpu().numpy(), n_iter=res["n_iter"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cuts", [(0, 3000, 6000), (0, 257, 6000)])
+def test_sharded_two_ranks_on_the_gpu(tmp_path, oracle, cuts):
+    """Two processes, real device shards (both on cuda:0), gloo for the exchange: every rank ends with the oracle's
+    single-process result -- the multi-GPU path minus RCCL."""
+    import socket
+    import torch.multiprocessing as mp
+    from eigentrajectory_amd.synth import gaussian_points_np, synthetic_trajectories_np
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_two_rank_gpu_worker, args=(2, port, cuts, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for key in ("U_pred", "count", "c0", "centroids", "n_iter"):
+        assert np.array_equal(r0[key], r1[key], equal_nan=True), key
+    obs, pred = synthetic_trajectories_np(6000, seed=5)
+    g_obs, g_pred, cnt = oracle.fit_gram(obs, pred, 2, 0.3, 1)
+    assert int(r0["count"]) == cnt
+    np.testing.assert_allclose(r0["U_pred"], oracle.eigh_topk(g_pred, 6)[0], atol=2e-6)
+    x = gaussian_points_np(6, 24000, seed=6, n_blobs=7)
+    x[:, ::97] *= 300.0
+    c0, _ = oracle.kmeans_init_farthest(x, 20, 4321)
+    assert np.array_equal(r0["c0"], c0)
+    ref = oracle.kmeans_fit(x, c0, 30, 1e-4)
+    assert int(r0["n_iter"]) == ref["n_iter"]
+    assert np.array_equal(r0["centroids"], ref["centroids"])
+    assert np.array_equal(np.concatenate([r0["labels"], r1["labels"]]), ref["labels"])
+
+
 def _filter_case(kind, n, seed):
     """Point clouds chosen to stress the matrix-core filter of the Lloyd assignment (d = 6, N % 4 == 0, N >= 1024)."""
     from eigentrajectory_amd.synth import gaussian_points_np
