@@ -10,6 +10,16 @@
 // 16 B (4 consecutive points) per row.  One Lloyd step reads d*4 B per point once and keeps
 // everything else (K centroids, K*(d+1)+2 accumulators) in LDS.
 //
+// Kernels of a single-GPU fit with d = 6, K <= 32 (the anchor clustering):
+//   farthest-first   kmeans_init_step_kernel        one launch per centroid; steps >= 2 skip the coordinate read of
+//                                                    points that provably keep their running maximum
+//   iteration 0      kmeans_assign_kernel body      exact scan + full accumulation (inside the filter kernel's launch)
+//   iterations >= 1  kmeans_assign_filter_kernel    f16 MFMA upper bounds + exact certification of the old label,
+//                                                    undecided points through an LDS queue; deltas leave as atomics
+//                    kmeans_update_lanes_kernel     fold 16 copies of the totals, means, error, inertia, convergence
+//   small shards     kmeans_lloyd_small_kernel      the whole iteration in one launch
+// Everything else (other d / K, given labels, the sharded step API) runs the exact scan and a two-kernel fold + update.
+//
 // Exactness: the reference sums per-cluster coordinates in fp32 in torch's reduction order,
 // which a parallel machine cannot reproduce.  Here every coordinate is converted to a 64-bit
 // fixed-point integer (truncation, power-of-two scale => exact) and integers are summed, so the
