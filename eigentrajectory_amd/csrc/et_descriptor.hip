@@ -263,8 +263,8 @@ __device__ __forceinline__ RowNorm fetch_row_norm(const float *s) {
 // The (S, TN, 2T) result tile is staged in LDS and written back with coalesced float4 stores
 // (each sample plane of the (S,N,T,2) output is a contiguous run of TN rows).
 // ------------------------------------------------------------------------------------------
-template <int TP, int K, int THREADS = kTile>
-__global__ __launch_bounds__(THREADS) void reconstruct_tile_kernel(
+template <int TP, int K>
+__global__ __launch_bounds__(kTile) void reconstruct_tile_kernel(
     const float *__restrict__ C, int64_t N, int S, int TN, int T_obs,
     const float *__restrict__ obs, const float *__restrict__ nrm,
     const float *__restrict__ A_m, const float *__restrict__ A_s,
@@ -297,11 +297,11 @@ __global__ __launch_bounds__(THREADS) void reconstruct_tile_kernel(
     } else if (tid < rows) {
         store_row_norm(sNorm + tid * kNormStride, load_row_norm(nrm, obs, N, n0 + tid, T_obs, mode, static_dist));
     }
-    for (int i = tid; i < 2 * DP * K; i += THREADS) {
+    for (int i = tid; i < 2 * DP * K; i += kTile) {
         const float *src = (i >= DP * K) ? U_m : U_s;
         sU[i] = src ? src[i % (DP * K)] : 0.f;
     }
-    for (int i = tid; i < 2 * K * S; i += THREADS) {
+    for (int i = tid; i < 2 * K * S; i += kTile) {
         const float *src = (i >= K * S) ? A_m : A_s;
         sA[i] = src ? src[i % (K * S)] : 0.f;
     }
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(THREADS) void reconstruct_tile_kernel(
     float4 *out4 = reinterpret_cast<float4 *>(out);
     const int per_plane = rows * QP;
     const int total = S * per_plane;
-    for (int q = tid; q < total; q += THREADS) {
+    for (int q = tid; q < total; q += kTile) {
         const int s = q / per_plane, r = q - s * per_plane;
         out4[((int64_t)s * N + n0) * QP + r] = src4[q];
     }
@@ -641,17 +641,7 @@ extern "C" int et_anchor_reconstruct_fwd(const float *C, int64_t N, int S, int k
     if ((need_m(mode) && !U_pred_m) || (need_s(mode) && !U_pred_s)) return ET_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     const bool fast = T_pred == 12 && k == 6 && S <= kTile && aligned16(out);
-    if (fast && S >= 8) {
-        // many samples per trajectory: 512 (trajectory, sample) pairs per workgroup, i.e. twice as long contiguous runs
-        // in every sample plane of the output
-        constexpr int kBig = 512;
-        const int TN = kBig / S;
-        const size_t lds = sizeof(float) * ((size_t)TN * S * 24 + (size_t)TN * kNormStride + 2 * 24 * 6 + 2 * 6 * (size_t)S);
-        ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(reconstruct_tile_kernel<12, 6, kBig>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        hipLaunchKernelGGL((reconstruct_tile_kernel<12, 6, kBig>), dim3((unsigned)ceil_div(N, TN)), dim3(kBig), lds, st, C, N,
-                           S, TN, T_obs, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, out);
-    } else if (fast) {
+    if (fast) {
         const int TN = kTile / S;
         const size_t lds = sizeof(float) * ((size_t)TN * S * 24 + (size_t)TN * kNormStride + 2 * 24 * 6 + 2 * 6 * (size_t)S);
         hipLaunchKernelGGL((reconstruct_tile_kernel<12, 6>), dim3((unsigned)ceil_div(N, TN)), dim3(kTile), lds, st, C, N,
