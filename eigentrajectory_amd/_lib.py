@@ -28,6 +28,7 @@ SYMBOLS = [
     "et_euc_sim", "et_kmeans_partials_len", "et_kmeans_workspace_bytes", "et_kmeans_scan", "et_kmeans_begin",
     "et_kmeans_init_step", "et_kmeans_init_set", "et_kmeans_init_select", "et_kmeans_gather_point", "et_kmeans_init_farthest",
     "et_kmeans_assign_accumulate", "et_kmeans_update", "et_kmeans_labels_i64", "et_kmeans_fit", "et_kmeans_predict",
+    "et_center_columns", "et_kmeanspp_workspace_bytes", "et_kmeanspp_seed",
 ]
 
 
@@ -63,7 +64,8 @@ def lib():
         l = C.CDLL(LIB_PATH)
         l.et_status_string.restype = C.c_char_p
         l.et_compiled_arch.restype = C.c_char_p
-        for name in ("et_fit_gram_workspace_bytes", "et_kmeans_partials_len", "et_kmeans_workspace_bytes"):
+        for name in ("et_fit_gram_workspace_bytes", "et_kmeans_partials_len", "et_kmeans_workspace_bytes",
+                     "et_kmeanspp_workspace_bytes"):
             getattr(l, name).restype = C.c_size_t
         _lib = l
     return _lib

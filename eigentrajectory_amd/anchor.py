@@ -3,21 +3,21 @@
 Reference: EigenTrajectory/anchor.py:5-88.  Same parameter (``C_anchor`` (k,S)).
 ``anchor_generation`` clusters the projected coefficients on the GPU where the reference
 calls ``sklearn.cluster.KMeans(n_clusters=S, random_state=0, init='k-means++', n_init=10)``
-(anchor.py:65-71).  Two modes:
+(anchor.py:65-71).  Two modes (``hyper_params.anchor_init``):
 
-* ``"farthest"`` (default): this build's BatchKMeans -- farthest-first seeding + Lloyd with
-  exact sums; deterministic for a given input and bit-identical to the CPU oracle.
-* ``"sklearn"``: the recipe of the reference's sklearn call -- mean-centred data,
-  ``tol = 1e-4 * mean(var)``, ``max_iter = 300``, ten initialisations of greedy k-means++
-  (D^2 sampling, 2 + log K local trials) driven by ONE ``numpy.random.RandomState(0)`` stream
-  exactly as sklearn consumes it, best inertia wins -- with the distance / potential passes and
-  the Lloyd iterations on the device.  sklearn itself is not bit-reproducible with more than
-  one thread, so this mode agrees with it in the seeds it draws and in quality
-  (inertia), not in the last bits of the centres.  Differences: an empty cluster becomes NaN
-  (kmeans.py:182) instead of being re-seeded (with k-means++ seeds this does not occur on the
-  datasets), and the inertia that ranks the initialisations is the one of the last assignment.
-
-Parity of the model is defined on loaded checkpoints (same anchors in -> same trajectories out).
+* ``"sklearn"`` (default -- the reference's semantics): the recipe of that sklearn call on the
+  device, in the arithmetic of sklearn's float32 code path (csrc/et_kmeanspp.hip): mean-centred
+  data, ``tol = 1e-4 * mean(var)``, ``max_iter = 300``, ten initialisations of greedy k-means++
+  (D^2 sampling, 2 + log K candidates per centre) fed with the draws of ONE
+  ``numpy.random.RandomState(0)`` exactly as sklearn consumes them, Lloyd iterations with exact sums
+  (``et_kmeans_fit``), best final inertia wins.  On the ETH/UCY fit sets this draws the same seed
+  points as sklearn and lands on the same anchors to ~1e-5 (tests/golden/g11, the own-fit ADE/FDE
+  test).  sklearn itself is not bit-reproducible with more than one thread.
+  Differences: an initialisation that produces an empty cluster is discarded (sklearn re-seeds the
+  cluster; with k-means++ seeds it does not occur on the datasets).
+* ``"farthest"``: this build's BatchKMeans (kmeans.py semantics) -- farthest-first seeding + Lloyd;
+  one initialisation, deterministic, bit-identical to the CPU oracle, ~10x cheaper; the anchors are a
+  different local optimum (ETH zero-predictor ADE/FDE 0.374/0.589 against the reference's 0.377/0.643).
 """
 from __future__ import annotations
 
@@ -63,27 +63,26 @@ class ETAnchor(nn.Module):
         self.generate_from_coefficients(C_pred, n_redo=n_redo, max_iter=max_iter, tol=tol, seed=seed, mode=mode)
 
     def generate_from_coefficients(self, C_pred, *, n_redo=1, max_iter=100, tol=1e-4, seed=0, mode=None):
-        r"""Cluster ET coefficients (k,N) into S anchors (``mode``: "farthest" | "sklearn", see the module docstring;
-        default: ``hyper_params.anchor_init`` if present, else "farthest")."""
+        r"""Cluster ET coefficients (k,N) into S anchors.  ``mode``: "sklearn" | "farthest" (module docstring);
+        default ``hyper_params.anchor_init`` if present, else "sklearn" (anchor.py:65-71).  ``n_redo``,
+        ``max_iter`` and ``tol`` are BatchKMeans' arguments and apply to "farthest" only."""
         n = C_pred.shape[1]
         if n < self.s:
             raise ValueError(f"anchor generation needs at least num_samples={self.s} trajectories, got {n}")
-        mode = mode or getattr(self.hyper_params, "anchor_init", None) or "farthest"
+        mode = mode or getattr(self.hyper_params, "anchor_init", None) or "sklearn"
         if mode == "sklearn":
             C_anchor, self.inertia_, self.seed_indices_ = sklearn_style_kmeans(C_pred, self.s, random_state=seed)
-            self.C_anchor = nn.Parameter(C_anchor.to(self.C_anchor.device))
-            return
-        if mode != "farthest":
+        elif mode == "farthest":
+            km = BatchKMeans(n_clusters=self.s, n_redo=n_redo, max_iter=max_iter, tol=tol, init_mode="kmeans++")
+            state = np.random.get_state()
+            try:
+                np.random.seed(seed)  # kmeans.py:92 draws the first centroid from numpy's global stream
+                km.fit(C_pred[None].contiguous())
+            finally:
+                np.random.set_state(state)
+            C_anchor, self.inertia_ = km.centroids[0], km.inertia_
+        else:
             raise ValueError(f"unknown anchor mode {mode!r}")
-        km = BatchKMeans(n_clusters=self.s, n_redo=n_redo, max_iter=max_iter, tol=tol, init_mode="kmeans++")
-        state = np.random.get_state()
-        try:
-            np.random.seed(seed)  # the reference fixes random_state=0 (anchor.py:71); kmeans.py:92 draws from numpy
-            km.fit(C_pred[None].contiguous())
-        finally:
-            np.random.set_state(state)
-        C_anchor = km.centroids[0]
-        self.inertia_ = km.inertia_
         # Register anchors as model parameters
         self.C_anchor = nn.Parameter(C_anchor.to(self.C_anchor.device))
 
@@ -96,53 +95,43 @@ class ETAnchor(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # The reference's sklearn call (anchor.py:65-71), restated on the device
 # ------------------------------------------------------------------------------------------------
-def greedy_kmeanspp(X, K, rng):
-    """Greedy k-means++ seeding (Arthur & Vassilvitskii 2007 with 2 + log K local trials, the variant behind
-    ``sklearn.cluster.KMeans(init='k-means++')``) on device points ``X`` (d,N) fp32.
-
-    ``rng`` is a ``numpy.random.RandomState``; it is consumed exactly like sklearn consumes its stream (one
-    uniform for the first centre, ``n_trials`` uniforms per further centre), so a shared stream stays aligned
-    over several initialisations.  Distances / potentials / cumulative sums run on the device; only the
-    ``n_trials`` random thresholds cross the PCIe bus per centre.  -> (indices list, centres (d,K)).
-    """
-    d, n = X.shape
-    n_trials = 2 + int(np.log(K))
-    first = min(int(rng.random_sample() * n), n - 1)  # choice(n, p=uniform): one uniform draw through the cdf
-    idx = [first]
-    closest = (-ops.euc_sim(X, X[:, first:first + 1].contiguous()))[:, 0].clamp_min_(0)  # squared distances (N,)
-    pot = float(closest.sum(dtype=torch.float64))
-    for _ in range(1, K):
-        thresholds = torch.from_numpy(rng.uniform(size=n_trials) * pot).to(X.device)
-        cum = torch.cumsum(closest, 0, dtype=torch.float64)
-        cand = torch.searchsorted(cum, thresholds).clamp_(max=n - 1)
-        D = (-ops.euc_sim(X, X[:, cand].contiguous())).clamp_min_(0)  # (N, n_trials)
-        D = torch.minimum(D, closest[:, None])
-        pots = D.sum(0, dtype=torch.float64)
-        best = int(torch.argmin(pots))
-        pot = float(pots[best])
-        closest = D[:, best].contiguous()
-        idx.append(int(cand[best]))
-    return idx, X[:, torch.tensor(idx, device=X.device)].contiguous()
+def seeding_uniforms(rng, K, n_init):
+    """The draws sklearn's k-means++ consumes from ``rng`` (a ``numpy.random.RandomState``), one row per
+    initialisation: one ``random_sample`` for the first centre (``choice`` with uniform p), then
+    ``uniform(size=2 + log K)`` thresholds per further centre."""
+    nt = ops.kmeanspp_trials(K)
+    U = np.empty((n_init, 1 + (K - 1) * nt), dtype=np.float64)
+    for i in range(n_init):
+        U[i, 0] = rng.random_sample()
+        for c in range(1, K):
+            U[i, 1 + (c - 1) * nt:1 + c * nt] = rng.uniform(size=nt)
+    return U
 
 
 def sklearn_style_kmeans(C, K, *, random_state=0, n_init=10, max_iter=300, tol=1e-4):
-    """``KMeans(n_clusters=K, random_state=random_state, init='k-means++', n_init=n_init).fit(C.T)`` as a recipe:
-    -> (cluster centres (d,K) fp32 on C's device, inertia = mean squared distance, seed indices of every init)."""
+    """``KMeans(n_clusters=K, random_state=random_state, init='k-means++', n_init=n_init).fit(C.T)`` as a recipe on
+    the device: -> (cluster centres (d,K) fp32 on C's device, inertia = mean squared distance to the final centres,
+    seed indices (n_init,K) int64 of every initialisation)."""
     dev = ops.L.require_device(C)  # no CPU fallback: raises without a HIP device
-    X = C.to(device=dev, dtype=torch.float32).contiguous()
-    mean = X.mean(dim=1, keepdim=True)
-    tol_ = float(X.var(dim=1, unbiased=False).mean()) * tol  # sklearn's _tolerance
-    X = (X - mean).contiguous()
-    rng = np.random.RandomState(random_state)
+    X, mean, tol_dev = ops.center_columns(C.to(device=dev, dtype=torch.float32), tol)
+    d, n = X.shape
+    U = torch.from_numpy(seeding_uniforms(np.random.RandomState(random_state), K, n_init)).to(dev)
+    nbytes = ops.L.lib().et_kmeanspp_workspace_bytes(ops.L.i64(n), d, ops.kmeanspp_trials(K))
+    ws_seed = torch.empty((max(nbytes, 8),), device=dev, dtype=torch.uint8)
+    ws_fit = ops.kmeans_workspace(n, d, K, dev)
+    seeded = [ops.kmeanspp_seed(X, K, U[i], ws_seed) for i in range(n_init)]  # all enqueued, no host round trip
+    tol_ = float(tol_dev.item())
     best = None
-    seeds = []
-    for _ in range(n_init):
-        idx, c0 = greedy_kmeanspp(X, K, rng)
-        seeds.append(idx)
-        res = ops.kmeans_fit(X, c0, max_iter, tol_)
-        inertia = float(res["inertia"])
-        if np.isfinite(inertia) and (best is None or inertia < best[0]):
-            best = (inertia, res["centroids"])
+    for c0, _ in seeded:
+        res = ops.kmeans_fit(X, c0, max_iter, tol_, workspace=ws_fit)
+        cen = res["centroids"]
+        if not bool(torch.isfinite(cen).all()):
+            continue  # an empty cluster (kmeans.py:182 semantics): sklearn would re-seed it, here the run is dropped
+        _, maxsims = ops.kmeans_predict(X, cen)  # sklearn ranks by the inertia of the FINAL centres
+        inertia = float((-maxsims.double()).sum())
+        if best is None or inertia < best[0]:
+            best = (inertia, cen)
     if best is None:
         raise RuntimeError("every k-means initialisation produced an empty cluster")
-    return (best[1] + mean).contiguous(), best[0], seeds
+    seeds = torch.stack([idx for _, idx in seeded])
+    return (best[1] + mean[:, None]).contiguous(), best[0] / n, seeds

@@ -283,6 +283,49 @@ def kmeans_predict(X, centroids, want_maxsims=True):
     return labels, maxsims
 
 
+# ---------------------------------------------------- sklearn-recipe anchors (anchor.py:65-71)
+def center_columns(X, rel_tol=1e-4):
+    """KMeans.fit's pre-processing on a COPY of X (d,N): -> (X - mean (d,N), mean (d,), tol (1,) = rel_tol * mean(var))
+    all on the device, in numpy's float32 reduction order (csrc/et_kmeanspp.hip)."""
+    dev = L.require_device(X)
+    Xc = L.on_device(X, dev).clone()
+    d, n = Xc.shape
+    mean = torch.empty((d,), device=dev)
+    tol = torch.empty((1,), device=dev)
+    ws = torch.empty((2 * L.KMEANS_MAX_D,), device=dev)
+    L.check(L.lib().et_center_columns(L.ptr(Xc), L.i64(n), d, L.f32(rel_tol), L.ptr(mean), L.ptr(tol), L.ptr(ws),
+                                      C.c_size_t(ws.numel() * 4), L.stream(dev)), "et_center_columns")
+    return Xc, mean, tol
+
+
+def kmeanspp_trials(K):
+    """sklearn's number of candidates per centre: 2 + floor(ln K)."""
+    import math
+    return 2 + int(math.log(K))
+
+
+def kmeanspp_seed(X, K, uniforms, workspace=None):
+    """Greedy k-means++ seeding of X (d,N) with the float64 draws ``uniforms`` (1 + (K-1)*n_trials,) on the device
+    -> (centers (d,K), indices (K,) int64).  No host synchronisation."""
+    dev = L.require_device(X)
+    (X,) = _dev_args(dev, X)
+    uniforms = L.on_device(uniforms, dev, torch.float64)
+    d, n = X.shape
+    nt = kmeanspp_trials(K)
+    if uniforms.numel() != 1 + (K - 1) * nt:
+        raise ValueError(f"k-means++ seeding of {K} centres consumes {1 + (K - 1) * nt} draws, got {uniforms.numel()}")
+    if workspace is None:
+        nbytes = L.lib().et_kmeanspp_workspace_bytes(L.i64(n), d, nt)
+        if nbytes == 0:
+            raise ValueError(f"k-means++ dimensions out of range: N={n}, d={d}, K={K}")
+        workspace = torch.empty((nbytes,), device=dev, dtype=torch.uint8)
+    centers = torch.empty((d, K), device=dev)
+    indices = torch.empty((K,), device=dev, dtype=torch.int64)
+    L.check(L.lib().et_kmeanspp_seed(L.ptr(X), L.i64(n), d, int(K), nt, L.ptr(uniforms), L.ptr(centers), L.ptr(indices),
+                                     L.ptr(workspace), C.c_size_t(workspace.numel()), L.stream(dev)), "et_kmeanspp_seed")
+    return centers, indices
+
+
 class KMeansShard:
     """Step-wise Lloyd iteration on one shard of the points (the sharded / multi-GPU form).
 

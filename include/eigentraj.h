@@ -250,6 +250,26 @@ int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_iter, float t
 int et_kmeans_predict(const float *X, int64_t N, int d, const float *centroids, int K, int64_t *labels,
                       float *maxsims, et_stream_t stream);
 
+/* ---- anchor clustering as the reference runs it: sklearn KMeans(init='k-means++', n_init=10) ----------
+ * EigenTrajectory/anchor.py:65-71 hands the coefficients to sklearn.cluster.KMeans (third-party; its published
+ * algorithm is restated, see csrc/et_kmeanspp.hip).  The Lloyd iterations are et_kmeans_fit; these two entry
+ * points are the parts sklearn does around them, in the arithmetic of its float32 code path.
+ *
+ * et_center_columns   KMeans.fit's pre-processing, in place on X (d,N): mean[j] = fp32 sum over the points in
+ *                     index order / N (numpy's add.reduce(axis=0) order), X[j] -= mean[j], and
+ *                     *tol = rel_tol * mean_j(var_j) (sklearn `_tolerance`).  mean (d), tol (1): device.
+ *                     workspace >= 2 * 4 * ET_KMEANS_MAX_D bytes.
+ * et_kmeanspp_seed    greedy k-means++ (n_trials = 2 + floor(ln K) candidates per centre): centers (d,K) fp32 and
+ *                     indices (K) int64 of the chosen points.  `uniforms` (device, float64) holds the
+ *                     1 + (K-1)*n_trials draws of the seeding in the order sklearn consumes its RandomState:
+ *                     [0] picks the first centre (index floor(u*N)), then n_trials thresholds per centre.
+ *                     Enqueues 4K-1 launches, no synchronisation. */
+int et_center_columns(float *X, int64_t N, int d, float rel_tol, float *mean, float *tol,
+                      void *workspace, size_t workspace_bytes, et_stream_t stream);
+size_t et_kmeanspp_workspace_bytes(int64_t N, int d, int n_trials);
+int et_kmeanspp_seed(const float *X, int64_t N, int d, int K, int n_trials, const double *uniforms,
+                     float *centers, int64_t *indices, void *workspace, size_t workspace_bytes, et_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
