@@ -72,8 +72,9 @@ __global__ __launch_bounds__(kTile) void project_tile_kernel(
             if (r < DO * K) {
                 src = desc ? U_obs_m : U_obs_s;
                 off = r;
-            } else {
-                src = desc ? U_pred_m : U_pred_s;
+            } else {  // the pred half is staged only when it is used: without pred the U_pred operands may belong
+                      // to another pred_len (shorter than TP rows) or be absent
+                src = has_pred ? (desc ? U_pred_m : U_pred_s) : nullptr;
                 off = r - DO * K;
             }
             sU[i] = src ? src[off] : 0.f;

@@ -24,54 +24,49 @@ from . import ops
 
 
 class BatchKMeans(nn.Module):
-    r"""Run multiple independent K-means algorithms in parallel.
+    r"""Independent k-means problems side by side, one per leading batch index of the data (kmeans.py:7-30).
 
-    Args:
-        n_clusters (int): Number of clusters
-        max_iter (int): Maximum number of iterations (default: 100)
-        tol (float): Tolerance (default: 0.0001)
-        n_redo (int): Number of time k-means will be run with differently initialized centroids.
-            the centroids with the lowest inertia will be selected as a final result. (default: 1)
-        init_mode (str): Initialization method.
-            'random': randomly chose initial centroids from input data.
-            'kmeans++': use k-means++ algorithm to initialize centroids. (default: 'kmeans++')
+    Args (same names, defaults and meaning as the reference's constructor):
+        n_clusters (int): clusters per problem
+        n_redo (int): restarts with fresh initial centroids; the run with the lowest inertia is kept (default 1)
+        max_iter (int): cap on Lloyd iterations per run (default 100)
+        tol (float): a run stops once the summed squared centroid movement is <= tol (default 1e-4)
+        init_mode (str): 'kmeans++' = farthest-first seeding (kmeans.py:78-112), 'random' = K distinct data points
+        verbose (bool): print the per-iteration error / inertia trace
     """
 
     def __init__(self, n_clusters, n_redo=1, max_iter=100, tol=1e-4, init_mode="kmeans++", verbose=False):
-        super(BatchKMeans, self).__init__()
-        self.n_redo = n_redo
-        self.n_clusters = n_clusters
-        self.max_iter = max_iter
-        self.tol = tol
-        self.init_mode = init_mode
-        self.verbose = verbose
+        super().__init__()
+        self.n_clusters, self.n_redo = n_clusters, n_redo
+        self.max_iter, self.tol = max_iter, tol
+        self.init_mode, self.verbose = init_mode, verbose
         self.inertia_ = None
         self.n_iter_ = None
-
-        self.register_buffer("centroids", None)
+        self.register_buffer("centroids", None)  # filled by fit(); part of the state_dict like in the reference
 
     def load_state_dict(self, state_dict, **kwargs):
-        r"""Override the default load_state_dict() to load custom buffers (kmeans.py:32-43)."""
-        for k, v in state_dict.items():
-            if "." not in k:
-                assert hasattr(self, k), f"attribute {k} does not exist"
-                delattr(self, k)
-                self.register_buffer(k, v)
-        for name, module in self.named_children():
-            sd = {k.replace(name + ".", ""): v for k, v in state_dict.items() if k.startswith(name + ".")}
-            module.load_state_dict(sd)
+        r"""``centroids`` is registered as ``None`` until ``fit`` ran, so nn.Module's own loader would reject it:
+        top-level entries replace the attribute of the same name as a buffer, dotted entries are handed to the
+        child module they name (behaviour of kmeans.py:32-43)."""
+        own = {key: val for key, val in state_dict.items() if "." not in key}
+        for key, val in own.items():
+            if not hasattr(self, key):
+                raise AssertionError(f"attribute {key} does not exist")
+            delattr(self, key)
+            self.register_buffer(key, val)
+        for child_name, child in self.named_children():
+            prefix = child_name + "."
+            child.load_state_dict({key[len(prefix):]: val for key, val in state_dict.items() if key.startswith(prefix)})
 
     @staticmethod
     def calculate_error(a, b):
-        r"""Compute L2 error between a and b (kmeans.py:45-51)"""
-        diff = a - b
-        diff.pow_(2)
-        return diff.sum()
+        r"""Summed squared difference of two centroid sets (the convergence measure, kmeans.py:45-51)."""
+        return torch.sum((a - b) ** 2)
 
     @staticmethod
     def calculate_inertia(a):
-        r"""Compute inertia of a (kmeans.py:53-57)"""
-        return (-a).mean()
+        r"""Mean negated similarity = mean squared distance to the assigned centroid (kmeans.py:53-57)."""
+        return torch.mean(torch.neg(a))
 
     @staticmethod
     def _batched(x):
@@ -96,19 +91,18 @@ class BatchKMeans(nn.Module):
         return cen.reshape(tuple(lead) + tuple(cen.shape[-2:]))
 
     def initialize_centroids(self, data):
-        r"""Initialize centroids with init_method specified in __init__ (kmeans.py:114-141)"""
-        n_data = data.size(-1)
-        if self.init_mode == "random":
-            random_index = np.random.choice(n_data, size=[self.n_clusters], replace=False)
-            centroids = data[:, :, random_index].clone()
-            if self.verbose:
-                print("centroids are randomly initialized.")
-        elif self.init_mode == "kmeans++":
+        r"""Initial centroids (..., d, n_clusters) according to ``init_mode`` (kmeans.py:114-141); both modes draw
+        from numpy's global RNG exactly where the reference does."""
+        if self.init_mode == "kmeans++":
             centroids = self.kmeanspp(data).clone()
-            if self.verbose:
-                print("centroids are initialized with kmeans++.")
+        elif self.init_mode == "random":
+            picks = np.random.choice(data.size(-1), size=[self.n_clusters], replace=False)
+            centroids = data[:, :, picks].clone()  # 3-D data only, like the reference's indexing
         else:
-            raise NotImplementedError
+            raise NotImplementedError(f"init_mode {self.init_mode!r}")
+        if self.verbose:
+            print("centroids are initialized with kmeans++." if self.init_mode == "kmeans++"
+                  else "centroids are randomly initialized.")
         return centroids
 
     def get_labels(self, data, centroids):

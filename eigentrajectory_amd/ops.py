@@ -47,23 +47,52 @@ def norm_params_from_nrm(nrm, want_ori=True, want_rot=True, want_sca=True):
     return ori, rot, sca
 
 
-def _traj_transform(fn, name, traj, ori, rot, sca):
-    dev = L.require_device(traj, ori, rot, sca)
-    traj, ori, rot, sca = _dev_args(dev, traj, ori, rot, sca)
+def _traj_transform(which, traj, ori, rot, sca):
+    """which: "normalize" | "denormalize" -> et_normalize / et_denormalize on contiguous device tensors."""
     n, t, _ = traj.shape
     out = torch.empty_like(traj)
-    L.check(fn(L.ptr(traj), L.i64(n), t, L.ptr(ori), L.ptr(rot), L.ptr(sca), L.ptr(out), L.stream(dev)), name)
+    fn = L.lib().et_normalize if which == "normalize" else L.lib().et_denormalize
+    L.check(fn(L.ptr(traj), L.i64(n), t, L.ptr(ori), L.ptr(rot), L.ptr(sca), L.ptr(out), L.stream(traj.device)),
+            "et_" + which)
     return out
 
 
+class _TrajTransform(torch.autograd.Function):
+    """normalizer.py:42-62 are ordinary differentiable torch ops in the reference; here the transform is a kernel,
+    so its backward is spelled out.  Differentiable w.r.t. the trajectory only (the parameters come from
+    ``calculate_params`` on the observations and carry no gradient path to a predictor):
+        normalize    y = ((x - o) @ R) * s      dx = (g * s) @ R^T   = denormalize(g; no origin, R, 1/s)
+        denormalize  y = (x / s) @ R^T + o      dx = (g @ R) / s     = normalize(g; no origin, R, 1/s)"""
+
+    @staticmethod
+    def forward(ctx, traj, ori, rot, sca, which):
+        ctx.saved = (rot, sca, which)
+        return _traj_transform(which, traj, ori, rot, sca)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        rot, sca, which = ctx.saved
+        inv = None if sca is None else (1.0 / sca).contiguous()
+        other = "denormalize" if which == "normalize" else "normalize"
+        return _traj_transform(other, grad_out.contiguous().float(), None, rot, inv), None, None, None, None
+
+
+def _traj_op(which, traj, ori, rot, sca):
+    dev = L.require_device(traj, ori, rot, sca)
+    if traj.device != dev or traj.dtype != torch.float32 or not traj.is_contiguous():
+        traj = traj.to(device=dev, dtype=torch.float32).contiguous()  # differentiable
+    ori, rot, sca = _dev_args(dev, ori, rot, sca)
+    return _TrajTransform.apply(traj, ori, rot, sca, which)
+
+
 def normalize(traj, ori=None, rot=None, sca=None):
-    """normalizer.py:42-51 with explicit parameter tensors (None = that step is off)."""
-    return _traj_transform(L.lib().et_normalize, "et_normalize", traj, ori, rot, sca)
+    """normalizer.py:42-51 with explicit parameter tensors (None = that step is off); autograd w.r.t. ``traj``."""
+    return _traj_op("normalize", traj, ori, rot, sca)
 
 
 def denormalize(traj, ori=None, rot=None, sca=None):
-    """normalizer.py:53-62"""
-    return _traj_transform(L.lib().et_denormalize, "et_denormalize", traj, ori, rot, sca)
+    """normalizer.py:53-62; autograd w.r.t. ``traj``."""
+    return _traj_op("denormalize", traj, ori, rot, sca)
 
 
 # ---------------------------------------------------------------------------- projection

@@ -910,8 +910,9 @@ def test_trainer_harness_learns_and_roundtrips_checkpoint(dev, mode):
     raw = os.path.join(G.GOLDEN, "raw")
     val = TrajectoryData(os.path.join(raw, "eth_val"))
     test = TrajectoryData(os.path.join(raw, "eth_test"))
-    hp = default_hyper_params(batch_size=128, lr=3e-3, weight_decay=1e-4, clip_grad=10, lr_schd=True, lr_schd_step=64,
-                              lr_schd_gamma=0.5)
+    # batch_size counts pedestrians in collated mode and scenes in sequenced mode (utils/trainer.py:120-154, 211-231)
+    hp = default_hyper_params(batch_size=128 if mode == "collated" else 16, lr=3e-3, weight_decay=1e-4, clip_grad=10,
+                              lr_schd=True, lr_schd_step=64, lr_schd_gamma=0.5)
     torch.manual_seed(0)
     model = EigenTrajectory(TinyPredictor(), stub_hooks(), hp)
     tr = ETTrainer(model, hp, train_data=val, val_data=val, test_data=test, mode=mode, device=dev)
@@ -929,6 +930,99 @@ def test_trainer_harness_learns_and_roundtrips_checkpoint(dev, mode):
     tr2 = ETTrainer(fresh, hp, val, val, test, mode=mode, device=dev)
     best = tr2.test()
     assert np.isfinite(best["ADE"]) and best["ADE"] < before["ADE"] + 0.02
+
+
+def _trainer_for(dev, mode, batch_size, epochs_seed=0):
+    """ETH-test scenes as the training set, the reference's fitted descriptors (G2), a seeded TinyPredictor."""
+    import os
+    from eigentrajectory_amd import EigenTrajectory
+    from eigentrajectory_amd.data import TrajectoryData
+    from eigentrajectory_amd.trainer import ETTrainer
+    from eigentrajectory_amd.utils import default_hyper_params
+    data = TrajectoryData(os.path.join(G.GOLDEN, "raw", "eth_test"))
+    hp = default_hyper_params(batch_size=batch_size, lr=1e-3, weight_decay=1e-4, clip_grad=10, lr_schd=True,
+                              lr_schd_step=64, lr_schd_gamma=0.5, static_dist=G.static_dist("eth"))
+    torch.manual_seed(1234)
+    model = EigenTrajectory(TinyPredictor(), stub_hooks(), hp)
+    g2 = G.load("g2_fit_all_scenes.npz")
+    sd = model.state_dict()
+    for key in list(sd):
+        if key.startswith("ET_"):
+            sd[key] = torch.from_numpy(g2[f"eth.{key}"])
+    model.load_state_dict(sd)
+    return ETTrainer(model, hp, train_data=data, val_data=data, test_data=data, mode=mode, device=dev), data
+
+
+def _ddp_trainer_worker(rank, world, port, mode, batch_size, epochs, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share cuda:0; gloo carries the gradients
+    try:
+        dev = torch.device("cuda:0")
+        tr, _ = _trainer_for(dev, mode, batch_size)
+        assert tr.world == world and tr.model.baseline_model is not tr.predictor  # DDP-wrapped
+        for epoch in range(epochs):
+            tr.train(epoch)
+        val = tr.valid()
+        res = tr.test()
+        w = {k: v.detach().cpu().numpy() for k, v in tr.state_dict().items() if k.startswith("baseline_model.")}
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), val=val, ade=res["ADE"], fde=res["FDE"],
+                 train_loss=tr.log["train_loss"][-1], **w)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_ddp(tmp_path, mode, batch_size, epochs):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_ddp_trainer_worker, args=(2, port, mode, batch_size, epochs, str(tmp_path)), nprocs=2, join=True)
+    return np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+
+
+@pytest.mark.timeout(600)
+def test_trainer_ddp_two_ranks_equal_single_process(dev, tmp_path):
+    """utils/trainer.py's sequenced strategy under data parallelism (two processes, DistributedDataParallel): both
+    ranks end with identical predictor weights, and they are the weights of a single-process run whose group size is
+    batch_size * world (gradients are averaged over ranks; 70 scenes / 4 -> 18 groups, 9 steps per rank)."""
+    r0, r1 = _run_ddp(tmp_path, "sequenced", 4, epochs=2)
+    keys = [k for k in r0.files if k.startswith("baseline_model.")]
+    assert keys
+    for k in keys:
+        assert np.array_equal(r0[k], r1[k]), k
+    for k in ("val", "ade", "fde", "train_loss"):
+        assert float(r0[k]) == float(r1[k]), k  # reduced over ranks: the same number everywhere
+    single, data = _trainer_for(dev, "sequenced", 8)
+    for epoch in range(2):
+        single.train(epoch)
+    sd = single.state_dict()
+    for k in keys:
+        np.testing.assert_allclose(r0[k], N_(sd[k]), rtol=0, atol=2e-5, err_msg=k)
+    assert abs(float(r0["val"]) - single.valid()) < 1e-4
+    t = single.test()
+    assert abs(float(r0["ade"]) - t["ADE"]) < 1e-4 and abs(float(r0["fde"]) - t["FDE"]) < 1e-4
+    assert abs(float(r0["train_loss"]) - single.log["train_loss"][-1]) < 1e-4
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode,batch_size", [("sequenced", 2), ("collated", 16)])
+def test_trainer_ddp_odd_batch_count_does_not_hang(tmp_path, mode, batch_size):
+    """An odd number of batches (35 groups of 2 scenes; 9 collated batches of >= 16 of 181 pedestrians would leave
+    one rank a step short): every rank must run the same number of optimiser steps, else DDP's gradient all-reduce
+    blocks forever or pairs with the validation all-reduce."""
+    from eigentrajectory_amd.data import TrajectoryData, scene_batches
+    import os
+    data = TrajectoryData(os.path.join(G.GOLDEN, "raw", "eth_test"))
+    if mode == "sequenced":
+        assert ((len(data) + batch_size - 1) // batch_size) % 2 == 1
+    r0, r1 = _run_ddp(tmp_path, mode, batch_size, epochs=3)
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), k
+    assert np.isfinite(float(r0["val"])) and np.isfinite(float(r0["ade"]))
 
 
 # ------------------------------------------------------------------------------------ edge cases
@@ -1012,9 +1106,13 @@ def test_descriptor_and_anchor_modules_standalone(dev, oracle):
     assert rec.shape == (20, 5000, 12, 2)
     assert float((rec[0] - T(pred, dev)).norm(dim=-1).mean()) < 0.2
     a = ETAnchor(hp).to(dev)
-    a.anchor_generation(pred_norm, U_pred)
+    a.anchor_generation(pred_norm, U_pred)  # default: the reference's sklearn recipe (anchor.py:65-71)
     A = N_(a.C_anchor)
     assert A.shape == (6, 20) and np.isfinite(A).all() and len({tuple(c) for c in A.T}) == 20
+    from oracle import sklearn_recipe as R
+    assert np.array_equal(A, R.kmeans(N_(C_pred), 20)["centers"])
+    a.anchor_generation(pred_norm, U_pred, mode="farthest")  # this build's BatchKMeans mode
+    A = N_(a.C_anchor)
     ref = oracle.kmeans_fit(N_(C_pred), oracle.kmeans_init_farthest(N_(C_pred), 20, np.random.RandomState(0).randint(5000))[0],
                             100, 1e-4)
     assert np.array_equal(A, ref["centroids"])  # same seeding draw as the reference's kmeans.py:92
@@ -1022,3 +1120,47 @@ def test_descriptor_and_anchor_modules_standalone(dev, oracle):
     back = d.to_Euclidean_space(d.to_ET_space(pred_norm, U_pred), U_pred)
     again = d.to_ET_space(back, U_pred)
     close(N_(again), N_(d.to_ET_space(pred_norm, U_pred)), tol=3e-6)
+
+
+def test_trajnorm_autograd_and_generic_reconstruction_gradient(ops, dev):
+    """normalizer.py:42-62 are differentiable torch ops in the reference: gradients must flow through the stand-alone
+    normalise / denormalise kernels, and through ETDescriptor.reconstruction when it runs on explicit TrajNorm
+    parameters (after normalize_trajectory / set_params) instead of the state a fused projection cached."""
+    from eigentrajectory_amd import ETDescriptor, TrajNorm
+    from eigentrajectory_amd.utils import default_hyper_params
+    obs, pred = synth(300, seed=9, min_disp=1e-3)
+    o, p = T(obs, dev), T(pred, dev)
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    for sca in (True, False):
+        tn = TrajNorm(True, True, sca)
+        tn.calculate_params(o)
+        ori, rot = tn.traj_ori, tn.traj_rot
+        s = tn.traj_sca if sca else torch.ones((300, 1, 1), device=dev)
+        g = torch.randn((300, 12, 2), generator=gen).to(dev)
+        for fn, ref in ((tn.normalize, lambda x: ((x - ori) @ rot) * s),
+                        (tn.denormalize, lambda x: (x / s) @ rot.transpose(1, 2) + ori)):
+            x1 = p.clone().requires_grad_()
+            y1 = fn(x1)
+            (y1 * g).sum().backward()
+            x2 = p.clone().requires_grad_()
+            y2 = ref(x2)
+            (y2 * g).sum().backward()
+            close(N_(y1), N_(y2), tol=3e-6)
+            close(N_(x1.grad), N_(x2.grad), tol=3e-6)
+    hp = default_hyper_params()
+    d = ETDescriptor(hp, norm_sca=True).to(dev)
+    d.parameter_initialization(o, p)
+    C = torch.randn((6, 300, 3), generator=gen).to(dev)
+    gt = torch.randn((3, 300, 12, 2), generator=gen).to(dev)
+    d.projection(o)                       # fused state cached
+    c1 = C.clone().requires_grad_()
+    r1 = d.reconstruction(c1)
+    (r1 * gt).sum().backward()
+    d.normalize_trajectory(o)             # explicit parameters: the generic path
+    assert d.traj_normalizer._nrm is None
+    c2 = C.clone().requires_grad_()
+    r2 = d.reconstruction(c2)
+    (r2 * gt).sum().backward()
+    assert c2.grad is not None and float(c2.grad.abs().max()) > 0
+    close(N_(r2), N_(r1), tol=3e-6)
+    close(N_(c2.grad), N_(c1.grad), tol=3e-6)
