@@ -111,7 +111,8 @@ def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None)
         c0 = ops.kmeans_init_farthest(c_pred, K, first_index)
         sw.stop("kmeans_init")
         sw.start("kmeans_lloyd")
-        res = ops.kmeans_fit(c_pred, c0, max_iter, 1e-4, timing=True)
+        # no per-iteration trace, like the reference (it only prints one when verbose); ET_BENCH_TRACE=1 records it
+        res = ops.kmeans_fit(c_pred, c0, max_iter, 1e-4, timing=True, trace=os.environ.get("ET_BENCH_TRACE") == "1")
         sw.stop("kmeans_lloyd")
         # the first launch of a fit is the plain exact scan (kmeans_assign_kernel<6,4>, full accumulation); the
         # others are the filter kernel, the dominant kernel of the path, of which every 8th launch is timed
@@ -128,7 +129,7 @@ def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None)
     return res["n_iter"]
 
 
-DOMINANT_KERNEL = "et::kmeans_assign_filter_kernel<10>"  # Lloyd iterations >= 1 (99 of 100 launches per step)
+DOMINANT_KERNEL = "et::kmeans_lloyd_large_kernel<10, false>"  # one launch per Lloyd iteration (100 per step)
 
 
 def pmc_traffic(n):

@@ -123,7 +123,7 @@ def sklearn_style_kmeans(C, K, *, random_state=0, n_init=10, max_iter=300, tol=1
     tol_ = float(tol_dev.item())
     best = None
     for c0, _ in seeded:
-        res = ops.kmeans_fit(X, c0, max_iter, tol_, workspace=ws_fit)
+        res = ops.kmeans_fit(X, c0, max_iter, tol_, workspace=ws_fit, trace=False)
         cen = res["centroids"]
         if not bool(torch.isfinite(cen).all()):
             continue  # an empty cluster (kmeans.py:182 semantics): sklearn would re-seed it, here the run is dropped

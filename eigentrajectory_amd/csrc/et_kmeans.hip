@@ -16,8 +16,10 @@
 //   iteration 0      kmeans_assign_kernel body      exact scan + full accumulation (inside the filter kernel's launch)
 //   iterations >= 1  kmeans_assign_filter_kernel    f16 MFMA upper bounds + exact certification of the old label,
 //                                                    undecided points through an LDS queue; deltas leave as atomics
-//                    kmeans_update_lanes_kernel     fold 16 copies of the totals, means, error, inertia, convergence
-//   small shards     kmeans_lloyd_small_kernel      the whole iteration in one launch
+//                    (kmeans_lloyd_large_kernel)    ... one launch per iteration: the last workgroup to finish folds the
+//                                                    16 copies of the totals and updates means / error / convergence
+//   small shards     kmeans_lloyd_small_kernel      the whole iteration in one launch, <= 32 workgroups
+//   after the loop   kmeans_inertia_kernel          inertia of the last assignment when no trace was requested
 // Everything else (other d / K, given labels, the sharded step API) runs the exact scan and a two-kernel fold + update.
 //
 // Exactness: the reference sums per-cluster coordinates in fp32 in torch's reduction order,
@@ -548,6 +550,7 @@ constexpr int kFilterSlots = 128;
 constexpr int kFilterQueue = 8 * kFilterSlots;  // 32-bit words per wavefront
 
 // full exact scan of `cnt` (<= 64) queued points, one per lane
+template <bool SIM>
 __device__ __forceinline__ void filter_drain(const unsigned *q, int cnt, int K, const float *sC,
                                              uint8_t *__restrict__ labels, long long *sAcc, int frac, int sfrac, int lane,
                                              long long &sim_acc) {
@@ -572,10 +575,13 @@ __device__ __forceinline__ void filter_drain(const unsigned *q, int cnt, int K, 
             atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[i * K + old]), 0ull - f);
         }
     }
-    sim_acc += to_fixed(best, sfrac);
+    if (SIM) sim_acc += to_fixed(best, sfrac);
 }
 
-template <int NREGS>
+// SIM = false: the similarity sum (the inertia of THIS assignment, kmeans.py:234) is not accumulated -- a fit that
+// does not record the per-iteration trace evaluates the inertia once, after its last assignment
+// (kmeans_inertia_kernel); the labels and the cluster sums are the same either way.
+template <int NREGS, bool SIM = true>
 __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, int64_t N, int K,
                                                    const et_kmeans_state *__restrict__ state, const float *cen,
                                                    uint8_t *__restrict__ labels, long long *__restrict__ block_partials,
@@ -722,8 +728,10 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
             const float wv = (y + an) * sg2;
             const float th = fmaf(fabsf(wv), 2.384185791015625e-7f, fmaf(rs, fmaf(rs, 1.52587890625e-5f, 9.5367431640625e-7f), 2.3283064365386963e-10f));
             const bool keep = wv - second > th;
-            const double term = trunc((double)y * sim_scale);
-            dsum += (valid && keep) ? term : 0.0;
+            if (SIM) {
+                const double term = trunc((double)y * sim_scale);
+                dsum += (valid && keep) ? term : 0.0;
+            }
             undecided |= (valid && !keep) ? (1u << q) : 0u;
         }
         if (__ballot(undecided != 0u)) {  // rare once Lloyd settles: queue the points that need the full scan
@@ -745,21 +753,25 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
 #endif
                 if (qn >= 64) {
                     qn -= 64;
-                    filter_drain(queue + qn, 64, K, sC, labels, sAcc, frac, sfrac, lane, sim_acc);
+                    filter_drain<SIM>(queue + qn, 64, K, sC, labels, sAcc, frac, sfrac, lane, sim_acc);
                 }
             }
         }
-        terms += 4;
-        if (terms + 4 > term_limit) {
-            sim_acc += (long long)dsum;
-            dsum = 0.0;
-            terms = 0;
+        if (SIM) {
+            terms += 4;
+            if (terms + 4 > term_limit) {
+                sim_acc += (long long)dsum;
+                dsum = 0.0;
+                terms = 0;
+            }
         }
     }
     sim_acc += (long long)dsum;
-    if (qn) filter_drain(queue, qn, K, sC, labels, sAcc, frac, sfrac, lane, sim_acc);
-    for (int o = 32; o > 0; o >>= 1) sim_acc += __shfl_xor(sim_acc, o);
-    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K]), (unsigned long long)sim_acc);
+    if (qn) filter_drain<SIM>(queue, qn, K, sC, labels, sAcc, frac, sfrac, lane, sim_acc);
+    if (SIM) {
+        for (int o = 32; o > 0; o >>= 1) sim_acc += __shfl_xor(sim_acc, o);
+        if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K]), (unsigned long long)sim_acc);
+    }
     __syncthreads();
     emit_partials(sAcc, plen, kFilterThreads, block_partials, lanes);
 }
@@ -802,8 +814,11 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_reduce_partials_kernel(cons
 // centroid update + convergence scalars from the (all-reduced) exact sums.  One workgroup.
 // `partials` may live in global memory or in LDS (flat addressing); `pre` = the state block if the caller has
 // already loaded it.
+// `last` (may be null): {d*K floats, then one int64 at the next 8-byte boundary} receives the centroids and sim_frac
+// the assignment just consumed was made with -- what kmeans_inertia_kernel needs to evaluate its inertia afterwards.
 __device__ __forceinline__ void update_body(et_kmeans_state *state, const long long *partials, int d, int K, float tol,
-                                            float *cen, float *trace, const et_kmeans_state *pre = nullptr) {
+                                            float *cen, float *trace, const et_kmeans_state *pre = nullptr,
+                                            float *last = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *sSq = reinterpret_cast<float *>(smem_raw);  // d*K squared differences
     float *sNew = sSq + d * K;
@@ -818,11 +833,14 @@ __device__ __forceinline__ void update_body(et_kmeans_state *state, const long l
         float c;
         if (cnt == 0) c = __int_as_float(0x7fc00000);  // 0/0 (kmeans.py:182)
         else c = (float)(((double)partials[e] * inv_scale) / (double)cnt);
-        const float diff = cen[e] - c;  // kmeans.py:48
-        sSq[e] = diff * diff;           // :49
+        const float prev = cen[e];
+        const float diff = prev - c;  // kmeans.py:48
+        sSq[e] = diff * diff;         // :49
         sNew[e] = c;
         cen[e] = c;
+        if (last) last[e] = prev;
     }
+    if (last && threadIdx.x == 0) *reinterpret_cast<long long *>(last + ((d * K + 1) & ~1)) = (long long)st.sim_frac;
     __syncthreads();
     // max |c| (NaN ignored), smallest non-zero |c| and a non-finite flag, reduced by the first wavefront
     __shared__ float sRed[3];
@@ -887,37 +905,6 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_update_kernel(et_kmeans_sta
     update_body(state, partials, d, K, tol, cen, trace);
 }
 
-// Single-GPU fit, large shards: the assignment kernel has already added its deltas onto kAccLanes copies of every
-// total (emit_partials); one workgroup folds the 16 copies, clears them for the next iteration and updates.
-__global__ __launch_bounds__(kKmThreads) void kmeans_update_lanes_kernel(long long *lanes, int plen, et_kmeans_state *state,
-                                                                         long long *partials, int d, int K, float tol,
-                                                                         float *cen, float *trace) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    long long *sTot = reinterpret_cast<long long *>(smem_raw) + 512;  // past the 2 d K floats update_body uses
-    const et_kmeans_state st = *state;  // one round trip for the state, the 16 copies and the running totals
-    for (int e = threadIdx.x; e < plen; e += kKmThreads) {
-        longlong2 *src = reinterpret_cast<longlong2 *>(lanes + (size_t)e * kAccLanes);
-        longlong2 v[kAccLanes / 2];
-#pragma unroll
-        for (int k = 0; k < kAccLanes / 2; ++k) v[k] = src[k];  // all loads first
-        const long long prev = partials[e];
-        long long s = 0;
-#pragma unroll
-        for (int k = 0; k < kAccLanes / 2; ++k) s += v[k].x + v[k].y;
-        if (!st.done) {
-            const long long tot = ((st.iter > 0 && e < plen - 2) ? prev : 0) + s;
-            partials[e] = tot;
-            sTot[e] = tot;
-            const longlong2 z = {0, 0};
-#pragma unroll
-            for (int k = 0; k < kAccLanes / 2; ++k) src[k] = z;
-        }
-    }
-    if (st.done) return;
-    __syncthreads();
-    update_body(state, sTot, d, K, tol, cen, trace, &st);
-}
-
 // Small shards (a few workgroups): the whole Lloyd iteration in ONE launch.  Every workgroup assigns its points
 // and writes its partials as above, then takes a ticket (release fence -> device-scope atomic -> acquire fence);
 // the last one to arrive folds the <= 32 partial blocks into the running totals and runs the update.  With so
@@ -926,13 +913,13 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_update_lanes_kernel(long lo
 // prologue only, i.e. before the last arrival, so updating it in place is safe.
 constexpr int kSmallMaxBlocks = 32;
 
-template <int NREGS>
+template <int NREGS, bool SIM>
 __global__ __launch_bounds__(kFilterThreads) void kmeans_lloyd_small_kernel(
     const float *__restrict__ X, int64_t N, int K, et_kmeans_state *state, float *cen, uint8_t *__restrict__ labels,
-    long long *block_partials, long long *partials, unsigned *ticket, float tol, float *trace) {
+    long long *block_partials, long long *partials, unsigned *ticket, float tol, float *trace, float *last) {
     if (state->done) return;
     constexpr int d = 6;
-    filter_assign_body<NREGS>(X, N, K, state, cen, labels, block_partials);
+    filter_assign_body<NREGS, SIM>(X, N, K, state, cen, labels, block_partials);
     __shared__ int sLast;
     __syncthreads();  // this workgroup's partials are written
     if (threadIdx.x == 0) {
@@ -971,7 +958,118 @@ __global__ __launch_bounds__(kFilterThreads) void kmeans_lloyd_small_kernel(
     for (int e = threadIdx.x; e < plen; e += kFilterThreads)
         partials[e] = ((have_totals && e < plen - 2) ? partials[e] : 0) + sTot[e];
     __syncthreads();
-    update_body(state, partials, d, K, tol, cen, trace);
+    update_body(state, partials, d, K, tol, cen, trace, nullptr, last);
+}
+
+// Large shards, single-GPU fit: the same idea with one 16-wavefront workgroup per CU.  The workgroups add their
+// non-zero deltas onto kAccLanes copies of the totals (emit_partials) and take a ticket; the last of the <= 256
+// arrivals folds the copies into the running totals, clears them and runs the update.  One launch per Lloyd
+// iteration: the separate fold + update launch (5 us and a dispatch gap on a 52 us kernel) is gone.  `cen` and
+// `state` are read in every workgroup's prologue, i.e. before that workgroup arrives, so the last arrival may
+// overwrite them.
+template <int NREGS, bool SIM>
+__global__ __launch_bounds__(kFilterThreads) void kmeans_lloyd_large_kernel(
+    const float *__restrict__ X, int64_t N, int K, et_kmeans_state *state, float *cen, uint8_t *__restrict__ labels,
+    long long *lanes, long long *partials, unsigned *ticket, float tol, float *trace, float *last) {
+    if (state->done) return;
+    constexpr int d = 6;
+    filter_assign_body<NREGS, SIM>(X, N, K, state, cen, labels, nullptr, lanes);
+    __shared__ int sLast;
+    __syncthreads();  // this workgroup's atomics are issued
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned arrived = atomicAdd(ticket, 1u);
+        sLast = arrived == gridDim.x - 1;
+        if (sLast) {
+            *ticket = 0u;  // ready for the next launch
+            __threadfence();
+        }
+    }
+    __syncthreads();
+    if (!sLast) return;
+    const int plen = d * K + K + 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    long long *sTot = reinterpret_cast<long long *>(smem_raw) + 512;  // past the 2 d K floats update_body uses
+    const et_kmeans_state st = *state;
+    // the copies are laid out [entry][copy]: a linear, fully coalesced sweep, 16 adjacent lanes per entry (the other
+    // workgroups' atomics were performed at device scope and the ticket's fence orders these loads after them)
+    const int total = plen * kAccLanes;
+    for (int base = 0; base < total; base += kFilterThreads) {
+        const int idx = base + threadIdx.x;
+        long long v = 0;
+        if (idx < total) {
+            v = lanes[idx];
+            lanes[idx] = 0;  // ready for the next iteration
+        }
+#pragma unroll
+        for (int o = kAccLanes / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (idx < total && (idx & (kAccLanes - 1)) == 0) {
+            const int e = idx / kAccLanes;
+            const long long tot = ((st.iter > 0 && e < plen - 2) ? partials[e] : 0) + v;
+            partials[e] = tot;
+            sTot[e] = tot;
+        }
+    }
+    __syncthreads();
+    update_body(state, sTot, d, K, tol, cen, trace, &st, last);
+}
+
+// Inertia of the LAST assignment of a fit that did not track it per iteration (kmeans.py:234 of that iteration):
+// the exact similarity of every point to the centroid its label names, centroids = the ones that assignment was
+// made with (`last`, saved by update_body), summed as the same fixed-point integers as in the assignment kernels
+// -> the same bits.  One pass over the coordinates per fit instead of fp64 work in every iteration.
+template <int D>
+__global__ __launch_bounds__(kKmThreads) void kmeans_inertia_kernel(const float *__restrict__ X, int64_t N, int d_rt, int K,
+                                                                     const float *__restrict__ last,
+                                                                     const uint8_t *__restrict__ labels,
+                                                                     long long *__restrict__ sim_total) {
+    const int d = D ? D : d_rt;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *sC = reinterpret_cast<float *>(smem_raw);
+    __shared__ long long sSum[2];
+    stage_centroids(last, d, K, sC);
+    if (threadIdx.x < 2) sSum[threadIdx.x] = 0;
+    __syncthreads();
+    const int sfrac = (int)*reinterpret_cast<const long long *>(last + ((d * K + 1) & ~1));
+    const int pitch = cpitch(d);
+    long long acc = 0, bad = 0;
+    for (int64_t n = (int64_t)blockIdx.x * kKmThreads + threadIdx.x; n < N; n += (int64_t)gridDim.x * kKmThreads) {
+        const float *c = sC + (int)labels[n] * pitch;
+        float an = 0.f, y = 0.f;
+#pragma unroll
+        for (int i = 0; i < (D ? D : ET_KMEANS_MAX_D); ++i)
+            if (i < d) {
+                const float x = X[(int64_t)i * N + n];
+                an = an + x * x;       // kmeans.py:73
+                y = fmaf(x, c[i], y);  // :71
+            }
+        y = y * 2.0f;
+        y = y - an;
+        y = y - c[d];
+        if (isnan(y) || isinf(y)) bad += 1;
+        else acc += to_fixed(y, sfrac);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_xor(acc, o);
+        bad += __shfl_xor(bad, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sSum[0]), (unsigned long long)acc);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sSum[1]), (unsigned long long)bad);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && sSum[threadIdx.x] != 0)
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sim_total[threadIdx.x]), (unsigned long long)sSum[threadIdx.x]);
+}
+
+__global__ void kmeans_inertia_finish_kernel(et_kmeans_state *state, const float *__restrict__ last, int d, int K,
+                                             const long long *__restrict__ sim_total) {
+    if (threadIdx.x != 0) return;
+    const int sfrac = (int)*reinterpret_cast<const long long *>(last + ((d * K + 1) & ~1));
+    float inertia;
+    if (sim_total[1] > 0) inertia = __int_as_float(0x7fc00000);
+    else inertia = (float)(-(((double)sim_total[0] * ldexp(1.0, -sfrac)) / (double)state->n_total));  // kmeans.py:57
+    state->inertia = (double)inertia;
 }
 
 
@@ -982,7 +1080,8 @@ __global__ __launch_bounds__(kFilterThreads) void kmeans_lloyd_small_kernel(
 __global__ __launch_bounds__(kKmThreads) void kmeans_reduce_update_kernel(const long long *__restrict__ block_partials,
                                                                           int n_blocks, int plen, et_kmeans_state *state,
                                                                           long long *partials, unsigned *ticket, int d,
-                                                                          int K, float tol, float *cen, float *trace) {
+                                                                          int K, float tol, float *cen, float *trace,
+                                                                          float *last) {
     __shared__ int sLast;
     const int lane = threadIdx.x & 63, e = blockIdx.x * (kKmThreads / 64) + (threadIdx.x >> 6);
     // every load is issued before the first result is looked at: one memory round trip instead of three
@@ -1008,7 +1107,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_reduce_update_kernel(const 
     }
     __syncthreads();
     if (!sLast) return;
-    update_body(state, partials, d, K, tol, cen, trace);
+    update_body(state, partials, d, K, tol, cen, trace, nullptr, last);
 }
 
 __global__ __launch_bounds__(kKmThreads) void kmeans_labels_i64_kernel(const uint8_t *__restrict__ lb, int64_t N,
@@ -1315,6 +1414,7 @@ static int km_resident_grid(Kernel kernel, size_t lds_bytes, int64_t work_items,
     return (int)(need < 1 ? 1 : (need < g ? need : g));
 }
 
+static int cpitch_host(int d) { return (d + 1 + 3) & ~3; }
 static bool km_dims_ok(int d, int K) { return d >= 1 && d <= ET_KMEANS_MAX_D && K >= 1 && K <= ET_KMEANS_MAX_CLUSTERS; }
 
 static size_t km_plen(int d, int K) { return (size_t)d * K + K + 2; }
@@ -1332,6 +1432,8 @@ struct KmWorkspace {
     unsigned *ticket;        // arrival counter of the fused reduce + update kernel
     unsigned *init_maxabs;   // farthest-first: fp32 bits of max|x| of this shard (collected by step 1)
     long long *acc_lanes;    // single-GPU fit: kAccLanes copies of every total, the assignment kernel's atomics land here
+    float *last;             // single-GPU fit: centroids (d*K floats) + sim_frac (int64) of the last assignment
+    long long *sim_total;    // kmeans_inertia_kernel: the exact similarity sum and the non-finite count
     size_t bytes;
 };
 
@@ -1363,6 +1465,10 @@ static KmWorkspace km_carve(void *base, int64_t N, int d, int K) {
     off = align_up(off + sizeof(unsigned), 256);
     w.acc_lanes = (long long *)(p + off);
     off = align_up(off + sizeof(long long) * km_plen(d, K) * 16, 256);
+    w.last = (float *)(p + off);
+    off = align_up(off + sizeof(float) * (((size_t)d * K + 1) & ~(size_t)1) + sizeof(long long), 256);
+    w.sim_total = (long long *)(p + off);
+    off = align_up(off + 2 * sizeof(long long), 256);
     w.bytes = off;
     return w;
 }
@@ -1421,7 +1527,7 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_km
                                   const float *centroids, const int64_t *given_labels, uint8_t *labels_u8,
                                   int64_t *partials, void *workspace, size_t workspace_bytes, hipStream_t st,
                                   hipEvent_t ev_begin, hipEvent_t ev_end, bool fused_update = false, float tol = 0.f,
-                                  float *trace = nullptr) {
+                                  float *trace = nullptr, bool want_sim = true) {
     if (!km_dims_ok(d, K) || N < 0 || !state || !centroids || !partials || (N > 0 && (!X || !labels_u8)))
         return ET_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < et_kmeans_workspace_bytes(N, d, K)) return ET_ERR_WORKSPACE;
@@ -1447,51 +1553,68 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_km
         ET_HIP_TRY(hipGetDevice(&dev_id));
         bool &lds_ok = lds_set[dev_id & 63];
         if (!lds_ok) {
-            ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kmeans_assign_filter_kernel<10>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kmeans_assign_filter_kernel<16>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<10>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<16>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            const void *fat[] = {reinterpret_cast<const void *>(kmeans_assign_filter_kernel<10>),
+                                 reinterpret_cast<const void *>(kmeans_assign_filter_kernel<16>),
+                                 reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<10, true>),
+                                 reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<10, false>),
+                                 reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<16, true>),
+                                 reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<16, false>),
+                                 reinterpret_cast<const void *>(kmeans_lloyd_large_kernel<10, true>),
+                                 reinterpret_cast<const void *>(kmeans_lloyd_large_kernel<10, false>),
+                                 reinterpret_cast<const void *>(kmeans_lloyd_large_kernel<16, true>),
+                                 reinterpret_cast<const void *>(kmeans_lloyd_large_kernel<16, false>)};
+            for (const void *f : fat) ET_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
             lds_ok = true;
         }
         // small shard (N <= 131072), single-GPU fit: assignment, reduction and update in one launch (at most
         // kSmallMaxBlocks workgroups, one pass per wavefront): 18 us instead of 11 + 7 us and a dispatch gap
         const int64_t passes = ceil_div(N, (int64_t)256);
+        float *cen_rw = const_cast<float *>(centroids);
         if (fused_update && passes <= kSmallMaxBlocks * (kFilterThreads / 64)) {
             grid = (int)ceil_div(passes, (int64_t)(kFilterThreads / 64));
             grid = grid > kSmallMaxBlocks ? kSmallMaxBlocks : grid;
-            float *cen_rw = const_cast<float *>(centroids);
-            if (K <= 20)
-                hipLaunchKernelGGL(kmeans_lloyd_small_kernel<10>, dim3(grid), dim3(kFilterThreads), lds, st, X, N, K, state,
-                                   cen_rw, labels_u8, w.block_partials, (long long *)partials, w.ticket, tol, trace);
-            else
-                hipLaunchKernelGGL(kmeans_lloyd_small_kernel<16>, dim3(grid), dim3(kFilterThreads), lds, st, X, N, K, state,
-                                   cen_rw, labels_u8, w.block_partials, (long long *)partials, w.ticket, tol, trace);
+#define ET_LAUNCH_SMALL(NR, SIM)                                                                                          \
+    hipLaunchKernelGGL((kmeans_lloyd_small_kernel<NR, SIM>), dim3(grid), dim3(kFilterThreads), lds, st, X, N, K, state,    \
+                       cen_rw, labels_u8, w.block_partials, (long long *)partials, w.ticket, tol, trace, w.last)
+            if (K <= 20) {
+                if (want_sim) ET_LAUNCH_SMALL(10, true);
+                else ET_LAUNCH_SMALL(10, false);
+            } else {
+                if (want_sim) ET_LAUNCH_SMALL(16, true);
+                else ET_LAUNCH_SMALL(16, false);
+            }
+#undef ET_LAUNCH_SMALL
             ET_LAUNCH_CHECK();
             if (ev_end) ET_HIP_TRY(hipEventRecord(ev_end, st));
             return ET_OK;
         }
-        long long *lanes = fused_update ? w.acc_lanes : nullptr;
+        if (fused_update) {  // large shard, single-GPU fit: one launch per iteration, the last workgroup folds + updates
+#define ET_LAUNCH_LARGE(NR, SIM)                                                                                          \
+    do {                                                                                                                  \
+        grid = km_resident_grid(kmeans_lloyd_large_kernel<NR, SIM>, lds, N / 4, kFilterThreads);                          \
+        hipLaunchKernelGGL((kmeans_lloyd_large_kernel<NR, SIM>), dim3(grid), dim3(kFilterThreads), lds, st, X, N, K,       \
+                           state, cen_rw, labels_u8, w.acc_lanes, (long long *)partials, w.ticket, tol, trace, w.last);   \
+    } while (0)
+            if (K <= 20) {
+                if (want_sim) ET_LAUNCH_LARGE(10, true);
+                else ET_LAUNCH_LARGE(10, false);
+            } else {
+                if (want_sim) ET_LAUNCH_LARGE(16, true);
+                else ET_LAUNCH_LARGE(16, false);
+            }
+#undef ET_LAUNCH_LARGE
+            ET_LAUNCH_CHECK();
+            if (ev_end) ET_HIP_TRY(hipEventRecord(ev_end, st));
+            return ET_OK;
+        }
         if (K <= 20) {
             grid = km_resident_grid(kmeans_assign_filter_kernel<10>, lds, N / 4, kFilterThreads);
             hipLaunchKernelGGL(kmeans_assign_filter_kernel<10>, dim3(grid), dim3(kFilterThreads), lds, st, X, N, K, state,
-                               centroids, labels_u8, w.block_partials, lanes);
+                               centroids, labels_u8, w.block_partials, (long long *)nullptr);
         } else {
             grid = km_resident_grid(kmeans_assign_filter_kernel<16>, lds, N / 4, kFilterThreads);
             hipLaunchKernelGGL(kmeans_assign_filter_kernel<16>, dim3(grid), dim3(kFilterThreads), lds, st, X, N, K, state,
-                               centroids, labels_u8, w.block_partials, lanes);
-        }
-        if (fused_update) {
-            ET_LAUNCH_CHECK();
-            if (ev_end) ET_HIP_TRY(hipEventRecord(ev_end, st));
-            const size_t ulds = 4096 + sizeof(long long) * plen_;  // update_body's 2 d K floats, then the folded totals
-            hipLaunchKernelGGL(kmeans_update_lanes_kernel, dim3(1), dim3(kKmThreads), ulds, st, w.acc_lanes, (int)plen_, state,
-                               (long long *)partials, d, K, tol, const_cast<float *>(centroids), trace);
-            ET_LAUNCH_CHECK();
-            return ET_OK;
+                               centroids, labels_u8, w.block_partials, (long long *)nullptr);
         }
     } else if (N > 0) {
         grid = d == 6 ? launch_assign<6>(X, N, d, K, state, centroids, given_labels, labels_u8, w.block_partials, vec4, st)
@@ -1509,7 +1632,7 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_km
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kmeans_reduce_update_kernel, dim3((plen + kKmThreads / 64 - 1) / (kKmThreads / 64)),
                            dim3(kKmThreads), lds, st, w.block_partials, grid, plen, state, (long long *)partials, w.ticket, d,
-                           K, tol, const_cast<float *>(centroids), trace);
+                           K, tol, const_cast<float *>(centroids), trace, w.last);
     } else {
         hipLaunchKernelGGL(kmeans_reduce_partials_kernel, dim3(plen), dim3(kKmThreads), 0, st, w.block_partials, grid,
                            plen, given_labels ? 1 : 0, state, w.partials, (long long *)partials);
@@ -1702,12 +1825,16 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     if (rc) return rc;
     ET_HIP_TRY(hipMemsetAsync(w.ticket, 0, sizeof(unsigned), st));
     ET_HIP_TRY(hipMemsetAsync(w.acc_lanes, 0, sizeof(long long) * km_plen(d, K) * 16, st));
+    // Without a trace the inertia of an iteration is not an output (kmeans.py:234 only prints it and keeps the last
+    // one): the assignment kernels skip the fp64 similarity sums and the inertia of the LAST assignment is evaluated
+    // by one extra pass after the loop -- the same bits as the per-iteration sum would have given.
+    const bool want_sim = trace != nullptr;
     int launched = 0, posted = 0, seen = 0;
     bool done = false;
     for (int it = 0; it < max_iter && !done; ++it) {
         rc = assign_accumulate_impl(X, N, d, K, w.state, centroids, nullptr, w.labels_u8, (int64_t *)w.partials, workspace,
                                     workspace_bytes, st, timed(it) ? events[2 * it] : nullptr,
-                                    timed(it) ? events[2 * it + 1] : nullptr, true, tol, trace);
+                                    timed(it) ? events[2 * it + 1] : nullptr, true, tol, trace, want_sim);
         if (rc) return rc;
         launched = it + 1;
         if (launched % kEvery == 0) {
@@ -1726,6 +1853,20 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
         }
     }
     (void)kLag;
+    if (!want_sim) {
+        ET_HIP_TRY(hipMemsetAsync(w.sim_total, 0, 2 * sizeof(long long), st));
+        const size_t ilds = sizeof(float) * (size_t)K * cpitch_host(d);
+        const int igrid = km_grid(N);
+        if (d == 6)
+            hipLaunchKernelGGL((kmeans_inertia_kernel<6>), dim3(igrid), dim3(kKmThreads), ilds, st, X, N, d, K,
+                               (const float *)w.last, (const uint8_t *)w.labels_u8, w.sim_total);
+        else
+            hipLaunchKernelGGL((kmeans_inertia_kernel<0>), dim3(igrid), dim3(kKmThreads), ilds, st, X, N, d, K,
+                               (const float *)w.last, (const uint8_t *)w.labels_u8, w.sim_total);
+        hipLaunchKernelGGL(kmeans_inertia_finish_kernel, dim3(1), dim3(64), 0, st, w.state, (const float *)w.last, d, K,
+                           (const long long *)w.sim_total);
+        ET_LAUNCH_CHECK();
+    }
     rc = et_kmeans_labels_i64(w.labels_u8, N, labels, stream);
     if (rc) return rc;
     ET_HIP_TRY(hipMemcpyAsync(state_host, w.state, sizeof(et_kmeans_state), hipMemcpyDeviceToHost, st));

@@ -154,7 +154,8 @@ class BatchKMeans(nn.Module):
         for i in range(self.n_redo):
             if centroids is None:
                 centroids = self.initialize_centroids(data)
-            runs = [ops.kmeans_fit(data[b], centroids[b], self.max_iter, self.tol) for b in range(data.shape[0])]
+            runs = [ops.kmeans_fit(data[b], centroids[b], self.max_iter, self.tol, trace=self.verbose)
+                    for b in range(data.shape[0])]
             new_centroids = torch.stack([r["centroids"] for r in runs], dim=0)
             labels = torch.stack([r["labels"] for r in runs], dim=0)
             # the reference's inertia is one mean over the whole batch (kmeans.py:234)

@@ -274,10 +274,12 @@ def kmeans_init_farthest(X, K, first_index, workspace=None):
     return c0
 
 
-def kmeans_fit(X, centroids, max_iter=100, tol=1e-4, workspace=None, timing=False):
+def kmeans_fit(X, centroids, max_iter=100, tol=1e-4, workspace=None, timing=False, trace=True):
     """kmeans.py:228-240 for one batch element from given initial centroids.
 
-    Returns dict(centroids (d,K), labels (N,) int64, n_iter, error, inertia, trace (n_iter,2), done).
+    Returns dict(centroids (d,K), labels (N,) int64, n_iter, error, inertia, trace (n_iter,2) | None, done).
+    ``trace=False`` skips the per-iteration (error, inertia) record -- the reference only prints it when verbose
+    (kmeans.py:236-237); the inertia of the last assignment is then evaluated once, after the loop (same bits).
     """
     dev = L.require_device(X)
     X, centroids = _dev_args(dev, X, centroids)
@@ -286,14 +288,14 @@ def kmeans_fit(X, centroids, max_iter=100, tol=1e-4, workspace=None, timing=Fals
     ws = workspace if workspace is not None else kmeans_workspace(n, d, K, dev)
     cen = centroids.clone()
     labels = torch.empty((n,), device=dev, dtype=torch.int64)
-    trace = torch.zeros((max_iter, 2), device=dev)
+    trace_t = torch.zeros((max_iter, 2), device=dev) if trace else None
     st = L.KMeansState()
     tm = L.KMeansTiming() if timing else None
     L.check(L.lib().et_kmeans_fit(L.ptr(X), L.i64(n), d, K, int(max_iter), L.f32(tol), L.ptr(cen), L.ptr(labels),
-                                  L.ptr(trace), C.byref(st), C.byref(tm) if timing else None, L.ptr(ws),
+                                  L.ptr(trace_t), C.byref(st), C.byref(tm) if timing else None, L.ptr(ws),
                                   C.c_size_t(ws.numel()), L.stream(dev)), "et_kmeans_fit")
     out = dict(centroids=cen, labels=labels, n_iter=int(st.iter), error=float(st.error), inertia=float(st.inertia),
-               trace=trace[:int(st.iter)], done=bool(st.done))
+               trace=trace_t[:int(st.iter)] if trace else None, done=bool(st.done))
     if timing:
         out["assign_ms"], out["assign_launches"] = float(tm.assign_ms), int(tm.assign_launches)
         out["first_assign_ms"] = float(tm.first_assign_ms)

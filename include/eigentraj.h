@@ -238,7 +238,10 @@ typedef struct et_kmeans_timing {
 } et_kmeans_timing;
 
 /* single-GPU fit of one batch element from given initial centroids (kmeans.py:228-240):
- * centroids (d,K) in/out, labels int64 (N) out, *state_host receives the final state,
+ * centroids (d,K) in/out, labels int64 (N) out, trace (max_iter,2) fp32 (error, inertia) per iteration or NULL:
+ * without a trace the per-iteration inertia is not evaluated (the reference only prints it, kmeans.py:236) and
+ * state.inertia -- the inertia of the last assignment -- comes from one extra pass after the loop (same bits).
+ * *state_host receives the final state,
  * *timing_host (may be NULL) the assign-kernel timing.  Synchronises the stream once, at the
  * end (the reference syncs every iteration at kmeans.py:239; here the convergence flag is polled
  * without blocking, a few iterations behind the launches). */

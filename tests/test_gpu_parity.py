@@ -281,6 +281,19 @@ def km_points(tag, z):
     return gaussian_points_np(6, n, seed=11, n_blobs=int(z[f"{tag}.blobs"]))
 
 
+def fit_and_check_traceless(ops, x_dev, c0, max_iter, tol):
+    """ops.kmeans_fit with the per-iteration trace, plus the trace-less form (no fp64 inertia sums inside the loop,
+    one inertia pass after it): the second must reproduce the first bit for bit.  -> the traced result."""
+    res = ops.kmeans_fit(x_dev, c0, max_iter, tol)
+    quiet = ops.kmeans_fit(x_dev, c0, max_iter, tol, trace=False)
+    assert quiet["trace"] is None and quiet["n_iter"] == res["n_iter"] and quiet["done"] == res["done"]
+    assert torch.equal(quiet["labels"], res["labels"])
+    assert np.array_equal(N_(quiet["centroids"]), N_(res["centroids"]), equal_nan=True)
+    assert np.array_equal(np.float64([quiet["inertia"], quiet["error"]]), np.float64([res["inertia"], res["error"]]),
+                          equal_nan=True), (quiet["inertia"], res["inertia"])
+    return res
+
+
 @pytest.mark.parametrize("tag", ["gauss1000", "gauss10000", "blobs10000", "gauss100000", "ethm"])
 def test_kmeans_bit_exact_vs_oracle_and_golden_g7(ops, oracle, dev, tag):
     z = G.load("g7_batchkmeans.npz")
@@ -288,7 +301,7 @@ def test_kmeans_bit_exact_vs_oracle_and_golden_g7(ops, oracle, dev, tag):
     first = int(z[f"{tag}.first_index"])
     c0 = ops.kmeans_init_farthest(T(x, dev), 20, first)
     assert np.array_equal(N_(c0), z[f"{tag}.c0"])  # the reference's 20 farthest-first picks, bit for bit
-    res = ops.kmeans_fit(T(x, dev), c0, 100, 1e-4)
+    res = fit_and_check_traceless(ops, T(x, dev), c0, 100, 1e-4)
     ref = oracle.kmeans_fit(x, z[f"{tag}.c0"], 100, 1e-4)
     assert res["n_iter"] == ref["n_iter"]
     assert np.array_equal(N_(res["labels"]), ref["labels"])            # bit-exact assignments
@@ -315,7 +328,7 @@ def test_kmeans_shapes_vs_oracle(ops, oracle, dev, n, d, K):
     c0 = ops.kmeans_init_farthest(T(x, dev), K, n // 2)
     r0, idx = oracle.kmeans_init_farthest(x, K, n // 2)
     assert np.array_equal(N_(c0), r0)
-    res = ops.kmeans_fit(T(x, dev), c0, 30, 1e-4)
+    res = fit_and_check_traceless(ops, T(x, dev), c0, 30, 1e-4)
     ref = oracle.kmeans_fit(x, r0, 30, 1e-4)
     assert res["n_iter"] == ref["n_iter"]
     assert np.array_equal(N_(res["labels"]), ref["labels"])
@@ -493,7 +506,7 @@ def test_kmeans_filter_kernel_bit_exact_on_adversarial_data(ops, oracle, dev, ki
     "label unchanged" when that is what the exact scan computes, whatever the data look like."""
     x = _filter_case(kind, n, seed=n + K)
     c0, _ = oracle.kmeans_init_farthest(x, K, n // 3)
-    res = ops.kmeans_fit(T(x, dev), T(c0, dev), 25, 1e-4)
+    res = fit_and_check_traceless(ops, T(x, dev), T(c0, dev), 25, 1e-4)
     ref = oracle.kmeans_fit(x, c0, 25, 1e-4)
     assert res["n_iter"] == ref["n_iter"]
     assert np.array_equal(N_(res["labels"]), ref["labels"])
@@ -528,7 +541,7 @@ def test_kmeans_fit_randomized_stress_vs_oracle(ops, oracle, dev):
         c0 = ops.kmeans_init_farthest(T(x, dev), K, first)
         r0, _ = oracle.kmeans_init_farthest(x, K, first)
         assert np.array_equal(N_(c0), r0, equal_nan=True), f"case {case}: farthest-first picks differ (n={n}, K={K})"
-        res = ops.kmeans_fit(T(x, dev), c0, 12, 1e-4)
+        res = fit_and_check_traceless(ops, T(x, dev), c0, 12, 1e-4)
         ref = oracle.kmeans_fit(x, r0, 12, 1e-4)
         assert res["n_iter"] == ref["n_iter"], f"case {case} (n={n}, K={K})"
         assert np.array_equal(N_(res["labels"]), ref["labels"]), f"case {case} (n={n}, K={K})"
@@ -872,7 +885,7 @@ def test_full_size_properties(ops, dev, n):
     assert float(err) < 0.2  # k=6 keeps the low-rank reconstruction error small (metres)
     x = c_pred.contiguous()
     c0 = ops.kmeans_init_farthest(x, 20, 12345)
-    res = ops.kmeans_fit(x, c0, 25, 1e-4)
+    res = fit_and_check_traceless(ops, x, c0, 25, 1e-4)  # both forms of the one-launch-per-iteration kernel
     tr = res["trace"].cpu().numpy()
     assert (np.diff(tr[:, 1]) <= 1e-6 * tr[0, 1]).all(), "Lloyd iterations must not increase the inertia"
     counts = torch.bincount(res["labels"], minlength=20)
