@@ -87,7 +87,7 @@ class Stage:
         return [a.elapsed_time(b) for a, b in self.t.get(name, [])]
 
 
-def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None):
+def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None, comm=None):
     """The hot path once.  Returns (n_iter of the Lloyd loop)."""
     n = obs.shape[0]
     mode = ops.MODE_MOVING
@@ -97,7 +97,7 @@ def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None)
         (U_obs, _), (U_pred, _) = ops.eigh_topk_batch([g_obs, g_pred], 6)
     else:
         from eigentrajectory_amd.dist import fit_descriptor_sharded
-        U_obs, U_pred, _, _, _ = fit_descriptor_sharded(obs, pred, 6, mode, 0.0, 1, want_count=False)
+        U_obs, U_pred, _, _, _ = fit_descriptor_sharded(obs, pred, 6, mode, 0.0, 1, want_count=False, comm=comm)
     sw.stop("fit")
     sw.start("project")
     c_obs, c_pred, nrm, _ = ops.norm_project(obs, pred, U_obs, U_pred, None, None, mode, want_flag=False)
@@ -336,10 +336,23 @@ def main():
     n = int(args.n)
     K = 20
     obs, pred = synthetic_trajectories_torch(n, dev, seed=rank, min_disp=1e-3)
-    km = None
+    km = comm = None
+    dist_path = "single"
     if world > 1 or force_dist:
-        from eigentrajectory_amd.dist import ShardedKMeans
-        km = ShardedKMeans
+        from eigentrajectory_amd.dist import Communicator, ShardedKMeans
+        # default: the native sharded entry points (the library enqueues its RCCL collectives on the stream, no Python
+        # inside the Lloyd loop); ET_BENCH_DIST=torch drives the step API with torch.distributed collectives instead
+        if os.environ.get("ET_BENCH_DIST", "native") == "native":
+            try:
+                comm = Communicator(dev)
+                dist_path = "native (et_kmeans_fit_sharded, RCCL ranks seen by the library: %d)" % comm.info()[0]
+            except Exception as exc:  # noqa: BLE001 -- fall back loudly, keep the run alive
+                print(f"[bench] native RCCL communicator unavailable ({exc!r}); using torch.distributed collectives",
+                      file=sys.stderr, flush=True)
+                comm = None
+        if comm is None:
+            dist_path = "torch.distributed step API"
+        km = (lambda x, k: ShardedKMeans(x, k, comm=comm))
     first_index = 12345
 
     def barrier():
@@ -349,14 +362,14 @@ def main():
 
     warm = Stage()
     for _ in range(args.warmup):
-        one_step(ops, obs, pred, K, args.max_iter, first_index, warm, km, [])
+        one_step(ops, obs, pred, K, args.max_iter, first_index, warm, km, [], comm)
     sw = Stage()
     timing = []
     barrier()
     t0 = time.perf_counter()
     iters = []
     for _ in range(args.steps):
-        iters.append(one_step(ops, obs, pred, K, args.max_iter, first_index, sw, km, timing))
+        iters.append(one_step(ops, obs, pred, K, args.max_iter, first_index, sw, km, timing, comm))
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -400,7 +413,7 @@ def main():
                                         f"fit + project(obs+pred) + reconstruct(S=1) + k-means(K=20, farthest-first, "
                                         f"max_iter={args.max_iter}, tol=1e-4)",
                                n_per_gpu=n, k=6, num_clusters=K, parallelism=f"shard{world}",
-                               rccl_ranks=dist.get_world_size() if dist.is_initialized() else 0),
+                               rccl_ranks=dist.get_world_size() if dist.is_initialized() else 0, dist_path=dist_path),
                    roofline=roofline, stages=stages)
         if world == 1 and not force_dist and not args.no_extras:
             more, sizes = extra_stages(ops, obs, pred, n, K, args.max_iter, first_index, dev)
@@ -412,6 +425,8 @@ def main():
             del obs, pred
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(args.max_iter, args.cpu_budget, args.c_port_sample)
+    if comm is not None:
+        comm.close()
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:

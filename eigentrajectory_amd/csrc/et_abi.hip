@@ -13,6 +13,7 @@ extern "C" const char *et_status_string(int status) {
         case ET_ERR_UNSUPPORTED: return "unsupported dimensions";
         case ET_ERR_WORKSPACE: return "workspace missing or too small";
         case ET_ERR_BAD_DATA: return "k-means input contains NaN/Inf";
+        case ET_ERR_RCCL: return "RCCL not loadable or a collective failed";
         default: return "unknown status";
     }
 }

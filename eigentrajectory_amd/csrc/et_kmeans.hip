@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "et_common.h"
+#include "et_hostring.h"
 
 namespace et {
 
@@ -1788,18 +1789,12 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     // dispatch gap on each side, so timing every launch would slow the loop it measures by ~15 %.
     constexpr int kTimeEvery = 8;
     auto timed = [&](int it) { return timing_host && (it == 0 || it % kTimeEvery == 1); };
-    // events belong to the device that is current when they are created: one cached set per (host thread, device)
+    // timing events belong to the device that is current when they are created: one cached set per (host thread, device)
     int dev_id = 0;
     ET_HIP_TRY(hipGetDevice(&dev_id));
-    struct PerDevice {
-        std::vector<hipEvent_t> events;  // timing; only touched when timing is requested
-        hipEvent_t ring_ev[4];
-        bool ring_ready = false;
-    };
-    static thread_local std::vector<PerDevice> per_device;
-    if ((int)per_device.size() <= dev_id) per_device.resize(dev_id + 1);
-    PerDevice &pd = per_device[dev_id];
-    std::vector<hipEvent_t> &events = pd.events;
+    static thread_local std::vector<std::vector<hipEvent_t>> per_device_events;
+    if ((int)per_device_events.size() <= dev_id) per_device_events.resize(dev_id + 1);
+    std::vector<hipEvent_t> &events = per_device_events[dev_id];
     if (timing_host) {
         while ((int)events.size() < 2 * max_iter) {
             hipEvent_t e;
@@ -1809,18 +1804,12 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     }
     // The reference synchronises every iteration (error <= tol on the host, kmeans.py:239).  Here convergence
     // lives on the device: once state->done is set the remaining launches are no-ops.  The host never waits
-    // for it inside the loop: every few iterations the state block is copied to a pinned ring slot, and a
-    // copy that has ARRIVED (event query, non-blocking) is looked at; the queue stays at most kLag iterations ahead.
-    constexpr int kSlots = 4, kEvery = 4, kLag = kSlots * kEvery;
-    static_assert(kSlots == 4, "PerDevice::ring_ev");
-    static thread_local et_kmeans_state *ring = nullptr;  // per host thread: concurrent fits on different streams do not share it
-    if (!ring) ET_HIP_TRY(hipHostMalloc((void **)&ring, sizeof(et_kmeans_state) * kSlots, hipHostMallocDefault));
-    hipEvent_t *ring_ev = pd.ring_ev;
-    if (!pd.ring_ready) {
-        for (int i = 0; i < kSlots; ++i) ET_HIP_TRY(hipEventCreateWithFlags(&ring_ev[i], hipEventDisableTiming));
-        pd.ring_ready = true;
-    }
-    int rc = et_kmeans_scan(X, N, d, w.state, stream);
+    // for it inside the loop (et_hostring.h): the queue stays at most kSlots * kEvery iterations ahead.
+    constexpr int kEvery = 4;
+    int rc = ET_OK;
+    StateRing *ring = StateRing::get(&rc);
+    if (!ring) return rc;
+    rc = et_kmeans_scan(X, N, d, w.state, stream);
     if (!rc) rc = et_kmeans_begin(w.state, N, centroids, d, K, stream);
     if (rc) return rc;
     ET_HIP_TRY(hipMemsetAsync(w.ticket, 0, sizeof(unsigned), st));
@@ -1829,7 +1818,7 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     // one): the assignment kernels skip the fp64 similarity sums and the inertia of the LAST assignment is evaluated
     // by one extra pass after the loop -- the same bits as the per-iteration sum would have given.
     const bool want_sim = trace != nullptr;
-    int launched = 0, posted = 0, seen = 0;
+    int launched = 0;
     bool done = false;
     for (int it = 0; it < max_iter && !done; ++it) {
         rc = assign_accumulate_impl(X, N, d, K, w.state, centroids, nullptr, w.labels_u8, (int64_t *)w.partials, workspace,
@@ -1838,21 +1827,11 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
         if (rc) return rc;
         launched = it + 1;
         if (launched % kEvery == 0) {
-            if (posted - seen == kSlots) {  // ring full: wait for the oldest copy
-                ET_HIP_TRY(hipEventSynchronize(ring_ev[seen % kSlots]));
-                done = ring[seen % kSlots].done != 0;
-                ++seen;
-            }
-            ET_HIP_TRY(hipMemcpyAsync(&ring[posted % kSlots], w.state, sizeof(et_kmeans_state), hipMemcpyDeviceToHost, st));
-            ET_HIP_TRY(hipEventRecord(ring_ev[posted % kSlots], st));
-            ++posted;
+            rc = ring->post(w.state, st, &done);
+            if (rc) return rc;
         }
-        while (seen < posted && hipEventQuery(ring_ev[seen % kSlots]) == hipSuccess) {
-            done = done || ring[seen % kSlots].done != 0;
-            ++seen;
-        }
+        ring->poll(&done);
     }
-    (void)kLag;
     if (!want_sim) {
         ET_HIP_TRY(hipMemsetAsync(w.sim_total, 0, 2 * sizeof(long long), st));
         const size_t ilds = sizeof(float) * (size_t)K * cpitch_host(d);

@@ -21,8 +21,11 @@
  *  - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
  *  - tensors are contiguous fp32; obs (N,T_obs,2), pred (N,T_pred,2) row-major "NTC";
  *    coefficients are k-major: C (k,N) and C (k,N,S); labels are int64;
- *  - the caller owns every buffer; the library never allocates user-visible memory.
- *    Scratch is passed in as a workspace whose size comes from *_workspace_bytes();
+ *  - the caller owns every buffer; the library never allocates device memory.
+ *    Scratch is passed in as a workspace whose size comes from *_workspace_bytes().  The only memory the library
+ *    keeps is host-side and private: per host thread and device a 4-slot pinned staging ring (4 x 96 B) + 4 events
+ *    for the non-blocking convergence polling of the Lloyd loops (csrc/et_hostring.h), and the timing events of
+ *    et_kmeans_fit when timing is requested -- created on first use, kept for the life of the process;
  *  - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work and
  *    never synchronise unless documented;
  *  - return value: ET_OK or an ET_ERR_* code; no exceptions cross this boundary;
@@ -54,6 +57,7 @@ extern "C" {
 #define ET_ERR_UNSUPPORTED 3  /* dimensions outside the compiled range */
 #define ET_ERR_WORKSPACE 4    /* workspace too small */
 #define ET_ERR_BAD_DATA 5     /* k-means input contains NaN/Inf */
+#define ET_ERR_RCCL 6         /* RCCL could not be loaded, or a collective / communicator call failed */
 
 #define ET_MODE_STATIC 0
 #define ET_MODE_MOVING 1
@@ -67,6 +71,7 @@ extern "C" {
 #define ET_KMEANS_MAX_CLUSTERS 255
 
 typedef void *et_stream_t;
+typedef void *et_comm_t; /* an ncclComm_t (RCCL); NULL = a single shard, no collective is enqueued */
 
 int et_abi_version(void);
 const char *et_status_string(int status);
@@ -272,6 +277,46 @@ int et_center_columns(float *X, int64_t N, int d, float rel_tol, float *mean, fl
 size_t et_kmeanspp_workspace_bytes(int64_t N, int d, int n_trials);
 int et_kmeanspp_seed(const float *X, int64_t N, int d, int K, int n_trials, const double *uniforms,
                      float *centers, int64_t *indices, void *workspace, size_t workspace_bytes, et_stream_t stream);
+
+/* ---- data-sharded fit and k-means: one process per GPU, RCCL over xGMI (csrc/et_sharded.hip) ------------------------
+ * The reference has no distributed code; these are the entry points of SURVEY.md §8(b) "with an optional
+ * ncclComm_t for the sharded variants".  `comm` is an ncclComm_t -- the caller's own, or one made with et_comm_* below
+ * (ncclGetUniqueId on rank 0, the 128 bytes handed to the other ranks by any side channel, ncclCommInitRank everywhere).
+ * RCCL is bound at run time with dlopen: an RCCL the process has already mapped (PyTorch's) is reused, otherwise
+ * librccl.so.1 is searched; et_comm_load(path) forces a specific library.  Every rank must make the same calls in the
+ * same order; all collectives are enqueued on `stream` (a few KB each, latency-bound).  comm == NULL: single shard. */
+#define ET_COMM_UNIQUE_ID_BYTES 128
+int et_comm_load(const char *librccl_path_or_null);
+int et_comm_unique_id(void *id128_host);
+int et_comm_init_rank(const void *id128_host, int nranks, int rank, et_comm_t *comm); /* on the CURRENT device */
+int et_comm_destroy(et_comm_t comm);
+int et_comm_info(et_comm_t comm, int *nranks, int *rank);
+
+/* et_fit_gram over all ranks' rows: the local pass + one grouped all-reduce(SUM) of G_obs, G_pred (fp64) and count. */
+int et_fit_gram_sharded(const float *obs, const float *pred, int64_t N_local, int T_obs, int T_pred,
+                        int mode, float static_dist, int which,
+                        double *G_obs, double *G_pred, int64_t *count,
+                        void *workspace, size_t workspace_bytes, et_comm_t comm, et_stream_t stream);
+
+/* workspace of the two calls below (>= et_kmeans_workspace_bytes + the gathered candidate records) */
+size_t et_kmeans_sharded_workspace_bytes(int64_t N_local, int d, int K, int nranks);
+/* farthest-first initialisation over all ranks' points (kmeans.py:78-112): C0 (d,K) identical on every rank.
+ * first_index is GLOBAL; this rank's points are the global indices [index_base, index_base + N_local); best (N_local)
+ * fp32 scratch.  One all-gather of an (8 + 4d)-byte record per rank and new centroid. */
+int et_kmeans_init_farthest_sharded(const float *X, int64_t N_local, int d, int K, int64_t first_index,
+                                    int64_t index_base, float *C0, float *best,
+                                    void *workspace, size_t workspace_bytes, et_comm_t comm, et_stream_t stream);
+/* Lloyd iterations over all ranks' points from given centroids (identical on every rank; updated in place):
+ * per iteration the assignment kernels, ONE in-place all-reduce(SUM) of the d K + K + 2 exact int64 partials and the
+ * update kernel, all on `stream`, no host round trip inside the loop (the convergence flag is looked at a few
+ * iterations late, on the same copy on every rank).  state / labels_u8 (N_local + 3) / partials
+ * (et_kmeans_partials_len) are caller-owned device buffers; labels (N_local) int64 may be NULL.  Synchronises the
+ * stream once, at the end; *state_host receives the final state. */
+int et_kmeans_fit_sharded(const float *X, int64_t N_local, int64_t N_total, int d, int K, int max_iter, float tol,
+                          float *centroids, int64_t *labels, float *trace,
+                          et_kmeans_state *state, uint8_t *labels_u8, int64_t *partials,
+                          et_kmeans_state *state_host, void *workspace, size_t workspace_bytes,
+                          et_comm_t comm, et_stream_t stream);
 
 #ifdef __cplusplus
 }

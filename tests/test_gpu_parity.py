@@ -413,6 +413,20 @@ def _nccl_world1_worker(rank, port, out_dir):
         km = ShardedKMeans(torch.from_numpy(x).to(dev), 20, check_every=3)
         c0 = km.init_farthest(first_index=4321)
         res = km.fit(c0.clone(), max_iter=30, tol=1e-4)
+        # the native form: the library's own ncclComm_t, collectives enqueued by et_*_sharded on the stream
+        from eigentrajectory_amd.dist import Communicator
+        comm = Communicator(dev)
+        assert comm.info() == (1, 0)
+        U_obs_n, U_pred_n, _, _, count_n = fit_descriptor_sharded(torch.from_numpy(obs).to(dev), torch.from_numpy(pred).to(dev),
+                                                                  6, ops.MODE_SPLIT, 0.3, 1, comm=comm)
+        assert count_n == count and torch.equal(U_pred_n, U_pred) and torch.equal(U_obs_n, U_obs)
+        kn = ShardedKMeans(torch.from_numpy(x).to(dev), 20, comm=comm)
+        c0n = kn.init_farthest(first_index=4321)
+        resn = kn.fit(c0n.clone(), max_iter=30, tol=1e-4)
+        assert torch.equal(c0n, c0) and resn["n_iter"] == res["n_iter"] and resn["done"] == res["done"]
+        assert torch.equal(resn["centroids"], res["centroids"]) and torch.equal(resn["labels"], res["labels"])
+        assert resn["inertia"] == res["inertia"] and resn["error"] == res["error"]
+        comm.close()
         np.savez(os.path.join(out_dir, "rank0.npz"), U_pred=U_pred.cpu().numpy(), count=count, c0=c0.cpu().numpy(),
                  centroids=res["centroids"].cpu().numpy(), labels=res["labels"].cpu().numpy(), n_iter=res["n_iter"])
     finally:
