@@ -271,6 +271,43 @@ def _median_ms(fn, reps=5, warm=1):
     return float(np.median([a.elapsed_time(b) for a, b in pairs]))
 
 
+def scene_latency(dev, U_obs, U_pred, n_peds=57, reps=2000):
+    """The reference's real inference regime: one scene of N <= 57 pedestrians per wrapper call (model.py:58-125), 20
+    samples, a predictor that returns zeros (so only the descriptor path and the hook plumbing are timed).  Wall
+    time per call over `reps` back-to-back calls (the stream is drained once at the end): host + launch overhead,
+    the kernels themselves take a few microseconds."""
+    from eigentrajectory_amd import EigenTrajectory
+    from eigentrajectory_amd.synth import synthetic_trajectories_torch
+    from eigentrajectory_amd.utils import DotDict, default_hyper_params
+
+    class Zero(torch.nn.Module):
+        def forward(self, x):
+            return torch.zeros((6, x.size(1), 20), device=x.device)
+
+    hooks = DotDict(model_forward_pre_hook=lambda c, o, a=None: torch.cat([c, o], dim=0),
+                    model_forward=lambda x, m: m(x), model_forward_post_hook=lambda y, a=None: y)
+    model = EigenTrajectory(Zero(), hooks, default_hyper_params(static_dist=0.3)).to(dev)
+    with torch.no_grad():
+        for d_ in (model.ET_m_descriptor, model.ET_s_descriptor):
+            d_.U_obs_trunc.copy_(U_obs)
+            d_.U_pred_trunc.copy_(U_pred)
+        model.ET_m_anchor.C_anchor.normal_()
+        model.ET_s_anchor.C_anchor.normal_()
+        obs, pred = synthetic_trajectories_torch(n_peds, dev, seed=5)
+        res = {}
+        for name, fn in (("evaluate", lambda: model.evaluate(obs, pred)), ("forward", lambda: model(obs))):
+            for _ in range(50):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            res[f"{name}_us_per_scene"] = round((time.perf_counter() - t0) / reps * 1e6, 2)
+    res.update(n_peds=n_peds, samples=20, predictor="zero stub")
+    return res
+
+
 def extra_stages(ops, obs, pred, n, K, max_iter, first_index, dev):
     """Measurements beside the headline step (single GPU): the model form of the reconstruction (S = 20 samples,
     descriptor.py:162-176: (k,N,20) -> (20,N,12,2), 2416 B per trajectory) forward, backward and with the fused
@@ -299,6 +336,7 @@ def extra_stages(ops, obs, pred, n, K, max_iter, first_index, dev):
               480.0 + 16.0 + 96.0 + 8.0)
         del rec, C20
         torch.cuda.empty_cache()
+        out["scene_latency"] = scene_latency(dev, U_obs, U_pred)
         for tag, m in (("1e5", 100_000), ("1e6", 1_000_000)):
             o, p = synthetic_trajectories_torch(m, dev, seed=0, min_disp=1e-3)
             sw = Stage()

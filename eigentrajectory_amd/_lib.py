@@ -18,12 +18,13 @@ LIB_PATH = os.path.join(_HERE, "libetamd.so")
 ET_OK = 0
 MODE_STATIC, MODE_MOVING, MODE_SPLIT, MODE_IDENTITY = 0, 1, 2, 3
 MAX_T, MAX_K, KMEANS_MAX_D, KMEANS_MAX_CLUSTERS = 32, 32, 32, 255
+SCENE_MAX_N = 16384  # ET_SCENE_MAX_N
 
 #: every symbol include/eigentraj.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "et_abi_version", "et_status_string", "et_compiled_arch",
     "et_norm_params", "et_norm_params_from_nrm", "et_normalize", "et_denormalize",
-    "et_norm_project", "et_anchor_reconstruct_fwd", "et_anchor_reconstruct_bwd", "et_anchor_reconstruct_metrics",
+    "et_norm_project", "et_scene_project", "et_anchor_reconstruct_fwd", "et_anchor_reconstruct_bwd", "et_anchor_reconstruct_metrics",
     "et_fit_gram_workspace_bytes", "et_fit_gram", "et_eigh_topk", "et_eigh_topk_batch",
     "et_euc_sim", "et_kmeans_partials_len", "et_kmeans_workspace_bytes", "et_kmeans_scan", "et_kmeans_begin",
     "et_kmeans_init_step", "et_kmeans_init_set", "et_kmeans_init_select", "et_kmeans_gather_point", "et_kmeans_init_farthest",
@@ -115,3 +116,38 @@ def i64(v):
 
 def f32(v):
     return C.c_float(float(v))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Lean call path for the scene-size regime (N <= a few dozen pedestrians per forward: everything is launch- and
+# host-bound there).  The entry points below get ctypes ``argtypes`` once, so that plain Python ints (``data_ptr()``,
+# sizes, the raw stream handle) cross the boundary without per-call wrapper objects.
+_P, _I64, _I, _F = C.c_void_p, C.c_int64, C.c_int, C.c_float
+_FAST_SIGNATURES = {
+    "et_scene_project": [_P, _I64, _I, _I, _P, _P, _I, _F, _P, _P, _P, _P, _P],
+    "et_anchor_reconstruct_fwd": [_P, _I64, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P],
+    "et_anchor_reconstruct_metrics": [_P, _I64, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P],
+}
+_fast = {}
+
+
+def fast(name):
+    """The C entry point ``name`` with its argument types declared (cached)."""
+    fn = _fast.get(name)
+    if fn is None:
+        fn = getattr(C.CDLL(LIB_PATH), name)  # a private handle: declaring argtypes must not affect lib()'s users
+        fn.argtypes = _FAST_SIGNATURES[name]
+        fn.restype = C.c_int
+        _fast[name] = fn
+    return fn
+
+
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream  # the current stream's hipStream_t as an int, ~0.2 us
+except AttributeError:  # pragma: no cover - older / newer torch without the private accessor
+    def _raw_stream(device_index):
+        return torch.cuda.current_stream(device_index).cuda_stream
+
+
+def raw_stream(device_index):
+    return _raw_stream(device_index)

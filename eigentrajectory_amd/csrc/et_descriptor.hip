@@ -209,6 +209,63 @@ __global__ __launch_bounds__(kTile) void project_generic_kernel(
     }
 }
 
+// Scene form of the projection (model.py:73-90 for ONE scene batch, obs only): a single workgroup, so that the
+// scene-wide mean of the last observed positions is available in the same launch --
+//   C_obs (k,N), nrm (4,N), obs_ori (2,N) = obs[:, -1].T - mean over the scene (model.py:86-89), flag (N).
+// The reference's real workload (N <= 57 pedestrians per forward) is launch-bound: this is one launch where the
+// generic path needs three (projection, mean, subtraction).
+__global__ __launch_bounds__(kTile) void scene_project_kernel(
+    const float *__restrict__ obs, int N, int T_obs, int k, const float *__restrict__ U_obs_m,
+    const float *__restrict__ U_obs_s, int mode, float static_dist, float *__restrict__ C_obs, float *__restrict__ nrm,
+    float *__restrict__ obs_ori, uint8_t *__restrict__ flag) {
+    __shared__ float sSum[2][kTile / kWave];
+    float sx = 0.f, sy = 0.f;
+    for (int n = threadIdx.x; n < N; n += kTile) {
+        const float *row = obs + (int64_t)n * 2 * T_obs;
+        const float ox = row[2 * (T_obs - 1)], oy = row[2 * (T_obs - 1) + 1];
+        const float dx = ox - row[2 * (T_obs - 3)], dy = oy - row[2 * (T_obs - 3) + 1];
+        const RowNorm p = row_norm(ox, oy, dx, dy, mode, static_dist);
+        nrm[n] = ox;
+        nrm[N + n] = oy;
+        nrm[2 * N + n] = dx;
+        nrm[3 * N + n] = dy;
+        if (flag) flag[n] = (uint8_t)p.mv;
+        sx += ox;
+        sy += oy;
+        const float *U = p.mv ? U_obs_m : U_obs_s;
+        for (int j = 0; j < k; ++j) {
+            float acc = 0.f;
+            for (int t = 0; t < T_obs; ++t) {
+                float a, b;
+                normalize_point(p, row[2 * t], row[2 * t + 1], a, b);
+                acc = fmaf(U[(2 * t) * k + j], a, acc);
+                acc = fmaf(U[(2 * t + 1) * k + j], b, acc);
+            }
+            C_obs[(int64_t)j * N + n] = acc;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sx += __shfl_xor(sx, o);
+        sy += __shfl_xor(sy, o);
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        sSum[0][threadIdx.x / kWave] = sx;
+        sSum[1][threadIdx.x / kWave] = sy;
+    }
+    __syncthreads();
+    float mx = 0.f, my = 0.f;
+    for (int w = 0; w < kTile / kWave; ++w) {
+        mx += sSum[0][w];
+        my += sSum[1][w];
+    }
+    mx = mx / (float)N;
+    my = my / (float)N;
+    for (int n = threadIdx.x; n < N; n += kTile) {  // this thread wrote nrm[n], nrm[N + n] itself
+        obs_ori[n] = nrm[n] - mx;
+        obs_ori[N + n] = nrm[N + n] - my;
+    }
+}
+
 // Normaliser state of trajectory n from the cached nrm (4,N) or, failing that, from obs.
 __device__ __forceinline__ RowNorm load_row_norm(const float *__restrict__ nrm, const float *__restrict__ obs,
                                                  int64_t N, int64_t n, int T_obs, int mode, float static_dist) {
@@ -628,6 +685,19 @@ extern "C" int et_norm_project(const float *obs, const float *pred, int64_t N, i
         hipLaunchKernelGGL(project_generic_kernel, dim3(grid), dim3(kTile), 0, st, obs, pred, N, T_obs, T_pred, k,
                            U_obs_m, U_pred_m, U_obs_s, U_pred_s, mode, static_dist, C_obs, C_pred, nrm, flag);
     }
+    ET_LAUNCH_CHECK();
+    return ET_OK;
+}
+
+extern "C" int et_scene_project(const float *obs, int64_t N, int T_obs, int k, const float *U_obs_m,
+                                const float *U_obs_s, int mode, float static_dist, float *C_obs, float *nrm,
+                                float *obs_ori, uint8_t *flag, et_stream_t stream) {
+    if (N < 0 || N > ET_SCENE_MAX_N || !dims_ok(T_obs, 1, k) || mode < 0 || mode > 3) return ET_ERR_INVALID_ARG;
+    if (N == 0) return ET_OK;
+    if (!obs || !C_obs || !nrm || !obs_ori) return ET_ERR_INVALID_ARG;
+    if ((need_m(mode) && !U_obs_m) || (need_s(mode) && !U_obs_s)) return ET_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(scene_project_kernel, dim3(1), dim3(kTile), 0, (hipStream_t)stream, obs, (int)N, T_obs, k, U_obs_m,
+                       U_obs_s, mode, static_dist, C_obs, nrm, obs_ori, flag);
     ET_LAUNCH_CHECK();
     return ET_OK;
 }

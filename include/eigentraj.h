@@ -106,6 +106,14 @@ int et_norm_project(const float *obs, const float *pred, int64_t N, int T_obs, i
                     int mode, float static_dist,
                     float *C_obs, float *C_pred, float *nrm, uint8_t *flag, et_stream_t stream);
 
+/* Scene form of the projection (one scene batch of model.py:73-90, obs only, N <= ET_SCENE_MAX_N): ONE single-workgroup
+ * launch that also produces obs_ori (2,N) = last observed positions minus their mean over the scene (model.py:86-89) --
+ * the reference's real workload is N <= 57 pedestrians per forward, i.e. launch-bound.  flag may be NULL. */
+#define ET_SCENE_MAX_N 16384
+int et_scene_project(const float *obs, int64_t N, int T_obs, int k, const float *U_obs_m, const float *U_obs_s,
+                     int mode, float static_dist, float *C_obs, float *nrm, float *obs_ori, uint8_t *flag,
+                     et_stream_t stream);
+
 /* ---- anchor refinement + reconstruction -------------------------------------------
  * out[s][n] = denormalize( reshape( U_pred . (C[:,n,s] + A[:,s]) ) )      (S,N,T_pred,2)
  * C (k,N,S); A_m/A_s (k,S) or NULL (no anchor add); normaliser state comes from `nrm`

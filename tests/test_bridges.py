@@ -57,3 +57,48 @@ def test_hook_protocol_drives_a_predictor():
     c, o = torch.randn(6, 5), torch.randn(2, 5)
     out = hooks.model_forward_post_hook(hooks.model_forward(hooks.model_forward_pre_hook(c, o), Net()))
     assert out.shape == (6, 5, 20) and torch.equal(out[:, :, 3], c)
+
+
+class ReplayAgentFormer(torch.nn.Module):
+    """Stands in for AgentFormerLight (third-party predictor, not on the path): checks that the bridge hands it what
+    the reference's bridge handed the real network, and answers with the real network's recorded output."""
+
+    def __init__(self, pre_motion, dec_motion, tol):
+        super().__init__()
+        self.expect, self.answer, self.tol, self.data = pre_motion, dec_motion, tol, None
+
+    def set_data(self, data):
+        got = data["pre_motion"]
+        assert data["anything_else"] is None and got.shape == self.expect.shape
+        assert torch.allclose(got.cpu(), self.expect, rtol=0, atol=self.tol), float((got.cpu() - self.expect).abs().max())
+        self._dev = got.device
+
+    def forward(self):
+        self.data = {"_dec_motion": self.answer.to(self._dev)}
+
+
+def test_agentformer_end_to_end_replay_through_the_oracle_g12(oracle):
+    """Config 5's data path on CPU: reference-fitted univ descriptors -> oracle projection -> THIS build's agentformer
+    bridge -> recorded AgentFormerLight output -> oracle reconstruction == what the reference's wrapper produced."""
+    from eigentrajectory_amd.bridges import get_hook_func
+    from oracle import wrapper_ref as W
+    z = G.load("g12_agentformer_univ.npz")
+    g2 = G.load("g2_fit_all_scenes.npz")
+    params = {k[len("univ."):]: g2[k] for k in g2.files if k.startswith("univ.ET_")}
+    obs, pred, sse = G.dataset("univ", "test")
+    hooks = get_hook_func("agentformer")
+    for j in range(3):
+        s, e = sse[int(z[f"scene{j}.index"])]
+        net = ReplayAgentFormer(torch.from_numpy(z[f"scene{j}.pre_motion"]), torch.from_numpy(z[f"scene{j}.dec_motion"]), 2e-5)
+
+        def predictor(x):  # x = cat(C_obs, obs_ori) (k+2, N), the oracle wrapper's stand-in for the pre-hook input
+            xt = torch.from_numpy(x)
+            data = hooks.model_forward_pre_hook(xt[:6], xt[6:], None)
+            return hooks.model_forward_post_hook(hooks.model_forward(data, net), None).contiguous().numpy()
+        out = W.forward(params, obs[s:e], pred[s:e], predictor, float(z["static_dist"]))
+        ref = z[f"scene{j}.recon_traj"]
+        np.testing.assert_allclose(out["recon_traj"], ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+        np.testing.assert_allclose(W.batch_ade(out["recon_traj"], pred[s:e]), z[f"scene{j}.ade"], atol=1e-5)
+        np.testing.assert_allclose(W.batch_fde(out["recon_traj"], pred[s:e]), z[f"scene{j}.fde"], atol=1e-5)
+        losses = [out["loss_eigentraj"], out["loss_euclidean_ade"], out["loss_euclidean_fde"]]
+        np.testing.assert_allclose(losses, z[f"scene{j}.losses"], rtol=1e-5, atol=1e-5)

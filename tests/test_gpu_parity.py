@@ -1191,3 +1191,64 @@ def test_trajnorm_autograd_and_generic_reconstruction_gradient(ops, dev):
     assert c2.grad is not None and float(c2.grad.abs().max()) > 0
     close(N_(r2), N_(r1), tol=3e-6)
     close(N_(c2.grad), N_(c1.grad), tol=3e-6)
+
+
+@pytest.mark.parametrize("n", [1, 2, 57, 256, 257, 1000])
+def test_scene_fast_path_matches_generic_path(dev, n):
+    """The lean scene path of the wrapper (one single-workgroup projection launch that also centres obs_ori, plain-int
+    ctypes calls) against the generic path (which non-contiguous / CPU inputs still take): same coefficients bit for
+    bit, obs_ori up to the summation order of the scene mean, same ADE/FDE and recon_traj."""
+    model = _loaded_wrapper(dev, "eth", LinearStub(torch.from_numpy(G.load("g6_wrapper_stub_predictors.npz")["linear_stub_w"])))
+    obs, pred = synth(n, seed=40 + n)
+    o, p = T(obs, dev), T(pred, dev)
+    assert model._scene_ok(o)
+    C_obs, obs_ori, nrm = model._scene_project(o)
+    U = model._U()
+    from eigentrajectory_amd import ops
+    c_ref, _, nrm_ref, _ = ops.norm_project(o, None, U[0], None, U[2], None, ops.MODE_SPLIT, model.static_dist, want_flag=False)
+    assert torch.equal(C_obs, c_ref) and torch.equal(nrm, nrm_ref)
+    ori_ref = nrm_ref[:2] - nrm_ref[:2].mean(dim=1, keepdim=True)
+    assert torch.allclose(obs_ori, ori_ref, rtol=0, atol=2e-6 * float(nrm_ref[:2].abs().max()))
+    with torch.no_grad():
+        a1, f1 = model.evaluate(o, p)
+        r1 = model(o)["recon_traj"]
+        # CPU inputs take the generic path (moved to the device inside)
+        a2, f2 = model.evaluate(torch.from_numpy(obs), torch.from_numpy(pred))
+        r2 = model(torch.from_numpy(obs))["recon_traj"]
+    scale = float(r2.abs().max())
+    assert torch.allclose(r1, r2.to(dev), rtol=0, atol=3e-6 * scale)
+    assert torch.allclose(a1, a2.to(dev), rtol=0, atol=3e-6 * scale) and torch.allclose(f1, f2.to(dev), rtol=0, atol=3e-6 * scale)
+
+
+def test_agentformer_bridge_end_to_end_replay_g12(dev):
+    """Config 5's data path through the PRODUCT: wrapper (HIP projection) -> agentformer bridge contract -> the
+    recorded output of the reference's AgentFormerLight -> HIP reconstruction / fused metrics, against what the
+    reference's wrapper + bridge + network produced on the same univ scenes (tools/make_golden_agentformer.py)."""
+    from eigentrajectory_amd import EigenTrajectory
+    from eigentrajectory_amd.bridges import get_hook_func
+    from eigentrajectory_amd.utils import default_hyper_params
+    from .test_bridges import ReplayAgentFormer
+    z = G.load("g12_agentformer_univ.npz")
+    g2 = G.load("g2_fit_all_scenes.npz")
+    obs, pred, sse = G.dataset("univ", "test")
+    for j in range(3):
+        s, e = sse[int(z[f"scene{j}.index"])]
+        net = ReplayAgentFormer(torch.from_numpy(z[f"scene{j}.pre_motion"]), torch.from_numpy(z[f"scene{j}.dec_motion"]), 2e-5)
+        model = EigenTrajectory(net, get_hook_func("agentformer"), default_hyper_params(static_dist=float(z["static_dist"])))
+        sd = model.state_dict()
+        for key in list(sd):
+            if key.startswith("ET_"):
+                sd[key] = torch.from_numpy(g2[f"univ.{key}"])
+        model.load_state_dict(sd)
+        model = model.to(dev).eval()
+        o, p = T(obs[s:e], dev), T(pred[s:e], dev)
+        ref = z[f"scene{j}.recon_traj"]
+        with torch.no_grad():
+            out = model(o, p)
+            close(N_(out["recon_traj"]), ref, tol=2e-5)
+            got = [float(out[k]) for k in ("loss_eigentraj", "loss_euclidean_ade", "loss_euclidean_fde")]
+            np.testing.assert_allclose(got, z[f"scene{j}.losses"], rtol=1e-5, atol=1e-5)
+            close(N_(model(o)["recon_traj"]), ref, tol=2e-5)     # inference form (lean scene path)
+            ade, fde = model.evaluate(o, p)                        # fused metrics epilogue
+        np.testing.assert_allclose(N_(ade), z[f"scene{j}.ade"], atol=1e-5)
+        np.testing.assert_allclose(N_(fde), z[f"scene{j}.fde"], atol=1e-5)
