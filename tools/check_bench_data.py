@@ -1,8 +1,8 @@
-"""Development aid: the benchmark's own data distribution (heavy-tailed projected coefficients) at a large N
+"""Exactness check (run on the GPU box): the benchmark's own data distribution (heavy-tailed projected coefficients) at a large N
 against the oracle, bit for bit."""
 import sys, os, time
 import numpy as np, torch
-R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 from eigentrajectory_amd import ops
 from eigentrajectory_amd.synth import synthetic_trajectories_torch

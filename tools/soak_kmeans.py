@@ -1,7 +1,7 @@
-"""Development aid: long randomized soak of the k-means kernels against the oracle (bit-exact)."""
+"""Exactness soak (run on the GPU box): long randomized soak of the k-means kernels against the oracle (bit-exact)."""
 import sys, os, time
 import numpy as np, torch
-R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 from eigentrajectory_amd import ops
 from oracle import et_oracle as oracle
