@@ -13,7 +13,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libetamd.so")
+#: ET_LIBETAMD selects another build of the library (kernel-variant A/B runs, tools/build_variant.sh)
+LIB_PATH = os.environ.get("ET_LIBETAMD") or os.path.join(_HERE, "libetamd.so")
 
 ET_OK = 0
 MODE_STATIC, MODE_MOVING, MODE_SPLIT, MODE_IDENTITY = 0, 1, 2, 3

@@ -307,7 +307,10 @@ __global__ __launch_bounds__(kFitThreads) void gram_generic_finish_kernel(const 
 // 24 x 24 converges in ~8 sweeps (23 rounds each).
 // ------------------------------------------------------------------------------------------
 constexpr int kJacobiMaxSweeps = 30;
-constexpr int kEighThreads = 256;  // 4 wavefronts share the element updates of a round
+#ifndef ET_EIGH_THREADS
+#define ET_EIGH_THREADS 1024
+#endif
+constexpr int kEighThreads = ET_EIGH_THREADS;  // 16 wavefronts share the element updates of a round: 290 us (256 threads) -> 245 us for 24 x 24; 64 threads: 630 us
 
 __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int n, int k, float *__restrict__ U,
                                                float *__restrict__ sigma) {
@@ -329,14 +332,18 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
     // work items of this thread in the update phase:
     //   V: e = lane + t*256 -> (pair i, row j): columns p_i, q_i of row j
     //   A: b = lane + t*256 -> (pair i1, pair i2): the 2 x 2 block rows {p1, q1} x columns {p2, q2}
-    constexpr int kSlots = (32 * 64 + kEighThreads - 1) / kEighThreads;
+    // (the V items start half a workgroup away from the A blocks: for the usual small n the two kinds of work land on
+    // different wavefronts and a round's critical path is the longer of the two, not their sum)
+    constexpr int kVShift = kEighThreads / 2;
+    constexpr int kSlots = (32 * 64 + kVShift + kEighThreads - 1) / kEighThreads;
     constexpr int kBlkSlots = (32 * 32 + kEighThreads - 1) / kEighThreads;
     int slot_i[kSlots], slot_j[kSlots], blk_1[kBlkSlots], blk_2[kBlkSlots];
 #pragma unroll
     for (int t = 0; t < kSlots; ++t) {
-        const int e = lane + t * kEighThreads;
-        slot_i[t] = e < half * n ? e / n : -1;
-        slot_j[t] = e < half * n ? e % n : 0;
+        const int e = lane + t * kEighThreads - kVShift;
+        const bool ok = e >= 0 && e < half * n;
+        slot_i[t] = ok ? e / n : -1;
+        slot_j[t] = ok ? e % n : 0;
     }
 #pragma unroll
     for (int t = 0; t < kBlkSlots; ++t) {
