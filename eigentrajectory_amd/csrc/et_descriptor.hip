@@ -321,6 +321,11 @@ __device__ __forceinline__ RowNorm fetch_row_norm(const float *s) {
 // The (S, TN, 2T) result tile is staged in LDS and written back with coalesced float4 stores
 // (each sample plane of the (S,N,T,2) output is a contiguous run of TN rows).
 // ------------------------------------------------------------------------------------------
+#ifndef ET_RECON_TILES
+#define ET_RECON_TILES 4
+#endif
+constexpr int kReconTiles = ET_RECON_TILES;  // consecutive tiles per workgroup when S > 1 (U / anchors staged once)
+
 template <int TP, int K>
 __global__ __launch_bounds__(kTile) void reconstruct_tile_kernel(
     const float *__restrict__ C, int64_t N, int S, int TN, int T_obs,
@@ -336,24 +341,23 @@ __global__ __launch_bounds__(kTile) void reconstruct_tile_kernel(
     float *sA = sU + 2 * DP * K;                      // 2 * K * S
 
     const int tid = threadIdx.x;
-    const int64_t n0 = (int64_t)blockIdx.x * TN;
-    const int rows = (int)min((int64_t)TN, N - n0);
+    const int tiles = S == 1 ? 1 : kReconTiles;
+    const int nl = tid / S, s = tid - nl * S;
+    int64_t n0 = (int64_t)blockIdx.x * tiles * TN;
+    int rows = (int)min((int64_t)TN, N - n0);
 
     // issue this lane's coefficient loads first: they are in flight while U / anchors / normaliser
     // state are staged (one exposed HBM latency per workgroup instead of two)
-    const int npairs = rows * S;
-    const int nl = tid / S, s = tid - nl * S;
-    const int64_t n = n0 + nl;
     float craw[K];
-    if (tid < npairs) {
+    if (tid < rows * S) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) craw[j] = C[((int64_t)j * N + n) * S + s];
+        for (int j = 0; j < K; ++j) craw[j] = C[((int64_t)j * N + n0 + nl) * S + s];
     }
     RowNorm p;
     if (S == 1) {  // lane == trajectory: the normaliser state never leaves the registers
-        if (tid < rows) p = load_row_norm(nrm, obs, N, n, T_obs, mode, static_dist);
+        if (tid < rows) p = load_row_norm(nrm, obs, N, n0 + nl, T_obs, mode, static_dist);
     } else if (tid < rows) {
-        store_row_norm(sNorm + tid * kNormStride, load_row_norm(nrm, obs, N, n0 + tid, T_obs, mode, static_dist));
+        p = load_row_norm(nrm, obs, N, n0 + tid, T_obs, mode, static_dist);
     }
     for (int i = tid; i < 2 * DP * K; i += kTile) {
         const float *src = (i >= DP * K) ? U_m : U_s;
@@ -363,45 +367,62 @@ __global__ __launch_bounds__(kTile) void reconstruct_tile_kernel(
         const float *src = (i >= K * S) ? A_m : A_s;
         sA[i] = src ? src[i % (K * S)] : 0.f;
     }
-    __syncthreads();
+    for (int it = 0; it < tiles && rows > 0; ++it) {
+        const int npairs = rows * S;
+        const int64_t n = n0 + nl;
+        if (S != 1 && tid < rows) store_row_norm(sNorm + tid * kNormStride, p);
+        __syncthreads();  // U / anchors / this tile's normaliser state staged; the previous tile's write-back is done
 
-    if (tid < npairs) {
-        if (S != 1) p = fetch_row_norm(sNorm + nl * kNormStride);
-        const float *u = sU + p.mv * DP * K;
-        const float *a = sA + p.mv * K * S;
-        float c[K];
+        if (tid < npairs) {
+            if (S != 1) p = fetch_row_norm(sNorm + nl * kNormStride);
+            const float *u = sU + p.mv * DP * K;
+            const float *a = sA + p.mv * K * S;
+            float c[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) c[j] = a[j * S + s] + craw[j];  // anchor.py:87
-        float4 *dst = kReconDirect ? reinterpret_cast<float4 *>(out + (((int64_t)s * N + n) * DP))
-                                   : reinterpret_cast<float4 *>(sOut + ((size_t)s * rows + nl) * DP);
+            for (int j = 0; j < K; ++j) c[j] = a[j * S + s] + craw[j];  // anchor.py:87
+            float4 *dst = kReconDirect ? reinterpret_cast<float4 *>(out + (((int64_t)s * N + n) * DP))
+                                       : reinterpret_cast<float4 *>(sOut + ((size_t)s * rows + nl) * DP);
 #pragma unroll
-        for (int q = 0; q < QP; ++q) {
-            float v[4];
+            for (int q = 0; q < QP; ++q) {
+                float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int f = 4 * q + e;
-                float acc = 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    const int f = 4 * q + e;
+                    float acc = 0.f;
 #pragma unroll
-                for (int j = 0; j < K; ++j) acc = fmaf(u[f * K + j], c[j], acc);  // descriptor.py:87
-                v[e] = acc;
+                    for (int j = 0; j < K; ++j) acc = fmaf(u[f * K + j], c[j], acc);  // descriptor.py:87
+                    v[e] = acc;
+                }
+                float4 o;
+                denormalize_point(p, v[0], v[1], o.x, o.y);
+                denormalize_point(p, v[2], v[3], o.z, o.w);
+                dst[q] = o;
             }
-            float4 o;
-            denormalize_point(p, v[0], v[1], o.x, o.y);
-            denormalize_point(p, v[2], v[3], o.z, o.w);
-            dst[q] = o;
         }
-    }
-    if (kReconDirect) return;
-    __syncthreads();
+        if (kReconDirect) return;
+        // the next tile's loads go out before this tile's write-back: they are in flight while the stores drain
+        const int64_t n0_next = n0 + TN;
+        const int rows_next = (it + 1 < tiles) ? (int)max((int64_t)0, min((int64_t)TN, N - n0_next)) : 0;
+        if (tid < rows_next * S) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) craw[j] = C[((int64_t)j * N + n0_next + nl) * S + s];
+        }
+        RowNorm p_next;
+        if (tid < rows_next) p_next = load_row_norm(nrm, obs, N, n0_next + tid, T_obs, mode, static_dist);
+        __syncthreads();
 
-    // coalesced write-back: plane s holds rows*QP consecutive float4 starting at row n0
-    const float4 *src4 = reinterpret_cast<const float4 *>(sOut);
-    float4 *out4 = reinterpret_cast<float4 *>(out);
-    const int per_plane = rows * QP;
-    const int total = S * per_plane;
-    for (int q = tid; q < total; q += kTile) {
-        const int s = q / per_plane, r = q - s * per_plane;
-        out4[((int64_t)s * N + n0) * QP + r] = src4[q];
+        // coalesced write-back: plane s holds rows*QP consecutive float4 starting at row n0
+        const float4 *src4 = reinterpret_cast<const float4 *>(sOut);
+        float4 *out4 = reinterpret_cast<float4 *>(out);
+        const int per_plane = rows * QP;
+        const int total = S * per_plane;
+        for (int q = tid; q < total; q += kTile) {
+            const int sp = q / per_plane, r = q - sp * per_plane;
+            out4[((int64_t)sp * N + n0) * QP + r] = src4[q];
+        }
+        if (tid < rows_next) p = p_next;
+        n0 = n0_next;
+        rows = rows_next;
     }
 }
 
@@ -715,7 +736,8 @@ extern "C" int et_anchor_reconstruct_fwd(const float *C, int64_t N, int S, int k
     if (fast) {
         const int TN = kTile / S;
         const size_t lds = sizeof(float) * ((size_t)TN * S * 24 + (size_t)TN * kNormStride + 2 * 24 * 6 + 2 * 6 * (size_t)S);
-        hipLaunchKernelGGL((reconstruct_tile_kernel<12, 6>), dim3((unsigned)ceil_div(N, TN)), dim3(kTile), lds, st, C, N,
+        const int64_t per_wg = (int64_t)TN * (S == 1 ? 1 : kReconTiles);
+        hipLaunchKernelGGL((reconstruct_tile_kernel<12, 6>), dim3((unsigned)ceil_div(N, per_wg)), dim3(kTile), lds, st, C, N,
                            S, TN, T_obs, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, out);
     } else {
         const int64_t pairs = N * S;
