@@ -12,10 +12,19 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1"
 
-# 1. kernel trace + stats of the default bench command (with the extra stages, without the CPU leg)
+# 0. the plain bench line (default command) next to the profiles, the box's bandwidth ceilings, and the sharded path
+#    forced onto one GPU (RCCL world 1): native entry points vs the torch.distributed step API
+python $R/bench.py > "$OUT/${TAG}_bench_line.json" 2> "$OUT/bench.err"
+python $R/tools/bw_ceiling.py > "$OUT/${TAG}_bw_ceiling.json" 2>/dev/null
+for mode in native torch; do
+    ET_BENCH_FORCE_DIST=1 ET_BENCH_DIST=$mode python $R/bench.py --no-cpu-baseline --no-extras --steps 5 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_line_forced_dist_$mode.json"
+done
+
+# 1. kernel trace + stats of the headline step only (N = 1e7; no extra stages, no CPU leg): the per-kernel averages
+#    here are what bench.py's roofline.avg_launch_ms must agree with
 rm -rf "$OUT/stats"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- \
-    python $R/bench.py --no-cpu-baseline --steps 5 --warmup 1 > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err"
+    python $R/bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 1 > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err"
 
 # 2. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes
 for C in FETCH_SIZE WRITE_SIZE; do

@@ -44,7 +44,7 @@ def main():
     path = find(os.path.join(out, "stats"), "*kernel_stats.csv")
     if path:
         rows = list(csv.DictReader(open(path)))
-        lines = ["# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 5 --warmup 1",
+        lines = ["# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 1   (N=1e+07)",
                  f"{'kernel':<72}{'calls':>8}{'total_ms':>12}{'avg_us':>12}{'pct':>8}"]
         for r in rows:
             lines.append(f"{kname(r['Name'])[:70]:<72}{int(r['Calls']):>8}{float(r['TotalDurationNs']) / 1e6:>12.3f}"
