@@ -581,32 +581,15 @@ __global__ __launch_bounds__(kTile) void reconstruct_bwd_tile_kernel(
     float4 *dst4 = reinterpret_cast<float4 *>(sIn);
     const int per_plane = rows * QP;
     const int total = S * per_plane;
-    // <= 256 pairs x QP float4: at most QP rounds of one float4 per lane.  All loads are issued before the first LDS
-    // write (one exposed HBM latency per workgroup instead of one per round); q / per_plane by multiplication.
-    {
-        const unsigned magic = 0xffffffffu / (unsigned)per_plane + 1u;  // exact for q < 2^16
-        float4 v[QP];
-#pragma unroll
-        for (int i = 0; i < QP; ++i) {
-            const int q = tid + i * kTile;
-            if (q < total) {
-                const int s = (int)__umulhi((unsigned)q, magic), r = q - s * per_plane;
-                v[i] = in4[((int64_t)s * N + n0) * QP + r];
-            }
-        }
-        RowNorm pn;
-        if (tid < rows) pn = load_row_norm(nrm, obs, N, n0 + tid, T_obs, mode, static_dist);
-        for (int i = tid; i < 2 * DP * K; i += kTile) {
-            const float *src = (i >= DP * K) ? U_m : U_s;
-            sU[i] = src ? src[i % (DP * K)] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < QP; ++i) {
-            const int q = tid + i * kTile;
-            if (q < total) dst4[q] = v[i];
-        }
-        if (tid < rows) store_row_norm(sNorm + tid * kNormStride, pn);
+    for (int q = tid; q < total; q += kTile) {
+        const int s = q / per_plane, r = q - s * per_plane;
+        dst4[q] = in4[((int64_t)s * N + n0) * QP + r];
     }
+    for (int i = tid; i < 2 * DP * K; i += kTile) {
+        const float *src = (i >= DP * K) ? U_m : U_s;
+        sU[i] = src ? src[i % (DP * K)] : 0.f;
+    }
+    if (tid < rows) store_row_norm(sNorm + tid * kNormStride, load_row_norm(nrm, obs, N, n0 + tid, T_obs, mode, static_dist));
     __syncthreads();
 
     const int npairs = rows * S;
