@@ -845,6 +845,24 @@ __device__ __forceinline__ void update_body(et_kmeans_state *state, const long l
     __syncthreads();
     // max |c| (NaN ignored), smallest non-zero |c| and a non-finite flag, reduced by the first wavefront
     __shared__ float sRed[3];
+    __shared__ double sErr;
+    if (threadIdx.x == 64 || (blockDim.x <= 64 && threadIdx.x == 0)) {
+        // kmeans.py:50 in the oracle's fixed order -- a serial chain of d K fp64 additions; it runs on the second
+        // wavefront next to the reductions below, and reads its operands four at a time
+        double err = 0.0;
+        const int dk = d * K;
+        const float4 *s4 = reinterpret_cast<const float4 *>(sSq);
+        int e = 0;
+        for (; e + 4 <= dk; e += 4) {
+            const float4 v = s4[e >> 2];
+            err += (double)v.x;
+            err += (double)v.y;
+            err += (double)v.z;
+            err += (double)v.w;
+        }
+        for (; e < dk; ++e) err += (double)sSq[e];
+        sErr = err;
+    }
     if (threadIdx.x < 64) {
         float mx = 0.f;
         unsigned mn = 0x7f800000u;
@@ -870,9 +888,7 @@ __device__ __forceinline__ void update_body(et_kmeans_state *state, const long l
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double err = 0.0;
-        for (int e = 0; e < d * K; ++e) err += (double)sSq[e];  // :50, fixed order
-        const float error = (float)err;
+        const float error = (float)sErr;
         const int64_t n_total = st.n_total;
         float inertia;
         if (nan_count > 0) inertia = __int_as_float(0x7fc00000);
