@@ -16,8 +16,9 @@
 //   iteration 0      kmeans_assign_kernel body      exact scan + full accumulation (inside the filter kernel's launch)
 //   iterations >= 1  kmeans_assign_filter_kernel    f16 MFMA upper bounds + exact certification of the old label,
 //                                                    undecided points through an LDS queue; deltas leave as atomics
-//                    (kmeans_lloyd_large_kernel)    ... one launch per iteration: the last workgroup to finish folds the
-//                                                    16 copies of the totals and updates means / error / convergence
+//                    kmeans_lloyd_chain_kernel      ... one launch per iteration: every workgroup applies the PREVIOUS
+//                                                    iteration's update itself (fold of 16 copies of the exact totals,
+//                                                    means, error, convergence) and then assigns; no serial section
 //   small shards     kmeans_lloyd_small_kernel      the whole iteration in one launch, <= 32 workgroups
 //   after the loop   kmeans_inertia_kernel          inertia of the last assignment when no trace was requested
 // Everything else (other d / K, given labels, the sharded step API) runs the exact scan and a two-kernel fold + update.
@@ -584,7 +585,7 @@ __device__ __forceinline__ void filter_drain(const unsigned *q, int cnt, int K, 
 // (kmeans_inertia_kernel); the labels and the cluster sums are the same either way.
 template <int NREGS, bool SIM = true>
 __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, int64_t N, int K,
-                                                   const et_kmeans_state *__restrict__ state, const float *cen,
+                                                   const et_kmeans_state *state, const float *cen,
                                                    uint8_t *__restrict__ labels, long long *__restrict__ block_partials,
                                                    long long *__restrict__ lanes = nullptr) {
     constexpr int d = 6;
@@ -978,57 +979,111 @@ __global__ __launch_bounds__(kFilterThreads) void kmeans_lloyd_small_kernel(
     update_body(state, partials, d, K, tol, cen, trace, nullptr, last);
 }
 
-// Large shards, single-GPU fit: the same idea with one 16-wavefront workgroup per CU.  The workgroups add their
-// non-zero deltas onto kAccLanes copies of the totals (emit_partials) and take a ticket; the last of the <= 256
-// arrivals folds the copies into the running totals, clears them and runs the update.  One launch per Lloyd
-// iteration: the separate fold + update launch (5 us and a dispatch gap on a 52 us kernel) is gone.  `cen` and
-// `state` are read in every workgroup's prologue, i.e. before that workgroup arrives, so the last arrival may
-// overwrite them.
-template <int NREGS, bool SIM>
-__global__ __launch_bounds__(kFilterThreads) void kmeans_lloyd_large_kernel(
-    const float *__restrict__ X, int64_t N, int K, et_kmeans_state *state, float *cen, uint8_t *__restrict__ labels,
-    long long *lanes, long long *partials, unsigned *ticket, float tol, float *trace, float *last) {
-    if (state->done) return;
-    constexpr int d = 6;
-    filter_assign_body<NREGS, SIM>(X, N, K, state, cen, labels, nullptr, lanes);
-    __shared__ int sLast;
-    __syncthreads();  // this workgroup's atomics are issued
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned arrived = atomicAdd(ticket, 1u);
-        sLast = arrived == gridDim.x - 1;
-        if (sLast) {
-            *ticket = 0u;  // ready for the next launch
-            __threadfence();
-        }
-    }
-    __syncthreads();
-    if (!sLast) return;
-    const int plen = d * K + K + 2;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    long long *sTot = reinterpret_cast<long long *>(smem_raw) + 512;  // past the 2 d K floats update_body uses
-    const et_kmeans_state st = *state;
-    // the copies are laid out [entry][copy]: a linear, fully coalesced sweep, 16 adjacent lanes per entry (the other
-    // workgroups' atomics were performed at device scope and the ticket's fence orders these loads after them)
-    const int total = plen * kAccLanes;
-    for (int base = 0; base < total; base += kFilterThreads) {
-        const int idx = base + threadIdx.x;
-        long long v = 0;
-        if (idx < total) {
-            v = lanes[idx];
-            lanes[idx] = 0;  // ready for the next iteration
-        }
+// Large shards, single-GPU fit: ONE launch per Lloyd iteration and NO serial section between two iterations.
+//
+// A launch first applies the update of the PREVIOUS iteration's assignment and then makes its own assignment:
+// every workgroup folds the 16 copies of the exact integer totals the previous launch's workgroups added their
+// deltas onto, and computes the new centroids, error and convergence flag ITSELF, straight into its LDS staging --
+// identical integers in, identical results in every workgroup, so nobody waits for a "last" workgroup (the ticket +
+// fence + one-workgroup fold and update + dispatch gap of the two-phase form cost ~9 of the ~20 us that an iteration
+// takes besides streaming the points).  Workgroup 0 also publishes the results (state, centroids, totals, trace,
+// the centroids of the last assignment).  Nothing a workgroup reads is written during the same launch:
+//   state / centroids / totals   two copies, launch t reads copy t % 2 and workgroup 0 writes copy (t+1) % 2
+//   the 16-copy delta table       three copies: launch t reads t % 3 (filled by launch t-1), adds onto (t+1) % 3 and
+//                                workgroup 0 clears (t+2) % 3 (read by launch t-1, to be filled by launch t+1)
+// The assignment of the final iteration is followed by kmeans_chain_finalize_kernel (its update, once).
+struct LloydChain {
+    const et_kmeans_state *st_rd;
+    et_kmeans_state *st_wr;
+    const float *cen_rd;
+    float *cen_wr;
+    const long long *tot_rd;
+    long long *tot_wr;
+    const long long *lanes_rd;
+    long long *lanes_wr;
+    long long *lanes_zero;
+    float *last;
+};
+
+// fold the 16 copies of every total (layout [entry][copy]: a linear, coalesced sweep, 16 adjacent lanes per entry) and
+// add the running totals of the earlier iterations -> sTot (LDS)
+__device__ __forceinline__ void fold_lanes(const long long *__restrict__ lanes, const long long *__restrict__ tot_prev,
+                                           bool have_prev, int plen, long long *sTot) {
+    const int total = plen * kAccLanes, n_threads = (int)blockDim.x;
+    for (int base = 0; base < total; base += n_threads) {
+        const int idx = base + (int)threadIdx.x;
+        long long v = idx < total ? lanes[idx] : 0;
 #pragma unroll
         for (int o = kAccLanes / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
         if (idx < total && (idx & (kAccLanes - 1)) == 0) {
             const int e = idx / kAccLanes;
-            const long long tot = ((st.iter > 0 && e < plen - 2) ? partials[e] : 0) + v;
-            partials[e] = tot;
-            sTot[e] = tot;
+            sTot[e] = ((have_prev && e < plen - 2) ? tot_prev[e] : 0) + v;
         }
     }
+}
+
+template <int NREGS, bool SIM>
+__global__ __launch_bounds__(kFilterThreads) void kmeans_lloyd_chain_kernel(
+    const float *__restrict__ X, int64_t N, int K, const LloydChain ch, uint8_t *__restrict__ labels, float tol,
+    float *trace, int has_pending) {
+    constexpr int d = 6;
+    const int plen = d * K + K + 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ et_kmeans_state sSt;
+    // scratch of this prologue, inside the area the assignment's LDS queues use later: the folded totals past the
+    // 2 d K floats update_body works in, then the centroids (old -> new, in place)
+    long long *sTot = reinterpret_cast<long long *>(smem_raw) + 512;
+    float *sCen = reinterpret_cast<float *>(sTot + ((plen + 1) & ~1));
+    const bool wg0 = blockIdx.x == 0;
+    const et_kmeans_state st0 = *ch.st_rd;
+    if (st0.done) {  // converged earlier: keep the published copies in step, nothing else to do
+        if (wg0) {
+            if (threadIdx.x == 0) *ch.st_wr = st0;
+            for (int e = threadIdx.x; e < d * K; e += kFilterThreads) ch.cen_wr[e] = ch.cen_rd[e];
+            for (int e = threadIdx.x; e < plen; e += kFilterThreads) ch.tot_wr[e] = ch.tot_rd[e];
+        }
+        return;
+    }
+    for (int e = threadIdx.x; e < d * K; e += kFilterThreads) sCen[e] = ch.cen_rd[e];
+    if (threadIdx.x == 0) sSt = st0;
+    if (has_pending) {
+        fold_lanes(ch.lanes_rd, ch.tot_rd, st0.iter > 0, plen, sTot);
+        __syncthreads();
+        update_body(&sSt, sTot, d, K, tol, sCen, wg0 ? trace : nullptr, &st0, wg0 ? ch.last : nullptr);
+    }
     __syncthreads();
-    update_body(state, sTot, d, K, tol, cen, trace, &st, last);
+    if (wg0) {  // publish (read by the next launch, the host's convergence polling and the finalize kernel)
+        if (threadIdx.x == 0) *ch.st_wr = sSt;
+        for (int e = threadIdx.x; e < d * K; e += kFilterThreads) ch.cen_wr[e] = sCen[e];
+        if (has_pending)
+            for (int e = threadIdx.x; e < plen; e += kFilterThreads) ch.tot_wr[e] = sTot[e];
+        const int total = plen * kAccLanes;
+        for (int i = threadIdx.x; i < total; i += kFilterThreads) ch.lanes_zero[i] = 0;
+    }
+    if (sSt.done) return;  // the update just applied met the tolerance: no further assignment (kmeans.py:239)
+    filter_assign_body<NREGS, SIM>(X, N, K, &sSt, sCen, labels, nullptr, ch.lanes_wr);
+}
+
+// After the loop: the update that belongs to the last assignment (if one is pending), into the caller's buffers.
+__global__ __launch_bounds__(kKmThreads) void kmeans_chain_finalize_kernel(const LloydChain ch, et_kmeans_state *state,
+                                                                           long long *partials, float *cen, int d, int K,
+                                                                           float tol, float *trace, int has_pending) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int plen = d * K + K + 2;
+    long long *sTot = reinterpret_cast<long long *>(smem_raw) + 512;
+    const et_kmeans_state st0 = *ch.st_rd;
+    for (int e = threadIdx.x; e < d * K; e += kKmThreads) cen[e] = ch.cen_rd[e];
+    if (st0.done || !has_pending) {
+        if (threadIdx.x == 0) *state = st0;
+        for (int e = threadIdx.x; e < plen; e += kKmThreads) partials[e] = ch.tot_rd[e];
+        return;
+    }
+    fold_lanes(ch.lanes_rd, ch.tot_rd, st0.iter > 0, plen, sTot);
+    __syncthreads();
+    for (int e = threadIdx.x; e < plen; e += kKmThreads) partials[e] = sTot[e];
+    if (threadIdx.x == 0) *state = st0;
+    __syncthreads();
+    update_body(state, sTot, d, K, tol, cen, trace, &st0, ch.last);
 }
 
 // Inertia of the LAST assignment of a fit that did not track it per iteration (kmeans.py:234 of that iteration):
@@ -1451,6 +1506,10 @@ struct KmWorkspace {
     long long *acc_lanes;    // single-GPU fit: kAccLanes copies of every total, the assignment kernel's atomics land here
     float *last;             // single-GPU fit: centroids (d*K floats) + sim_frac (int64) of the last assignment
     long long *sim_total;    // kmeans_inertia_kernel: the exact similarity sum and the non-finite count
+    et_kmeans_state *chain_state[2];  // kmeans_lloyd_chain_kernel: two copies of state / centroids / totals,
+    float *chain_cen[2];              // three of the 16-copy delta table (see LloydChain)
+    long long *chain_tot[2];
+    long long *chain_lanes[3];
     size_t bytes;
 };
 
@@ -1486,6 +1545,18 @@ static KmWorkspace km_carve(void *base, int64_t N, int d, int K) {
     off = align_up(off + sizeof(float) * (((size_t)d * K + 1) & ~(size_t)1) + sizeof(long long), 256);
     w.sim_total = (long long *)(p + off);
     off = align_up(off + 2 * sizeof(long long), 256);
+    for (int i = 0; i < 2; ++i) {
+        w.chain_state[i] = (et_kmeans_state *)(p + off);
+        off = align_up(off + sizeof(et_kmeans_state), 256);
+        w.chain_cen[i] = (float *)(p + off);
+        off = align_up(off + sizeof(float) * (size_t)d * K, 256);
+        w.chain_tot[i] = (long long *)(p + off);
+        off = align_up(off + sizeof(long long) * km_plen(d, K), 256);
+    }
+    for (int i = 0; i < 3; ++i) {
+        w.chain_lanes[i] = (long long *)(p + off);
+        off = align_up(off + sizeof(long long) * km_plen(d, K) * 16, 256);
+    }
     w.bytes = off;
     return w;
 }
@@ -1540,6 +1611,48 @@ extern "C" int et_kmeans_begin(et_kmeans_state *state, int64_t n_total, const fl
     return ET_OK;
 }
 
+static char km_argmax_mode() {
+    static const char mode = [] {
+        const char *e = getenv("ET_KMEANS_ARGMAX");
+        return e ? e[0] : 'f';
+    }();
+    return mode;
+}
+
+// matrix-core filter + exact certification (default; ET_KMEANS_ARGMAX=valu disables it)
+static bool km_use_filter(const float *X, int64_t N, int d, int K, const uint8_t *labels_u8) {
+    const bool vec4 = (N % 4 == 0) && aligned16(X) && ((reinterpret_cast<uintptr_t>(labels_u8) & 3u) == 0);
+    return km_argmax_mode() == 'f' && vec4 && d == 6 && K >= 3 && K <= 32 && N >= 1024 && N <= 0xffffffffll;
+}
+
+// 96 KB of dynamic LDS for the fat (16-wavefront) kernels: above the default 64 KB window; the attribute is per device
+static int km_fat_lds_attribute() {
+    static bool lds_set[64] = {};
+    int dev_id = 0;
+    ET_HIP_TRY(hipGetDevice(&dev_id));
+    bool &lds_ok = lds_set[dev_id & 63];
+    if (lds_ok) return ET_OK;
+    const void *fat[] = {reinterpret_cast<const void *>(kmeans_assign_filter_kernel<10>),
+                         reinterpret_cast<const void *>(kmeans_assign_filter_kernel<16>),
+                         reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<10, true>),
+                         reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<10, false>),
+                         reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<16, true>),
+                         reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<16, false>),
+                         reinterpret_cast<const void *>(kmeans_lloyd_chain_kernel<10, true>),
+                         reinterpret_cast<const void *>(kmeans_lloyd_chain_kernel<10, false>),
+                         reinterpret_cast<const void *>(kmeans_lloyd_chain_kernel<16, true>),
+                         reinterpret_cast<const void *>(kmeans_lloyd_chain_kernel<16, false>)};
+    for (const void *f : fat) ET_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    lds_ok = true;
+    return ET_OK;
+}
+
+static size_t km_filter_lds_bytes(int d, int K) {
+    const size_t plen_ = km_plen(d, K);
+    return sizeof(long long) * ((plen_ + 1) & ~(size_t)1) + sizeof(float) * (size_t)K * 8 +
+           sizeof(unsigned) * kFilterQueue * (kFilterThreads / 64);
+}
+
 static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_kmeans_state *state,
                                   const float *centroids, const int64_t *given_labels, uint8_t *labels_u8,
                                   int64_t *partials, void *workspace, size_t workspace_bytes, hipStream_t st,
@@ -1550,39 +1663,15 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_km
     if (!workspace || workspace_bytes < et_kmeans_workspace_bytes(N, d, K)) return ET_ERR_WORKSPACE;
     const KmWorkspace w = km_carve(workspace, N, d, K);
     const bool vec4 = (N % 4 == 0) && aligned16(X) && ((reinterpret_cast<uintptr_t>(labels_u8) & 3u) == 0);
-    static const char argmax_mode = [] {
-        const char *e = getenv("ET_KMEANS_ARGMAX");
-        return e ? e[0] : 'f';
-    }();
-    // matrix-core filter + exact certification (default; ET_KMEANS_ARGMAX=valu disables it).  The kernel itself
-    // runs the plain exact scan for the first iteration of a fit (state->iter == 0: no labels to confirm yet).
-    const bool use_filter = argmax_mode == 'f' && vec4 && d == 6 && K >= 3 && K <= 32 && !given_labels && N >= 1024 &&
-                            N <= 0xffffffffll;
+    // The filter kernel itself runs the plain exact scan for the first iteration of a fit (state->iter == 0: no
+    // labels to confirm yet).
+    const bool use_filter = !given_labels && km_use_filter(X, N, d, K, labels_u8);
     int grid = 1;
     if (ev_begin) ET_HIP_TRY(hipEventRecord(ev_begin, st));
     if (use_filter) {
-        const size_t plen_ = km_plen(d, K);
-        const size_t lds = sizeof(long long) * ((plen_ + 1) & ~(size_t)1) + sizeof(float) * (size_t)K * 8 +
-                           sizeof(unsigned) * kFilterQueue * (kFilterThreads / 64);
-        // 66 KB of dynamic LDS: above the default 64 KB window (the attribute is per device)
-        static bool lds_set[64] = {};
-        int dev_id = 0;
-        ET_HIP_TRY(hipGetDevice(&dev_id));
-        bool &lds_ok = lds_set[dev_id & 63];
-        if (!lds_ok) {
-            const void *fat[] = {reinterpret_cast<const void *>(kmeans_assign_filter_kernel<10>),
-                                 reinterpret_cast<const void *>(kmeans_assign_filter_kernel<16>),
-                                 reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<10, true>),
-                                 reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<10, false>),
-                                 reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<16, true>),
-                                 reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<16, false>),
-                                 reinterpret_cast<const void *>(kmeans_lloyd_large_kernel<10, true>),
-                                 reinterpret_cast<const void *>(kmeans_lloyd_large_kernel<10, false>),
-                                 reinterpret_cast<const void *>(kmeans_lloyd_large_kernel<16, true>),
-                                 reinterpret_cast<const void *>(kmeans_lloyd_large_kernel<16, false>)};
-            for (const void *f : fat) ET_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            lds_ok = true;
-        }
+        const size_t lds = km_filter_lds_bytes(d, K);
+        int rc_attr = km_fat_lds_attribute();
+        if (rc_attr) return rc_attr;
         // small shard (N <= 131072), single-GPU fit: assignment, reduction and update in one launch (at most
         // kSmallMaxBlocks workgroups, one pass per wavefront): 18 us instead of 11 + 7 us and a dispatch gap
         const int64_t passes = ceil_div(N, (int64_t)256);
@@ -1601,25 +1690,6 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_km
                 else ET_LAUNCH_SMALL(16, false);
             }
 #undef ET_LAUNCH_SMALL
-            ET_LAUNCH_CHECK();
-            if (ev_end) ET_HIP_TRY(hipEventRecord(ev_end, st));
-            return ET_OK;
-        }
-        if (fused_update) {  // large shard, single-GPU fit: one launch per iteration, the last workgroup folds + updates
-#define ET_LAUNCH_LARGE(NR, SIM)                                                                                          \
-    do {                                                                                                                  \
-        grid = km_resident_grid(kmeans_lloyd_large_kernel<NR, SIM>, lds, N / 4, kFilterThreads);                          \
-        hipLaunchKernelGGL((kmeans_lloyd_large_kernel<NR, SIM>), dim3(grid), dim3(kFilterThreads), lds, st, X, N, K,       \
-                           state, cen_rw, labels_u8, w.acc_lanes, (long long *)partials, w.ticket, tol, trace, w.last);   \
-    } while (0)
-            if (K <= 20) {
-                if (want_sim) ET_LAUNCH_LARGE(10, true);
-                else ET_LAUNCH_LARGE(10, false);
-            } else {
-                if (want_sim) ET_LAUNCH_LARGE(16, true);
-                else ET_LAUNCH_LARGE(16, false);
-            }
-#undef ET_LAUNCH_LARGE
             ET_LAUNCH_CHECK();
             if (ev_end) ET_HIP_TRY(hipEventRecord(ev_end, st));
             return ET_OK;
@@ -1836,7 +1906,66 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     const bool want_sim = trace != nullptr;
     int launched = 0;
     bool done = false;
-    for (int it = 0; it < max_iter && !done; ++it) {
+    // large shards with the matrix-core filter: the chained form (kmeans_lloyd_chain_kernel) -- every launch applies the
+    // previous iteration's update in its prologue, in every workgroup; one more update after the loop
+    const bool chained = km_use_filter(X, N, d, K, w.labels_u8) &&
+                         ceil_div(N, (int64_t)256) > (int64_t)kSmallMaxBlocks * (kFilterThreads / 64);
+    if (chained) {
+        const size_t plen = km_plen(d, K), lds = km_filter_lds_bytes(d, K);
+        rc = km_fat_lds_attribute();
+        if (rc) return rc;
+        ET_HIP_TRY(hipMemcpyAsync(w.chain_state[0], w.state, sizeof(et_kmeans_state), hipMemcpyDeviceToDevice, st));
+        ET_HIP_TRY(hipMemcpyAsync(w.chain_cen[0], centroids, sizeof(float) * (size_t)d * K, hipMemcpyDeviceToDevice, st));
+        ET_HIP_TRY(hipMemsetAsync(w.chain_tot[0], 0, sizeof(long long) * plen, st));
+        for (int i = 0; i < 3; ++i) ET_HIP_TRY(hipMemsetAsync(w.chain_lanes[i], 0, sizeof(long long) * plen * 16, st));
+        auto chain_for = [&](int t) {
+            LloydChain ch;
+            ch.st_rd = w.chain_state[t & 1];
+            ch.st_wr = w.chain_state[(t + 1) & 1];
+            ch.cen_rd = w.chain_cen[t & 1];
+            ch.cen_wr = w.chain_cen[(t + 1) & 1];
+            ch.tot_rd = w.chain_tot[t & 1];
+            ch.tot_wr = w.chain_tot[(t + 1) & 1];
+            ch.lanes_rd = w.chain_lanes[t % 3];
+            ch.lanes_wr = w.chain_lanes[(t + 1) % 3];
+            ch.lanes_zero = w.chain_lanes[(t + 2) % 3];
+            ch.last = w.last;
+            return ch;
+        };
+        int grid = 0;
+        for (int it = 0; it < max_iter && !done; ++it) {
+            const LloydChain ch = chain_for(it);
+            if (timed(it)) ET_HIP_TRY(hipEventRecord(events[2 * it], st));
+#define ET_LAUNCH_CHAIN(NR, SIM)                                                                                          \
+    do {                                                                                                                  \
+        if (!grid) grid = km_resident_grid(kmeans_lloyd_chain_kernel<NR, SIM>, lds, N / 4, kFilterThreads);               \
+        hipLaunchKernelGGL((kmeans_lloyd_chain_kernel<NR, SIM>), dim3(grid), dim3(kFilterThreads), lds, st, X, N, K, ch,   \
+                           w.labels_u8, tol, trace, it > 0 ? 1 : 0);                                                      \
+    } while (0)
+            if (K <= 20) {
+                if (want_sim) ET_LAUNCH_CHAIN(10, true);
+                else ET_LAUNCH_CHAIN(10, false);
+            } else {
+                if (want_sim) ET_LAUNCH_CHAIN(16, true);
+                else ET_LAUNCH_CHAIN(16, false);
+            }
+#undef ET_LAUNCH_CHAIN
+            ET_LAUNCH_CHECK();
+            if (timed(it)) ET_HIP_TRY(hipEventRecord(events[2 * it + 1], st));
+            launched = it + 1;
+            if (launched % kEvery == 0) {
+                rc = ring->post(ch.st_wr, st, &done);
+                if (rc) return rc;
+            }
+            ring->poll(&done);
+        }
+        const LloydChain ch = chain_for(launched);
+        const size_t flds = 4096 + sizeof(long long) * plen;
+        hipLaunchKernelGGL(kmeans_chain_finalize_kernel, dim3(1), dim3(kKmThreads), flds, st, ch, w.state,
+                           (long long *)w.partials, centroids, d, K, tol, trace, launched > 0 ? 1 : 0);
+        ET_LAUNCH_CHECK();
+    }
+    for (int it = 0; !chained && it < max_iter && !done; ++it) {
         rc = assign_accumulate_impl(X, N, d, K, w.state, centroids, nullptr, w.labels_u8, (int64_t *)w.partials, workspace,
                                     workspace_bytes, st, timed(it) ? events[2 * it] : nullptr,
                                     timed(it) ? events[2 * it + 1] : nullptr, true, tol, trace, want_sim);
