@@ -129,7 +129,7 @@ def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None,
     return res["n_iter"]
 
 
-DOMINANT_KERNEL = "et::kmeans_lloyd_large_kernel<10, false>"  # one launch per Lloyd iteration (100 per step)
+DOMINANT_KERNEL = "et::kmeans_lloyd_chain_kernel<10, false>"  # one launch per Lloyd iteration (100 per step)
 
 
 def pmc_traffic(n):

@@ -200,7 +200,9 @@ int et_kmeans_scan(const float *X, int64_t N, int d, et_kmeans_state *state, et_
 int et_kmeans_begin(et_kmeans_state *state, int64_t n_total, const float *centroids, int d, int K,
                     et_stream_t stream);
 
-/* farthest-first initialisation (kmeans.py:78-112).  best (N) fp32 scratch.
+/* ABI limit: the farthest-first keys and the filter kernel's queue carry 32-bit GLOBAL point indices, so the number
+ * of points over all shards of one k-means problem must be < 2^32 (checked: ET_ERR_INVALID_ARG).
+ * farthest-first initialisation (kmeans.py:78-112).  best (N) fp32 scratch.
  *   step i (1 <= i < K): similarity of every local point to centroid column i-1 of C0,
  *   running max into best, local arg-min -> cand: {uint64 key, d floats} where
  *   key = orderable(best) << 32 | (index_base + local index); smaller key wins and a
