@@ -1470,12 +1470,13 @@ static int km_grid(int64_t work_items) {
 // chip 80 % idle for its fourth round).
 template <typename Kernel>
 static int km_resident_grid(Kernel kernel, size_t lds_bytes, int64_t work_items, int threads = kKmThreads) {
-    static int n_cu = 0;
+    // CU count of the CURRENT device (cached per device id; a process may drive several GPUs)
+    static int cu_of_device[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    int &n_cu = cu_of_device[dev & 63];
     if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
     }
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds_bytes) != hipSuccess || per_cu < 1)
