@@ -140,3 +140,30 @@ def test_augment_and_metrics_helpers():
     fo, fp = G.eth_fit_input()
     assert ao.shape[0] == 2 * o.shape[0] and np.array_equal(ao[len(o):, :, 1].numpy(), -o[:, :, 1])
     assert fo.shape == (70316, 8, 2) and fp.shape == (70316, 12, 2)
+
+
+def test_round2_entry_points_validate_arguments_on_the_host():
+    """The entry points added for the sklearn-recipe anchors, the scene path and the sharded drivers reject bad
+    arguments before touching a device or RCCL."""
+    from eigentrajectory_amd import _lib
+    lib = _lib.lib()
+    null, i64, f32 = ctypes.c_void_p(0), ctypes.c_int64, ctypes.c_float
+    lib.et_kmeans_sharded_workspace_bytes.restype = ctypes.c_size_t
+    assert lib.et_kmeanspp_workspace_bytes(i64(10_000), 6, 4) > 4 * 10_000 * 5
+    assert lib.et_kmeanspp_workspace_bytes(i64(10_000), 6, 9) == 0          # more candidates than 2 + ln(255)
+    assert lib.et_kmeanspp_workspace_bytes(i64(0), 6, 4) == 0
+    assert lib.et_kmeanspp_seed(null, i64(100), 6, 20, 4, null, null, null, null, ctypes.c_size_t(0), null) == 1
+    assert lib.et_center_columns(null, i64(100), 6, f32(1e-4), null, null, null, ctypes.c_size_t(0), null) == 1
+    assert lib.et_scene_project(null, i64(0), 8, 6, null, null, 2, f32(0.3), null, null, null, null, null) == 0   # N == 0
+    assert lib.et_scene_project(null, i64(5), 8, 6, null, null, 2, f32(0.3), null, null, null, null, null) == 1   # no obs
+    assert lib.et_scene_project(null, i64(_lib.SCENE_MAX_N + 1), 8, 6, null, null, 2, f32(0.3), null, null, null, null,
+                                null) == 1
+    base = lib.et_kmeans_workspace_bytes(i64(4096), 6, 20)
+    assert lib.et_kmeans_sharded_workspace_bytes(i64(4096), 6, 20, 8) >= base + 8 * 32
+    assert lib.et_kmeans_sharded_workspace_bytes(i64(4096), 6, 20, 0) == 0
+    assert lib.et_comm_info(null, null, null) == 1
+    assert lib.et_comm_destroy(null) == 0                                      # NULL communicator: nothing to destroy
+    assert lib.et_comm_init_rank(null, 2, 0, null) == 1
+    assert lib.et_kmeans_fit_sharded(null, i64(10), i64(5), 6, 20, 100, f32(1e-4), null, null, null, null, null, null, null,
+                                     null, ctypes.c_size_t(0), null, null) == 1   # N_total < N_local
+    assert b"RCCL" in lib.et_status_string(6)
