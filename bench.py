@@ -304,6 +304,18 @@ def scene_latency(dev, U_obs, U_pred, n_peds=57, reps=2000):
                 fn()
             torch.cuda.synchronize()
             res[f"{name}_us_per_scene"] = round((time.perf_counter() - t0) / reps * 1e6, 2)
+        # W1 (model.py:34-56) at the size of the reference's own fit sets (ETH train+val+flip: 70 316 trajectories):
+        # two descriptor fits + two anchor clusterings in the reference's sklearn recipe (k-means++, n_init = 10)
+        o, p = synthetic_trajectories_torch(70_316, dev, seed=6)
+        model.calculate_parameters(o, p)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            model.calculate_parameters(o, p)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        res["calculate_parameters_ms_at_70316"] = round(min(ts) * 1e3, 2)
     res.update(n_peds=n_peds, samples=20, predictor="zero stub")
     return res
 

@@ -104,8 +104,25 @@ class EigenTrajectory(nn.Module):
         _, C_pred, _, flag = ops.norm_project(obs_traj, pred_traj, None, U_pred_m, None, U_pred_s, ops.MODE_SPLIT, sd,
                                               want_nrm=False, want_obs=False)
         moving = flag.bool()
-        self.ET_m_anchor.generate_from_coefficients(C_pred[:, moving].contiguous())
-        self.ET_s_anchor.generate_from_coefficients(C_pred[:, ~moving].contiguous())
+        C_m, C_s = C_pred[:, moving].contiguous(), C_pred[:, ~moving].contiguous()
+        # the two clusterings are independent (model.py:55-56 runs them one after the other): side by side, each
+        # from its own host thread on its own HIP stream -- they are launch-latency-bound at dataset sizes
+        dev, main = C_pred.device, torch.cuda.current_stream(C_pred.device)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+
+        def run(anchor, coeff, stream):
+            with torch.cuda.device(dev), torch.cuda.stream(stream):
+                stream.wait_stream(main)
+                anchor.generate_from_coefficients(coeff)
+
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=2) as pool:
+            jobs = [pool.submit(run, a, c, st) for a, c, st in ((self.ET_m_anchor, C_m, streams[0]),
+                                                                 (self.ET_s_anchor, C_s, streams[1]))]
+            for j in jobs:
+                j.result()  # re-raises what a worker raised
+        for st in streams:
+            main.wait_stream(st)
 
     @torch.no_grad()
     def evaluate(self, obs_traj, pred_traj, addl_info=None):

@@ -848,6 +848,9 @@ def test_sklearn_recipe_seeds_and_centres_vs_sklearn_g11(ops, dev):
         assert abs(inertia * C.shape[1] / float(g11[f"{tag}.inertia"]) - 1) < 1e-5
         r = R.kmeans(C, 20)
         assert np.array_equal(N_(A), r["centers"])  # device recipe == numpy restatement, bit for bit
+        # ten initialisations on ten streams / host threads or one after the other: the same result
+        A_seq, inertia_seq, seeds_seq = sklearn_style_kmeans(T(C, dev), 20, concurrent=False)
+        assert torch.equal(A_seq, A) and inertia_seq == inertia and torch.equal(seeds_seq, seeds)
 
 
 def test_kmeanspp_seed_shapes_vs_oracle(ops, dev):
