@@ -154,8 +154,7 @@ class BatchKMeans(nn.Module):
         for i in range(self.n_redo):
             if centroids is None:
                 centroids = self.initialize_centroids(data)
-            runs = [ops.kmeans_fit(data[b], centroids[b], self.max_iter, self.tol, trace=self.verbose)
-                    for b in range(data.shape[0])]
+            runs = self._fit_batch(data, centroids)
             new_centroids = torch.stack([r["centroids"] for r in runs], dim=0)
             labels = torch.stack([r["labels"] for r in runs], dim=0)
             # the reference's inertia is one mean over the whole batch (kmeans.py:234)
@@ -175,6 +174,28 @@ class BatchKMeans(nn.Module):
         self.inertia_ = best_inertia if best_centroids is not None else float("nan")
         self.n_iter_ = best_iters
         return best_labels
+
+    def _fit_batch(self, data, centroids):
+        """One Lloyd fit per batch element (the reference iterates all `l` problems in one batched pass,
+        kmeans.py:228-240).  The problems are independent: with more than one, each runs on its own HIP stream from
+        its own host thread (``et_kmeans_fit`` blocks only the calling thread), side by side."""
+        n_b = data.shape[0]
+        if n_b == 1 or not data.is_cuda:
+            return [ops.kmeans_fit(data[b], centroids[b], self.max_iter, self.tol, trace=self.verbose) for b in range(n_b)]
+        dev, main = data.device, torch.cuda.current_stream(data.device)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(n_b)]
+
+        def run(b):
+            with torch.cuda.device(dev), torch.cuda.stream(streams[b]):
+                streams[b].wait_stream(main)
+                return ops.kmeans_fit(data[b], centroids[b], self.max_iter, self.tol, trace=self.verbose)
+
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(n_b, 16)) as pool:
+            runs = list(pool.map(run, range(n_b)))
+        for st in streams:
+            main.wait_stream(st)
+        return runs
 
     def predict(self, query):
         r"""Predict the closest cluster center each sample in query belongs to (kmeans.py:261-272)."""

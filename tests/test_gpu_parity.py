@@ -1255,3 +1255,22 @@ def test_agentformer_bridge_end_to_end_replay_g12(dev):
             ade, fde = model.evaluate(o, p)                        # fused metrics epilogue
         np.testing.assert_allclose(N_(ade), z[f"scene{j}.ade"], atol=1e-5)
         np.testing.assert_allclose(N_(fde), z[f"scene{j}.fde"], atol=1e-5)
+
+
+def test_batchkmeans_batch_of_problems_equals_single_fits(ops, oracle, dev):
+    """BatchKMeans.fit on (l, d, n) data (kmeans.py:200-259): the l problems run side by side (one stream / host thread
+    each) and give what l separate fits give, bit for bit -- and what the oracle gives."""
+    from eigentrajectory_amd import BatchKMeans
+    from eigentrajectory_amd.synth import gaussian_points_np
+    xs = np.stack([gaussian_points_np(6, 3000, seed=60 + b, n_blobs=4 + b) for b in range(5)])
+    km = BatchKMeans(n_clusters=12, max_iter=40)
+    np.random.seed(3)
+    labels = km.fit(T(xs, dev))
+    assert labels.shape == (5, 3000) and km.centroids.shape == (5, 6, 12)
+    np.random.seed(3)
+    first = np.random.randint(3000)
+    for b in range(5):
+        c0, _ = oracle.kmeans_init_farthest(xs[b], 12, first)
+        ref = oracle.kmeans_fit(xs[b], c0, 40, 1e-4)
+        assert np.array_equal(N_(labels[b]), ref["labels"]) and np.array_equal(N_(km.centroids[b]), ref["centroids"])
+        assert km.n_iter_[b] == ref["n_iter"]
