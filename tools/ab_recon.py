@@ -20,8 +20,9 @@ def t(fn, reps=7):
 with torch.no_grad():
     rec = ops.anchor_reconstruct(C, A, None, U, None, 1, nrm=nrm)
     chk = float(rec.double().abs().sum())
+    chk_b = float(ops._reconstruct_bwd(rec, None, nrm, U, None, 1, 0.0, 8).double().abs().sum())
     f = t(lambda: ops.anchor_reconstruct(C, A, None, U, None, 1, nrm=nrm))
     b = t(lambda: ops._reconstruct_bwd(rec, None, nrm, U, None, 1, 0.0, 8))
     m = t(lambda: ops.anchor_reconstruct_metrics(C, gt, A, None, U, None, 1, nrm=nrm))
-print(os.path.basename(os.environ.get("ET_LIBETAMD", "default")), f"checksum {chk:.6e}",
+print(os.path.basename(os.environ.get("ET_LIBETAMD", "default")), f"checksum {chk:.6e} bwd {chk_b:.9e}",
       f"fwd {f:.3f} ms {2416*n/f/1e6:.0f} GB/s | bwd {b:.3f} ms {2416*n/b/1e6:.0f} GB/s | metrics {m:.3f} ms {600*n/m/1e6:.0f} GB/s")
