@@ -400,6 +400,12 @@ def main():
                 print(f"[bench] native RCCL communicator unavailable ({exc!r}); using torch.distributed collectives",
                       file=sys.stderr, flush=True)
                 comm = None
+            if world > 1:  # every rank must take the same path: one failure sends all of them to the step API
+                ok = torch.tensor([0 if comm is None else 1], device=dev, dtype=torch.int32)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0 and comm is not None:
+                    comm.close()
+                    comm = None
         if comm is None:
             dist_path = "torch.distributed step API"
         km = (lambda x, k: ShardedKMeans(x, k, comm=comm))

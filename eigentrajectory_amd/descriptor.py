@@ -23,13 +23,10 @@ from .normalizer import TrajNorm
 
 
 class ETDescriptor(nn.Module):
-    r"""EigenTrajectory descriptor model
+    r"""Truncated-SVD descriptor of normalised trajectories (descriptor.py:6-27 of the reference).
 
-    Args:
-        hyper_params (DotDict): The hyper-parameters
-        norm_ori (bool): Whether to normalize the trajectory with the origin
-        norm_rot (bool): Whether to normalize the trajectory with the rotation
-        norm_sca (bool): Whether to normalize the trajectory with the scale"""
+    ``hyper_params``: DotDict (``obs_len, pred_len, obs_svd, pred_svd, k, num_samples, traj_dim``); the three flags
+    choose which of origin / rotation / scale the embedded :class:`TrajNorm` removes."""
 
     def __init__(self, hyper_params, norm_ori=True, norm_rot=True, norm_sca=True):
         super().__init__()
@@ -59,11 +56,10 @@ class ETDescriptor(nn.Module):
         return ops.MODE_MOVING if self.traj_normalizer.sca else ops.MODE_STATIC
 
     def normalize_trajectory(self, obs_traj, pred_traj=None):
-        r"""Trajectory normalization (descriptor.py:29-44)"""
-        self.traj_normalizer.calculate_params(obs_traj)
-        obs_traj_norm = self.traj_normalizer.normalize(obs_traj)
-        pred_traj_norm = self.traj_normalizer.normalize(pred_traj) if pred_traj is not None else None
-        return obs_traj_norm, pred_traj_norm
+        r"""descriptor.py:29-44: normaliser state from the observations, applied to both halves"""
+        tn = self.traj_normalizer
+        tn.calculate_params(obs_traj)
+        return tn.normalize(obs_traj), (None if pred_traj is None else tn.normalize(pred_traj))
 
     def denormalize_trajectory(self, traj_norm):
         r"""Trajectory denormalization (descriptor.py:46-57)"""
@@ -103,25 +99,21 @@ class ETDescriptor(nn.Module):
             (U_obs_trunc, _), (U_pred_trunc, _) = ops.eigh_topk_batch([g_obs, g_pred], self.k)  # one launch
             self.traj_normalizer.calculate_params(obs_traj)
             pred_traj_norm = self.traj_normalizer.normalize(pred_traj)
-        else:
-            obs_traj_norm, pred_traj_norm = self.normalize_trajectory(obs_traj, pred_traj)
-            U_obs_trunc, _, _ = self.truncated_SVD(obs_traj_norm)
-            U_pred_trunc, _, _ = self.truncated_SVD(pred_traj_norm)
+        else:  # any other flag combination: stand-alone normalise, then one Gram + eigh per half
+            obs_norm, pred_traj_norm = self.normalize_trajectory(obs_traj, pred_traj)
+            U_obs_trunc, U_pred_trunc = self.truncated_SVD(obs_norm)[0], self.truncated_SVD(pred_traj_norm)[0]
 
-        # Register eigenvectors as model parameters
-        self.U_obs_trunc = nn.Parameter(U_obs_trunc.to(self.U_obs_trunc.device))
-        self.U_pred_trunc = nn.Parameter(U_pred_trunc.to(self.U_pred_trunc.device))
-
-        # Reuse values for anchor generation
-        return pred_traj_norm, U_pred_trunc
+        # fresh Parameters like descriptor.py:134-135 (the reference re-registers instead of copying in place)
+        for name, U in (("U_obs_trunc", U_obs_trunc), ("U_pred_trunc", U_pred_trunc)):
+            setattr(self, name, nn.Parameter(U.to(getattr(self, name).device)))
+        return pred_traj_norm, U_pred_trunc  # what the anchor fit consumes (model.py:55-56)
 
     def projection(self, obs_traj, pred_traj=None):
         r"""Trajectory projection to the ET space (descriptor.py:144-160) -> C_obs (k,N), C_pred (k,N)|None"""
         if not self._fused:
-            obs_traj_norm, pred_traj_norm = self.normalize_trajectory(obs_traj, pred_traj)
-            C_obs = self.to_ET_space(obs_traj_norm, evec=self.U_obs_trunc).detach()
-            C_pred = self.to_ET_space(pred_traj_norm, evec=self.U_pred_trunc).detach() if pred_traj is not None else None
-            return C_obs, C_pred
+            obs_norm, pred_norm = self.normalize_trajectory(obs_traj, pred_traj)
+            C_obs = self.to_ET_space(obs_norm, self.U_obs_trunc.detach())
+            return C_obs, (None if pred_norm is None else self.to_ET_space(pred_norm, self.U_pred_trunc.detach()))
         mv = self._mode == ops.MODE_MOVING
         u_o, u_p = self.U_obs_trunc.detach(), self.U_pred_trunc.detach()
         C_obs, C_pred, nrm, _ = ops.norm_project(obs_traj, pred_traj, u_o if mv else None, u_p if mv else None,
@@ -143,5 +135,5 @@ class ETDescriptor(nn.Module):
                                       nrm=tn._nrm, t_obs=tn._t_obs)
 
     def forward(self, C_pred):
-        r"""Alias for reconstruction"""
+        r"""nn.Module call == :meth:`reconstruction` (descriptor.py:178-181)"""
         return self.reconstruction(C_pred)

@@ -23,12 +23,12 @@ from .descriptor import ETDescriptor
 
 
 class EigenTrajectory(nn.Module):
-    r"""The EigenTrajectory model
+    r"""Wrapper that runs any trajectory predictor in the ET coefficient space (model.py:9-32 of the reference).
 
-    Args:
-        baseline_model (nn.Module): The baseline model
-        hook_func (dict): The bridge functions for the baseline model
-        hyper_params (DotDict): The hyper-parameters
+    ``baseline_model``: the predictor network; ``hook_func``: its three bridge functions (``model_forward_pre_hook``,
+    ``model_forward``, ``model_forward_post_hook``); ``hyper_params``: DotDict with ``obs_len, pred_len, obs_svd,
+    pred_svd, k, num_samples, traj_dim, static_dist``.  Sub-module and attribute names are the reference's, so its
+    checkpoints load unchanged.
     """
 
     def __init__(self, baseline_model, hook_func, hyper_params):
@@ -72,20 +72,21 @@ class EigenTrajectory(nn.Module):
             ops.L.check(rc, "et_scene_project")
         return block[:k], block[k:k + 2], block[k + 2:]
 
+    def _predict(self, C_obs, obs_ori, addl_info):
+        """bridge protocol of baseline/<name>/bridge.py: pre-hook -> predictor -> post-hook; returns the refinement
+        coefficients (k, N, S) the predictor proposes for the scene"""
+        hooks = self.hook_func
+        net_in = hooks.model_forward_pre_hook(C_obs, obs_ori, addl_info)
+        net_out = hooks.model_forward(net_in, self.baseline_model)
+        return hooks.model_forward_post_hook(net_out, addl_info)
+
     def _U(self):
         return (self.ET_m_descriptor.U_obs_trunc.detach(), self.ET_m_descriptor.U_pred_trunc.detach(),
                 self.ET_s_descriptor.U_obs_trunc.detach(), self.ET_s_descriptor.U_pred_trunc.detach())
 
     def calculate_parameters(self, obs_traj, pred_traj):
-        r"""Calculate the ET descriptors of the EigenTrajectory model (model.py:34-56)
-
-        Args:
-            obs_traj (torch.Tensor): The observed trajectory
-            pred_traj (torch.Tensor): The predicted trajectory
-
-        Note:
-            This function should be called once before training the model.
-        """
+        r"""Fit both descriptors and both anchor sets on the training trajectories (model.py:34-56); run once, before
+        training.  ``obs_traj`` (N, t_obs, 2) and ``pred_traj`` (N, t_pred, 2) may live on the CPU or on the GPU."""
         sd = self.static_dist
         # Descriptor initialization: one pass over ALL rows per descriptor; the kernel masks out the
         # rows of the other one (model.py:46-52 splits the tensors instead).
@@ -141,9 +142,7 @@ class EigenTrajectory(nn.Module):
             C_obs, _, nrm, _ = ops.norm_project(obs_traj, None, U_obs_m, None, U_obs_s, None, ops.MODE_SPLIT, sd,
                                                 want_flag=False)
             obs_ori = nrm[:2] - nrm[:2].mean(dim=1, keepdim=True)
-        input_data = self.hook_func.model_forward_pre_hook(C_obs, obs_ori, addl_info)
-        output_data = self.hook_func.model_forward(input_data, self.baseline_model)
-        C_pred_refine = self.hook_func.model_forward_post_hook(output_data, addl_info)
+        C_pred_refine = self._predict(C_obs, obs_ori, addl_info)
         if fast and C_pred_refine.is_cuda and C_pred_refine.dtype == torch.float32 and C_pred_refine.dim() == 3:
             Cc = C_pred_refine if C_pred_refine.is_contiguous() else C_pred_refine.contiguous()
             k, n, s = Cc.shape
@@ -162,22 +161,16 @@ class EigenTrajectory(nn.Module):
                                               ops.MODE_SPLIT, sd, nrm=nrm, t_obs=obs_traj.shape[1])
 
     def forward(self, obs_traj, pred_traj=None, addl_info=None):
-        r"""The forward function of the EigenTrajectory model (model.py:58-125)
+        r"""One scene through projection -> predictor -> anchor refinement -> reconstruction (model.py:58-125).
 
-        Args:
-            obs_traj (torch.Tensor): The observed trajectory
-            pred_traj (torch.Tensor): The predicted trajectory (optional, for training only)
-            addl_info (dict): The additional information (optional, if baseline model requires)
-
-        Returns:
-            output (dict): The output of the model (recon_traj, loss, etc.)
+        ``obs_traj`` (N, t_obs, 2); ``pred_traj`` (N, t_pred, 2) only when training (adds the three loss terms);
+        ``addl_info`` is handed to the bridge hooks untouched.  Returns ``{"recon_traj": (S, N, t_pred, 2)}`` plus
+        ``loss_eigentraj``, ``loss_euclidean_ade``, ``loss_euclidean_fde`` when ``pred_traj`` is given.
         """
         sd = self.static_dist
         if pred_traj is None and self._scene_ok(obs_traj):  # inference on one scene: the lean path
             C_obs, obs_ori, nrm = self._scene_project(obs_traj)
-            input_data = self.hook_func.model_forward_pre_hook(C_obs, obs_ori, addl_info)
-            output_data = self.hook_func.model_forward(input_data, self.baseline_model)
-            C_pred_refine = self.hook_func.model_forward_post_hook(output_data, addl_info)
+            C_pred_refine = self._predict(C_obs, obs_ori, addl_info)
             if (C_pred_refine.is_cuda and C_pred_refine.dtype == torch.float32 and C_pred_refine.dim() == 3
                     and not (C_pred_refine.requires_grad and torch.is_grad_enabled())):
                 Cc = C_pred_refine if C_pred_refine.is_contiguous() else C_pred_refine.contiguous()
@@ -206,10 +199,8 @@ class EigenTrajectory(nn.Module):
             U_obs_s, U_pred_s if pred_traj is not None else None, ops.MODE_SPLIT, sd, want_flag=pred_traj is not None)
         obs_ori = nrm[:2] - nrm[:2].mean(dim=1, keepdim=True)  # move scene to origin (model.py:89)
 
-        # Trajectory prediction (model.py:93-95)
-        input_data = self.hook_func.model_forward_pre_hook(C_obs, obs_ori, addl_info)
-        output_data = self.hook_func.model_forward(input_data, self.baseline_model)
-        C_pred_refine = self.hook_func.model_forward_post_hook(output_data, addl_info)
+        # the plugged-in predictor, through its bridge (model.py:93-95)
+        C_pred_refine = self._predict(C_obs, obs_ori, addl_info)
 
         # Anchor refinement + reconstruction in one kernel (model.py:98-105)
         pred_traj_recon = ops.anchor_reconstruct(C_pred_refine, A_m, A_s, U_pred_m, U_pred_s, ops.MODE_SPLIT, sd,
@@ -224,11 +215,11 @@ class EigenTrajectory(nn.Module):
             C_pred_gt = C_pred_gt.detach()  # low-rank approximation of the gt trajectory (model.py:113-116)
             gt = pred_traj.to(pred_traj_recon.device)
 
-            # Loss calculation (model.py:119-123)
-            error_coefficient = (C_pred - C_pred_gt.unsqueeze(dim=-1)).norm(p=2, dim=0)
-            error_displacement = (pred_traj_recon - gt.unsqueeze(dim=0)).norm(p=2, dim=-1)
-            output["loss_eigentraj"] = error_coefficient.min(dim=-1)[0].mean()
-            output["loss_euclidean_ade"] = error_displacement.mean(dim=-1).min(dim=0)[0].mean()
-            output["loss_euclidean_fde"] = error_displacement[:, :, -1].min(dim=0)[0].mean()
+            # model.py:119-123: best-of-S distances in coefficient space and in metres (mean / final step)
+            coef_err = torch.linalg.vector_norm(C_pred - C_pred_gt[:, :, None], dim=0)        # (N, S)
+            step_err = torch.linalg.vector_norm(pred_traj_recon - gt[None], dim=-1)           # (S, N, t_pred)
+            output["loss_eigentraj"] = coef_err.amin(dim=-1).mean()
+            output["loss_euclidean_ade"] = step_err.mean(dim=-1).amin(dim=0).mean()
+            output["loss_euclidean_fde"] = step_err[:, :, -1].amin(dim=0).mean()
 
         return output
