@@ -25,16 +25,26 @@ struct GramLayout {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-// Gram kernel, (T_obs, T_pred) = (8, 12): one workgroup pass = 256 trajectories.
+// Gram kernel, (T_obs, T_pred) = (8, 12).  A wavefront takes 64 trajectories per pass, in its own 12 KB LDS slice:
 //  1. coalesced float4 loads (prefetched one pass ahead into registers) -> LDS rows (pitch + 16 B)
 //  2. lane = trajectory: normaliser state, normalise the row IN PLACE (fp32; rows that do not belong
 //     to descriptor `which` become zeros)
 //  3. fp64 matrix cores: per group of 4 trajectories three v_mfma_f64_16x16x4_f64 add the outer
 //     products to three 16x16 tiles (A[i][k] = feature i of trajectory k).  Products of fp32 values
-//     are exact in fp64 and every tile entry is one k-ordered fma chain.
+//     are exact in fp64 and every tile entry is one k-ordered fma chain.  The loop over the wavefront's 16 groups
+//     is unrolled: the LDS operand reads use immediate offsets.
 //  4. waves are summed through LDS in a fixed order; every workgroup writes one partial.
+// On this chip VALU and MFMA issue do not overlap (profiles/r02e_mfma_valu_issue.txt: a SIMD's time is matrix time
+// PLUS vector time), so the kernel is built for the fewest vector instructions per row -- lane = trajectory
+// normalisation, 5.7 VALU instructions per row -- and, the slices being wavefront-private, there is no workgroup
+// barrier inside the loop: the three resident wavefronts of a SIMD drift apart and fill each other's waits.
+// (Round 2 A/B at N = 1e7, gram + reduce + finish: 256-row workgroup tiles with three barriers per pass 496-506 us;
+// operands loaded straight into the MFMA layout and normalised there with DPP, no LDS staging, 6 wavefronts per SIMD:
+// 484-490 us, 11 VALU instructions per row; this form: 457-464 us.)
+constexpr int kWaveGramThreads = 256;
+
 template <int TO, int TP>
-__global__ __launch_bounds__(kFitThreads) void gram_tile_kernel(
+__global__ __launch_bounds__(kWaveGramThreads) void gram_wave_kernel(
     const float *__restrict__ obs, const float *__restrict__ pred, int64_t N, int mode, float static_dist, int which,
     double *__restrict__ partials) {
     using L = GramLayout<TO, TP>;
@@ -42,63 +52,67 @@ __global__ __launch_bounds__(kFitThreads) void gram_tile_kernel(
     constexpr int DO = L::DO, DP = L::DP;
     constexpr int QO = DO / 4, QP = DP / 4;
     constexpr int PO = QO + 1, PP = QP + 1;
-    constexpr int kTileRows = kFitThreads;  // one trajectory per lane in the normalise phase
-
-    constexpr int kStageF4 = kTileRows * (PO + PP);
-    constexpr int kRedDoubles = (kFitThreads / 64) * L::kBlocks * 256;
-    constexpr int kLdsDoubles = (2 * kStageF4 > kRedDoubles ? 2 * kStageF4 : kRedDoubles) + 2;
+    constexpr int kWaves = kWaveGramThreads / 64;
+    constexpr int kSliceF4 = 64 * (PO + PP);  // float4 per wavefront slice
+    constexpr int kRedDoubles = kWaves * L::kBlocks * 256;
+    constexpr int kLdsDoubles = (2 * kWaves * kSliceF4 > kRedDoubles ? 2 * kWaves * kSliceF4 : kRedDoubles) + 2;
     __shared__ __attribute__((aligned(16))) double sMem[kLdsDoubles];
-    float4 *sObs = reinterpret_cast<float4 *>(sMem);
-    float4 *sPred = sObs + kTileRows * PO;
-    double *sRed = sMem;  // reused after the last pass
+    double *sRed = sMem;  // reused after the loop
     int *sCountPtr = reinterpret_cast<int *>(sMem + kLdsDoubles - 2);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int feat = lane & 15, kslot = lane >> 4;  // MFMA operand slot: feature index, trajectory within a group of 4
+    const int feat = lane & 15, kslot = lane >> 4;
+    float4 *sObs = reinterpret_cast<float4 *>(sMem) + wave * kSliceF4;
+    float4 *sPred = sObs + 64 * PO;
 
     f64x4 accO = {0.0, 0.0, 0.0, 0.0}, accP = accO, accQ = accO;
     int my_count = 0;
-
-    const int64_t n_tiles = ceil_div(N, (int64_t)kTileRows);
+    const int64_t n_tiles = ceil_div(N, (int64_t)64);
+    const int64_t first = (int64_t)blockIdx.x * kWaves + wave, stride = (int64_t)gridDim.x * kWaves;
     float4 ro[QO], rp[QP];
     auto fetch = [&](int64_t tile) {
-        const int64_t n0 = tile * kTileRows;
-        const int rows = (int)min((int64_t)kTileRows, N - n0);
+        const int64_t n0 = tile * 64;
+        const int rows = (int)min((int64_t)64, N - n0);
         const float4 *go = reinterpret_cast<const float4 *>(obs + n0 * DO);
         const float4 *gp = reinterpret_cast<const float4 *>(pred + n0 * DP);
+        if (rows == 64) {
 #pragma unroll
-        for (int j = 0; j < QO; ++j) {
-            const int q = tid + j * kFitThreads;
-            ro[j] = q < rows * QO ? go[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+            for (int j = 0; j < QO; ++j) ro[j] = go[lane + j * 64];
 #pragma unroll
-        for (int j = 0; j < QP; ++j) {
-            const int q = tid + j * kFitThreads;
-            rp[j] = q < rows * QP ? gp[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < QP; ++j) rp[j] = gp[lane + j * 64];
+        } else {
+#pragma unroll
+            for (int j = 0; j < QO; ++j) ro[j] = lane + j * 64 < rows * QO ? go[lane + j * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < QP; ++j) rp[j] = lane + j * 64 < rows * QP ? gp[lane + j * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x);
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t n0 = tile * kTileRows;
-        const int rows = (int)min((int64_t)kTileRows, N - n0);
-        __syncthreads();  // previous pass done with the staged rows
+    auto wave_sync = [&]() {  // LDS hand-over between the lanes of this wavefront
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    if (first < n_tiles) fetch(first);
+    for (int64_t tile = first; tile < n_tiles; tile += stride) {
+        const int rows = (int)min((int64_t)64, N - tile * 64);
+        wave_sync();  // the previous pass is done with the slice
 #pragma unroll
         for (int j = 0; j < QO; ++j) {
-            const int q = tid + j * kFitThreads;
+            const int q = lane + j * 64;
             sObs[(q / QO) * PO + (q % QO)] = ro[j];
         }
 #pragma unroll
         for (int j = 0; j < QP; ++j) {
-            const int q = tid + j * kFitThreads;
+            const int q = lane + j * 64;
             sPred[(q / QP) * PP + (q % QP)] = rp[j];
         }
-        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);  // in flight during the rest of this pass
-        __syncthreads();
+        if (tile + stride < n_tiles) fetch(tile + stride);  // in flight during the rest of this pass
+        wave_sync();
         {
-            float4 *orow = sObs + tid * PO, *prow = sPred + tid * PP;
+            float4 *orow = sObs + lane * PO, *prow = sPred + lane * PP;
             bool use = false;
-            if (tid < rows) {
+            if (lane < rows) {
                 float xo[DO];
 #pragma unroll
                 for (int j = 0; j < QO; ++j) {
@@ -138,27 +152,28 @@ __global__ __launch_bounds__(kFitThreads) void gram_tile_kernel(
                 for (int q = 0; q < QP; ++q) prow[q] = z;
             }
         }
-        __syncthreads();
-        const float *fo = reinterpret_cast<const float *>(sObs);
-        const float *fp = reinterpret_cast<const float *>(sPred);
-        for (int grp = wave; grp < kTileRows / 4; grp += kFitThreads / 64) {
-            const int r = 4 * grp + kslot;
-            const double vo = (double)fo[r * (4 * PO) + feat];
-            const float *pr = fp + r * (4 * PP);
-            const double vp = (double)pr[feat];
-            const double va = (double)pr[8 + feat];
-            const double vb = (double)pr[feat < 8 ? 16 + feat : feat - 8];
-            accO = __builtin_amdgcn_mfma_f64_16x16x4f64(vo, vo, accO, 0, 0, 0);
-            accP = __builtin_amdgcn_mfma_f64_16x16x4f64(vp, vp, accP, 0, 0, 0);
-            accQ = __builtin_amdgcn_mfma_f64_16x16x4f64(va, vb, accQ, 0, 0, 0);
+        wave_sync();
+        {
+            const float *po = reinterpret_cast<const float *>(sObs) + kslot * (4 * PO) + feat;
+            const float *pr = reinterpret_cast<const float *>(sPred) + kslot * (4 * PP);
+            const int featb = feat < 8 ? 16 + feat : feat - 8;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const double vo = (double)po[g * 4 * (4 * PO)];
+                const double vp = (double)pr[g * 4 * (4 * PP) + feat];
+                const double va = (double)pr[g * 4 * (4 * PP) + 8 + feat];
+                const double vb = (double)pr[g * 4 * (4 * PP) + featb];
+                accO = __builtin_amdgcn_mfma_f64_16x16x4f64(vo, vo, accO, 0, 0, 0);
+                accP = __builtin_amdgcn_mfma_f64_16x16x4f64(vp, vp, accP, 0, 0, 0);
+                accQ = __builtin_amdgcn_mfma_f64_16x16x4f64(va, vb, accQ, 0, 0, 0);
+            }
         }
     }
 
-    // ---- combine the 4 waves (fixed order), one partial per workgroup
-    __syncthreads();  // all waves finished reading the staged rows (aliased by sRed)
+    // ---- combine the wavefronts (fixed order), one partial per workgroup
+    __syncthreads();  // every wavefront is done with its slice (aliased by sRed)
     if (tid == 0) *sCountPtr = 0;
     __syncthreads();
-    // f64 16x16x4 result layout: lane l holds D[row = (l>>4) + 4*r][col = l&15] in register r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int e = ((kslot + 4 * r) * 16 + feat);
@@ -169,9 +184,9 @@ __global__ __launch_bounds__(kFitThreads) void gram_tile_kernel(
     if (my_count) atomicAdd(sCountPtr, my_count);
     __syncthreads();
     double *dst = partials + (size_t)blockIdx.x * L::kPartial;
-    for (int i = tid; i < L::kBlocks * 256; i += kFitThreads) {
+    for (int i = tid; i < L::kBlocks * 256; i += kWaveGramThreads) {
         double sum = 0.0;
-        for (int w = 0; w < kFitThreads / 64; ++w) sum += sRed[w * L::kBlocks * 256 + i];
+        for (int w = 0; w < kWaves; ++w) sum += sRed[w * L::kBlocks * 256 + i];
         dst[i] = sum;
     }
     if (tid == 0) dst[L::kBlocks * 256] = (double)*sCountPtr;
@@ -514,9 +529,9 @@ __global__ __launch_bounds__(kEighThreads) void eigh_topk_batch_kernel(const Eig
 }
 
 static int fit_grid(int64_t N) {
-    // one resident round of workgroups (3 per CU at 48 KB of LDS), few enough that the partial
-    // reduction stays trivial
-    const int64_t tiles = ceil_div(N, (int64_t)kFitThreads);
+    // one resident round of workgroups (3 per CU at 48 KB of LDS: four wavefront slices), few enough that the
+    // partial reduction stays trivial
+    const int64_t tiles = ceil_div(N, (int64_t)kWaveGramThreads);
     return (int)(tiles < 768 ? (tiles > 0 ? tiles : 1) : 768);
 }
 
@@ -549,7 +564,7 @@ extern "C" int et_fit_gram(const float *obs, const float *pred, int64_t N, int T
     const int grid = fit_grid(N);
     double *partials = (double *)workspace;
     if (T_obs == 8 && T_pred == 12 && aligned16(obs) && aligned16(pred)) {
-        hipLaunchKernelGGL((gram_tile_kernel<8, 12>), dim3(grid), dim3(kFitThreads), 0, st, obs, pred, N, mode,
+        hipLaunchKernelGGL((gram_wave_kernel<8, 12>), dim3(grid), dim3(kWaveGramThreads), 0, st, obs, pred, N, mode,
                            static_dist, which, partials);
         ET_LAUNCH_CHECK();
         constexpr int per = GramLayout<8, 12>::kPartial;

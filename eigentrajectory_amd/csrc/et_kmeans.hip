@@ -930,6 +930,10 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_update_kernel(et_kmeans_sta
 // from a loop whose kernels themselves only take a few microseconds.  `cen` is read by every workgroup in its
 // prologue only, i.e. before the last arrival, so updating it in place is safe.
 constexpr int kSmallMaxBlocks = 32;
+#ifndef ET_CHAIN_MIN_PASSES
+#define ET_CHAIN_MIN_PASSES (32 * 16)
+#endif
+constexpr int kChainMinPasses = ET_CHAIN_MIN_PASSES;  // shards above this many 256-point passes run the chained form
 
 template <int NREGS, bool SIM>
 __global__ __launch_bounds__(kFilterThreads) void kmeans_lloyd_small_kernel(
@@ -1910,7 +1914,7 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     // large shards with the matrix-core filter: the chained form (kmeans_lloyd_chain_kernel) -- every launch applies the
     // previous iteration's update in its prologue, in every workgroup; one more update after the loop
     const bool chained = km_use_filter(X, N, d, K, w.labels_u8) &&
-                         ceil_div(N, (int64_t)256) > (int64_t)kSmallMaxBlocks * (kFilterThreads / 64);
+                         ceil_div(N, (int64_t)256) > (int64_t)kChainMinPasses;
     if (chained) {
         const size_t plen = km_plen(d, K), lds = km_filter_lds_bytes(d, K);
         rc = km_fat_lds_attribute();
