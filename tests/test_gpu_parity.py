@@ -201,7 +201,7 @@ def test_fit_gram_and_eigh_vs_oracle_and_golden_g2(ops, oracle, dev):
             np.testing.assert_allclose(N_(sigma), g2[f"eth.sigma_{name}_{tag}"][:6], rtol=1e-5)
 
 
-@pytest.mark.parametrize("n,t_obs,t_pred", [(100000, 8, 12), (12345, 8, 12), (5000, 5, 7)])
+@pytest.mark.parametrize("n,t_obs,t_pred", [(100000, 8, 12), (12345, 8, 12), (5000, 5, 7), (1, 8, 12), (63, 8, 12), (65, 8, 12), (257, 8, 12)])
 def test_fit_gram_summation_exact(ops, dev, n, t_obs, t_pred):
     """Identity mode takes the rows as they are, so the only arithmetic is sum_n x_i x_j: products of
     fp32 values are exact in fp64 and the fp64 sums must agree with numpy's to ~1e-13."""
@@ -214,6 +214,28 @@ def test_fit_gram_summation_exact(ops, dev, n, t_obs, t_pred):
         m = x.reshape(n, -1).astype(np.float64)
         ref = m.T @ m
         np.testing.assert_allclose(N_(g), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("n", [1, 3, 63, 64, 65, 127, 255, 256, 257, 1000, 49153])
+def test_fit_gram_ragged_sizes_vs_oracle(ops, oracle, dev, n):
+    """The (8, 12) Gram kernel takes 64 trajectories per wavefront pass: sizes around the pass / workgroup edges, every
+    normalising mode (identity: test_fit_gram_summation_exact), against the oracle (normalised rows agree to the last ulp or two, hence the 1e-6) and the row counts exactly."""
+    rng = np.random.default_rng(n)
+    obs = np.cumsum(rng.standard_normal((n, 8, 2)).astype(np.float32) * 0.4 + 0.3, axis=1).astype(np.float32)
+    pred = (obs[:, -1:] + np.cumsum(rng.standard_normal((n, 12, 2)).astype(np.float32) * 0.4 + 0.3, axis=1)).astype(np.float32)
+    obs[::7, -3] = obs[::7, -1]  # motionless rows: static in SPLIT mode, identity rotation
+    for mode, which in ((ops.MODE_MOVING, 1), (ops.MODE_STATIC, 0), (ops.MODE_SPLIT, 1), (ops.MODE_SPLIT, 0)):
+        o, p = obs, pred
+        if mode == ops.MODE_MOVING:  # the scale normalisation divides by the last displacement: no motionless rows here
+            o = obs.copy()
+            o[::7, -3] = o[::7, -1] - 0.25
+        g_obs, g_pred, cnt = ops.fit_gram(T(o, dev), T(p, dev), mode, 0.2, which)
+        r_obs, r_pred, r_cnt = oracle.fit_gram(o, p, mode, 0.2, which)
+        assert int(cnt.item()) == r_cnt, (mode, which)
+        for g, r in ((g_obs, r_obs), (g_pred, r_pred)):
+            g = N_(g)
+            assert np.array_equal(g, g.T)
+            close(g, r, tol=1e-6)
 
 
 def test_eigh_bit_exact_vs_oracle(ops, oracle, dev):
