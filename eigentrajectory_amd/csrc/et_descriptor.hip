@@ -456,8 +456,10 @@ __global__ __launch_bounds__(kTile) void reconstruct_metrics_tile_kernel(
     const int64_t n = n0 + nl;
     float craw[K];
     if (tid < npairs) {
+        const float *cp = C + (n * S + s);  // + j N S: one 64-bit stride, no per-load index arithmetic
+        const int64_t plane = N * S;
 #pragma unroll
-        for (int j = 0; j < K; ++j) craw[j] = C[((int64_t)j * N + n) * S + s];
+        for (int j = 0; j < K; ++j) craw[j] = cp[j * plane];
     }
     {
         const float4 *g4 = reinterpret_cast<const float4 *>(gt + n0 * DP);
@@ -472,6 +474,22 @@ __global__ __launch_bounds__(kTile) void reconstruct_metrics_tile_kernel(
     for (int i = tid; i < 2 * K * S; i += kTile) {
         const float *src = (i >= K * S) ? A_m : A_s;
         sA[i] = src ? src[i % (K * S)] : 0.f;
+    }
+    __syncthreads();
+    // The displacement norms are taken in the NORMALISED frame: denormalisation is a rotation, a translation and a
+    // division by sca, so ||denorm(w) - gt|| = ||w - normalise(gt)|| / sca; the ground truth is normalised once per row
+    // (12 points) instead of denormalising 12 points for each of the S samples.
+    if (tid < rows) {
+        const RowNorm p = fetch_row_norm(sNorm + tid * kNormStride);
+        float4 *g4 = reinterpret_cast<float4 *>(sGt + tid * DP);
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+            const float4 g = g4[q];
+            float4 o;
+            normalize_point(p, g.x, g.y, o.x, o.y);
+            normalize_point(p, g.z, g.w, o.z, o.w);
+            g4[q] = o;
+        }
     }
     __syncthreads();
 
@@ -495,28 +513,36 @@ __global__ __launch_bounds__(kTile) void reconstruct_metrics_tile_kernel(
                 for (int j = 0; j < K; ++j) acc = fmaf(u[f * K + j], c[j], acc);
                 v[e] = acc;
             }
-            float4 o;
-            denormalize_point(p, v[0], v[1], o.x, o.y);
-            denormalize_point(p, v[2], v[3], o.z, o.w);
-            const float4 g = g4[q];
-            const float ex = o.x - g.x, ey = o.y - g.y, fx = o.z - g.z, fy = o.w - g.w;
-            const float d0 = sqrtf(ex * ex + ey * ey), d1 = sqrtf(fx * fx + fy * fy);
+            const float4 g = g4[q];  // normalised ground truth
+            const float ex = v[0] - g.x, ey = v[1] - g.y, fx = v[2] - g.z, fy = v[3] - g.w;
+            // v_sqrt_f32 (1 ulp) instead of the correctly rounded sqrtf() sequence (a dozen VALU instructions each, 24 per
+            // pair): the metric is compared at 1e-5 m, the difference is 6e-8 relative
+            const float d0 = __builtin_amdgcn_sqrtf(ex * ex + ey * ey), d1 = __builtin_amdgcn_sqrtf(fx * fx + fy * fy);
             sum = (sum + d0) + d1;
             last = d1;
         }
-        sMet[2 * tid] = sum / (float)TP;
-        sMet[2 * tid + 1] = last;
+        const float back = p.mv ? p.inv : 1.0f;  // back to metres
+        sMet[2 * tid] = (sum / (float)TP) * back;
+        sMet[2 * tid + 1] = last * back;
     }
     __syncthreads();
-    if (tid < rows) {
-        float best_a = sMet[2 * (tid * S)], best_f = sMet[2 * (tid * S) + 1];
-        for (int t = 1; t < S; ++t) {
-            const float va = sMet[2 * (tid * S + t)], vf = sMet[2 * (tid * S + t) + 1];
-            best_a = (va < best_a || isnan(va)) ? va : best_a;  // torch.min propagates NaN
-            best_f = (vf < best_f || isnan(vf)) ? vf : best_f;
+    // best of S per pedestrian: a tree over the S consecutive pairs of a row, every pair's lane taking part
+    // (a lane-per-row loop over S left one wavefront busy for 19 dependent steps while the other three waited)
+    for (int len = S; len > 1;) {
+        const int half = (len + 1) >> 1;
+        if (tid < npairs && s + half < len) {  // the partner slot s + half >= len - half is not written in this step
+            float2 mine = *reinterpret_cast<const float2 *>(sMet + 2 * tid);
+            const float2 other = *reinterpret_cast<const float2 *>(sMet + 2 * (tid + half));
+            mine.x = (other.x < mine.x || isnan(other.x)) ? other.x : mine.x;  // torch.min propagates NaN
+            mine.y = (other.y < mine.y || isnan(other.y)) ? other.y : mine.y;
+            *reinterpret_cast<float2 *>(sMet + 2 * tid) = mine;
         }
-        ade[n0 + tid] = best_a;
-        fde[n0 + tid] = best_f;
+        __syncthreads();
+        len = half;
+    }
+    if (tid < rows) {
+        ade[n0 + tid] = sMet[2 * (tid * S)];
+        fde[n0 + tid] = sMet[2 * (tid * S) + 1];
     }
 }
 
