@@ -14,7 +14,7 @@ BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-un
 EXTRA=""
 [ "$SRC" = "et_kmeans.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize"
 [ "$SRC" = "et_descriptor.hip" ] && EXTRA="-fno-slp-vectorize"
-[ "$SRC" = "et_fit.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"
+[ "$SRC" = "et_fit.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize"
 /opt/rocm/bin/hipcc $BASE $EXTRA $FLAGS -c "$C/$SRC" -o "$V/${SRC%.hip}_$NAME.o"
 OBJS=""
 for f in et_abi et_trajnorm et_descriptor et_fit et_kmeans et_kmeanspp et_sharded; do
