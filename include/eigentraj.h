@@ -149,8 +149,8 @@ int et_fit_gram(const float *obs, const float *pred, int64_t N, int T_obs, int T
                 double *G_obs, double *G_pred, int64_t *count,
                 void *workspace, size_t workspace_bytes, et_stream_t stream);
 
-/* Top-k eigenpairs of a symmetric n x n fp64 matrix (n <= 64), cyclic Jacobi on one
- * wavefront: U (n,k) fp32 = eigenvectors by descending eigenvalue, each signed so its
+/* Top-k eigenpairs of a symmetric n x n fp64 matrix (n <= 64), parallel-order (round-robin) Jacobi in one
+ * workgroup: U (n,k) fp32 = eigenvectors by descending eigenvalue, each signed so its
  * largest-|.| component is positive; sigma[k] = sqrt(max(lambda,0)) -- U[:, :k], S[:k]
  * of torch.linalg.svd at descriptor.py:110-113 up to sign. */
 int et_eigh_topk(const double *G, int n, int k, float *U, float *sigma, et_stream_t stream);
