@@ -37,10 +37,16 @@
 namespace et {
 
 constexpr int kKmThreads = 256;
-// The filter kernel runs as ONE 16-wavefront workgroup per CU: same occupancy as four 256-thread ones, but a
-// quarter of the workgroup partials, so that a single workgroup can fold them and update the centroids in one
-// short launch (kmeans_reduce_update_kernel) without any inter-workgroup hand-off.
-constexpr int kFilterThreads = 1024;
+// The filter kernels run as ONE fat workgroup per CU: few workgroup partials (a single workgroup can fold them and
+// update the centroids in one short launch, kmeans_reduce_update_kernel, without any inter-workgroup hand-off).  They
+// are compiled for up to 1024 threads and take their size from blockDim.x: the host launches 12 wavefronts (768
+// threads, three per SIMD) or 16 (four per SIMD), whichever finishes the shard earlier -- a 256-point pass takes
+// 0.73x as long with three wavefronts per SIMD as with four (the kernel is short of instruction-level parallelism,
+// not of wavefronts), but a wavefront then has 4/3 as many passes to do, and the count is an integer.  Per Lloyd
+// launch at N = 1e7 (same box): 256 threads 60.3 us, 512: 58.0, 640: 60.5, 704: 57.1, 768: 54.7, 832: 59.3, 896: 57.8,
+// 960: 58.7, 1024: 57.2 (sizes that load the four SIMDs unevenly lose); at N = 1e6 768 needs two passes, 1024 one.
+constexpr int kFilterMaxThreads = 1024;
+constexpr int kFilterMinThreads = 768;
 constexpr int kKmMaxBlocks = 4096;
 
 // ---- scalar helpers shared with the oracle's definitions -----------------------------------
@@ -338,7 +344,7 @@ __device__ __forceinline__ void assign_body_valu(
     // (the expensive part of this kernel) all but disappear.
     const bool incremental = (state->iter > 0) && (given == nullptr);
     const bool fast = state->fast_ok != 0;
-    const int n_threads = (int)blockDim.x;  // 256, or kFilterThreads when called from the filter kernel
+    const int n_threads = (int)blockDim.x;  // 256, or the filter launch size (768 / 1024)
     for (int i = threadIdx.x; i < plen; i += n_threads) sAcc[i] = 0;
     stage_centroids(cen, d, K, sC);
     __syncthreads();
@@ -605,13 +611,23 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
     unsigned *queue = reinterpret_cast<unsigned *>(sC + K * 8) + wave * kFilterQueue;
     const int frac = (int)state->frac, sfrac = (int)state->sim_frac;
-    for (int i = threadIdx.x; i < plen; i += kFilterThreads) sAcc[i] = 0;
-    stage_centroids(cen, d, K, sC);
-    __syncthreads();
-
-    const float sg = ldexpf(1.0f, 5 - e_max), sg2 = sg * sg;
     // threshold polynomial in rr, already multiplied by sg^2 (the MFMA works on scaled operands)
     constexpr float kUp = 1.001953125f, kTiny = 1.1920928955078125e-7f;  // (1 + 2^-9) v + 2^-23 survives the rtz to f16
+    // Trace-less fits (SIM = false) certify with w' = 2 x.c_l - |c_l|^2 instead of the reference's Y_l + |x|^2 (no |x|^2
+    // chain, no square root).  With u = 2^-24, a = 2 d - an, Y_l = fl(fl(a) - cc):  Y_l + an = (2 d - cc) + a d1 +
+    // (fl(a) - cc) d2, |d1|, |d2| <= u, so |Y_l + an - (2 d - cc)| <= u (2 |a| + cc)(1 + u) <= 3 u (r + C)^2 (1 + 2^-18)
+    // <= 2^-21 (r^2 + C^2) (1 + 2^-10); w' itself adds one rounding, u |w'|.  r is bounded by sqrt(6) max|x_i|.
+    constexpr float kSqrt6Up = 2.4543f;       // sqrt(6) (1 + 2^-9)
+    constexpr float kR2Slack = 1.57365e-5f;   // 2^-16 + 2^-21 (1 + 2^-10), rounded up: eps(r)'s r^2 term + the slack above
+    constexpr float kCcSlack = 4.7731e-7f;    // 2^-21 (1 + 2^-10), rounded up
+    const float sg = ldexpf(1.0f, 5 - e_max), sg2 = sg * sg;
+    const int n_thr = (int)blockDim.x, n_wav = n_thr >> 6;  // 768 or 1024 threads (host's choice)
+    for (int i = threadIdx.x; i < plen; i += n_thr) sAcc[i] = 0;
+    stage_centroids(cen, d, K, sC);
+    // slot 7 of a centroid row: the |c|^2 part of the rounding slack of the trace-less certification (below)
+    for (int j = threadIdx.x; j < K; j += n_thr) sC[j * 8 + 7] = fmaf(sC[j * 8 + 6] * sg2, kCcSlack, 2.3283064365386963e-10f);
+    __syncthreads();
+
 
     // A operands: this lane feeds accumulator row m = col, k-half = half.  Row m is read back by lanes
     // of half (m >> 2) & 1 in register 4 (m >> 3) + (m & 3); cluster j sits in register j >> 1 of half j & 1,
@@ -656,7 +672,7 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
     int terms = 0;
     int qn = 0;  // wave-uniform number of queued points
     const int64_t n_groups = (N + 255) / 256;
-    for (int64_t g = (int64_t)blockIdx.x * (kFilterThreads / 64) + wave; g < n_groups; g += (int64_t)gridDim.x * (kFilterThreads / 64)) {
+    for (int64_t g = (int64_t)blockIdx.x * n_wav + wave; g < n_groups; g += (int64_t)gridDim.x * n_wav) {
         const int64_t n = g * 256 + 128 * half + 4 * col;
         const bool valid = n < N;  // N % 4 == 0
         float4 v[6];
@@ -675,10 +691,16 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
             float x[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) x[i] = q == 0 ? v[i].x : (q == 1 ? v[i].y : (q == 2 ? v[i].z : v[i].w));
-            float an = 0.f;
+            float an = 0.f, rs;
+            if constexpr (SIM) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) an = an + x[i] * x[i];  // kmeans.py:73
-            const float rs = fmaf(__builtin_amdgcn_sqrtf(an) * sg, kUp, kTiny);  // >= sg ||x||
+                for (int i = 0; i < 6; ++i) an = an + x[i] * x[i];  // kmeans.py:73
+                rs = fmaf(__builtin_amdgcn_sqrtf(an) * sg, kUp, kTiny);  // >= sg ||x||
+            } else {
+                const float m = fmaxf(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fabsf(x[2])),
+                                      fmaxf(fmaxf(fabsf(x[3]), fabsf(x[4])), fabsf(x[5])));
+                rs = fmaf(m * sg, kSqrt6Up, kTiny);  // >= sg ||x|| as well: ||x|| <= sqrt(6) max |x_i|
+            }
             unsigned w[7];  // {xh01, xh23, xh45, xl01, xl23, xl45, (r, 1)}
 #pragma unroll
             for (int p = 0; p < 3; ++p) split_f16(x[2 * p], x[2 * p + 1], sg, w[p], w[3 + p]);
@@ -723,12 +745,19 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
             y = fmaf(x[3], r0.w, y);
             y = fmaf(x[4], r1.x, y);
             y = fmaf(x[5], r1.y, y);
-            y = y * 2.0f;
-            y = y - an;
-            y = y - r1.z;
-            // keep <=> (Y_l + |x|^2) sg^2 exceeds every other cluster's upper bound: w - second > eps(r) + rounding of w
-            const float wv = (y + an) * sg2;
-            const float th = fmaf(fabsf(wv), 2.384185791015625e-7f, fmaf(rs, fmaf(rs, 1.52587890625e-5f, 9.5367431640625e-7f), 2.3283064365386963e-10f));
+            float wv, th;
+            if constexpr (SIM) {
+                y = y * 2.0f;
+                y = y - an;
+                y = y - r1.z;
+                // keep <=> (Y_l + |x|^2) sg^2 exceeds every other cluster's upper bound: w - second > eps(r) + rounding of w
+                wv = (y + an) * sg2;
+                th = fmaf(fabsf(wv), 2.384185791015625e-7f, fmaf(rs, fmaf(rs, 1.52587890625e-5f, 9.5367431640625e-7f), 2.3283064365386963e-10f));
+            } else {
+                // the same test on a certified lower bound of Y_l + |x|^2 (see kR2Slack above; r1.w = the |c_l|^2 slack)
+                wv = fmaf(y, 2.0f, -r1.z) * sg2;
+                th = fmaf(fabsf(wv), 1.1920928955078125e-7f, fmaf(rs, fmaf(rs, kR2Slack, 9.5367431640625e-7f), r1.w));
+            }
             const bool keep = wv - second > th;
             if (SIM) {
                 const double term = trunc((double)y * sim_scale);
@@ -775,11 +804,11 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
         if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K]), (unsigned long long)sim_acc);
     }
     __syncthreads();
-    emit_partials(sAcc, plen, kFilterThreads, block_partials, lanes);
+    emit_partials(sAcc, plen, n_thr, block_partials, lanes);
 }
 
 template <int NREGS>
-__global__ __launch_bounds__(kFilterThreads) void kmeans_assign_filter_kernel(
+__global__ __launch_bounds__(kFilterMaxThreads) void kmeans_assign_filter_kernel(
     const float *__restrict__ X, int64_t N, int K, const et_kmeans_state *__restrict__ state,
     const float *__restrict__ cen, uint8_t *__restrict__ labels, long long *__restrict__ block_partials,
     long long *__restrict__ lanes) {
@@ -931,12 +960,12 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_update_kernel(et_kmeans_sta
 // prologue only, i.e. before the last arrival, so updating it in place is safe.
 constexpr int kSmallMaxBlocks = 32;
 #ifndef ET_CHAIN_MIN_PASSES
-#define ET_CHAIN_MIN_PASSES (32 * 16)
+#define ET_CHAIN_MIN_PASSES (kSmallMaxBlocks * (kFilterMaxThreads / 64))  // right above what the one-launch small form takes
 #endif
 constexpr int kChainMinPasses = ET_CHAIN_MIN_PASSES;  // shards above this many 256-point passes run the chained form
 
 template <int NREGS, bool SIM>
-__global__ __launch_bounds__(kFilterThreads) void kmeans_lloyd_small_kernel(
+__global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_small_kernel(
     const float *__restrict__ X, int64_t N, int K, et_kmeans_state *state, float *cen, uint8_t *__restrict__ labels,
     long long *block_partials, long long *partials, unsigned *ticket, float tol, float *trace, float *last) {
     if (state->done) return;
@@ -958,26 +987,27 @@ __global__ __launch_bounds__(kFilterThreads) void kmeans_lloyd_small_kernel(
     const int plen = d * K + K + 2, n_blocks = (int)gridDim.x;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     long long *sTot = reinterpret_cast<long long *>(smem_raw) + 512;  // past the 2 d K floats update_body uses
-    for (int i = threadIdx.x; i < plen; i += kFilterThreads) sTot[i] = 0;
+    const int n_thr = (int)blockDim.x;
+    for (int i = threadIdx.x; i < plen; i += n_thr) sTot[i] = 0;
     __syncthreads();
     // [entry][workgroup] partials: all loads first, then exact integer sums through LDS atomics
-    constexpr int kPer = ((6 * 32 + 32 + 2) * kSmallMaxBlocks + kFilterThreads - 1) / kFilterThreads;  // K <= 32
+    constexpr int kPer = ((6 * 32 + 32 + 2) * kSmallMaxBlocks + kFilterMinThreads - 1) / kFilterMinThreads;  // K <= 32, any launch size
     long long v[kPer];
     const int total = plen * n_blocks;
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
-        const int idx = threadIdx.x + k * kFilterThreads;
+        const int idx = threadIdx.x + k * n_thr;
         v[k] = idx < total ? block_partials[idx] : 0;
     }
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
-        const int idx = threadIdx.x + k * kFilterThreads;
+        const int idx = threadIdx.x + k * n_thr;
         if (idx < total && v[k] != 0)
             atomicAdd(reinterpret_cast<unsigned long long *>(&sTot[idx / n_blocks]), (unsigned long long)v[k]);
     }
     __syncthreads();
     const bool have_totals = state->iter > 0;
-    for (int e = threadIdx.x; e < plen; e += kFilterThreads)
+    for (int e = threadIdx.x; e < plen; e += n_thr)
         partials[e] = ((have_totals && e < plen - 2) ? partials[e] : 0) + sTot[e];
     __syncthreads();
     update_body(state, partials, d, K, tol, cen, trace, nullptr, last);
@@ -1027,7 +1057,7 @@ __device__ __forceinline__ void fold_lanes(const long long *__restrict__ lanes, 
 }
 
 template <int NREGS, bool SIM>
-__global__ __launch_bounds__(kFilterThreads) void kmeans_lloyd_chain_kernel(
+__global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     const float *__restrict__ X, int64_t N, int K, const LloydChain ch, uint8_t *__restrict__ labels, float tol,
     float *trace, int has_pending) {
     constexpr int d = 6;
@@ -1043,12 +1073,12 @@ __global__ __launch_bounds__(kFilterThreads) void kmeans_lloyd_chain_kernel(
     if (st0.done) {  // converged earlier: keep the published copies in step, nothing else to do
         if (wg0) {
             if (threadIdx.x == 0) *ch.st_wr = st0;
-            for (int e = threadIdx.x; e < d * K; e += kFilterThreads) ch.cen_wr[e] = ch.cen_rd[e];
-            for (int e = threadIdx.x; e < plen; e += kFilterThreads) ch.tot_wr[e] = ch.tot_rd[e];
+            for (int e = threadIdx.x; e < d * K; e += (int)blockDim.x) ch.cen_wr[e] = ch.cen_rd[e];
+            for (int e = threadIdx.x; e < plen; e += (int)blockDim.x) ch.tot_wr[e] = ch.tot_rd[e];
         }
         return;
     }
-    for (int e = threadIdx.x; e < d * K; e += kFilterThreads) sCen[e] = ch.cen_rd[e];
+    for (int e = threadIdx.x; e < d * K; e += (int)blockDim.x) sCen[e] = ch.cen_rd[e];
     if (threadIdx.x == 0) sSt = st0;
     if (has_pending) {
         fold_lanes(ch.lanes_rd, ch.tot_rd, st0.iter > 0, plen, sTot);
@@ -1058,11 +1088,11 @@ __global__ __launch_bounds__(kFilterThreads) void kmeans_lloyd_chain_kernel(
     __syncthreads();
     if (wg0) {  // publish (read by the next launch, the host's convergence polling and the finalize kernel)
         if (threadIdx.x == 0) *ch.st_wr = sSt;
-        for (int e = threadIdx.x; e < d * K; e += kFilterThreads) ch.cen_wr[e] = sCen[e];
+        for (int e = threadIdx.x; e < d * K; e += (int)blockDim.x) ch.cen_wr[e] = sCen[e];
         if (has_pending)
-            for (int e = threadIdx.x; e < plen; e += kFilterThreads) ch.tot_wr[e] = sTot[e];
+            for (int e = threadIdx.x; e < plen; e += (int)blockDim.x) ch.tot_wr[e] = sTot[e];
         const int total = plen * kAccLanes;
-        for (int i = threadIdx.x; i < total; i += kFilterThreads) ch.lanes_zero[i] = 0;
+        for (int i = threadIdx.x; i < total; i += (int)blockDim.x) ch.lanes_zero[i] = 0;
     }
     if (sSt.done) return;  // the update just applied met the tolerance: no further assignment (kmeans.py:239)
     filter_assign_body<NREGS, SIM>(X, N, K, &sSt, sCen, labels, nullptr, ch.lanes_wr);
@@ -1652,10 +1682,23 @@ static int km_fat_lds_attribute() {
     return ET_OK;
 }
 
-static size_t km_filter_lds_bytes(int d, int K) {
+static size_t km_filter_lds_bytes(int d, int K, int threads) {
     const size_t plen_ = km_plen(d, K);
     return sizeof(long long) * ((plen_ + 1) & ~(size_t)1) + sizeof(float) * (size_t)K * 8 +
-           sizeof(unsigned) * kFilterQueue * (kFilterThreads / 64);
+           sizeof(unsigned) * kFilterQueue * (size_t)(threads / 64);
+}
+
+// 12 or 16 wavefronts per CU for a shard of N points (one workgroup per CU, 256 points per wavefront pass): the
+// launch ends with its slowest wavefront, a pass costs 0.73x as much with three wavefronts per SIMD as with four.
+static int km_filter_threads(int64_t N) {
+    int dev = 0, n_cu = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        n_cu <= 0)
+        n_cu = 256;
+    const int64_t groups = ceil_div(N, (int64_t)256);
+    const int64_t p12 = ceil_div(groups, (int64_t)n_cu * (kFilterMinThreads / 64));
+    const int64_t p16 = ceil_div(groups, (int64_t)n_cu * (kFilterMaxThreads / 64));
+    return (double)p12 * 0.73 < (double)p16 ? kFilterMinThreads : kFilterMaxThreads;
 }
 
 static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_kmeans_state *state,
@@ -1674,18 +1717,18 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_km
     int grid = 1;
     if (ev_begin) ET_HIP_TRY(hipEventRecord(ev_begin, st));
     if (use_filter) {
-        const size_t lds = km_filter_lds_bytes(d, K);
         int rc_attr = km_fat_lds_attribute();
         if (rc_attr) return rc_attr;
-        // small shard (N <= 131072), single-GPU fit: assignment, reduction and update in one launch (at most
+        // small shard (N <= 98304), single-GPU fit: assignment, reduction and update in one launch (at most
         // kSmallMaxBlocks workgroups, one pass per wavefront): 18 us instead of 11 + 7 us and a dispatch gap
         const int64_t passes = ceil_div(N, (int64_t)256);
         float *cen_rw = const_cast<float *>(centroids);
-        if (fused_update && passes <= kSmallMaxBlocks * (kFilterThreads / 64)) {
-            grid = (int)ceil_div(passes, (int64_t)(kFilterThreads / 64));
+        if (fused_update && passes <= kSmallMaxBlocks * (kFilterMaxThreads / 64)) {
+            const size_t lds = km_filter_lds_bytes(d, K, kFilterMaxThreads);  // one pass per wavefront: the wide form
+            grid = (int)ceil_div(passes, (int64_t)(kFilterMaxThreads / 64));
             grid = grid > kSmallMaxBlocks ? kSmallMaxBlocks : grid;
 #define ET_LAUNCH_SMALL(NR, SIM)                                                                                          \
-    hipLaunchKernelGGL((kmeans_lloyd_small_kernel<NR, SIM>), dim3(grid), dim3(kFilterThreads), lds, st, X, N, K, state,    \
+    hipLaunchKernelGGL((kmeans_lloyd_small_kernel<NR, SIM>), dim3(grid), dim3(kFilterMaxThreads), lds, st, X, N, K, state, \
                        cen_rw, labels_u8, w.block_partials, (long long *)partials, w.ticket, tol, trace, w.last)
             if (K <= 20) {
                 if (want_sim) ET_LAUNCH_SMALL(10, true);
@@ -1699,13 +1742,15 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_km
             if (ev_end) ET_HIP_TRY(hipEventRecord(ev_end, st));
             return ET_OK;
         }
+        const int threads = km_filter_threads(N);
+        const size_t lds = km_filter_lds_bytes(d, K, threads);
         if (K <= 20) {
-            grid = km_resident_grid(kmeans_assign_filter_kernel<10>, lds, N / 4, kFilterThreads);
-            hipLaunchKernelGGL(kmeans_assign_filter_kernel<10>, dim3(grid), dim3(kFilterThreads), lds, st, X, N, K, state,
+            grid = km_resident_grid(kmeans_assign_filter_kernel<10>, lds, N / 4, threads);
+            hipLaunchKernelGGL(kmeans_assign_filter_kernel<10>, dim3(grid), dim3(threads), lds, st, X, N, K, state,
                                centroids, labels_u8, w.block_partials, (long long *)nullptr);
         } else {
-            grid = km_resident_grid(kmeans_assign_filter_kernel<16>, lds, N / 4, kFilterThreads);
-            hipLaunchKernelGGL(kmeans_assign_filter_kernel<16>, dim3(grid), dim3(kFilterThreads), lds, st, X, N, K, state,
+            grid = km_resident_grid(kmeans_assign_filter_kernel<16>, lds, N / 4, threads);
+            hipLaunchKernelGGL(kmeans_assign_filter_kernel<16>, dim3(grid), dim3(threads), lds, st, X, N, K, state,
                                centroids, labels_u8, w.block_partials, (long long *)nullptr);
         }
     } else if (N > 0) {
@@ -1916,7 +1961,8 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     const bool chained = km_use_filter(X, N, d, K, w.labels_u8) &&
                          ceil_div(N, (int64_t)256) > (int64_t)kChainMinPasses;
     if (chained) {
-        const size_t plen = km_plen(d, K), lds = km_filter_lds_bytes(d, K);
+        const int threads = km_filter_threads(N);
+        const size_t plen = km_plen(d, K), lds = km_filter_lds_bytes(d, K, threads);
         rc = km_fat_lds_attribute();
         if (rc) return rc;
         ET_HIP_TRY(hipMemcpyAsync(w.chain_state[0], w.state, sizeof(et_kmeans_state), hipMemcpyDeviceToDevice, st));
@@ -1943,8 +1989,8 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
             if (timed(it)) ET_HIP_TRY(hipEventRecord(events[2 * it], st));
 #define ET_LAUNCH_CHAIN(NR, SIM)                                                                                          \
     do {                                                                                                                  \
-        if (!grid) grid = km_resident_grid(kmeans_lloyd_chain_kernel<NR, SIM>, lds, N / 4, kFilterThreads);               \
-        hipLaunchKernelGGL((kmeans_lloyd_chain_kernel<NR, SIM>), dim3(grid), dim3(kFilterThreads), lds, st, X, N, K, ch,   \
+        if (!grid) grid = km_resident_grid(kmeans_lloyd_chain_kernel<NR, SIM>, lds, N / 4, threads);                      \
+        hipLaunchKernelGGL((kmeans_lloyd_chain_kernel<NR, SIM>), dim3(grid), dim3(threads), lds, st, X, N, K, ch,          \
                            w.labels_u8, tol, trace, it > 0 ? 1 : 0);                                                      \
     } while (0)
             if (K <= 20) {
