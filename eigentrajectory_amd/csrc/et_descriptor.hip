@@ -607,9 +607,30 @@ __global__ __launch_bounds__(kTile) void reconstruct_bwd_tile_kernel(
     float4 *dst4 = reinterpret_cast<float4 *>(sIn);
     const int per_plane = rows * QP;
     const int total = S * per_plane;
-    for (int q = tid; q < total; q += kTile) {
-        const int s = q / per_plane, r = q - s * per_plane;
-        dst4[q] = in4[((int64_t)s * N + n0) * QP + r];
+    {
+        // The gradient tile is S runs of per_plane float4, one per sample plane: ALL of a thread's loads (<= QP, as
+        // S * TN <= kTile) are issued before the first LDS write -- a load / wait / write loop keeps one 16-byte request
+        // per thread in flight and is bound by the memory latency (4.9 TB/s at S = 20), not the bandwidth.  (plane,
+        // offset) advance incrementally: one division per thread instead of one per element.
+        int sp = tid / per_plane, r = tid - sp * per_plane;
+        const int da = kTile / per_plane, db = kTile - da * per_plane;
+        float4 buf[QP];
+#pragma unroll
+        for (int it = 0; it < QP; ++it) {
+            const bool in = tid + it * kTile < total;
+            buf[it] = in4[in ? ((int64_t)sp * N + n0) * QP + r : (int64_t)0];  // (index 0 is always readable)
+            sp += da;
+            r += db;
+            if (r >= per_plane) {
+                r -= per_plane;
+                ++sp;
+            }
+        }
+        // unconditional stores (threads past the tile's end hit a spare slot): a conditional store would let the compiler
+        // sink each load next to it again
+        const int spare = (int)((sU + 2 * DP * K - sIn) / 4);
+#pragma unroll
+        for (int it = 0; it < QP; ++it) dst4[tid + it * kTile < total ? tid + it * kTile : spare] = buf[it];
     }
     for (int i = tid; i < 2 * DP * K; i += kTile) {
         const float *src = (i >= DP * K) ? U_m : U_s;
@@ -811,7 +832,7 @@ extern "C" int et_anchor_reconstruct_bwd(const float *dtraj, int64_t N, int S, i
     const bool fast = T_pred == 12 && k == 6 && S <= kTile && aligned16(dtraj);
     if (fast) {
         const int TN = kTile / S;
-        const size_t lds = sizeof(float) * ((size_t)TN * S * 24 + (size_t)TN * kNormStride + 2 * 24 * 6);
+        const size_t lds = sizeof(float) * ((size_t)TN * S * 24 + (size_t)TN * kNormStride + 2 * 24 * 6 + 4);  // + a spare float4
         hipLaunchKernelGGL((reconstruct_bwd_tile_kernel<12, 6>), dim3((unsigned)ceil_div(N, TN)), dim3(kTile), lds, st,
                            dtraj, N, S, TN, T_obs, obs, nrm, U_pred_m, U_pred_s, mode, static_dist, dC);
     } else {
