@@ -1135,21 +1135,22 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     long long *sTot = reinterpret_cast<long long *>(smem_raw) + 512;
     float *sCen = reinterpret_cast<float *>(sTot + ((plen + 1) & ~1));
     const bool wg0 = blockIdx.x == 0;
-    const et_kmeans_state st0 = *ch.st_rd;
-    if (st0.done) {  // converged earlier: keep the published copies in step, nothing else to do
+    // (no local copy of the state block: a by-value et_kmeans_state whose address is taken ends up in scratch memory,
+    // and a kernel with a private segment pays for it at every wavefront launch)
+    if (ch.st_rd->done) {  // converged earlier: keep the published copies in step, nothing else to do
         if (wg0) {
-            if (threadIdx.x == 0) *ch.st_wr = st0;
+            if (threadIdx.x == 0) *ch.st_wr = *ch.st_rd;
             for (int e = threadIdx.x; e < d * K; e += (int)blockDim.x) ch.cen_wr[e] = ch.cen_rd[e];
             for (int e = threadIdx.x; e < plen; e += (int)blockDim.x) ch.tot_wr[e] = ch.tot_rd[e];
         }
         return;
     }
     for (int e = threadIdx.x; e < d * K; e += (int)blockDim.x) sCen[e] = ch.cen_rd[e];
-    if (threadIdx.x == 0) sSt = st0;
+    if (threadIdx.x == 0) sSt = *ch.st_rd;
     if (has_pending) {
-        fold_lanes(ch.lanes_rd, ch.tot_rd, st0.iter > 0, plen, sTot);
+        fold_lanes(ch.lanes_rd, ch.tot_rd, ch.st_rd->iter > 0, plen, sTot);
         __syncthreads();
-        update_body(&sSt, sTot, d, K, tol, sCen, wg0 ? trace : nullptr, &st0, wg0 ? ch.last : nullptr);
+        update_body(&sSt, sTot, d, K, tol, sCen, wg0 ? trace : nullptr, ch.st_rd, wg0 ? ch.last : nullptr);
     }
     __syncthreads();
     if (wg0) {  // publish (read by the next launch, the host's convergence polling and the finalize kernel)
@@ -1171,19 +1172,18 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_chain_finalize_kernel(const
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int plen = d * K + K + 2;
     long long *sTot = reinterpret_cast<long long *>(smem_raw) + 512;
-    const et_kmeans_state st0 = *ch.st_rd;
     for (int e = threadIdx.x; e < d * K; e += kKmThreads) cen[e] = ch.cen_rd[e];
-    if (st0.done || !has_pending) {
-        if (threadIdx.x == 0) *state = st0;
+    if (ch.st_rd->done || !has_pending) {
+        if (threadIdx.x == 0) *state = *ch.st_rd;
         for (int e = threadIdx.x; e < plen; e += kKmThreads) partials[e] = ch.tot_rd[e];
         return;
     }
-    fold_lanes(ch.lanes_rd, ch.tot_rd, st0.iter > 0, plen, sTot);
+    fold_lanes(ch.lanes_rd, ch.tot_rd, ch.st_rd->iter > 0, plen, sTot);
     __syncthreads();
     for (int e = threadIdx.x; e < plen; e += kKmThreads) partials[e] = sTot[e];
-    if (threadIdx.x == 0) *state = st0;
+    if (threadIdx.x == 0) *state = *ch.st_rd;
     __syncthreads();
-    update_body(state, sTot, d, K, tol, cen, trace, &st0, ch.last);
+    update_body(state, sTot, d, K, tol, cen, trace, ch.st_rd, ch.last);
 }
 
 // Inertia of the LAST assignment of a fit that did not track it per iteration (kmeans.py:234 of that iteration):
