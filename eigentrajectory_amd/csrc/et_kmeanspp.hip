@@ -207,10 +207,15 @@ __global__ __launch_bounds__(kPpThreads) void kpp_locate_kernel(const float *__r
 
 // D[j][n] = min(closest[n], max((float)(((-2 x_n.c_j) + |c_j|^2) + |x_n|^2), 0)); partials[j][block] = sum_n D[j][n] (fp64).
 // closest == nullptr (first centre): no min.
-__global__ __launch_bounds__(kPpThreads) void kpp_dist_kernel(const float *__restrict__ X, int64_t N, int d,
+// DIM = 6: the coefficient dimension of the path, compile-time loops and the point in registers; DIM = 0: any
+// d <= ET_KMEANS_MAX_D with runtime loops (its runtime-indexed `double x[d]` lives in scratch memory)
+template <int DIM>
+__global__ __launch_bounds__(kPpThreads) void kpp_dist_kernel(const float *__restrict__ X, int64_t N, int d_rt,
                                                                const int64_t *__restrict__ cand, int n_trials,
                                                                const float *__restrict__ closest, float *__restrict__ D,
                                                                double *__restrict__ partials, int64_t n_blocks) {
+    constexpr int DM = DIM ? DIM : ET_KMEANS_MAX_D;
+    const int d = DIM ? DIM : d_rt;
     __shared__ double cen[kPpMaxTrials][ET_KMEANS_MAX_D + 1];  // [j][r], [j][d] = |c_j|^2
     __shared__ double part[kPpMaxTrials][kPpThreads / kWave];
     if (threadIdx.x < n_trials * d) {
@@ -231,18 +236,31 @@ __global__ __launch_bounds__(kPpThreads) void kpp_dist_kernel(const float *__res
     for (int i = threadIdx.x; i < kPpBlock; i += kPpThreads) {
         const int64_t n = base + i;
         if (n >= N) break;
-        double x[ET_KMEANS_MAX_D];
+        double x[DM];
         double xx = 0.0;
-        for (int r = 0; r < d; ++r) {
-            x[r] = (double)X[(int64_t)r * N + n];
-            xx += x[r] * x[r];
+        if constexpr (DIM != 0) {
+#pragma unroll
+            for (int r = 0; r < DM; ++r) {
+                x[r] = (double)X[(int64_t)r * N + n];
+                xx += x[r] * x[r];
+            }
+        } else {
+            for (int r = 0; r < d; ++r) {
+                x[r] = (double)X[(int64_t)r * N + n];
+                xx += x[r] * x[r];
+            }
         }
         const float cl = closest ? closest[n] : 0.0f;
 #pragma unroll
         for (int j = 0; j < kPpMaxTrials; ++j) {
             if (j < n_trials) {
                 double dot = 0.0;
-                for (int r = 0; r < d; ++r) dot += cen[j][r] * x[r];
+                if constexpr (DIM != 0) {
+#pragma unroll
+                    for (int r = 0; r < DM; ++r) dot += cen[j][r] * x[r];
+                } else {
+                    for (int r = 0; r < d; ++r) dot += cen[j][r] * x[r];
+                }
                 const double dd = (-2.0 * dot + cen[j][d]) + xx;
                 float f = (float)dd;
                 f = f > 0.0f ? f : 0.0f;          // np.maximum(distances, 0)
@@ -370,8 +388,12 @@ extern "C" int et_kmeanspp_seed(const float *X, int64_t N, int d, int K, int n_t
     // first centre: index floor(u0 * N); closest = its distances (no min), potential = their sum
     hipLaunchKernelGGL(kpp_locate_kernel, dim3(1), dim3(kPpThreads), 0, st, (const float *)nullptr, N,
                        (const double *)nullptr, nb, w.prefix, uniforms, 1, 0, (const float *)nullptr, w.cand);
-    hipLaunchKernelGGL(kpp_dist_kernel, dim3((unsigned)nb), dim3(kPpThreads), 0, st, X, N, d, (const int64_t *)w.cand, 1,
-                       (const float *)nullptr, w.D, w.partials, nb);
+    if (d == 6)
+        hipLaunchKernelGGL(kpp_dist_kernel<6>, dim3((unsigned)nb), dim3(kPpThreads), 0, st, X, N, d, (const int64_t *)w.cand, 1,
+                           (const float *)nullptr, w.D, w.partials, nb);
+    else
+        hipLaunchKernelGGL(kpp_dist_kernel<0>, dim3((unsigned)nb), dim3(kPpThreads), 0, st, X, N, d, (const int64_t *)w.cand, 1,
+                           (const float *)nullptr, w.D, w.partials, nb);
     hipLaunchKernelGGL(kpp_select_kernel, dim3(1), dim3(kPpThreads), 0, st, (const double *)w.partials, nb, 1,
                        (const int64_t *)w.cand, X, N, d, K, 0, w.pot, w.best, centers, indices);
     for (int c = 1; c < K; ++c) {
@@ -380,8 +402,12 @@ extern "C" int et_kmeanspp_seed(const float *X, int64_t N, int d, int K, int n_t
         hipLaunchKernelGGL(kpp_locate_kernel, dim3(1), dim3(kPpThreads), 0, st, (const float *)w.closest, N,
                            (const double *)w.blocksums, nb, w.prefix, uniforms + 1 + (size_t)(c - 1) * n_trials, n_trials, c,
                            (const float *)w.pot, w.cand);
-        hipLaunchKernelGGL(kpp_dist_kernel, dim3((unsigned)nb), dim3(kPpThreads), 0, st, X, N, d, (const int64_t *)w.cand,
-                           n_trials, (const float *)w.closest, w.D, w.partials, nb);
+        if (d == 6)
+            hipLaunchKernelGGL(kpp_dist_kernel<6>, dim3((unsigned)nb), dim3(kPpThreads), 0, st, X, N, d, (const int64_t *)w.cand,
+                               n_trials, (const float *)w.closest, w.D, w.partials, nb);
+        else
+            hipLaunchKernelGGL(kpp_dist_kernel<0>, dim3((unsigned)nb), dim3(kPpThreads), 0, st, X, N, d, (const int64_t *)w.cand,
+                               n_trials, (const float *)w.closest, w.D, w.partials, nb);
         hipLaunchKernelGGL(kpp_select_kernel, dim3(1), dim3(kPpThreads), 0, st, (const double *)w.partials, nb, n_trials,
                            (const int64_t *)w.cand, X, N, d, K, c, w.pot, w.best, centers, indices);
     }
