@@ -692,6 +692,8 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
     stage_centroids(cen, d, K, sC);
     // slot 7 of a centroid row: the |c|^2 part of the rounding slack of the trace-less certification (below)
     for (int j = threadIdx.x; j < K; j += n_thr) sC[j * 8 + 7] = fmaf(sC[j * 8 + 6] * sg2, kCcSlack, 2.3283064365386963e-10f);
+    __shared__ int sNext;  // next of this workgroup's passes: the wavefronts take them as they come (see the loop)
+    if (threadIdx.x == 0) sNext = 0;
     __syncthreads();
 
 
@@ -738,7 +740,26 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
     int terms = 0;
     int qn = 0;  // wave-uniform number of queued points
     const int64_t n_groups = (N + 255) / 256;
-    for (int64_t g = (int64_t)blockIdx.x * n_wav + wave; g < n_groups; g += (int64_t)gridDim.x * n_wav) {
+    // The workgroup's passes (the same set as with a fixed wavefront -> pass map) are handed out through an LDS counter:
+    // a SIMD serves its oldest wavefront first, so with a fixed map the first wavefront of a SIMD finished its share at
+    // 27 us of a 41 us assignment phase and the SIMD ran its tail with two, then one wavefront.  Sums are exact integers
+    // and labels per point, so who processes a pass does not matter.
+    // (shards with at most one pass per wavefront keep the fixed map: nothing to balance, and no counter round trip)
+    const bool dynamic = n_groups > (int64_t)gridDim.x * n_wav;
+    bool first = true;
+    for (;;) {
+        int64_t g;
+        if (dynamic) {
+            int i = 0;
+            if (lane == 0) i = atomicAdd(&sNext, 1);
+            i = __builtin_amdgcn_readfirstlane(i);
+            g = (int64_t)blockIdx.x * n_wav + (i % n_wav) + (int64_t)(i / n_wav) * gridDim.x * n_wav;
+        } else {
+            if (!first) break;
+            first = false;
+            g = (int64_t)blockIdx.x * n_wav + wave;
+        }
+        if (g >= n_groups) break;
         const int64_t n = g * 256 + 128 * half + 4 * col;
         const bool valid = n < N;  // N % 4 == 0
         float4 v[6];
