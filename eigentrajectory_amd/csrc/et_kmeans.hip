@@ -963,22 +963,24 @@ __device__ __forceinline__ void update_body(et_kmeans_state *state, const long l
     // max |c| (NaN ignored), smallest non-zero |c| and a non-finite flag, reduced by the first wavefront
     __shared__ float sRed[3];
     __shared__ double sErr;
-    if (threadIdx.x == 64 || (blockDim.x <= 64 && threadIdx.x == 0)) {
-        // kmeans.py:50 in the oracle's fixed order -- a serial chain of d K fp64 additions; it runs on the second
-        // wavefront next to the reductions below, and reads its operands four at a time
-        double err = 0.0;
-        const int dk = d * K;
-        const float4 *s4 = reinterpret_cast<const float4 *>(sSq);
-        int e = 0;
-        for (; e + 4 <= dk; e += 4) {
-            const float4 v = s4[e >> 2];
-            err += (double)v.x;
-            err += (double)v.y;
-            err += (double)v.z;
-            err += (double)v.w;
+    if (blockDim.x <= 64 || (threadIdx.x >> 6) == 1) {
+        // kmeans.py:50 in the oracle's fixed order (oracle/et_oracle.c: eto_error_sum): fp64, blocks of 256 consecutive
+        // terms, each a balanced tree x[i] += x[i + s], s = 1 ... 128, block results added in block order.  A lane holds
+        // four consecutive terms (levels s = 1, 2), the lanes combine through shuffles (s = 4 ... 128): seven dependent
+        // additions instead of the d K of a running sum (1.7 us of every Lloyd launch's prologue with d K = 120).
+        // It runs on the second wavefront next to the reductions below.
+        const int l = threadIdx.x & 63, dk = d * K;
+        double total = 0.0;
+        for (int b0 = 0; b0 < dk; b0 += 256) {
+            float f[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f[q] = b0 + 4 * l + q < dk ? sSq[b0 + 4 * l + q] : 0.f;
+            double t = ((double)f[0] + (double)f[1]) + ((double)f[2] + (double)f[3]);
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) t = t + __shfl_down(t, o);  // valid in the lanes that are multiples of 2 o
+            total = total + t;
         }
-        for (; e < dk; ++e) err += (double)sSq[e];
-        sErr = err;
+        if (l == 0) sErr = total;
     }
     if (threadIdx.x < 64) {
         float mx = 0.f;

@@ -588,6 +588,23 @@ int eto_kmeans_assign_accumulate(const float *X, int64_t N, int d, const float *
     return ETO_OK;
 }
 
+/* kmeans.py:45-51 sums the d K squared differences with torch's fp32 reduction.  The summation ORDER is this build's own
+ * choice (the result is compared with the reference's at a tolerance): fp64, blocks of 256 consecutive terms (zero padded),
+ * each reduced by the balanced tree x[i] += x[i + s] for s = 1, 2, 4, ..., 128 -- seven dependent additions, a wavefront's
+ * natural reduction -- and the block results added in block order. */
+static double eto_error_sum(const float *sq, int n)
+{
+    double total = 0.0;
+    for (int b0 = 0; b0 < n; b0 += 256) {
+        double x[256];
+        for (int i = 0; i < 256; ++i) x[i] = b0 + i < n ? (double)sq[b0 + i] : 0.0;
+        for (int s = 1; s < 256; s <<= 1)
+            for (int i = 0; i + s < 256; i += 2 * s) x[i] = x[i] + x[i + s];
+        total = total + x[0];
+    }
+    return total;
+}
+
 /* Centroid update + convergence scalars from (all-reduced) exact sums:
  * kmeans.py:180-182 (mean; empty cluster -> 0/0 = NaN), :45-51 (error),
  * :53-57 (inertia), :239 (error <= tol).  Returns converged flag in *done. */
@@ -595,7 +612,8 @@ int eto_kmeans_update(const int64_t *sums, const int64_t *counts, int64_t sim_su
                       int64_t n_total, int d, int K, int frac, int sim_frac, float tol,
                       const float *C_old, float *C_new, float *error, float *inertia, int *done)
 {
-    double err = 0.0;
+    float *sq = (float *)malloc(sizeof(float) * (size_t)d * K);
+    if (!sq) return ETO_EINVAL;
     for (int t = 0; t < d; ++t)
         for (int j = 0; j < K; ++j) {
             float c;
@@ -603,9 +621,10 @@ int eto_kmeans_update(const int64_t *sums, const int64_t *counts, int64_t sim_su
             else c = (float)(ldexp((double)sums[t * K + j], -frac) / (double)counts[j]);
             C_new[t * K + j] = c;
             const float diff = C_old[t * K + j] - c;
-            err += (double)(diff * diff);
+            sq[t * K + j] = diff * diff;
         }
-    *error = (float)err;
+    *error = (float)eto_error_sum(sq, d * K);
+    free(sq);
     *inertia = nan_count > 0 ? NAN : (float)(-(ldexp((double)sim_sum, -sim_frac) / (double)n_total));
     *done = (*error <= tol) ? 1 : 0;
     return ETO_OK;
