@@ -1130,36 +1130,50 @@ struct LloydChain {
 
 // fold the 16 copies of every total (layout [entry][copy]: a linear, coalesced sweep, 16 adjacent lanes per entry) and
 // add the running totals of the earlier iterations -> sTot (LDS)
+// The fold of the kAccLanes copies of the delta table onto the previous totals, in two halves so that the caller can
+// put its other loads between them: fold_issue() requests every value (clamped indices keep the register arrays out
+// of scratch memory), fold_combine() sums.  d = 6, K <= 32 with the filter kernels' 768 / 1024 threads needs 3 ... 5
+// sweeps of blockDim.x entries; fold_lanes() is the plain loop for any other shape.
+constexpr int kFoldSweeps = 5;
+struct FoldRegs {
+    long long v[kFoldSweeps], prev[kFoldSweeps];
+};
+__device__ __forceinline__ bool fold_fits(int plen) { return kFoldSweeps * (int)blockDim.x >= plen * kAccLanes; }
+__device__ __forceinline__ void fold_issue(const long long *__restrict__ lanes, const long long *__restrict__ tot_prev,
+                                           int plen, FoldRegs &r) {
+    const int total = plen * kAccLanes, n_threads = (int)blockDim.x;
+#pragma unroll
+    for (int it = 0; it < kFoldSweeps; ++it) {
+        const int idx = it * n_threads + (int)threadIdx.x;
+        const int ci = idx < total ? idx : 0;
+        r.v[it] = lanes[ci];
+        r.prev[it] = tot_prev[ci / kAccLanes];
+    }
+}
+__device__ __forceinline__ void fold_combine(const FoldRegs &r, bool have_prev, int plen, long long *sTot) {
+    const int total = plen * kAccLanes, n_threads = (int)blockDim.x;
+#pragma unroll
+    for (int it = 0; it < kFoldSweeps; ++it) {
+        const int idx = it * n_threads + (int)threadIdx.x;
+        if (it * n_threads >= total) break;  // uniform
+        long long x = idx < total ? r.v[it] : 0;
+#pragma unroll
+        for (int o = kAccLanes / 2; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        if (idx < total && (idx & (kAccLanes - 1)) == 0) {
+            const int e = idx / kAccLanes;
+            sTot[e] = ((have_prev && e < plen - 2) ? r.prev[it] : 0) + x;
+        }
+    }
+}
 __device__ __forceinline__ void fold_lanes(const long long *__restrict__ lanes, const long long *__restrict__ tot_prev,
                                            bool have_prev, int plen, long long *sTot) {
-    // every load of the fold -- the kAccLanes copies and the previous totals -- is requested before the first one is
-    // used (clamped indices keep the register arrays out of scratch memory): one memory round trip instead of two per
-    // sweep of blockDim.x entries (2.1 -> 0.9 us of every Lloyd launch's prologue)
-    const int total = plen * kAccLanes, n_threads = (int)blockDim.x;
-    constexpr int kSweeps = 5;  // d = 6, K <= 32 with the filter kernels' 768 / 1024 threads: 3 ... 5 sweeps
-    if (kSweeps * n_threads >= total) {
-        long long v[kSweeps], prev[kSweeps];
-#pragma unroll
-        for (int it = 0; it < kSweeps; ++it) {
-            const int idx = it * n_threads + (int)threadIdx.x;
-            const int ci = idx < total ? idx : 0;
-            v[it] = lanes[ci];
-            prev[it] = tot_prev[ci / kAccLanes];
-        }
-#pragma unroll
-        for (int it = 0; it < kSweeps; ++it) {
-            const int idx = it * n_threads + (int)threadIdx.x;
-            if (it * n_threads >= total) break;  // uniform
-            long long x = idx < total ? v[it] : 0;
-#pragma unroll
-            for (int o = kAccLanes / 2; o > 0; o >>= 1) x += __shfl_xor(x, o);
-            if (idx < total && (idx & (kAccLanes - 1)) == 0) {
-                const int e = idx / kAccLanes;
-                sTot[e] = ((have_prev && e < plen - 2) ? prev[it] : 0) + x;
-            }
-        }
+    if (fold_fits(plen)) {
+        FoldRegs r;
+        fold_issue(lanes, tot_prev, plen, r);
+        fold_combine(r, have_prev, plen, sTot);
         return;
     }
+    const int total = plen * kAccLanes, n_threads = (int)blockDim.x;
     for (int base = 0; base < total; base += n_threads) {
         const int idx = base + (int)threadIdx.x;
         long long v = idx < total ? lanes[idx] : 0;
@@ -1187,7 +1201,13 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     const bool wg0 = blockIdx.x == 0;
     // (no local copy of the state block: a by-value et_kmeans_state whose address is taken ends up in scratch memory,
     // and a kernel with a private segment pays for it at every wavefront launch)
-    if (ch.st_rd->done) {  // converged earlier: keep the published copies in step, nothing else to do
+    // Everything the prologue needs from memory is requested at once -- the convergence flag, the centroids (d K <= 192
+    // <= blockDim.x values), the delta table and the previous totals: one round trip, not three dependent ones.
+    const int64_t done0 = ch.st_rd->done, iter0 = ch.st_rd->iter;
+    const float cen0 = ch.cen_rd[(int)threadIdx.x < d * K ? (int)threadIdx.x : 0];
+    FoldRegs fr;
+    fold_issue(ch.lanes_rd, ch.tot_rd, plen, fr);  // (the filter kernels' launch sizes always fit: fold_fits())
+    if (done0) {  // converged earlier: keep the published copies in step, nothing else to do
         if (wg0) {
             if (threadIdx.x == 0) *ch.st_wr = *ch.st_rd;
             for (int e = threadIdx.x; e < d * K; e += (int)blockDim.x) ch.cen_wr[e] = ch.cen_rd[e];
@@ -1195,10 +1215,10 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
         }
         return;
     }
-    for (int e = threadIdx.x; e < d * K; e += (int)blockDim.x) sCen[e] = ch.cen_rd[e];
+    if ((int)threadIdx.x < d * K) sCen[threadIdx.x] = cen0;
     if (threadIdx.x == 0) sSt = *ch.st_rd;
     if (has_pending) {
-        fold_lanes(ch.lanes_rd, ch.tot_rd, ch.st_rd->iter > 0, plen, sTot);
+        fold_combine(fr, iter0 > 0, plen, sTot);
         __syncthreads();
         update_body(&sSt, sTot, d, K, tol, sCen, wg0 ? trace : nullptr, ch.st_rd, wg0 ? ch.last : nullptr);
     }
