@@ -1204,6 +1204,8 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     // Everything the prologue needs from memory is requested at once -- the convergence flag, the centroids (d K <= 192
     // <= blockDim.x values), the delta table and the previous totals: one round trip, not three dependent ones.
     const int64_t done0 = ch.st_rd->done, iter0 = ch.st_rd->iter;
+    constexpr int kStateWords = (int)(sizeof(et_kmeans_state) / sizeof(unsigned));
+    const unsigned st_word = reinterpret_cast<const unsigned *>(ch.st_rd)[(int)threadIdx.x < kStateWords ? (int)threadIdx.x : 0];
     const float cen0 = ch.cen_rd[(int)threadIdx.x < d * K ? (int)threadIdx.x : 0];
     FoldRegs fr;
     fold_issue(ch.lanes_rd, ch.tot_rd, plen, fr);  // (the filter kernels' launch sizes always fit: fold_fits())
@@ -1216,11 +1218,11 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
         return;
     }
     if ((int)threadIdx.x < d * K) sCen[threadIdx.x] = cen0;
-    if (threadIdx.x == 0) sSt = *ch.st_rd;
+    if ((int)threadIdx.x < kStateWords) reinterpret_cast<unsigned *>(&sSt)[threadIdx.x] = st_word;  // the state block, word by word
     if (has_pending) {
         fold_combine(fr, iter0 > 0, plen, sTot);
         __syncthreads();
-        update_body(&sSt, sTot, d, K, tol, sCen, wg0 ? trace : nullptr, ch.st_rd, wg0 ? ch.last : nullptr);
+        update_body(&sSt, sTot, d, K, tol, sCen, wg0 ? trace : nullptr, nullptr, wg0 ? ch.last : nullptr);  // reads its copy in LDS
     }
     __syncthreads();
     if (wg0) {  // publish (read by the next launch, the host's convergence polling and the finalize kernel)
