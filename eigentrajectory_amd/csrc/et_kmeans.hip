@@ -19,7 +19,6 @@
 //                    kmeans_lloyd_chain_kernel      ... one launch per iteration: every workgroup applies the PREVIOUS
 //                                                    iteration's update itself (fold of 16 copies of the exact totals,
 //                                                    means, error, convergence) and then assigns; no serial section
-//   small shards     kmeans_lloyd_small_kernel      the whole iteration in one launch, <= 32 workgroups
 //   after the loop   kmeans_inertia_kernel          inertia of the last assignment when no trace was requested
 // Everything else (other d / K, given labels, the sharded step API) runs the exact scan and a two-kernel fold + update.
 //
@@ -1041,67 +1040,6 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_update_kernel(et_kmeans_sta
     update_body(state, partials, d, K, tol, cen, trace);
 }
 
-// Small shards (a few workgroups): the whole Lloyd iteration in ONE launch.  Every workgroup assigns its points
-// and writes its partials as above, then takes a ticket (release fence -> device-scope atomic -> acquire fence);
-// the last one to arrive folds the <= 32 partial blocks into the running totals and runs the update.  With so
-// few arrivals the ticket costs well under a microsecond, and a launch (~7 us + its dispatch gap) disappears
-// from a loop whose kernels themselves only take a few microseconds.  `cen` is read by every workgroup in its
-// prologue only, i.e. before the last arrival, so updating it in place is safe.
-constexpr int kSmallMaxBlocks = 32;
-#ifndef ET_CHAIN_MIN_PASSES
-#define ET_CHAIN_MIN_PASSES (kSmallMaxBlocks * (kFilterMaxThreads / 64))  // right above what the one-launch small form takes
-#endif
-constexpr int kChainMinPasses = ET_CHAIN_MIN_PASSES;  // shards above this many 256-point passes run the chained form
-
-template <int NREGS, bool SIM>
-__global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_small_kernel(
-    const float *__restrict__ X, int64_t N, int K, et_kmeans_state *state, float *cen, uint8_t *__restrict__ labels,
-    long long *block_partials, long long *partials, unsigned *ticket, float tol, float *trace, float *last) {
-    if (state->done) return;
-    constexpr int d = 6;
-    filter_assign_body<NREGS, SIM>(X, N, K, state, cen, labels, block_partials);
-    __shared__ int sLast;
-    __syncthreads();  // this workgroup's partials are written
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned arrived = atomicAdd(ticket, 1u);
-        sLast = arrived == gridDim.x - 1;
-        if (sLast) {
-            *ticket = 0u;  // ready for the next launch
-            __threadfence();
-        }
-    }
-    __syncthreads();
-    if (!sLast) return;
-    const int plen = d * K + K + 2, n_blocks = (int)gridDim.x;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    long long *sTot = reinterpret_cast<long long *>(smem_raw) + 512;  // past the 2 d K floats update_body uses
-    const int n_thr = (int)blockDim.x;
-    for (int i = threadIdx.x; i < plen; i += n_thr) sTot[i] = 0;
-    __syncthreads();
-    // [entry][workgroup] partials: all loads first, then exact integer sums through LDS atomics
-    constexpr int kPer = ((6 * 32 + 32 + 2) * kSmallMaxBlocks + kFilterMinThreads - 1) / kFilterMinThreads;  // K <= 32, any launch size
-    long long v[kPer];
-    const int total = plen * n_blocks;
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-        const int idx = threadIdx.x + k * n_thr;
-        v[k] = idx < total ? block_partials[idx] : 0;
-    }
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-        const int idx = threadIdx.x + k * n_thr;
-        if (idx < total && v[k] != 0)
-            atomicAdd(reinterpret_cast<unsigned long long *>(&sTot[idx / n_blocks]), (unsigned long long)v[k]);
-    }
-    __syncthreads();
-    const bool have_totals = state->iter > 0;
-    for (int e = threadIdx.x; e < plen; e += n_thr)
-        partials[e] = ((have_totals && e < plen - 2) ? partials[e] : 0) + sTot[e];
-    __syncthreads();
-    update_body(state, partials, d, K, tol, cen, trace, nullptr, last);
-}
-
 // Large shards, single-GPU fit: ONE launch per Lloyd iteration and NO serial section between two iterations.
 //
 // A launch first applies the update of the PREVIOUS iteration's assignment and then makes its own assignment:
@@ -1807,10 +1745,6 @@ static int km_fat_lds_attribute() {
     if (lds_ok) return ET_OK;
     const void *fat[] = {reinterpret_cast<const void *>(kmeans_assign_filter_kernel<10>),
                          reinterpret_cast<const void *>(kmeans_assign_filter_kernel<16>),
-                         reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<10, true>),
-                         reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<10, false>),
-                         reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<16, true>),
-                         reinterpret_cast<const void *>(kmeans_lloyd_small_kernel<16, false>),
                          reinterpret_cast<const void *>(kmeans_lloyd_chain_kernel<10, true>),
                          reinterpret_cast<const void *>(kmeans_lloyd_chain_kernel<10, false>),
                          reinterpret_cast<const void *>(kmeans_lloyd_chain_kernel<16, true>),
@@ -1857,29 +1791,6 @@ static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_km
     if (use_filter) {
         int rc_attr = km_fat_lds_attribute();
         if (rc_attr) return rc_attr;
-        // small shard (N <= 98304), single-GPU fit: assignment, reduction and update in one launch (at most
-        // kSmallMaxBlocks workgroups, one pass per wavefront): 18 us instead of 11 + 7 us and a dispatch gap
-        const int64_t passes = ceil_div(N, (int64_t)256);
-        float *cen_rw = const_cast<float *>(centroids);
-        if (fused_update && passes <= kSmallMaxBlocks * (kFilterMaxThreads / 64)) {
-            const size_t lds = km_filter_lds_bytes(d, K, kFilterMaxThreads);  // one pass per wavefront: the wide form
-            grid = (int)ceil_div(passes, (int64_t)(kFilterMaxThreads / 64));
-            grid = grid > kSmallMaxBlocks ? kSmallMaxBlocks : grid;
-#define ET_LAUNCH_SMALL(NR, SIM)                                                                                          \
-    hipLaunchKernelGGL((kmeans_lloyd_small_kernel<NR, SIM>), dim3(grid), dim3(kFilterMaxThreads), lds, st, X, N, K, state, \
-                       cen_rw, labels_u8, w.block_partials, (long long *)partials, w.ticket, tol, trace, w.last)
-            if (K <= 20) {
-                if (want_sim) ET_LAUNCH_SMALL(10, true);
-                else ET_LAUNCH_SMALL(10, false);
-            } else {
-                if (want_sim) ET_LAUNCH_SMALL(16, true);
-                else ET_LAUNCH_SMALL(16, false);
-            }
-#undef ET_LAUNCH_SMALL
-            ET_LAUNCH_CHECK();
-            if (ev_end) ET_HIP_TRY(hipEventRecord(ev_end, st));
-            return ET_OK;
-        }
         const int threads = km_filter_threads(N);
         const size_t lds = km_filter_lds_bytes(d, K, threads);
         if (K <= 20) {
@@ -2094,10 +2005,11 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     const bool want_sim = trace != nullptr;
     int launched = 0;
     bool done = false;
-    // large shards with the matrix-core filter: the chained form (kmeans_lloyd_chain_kernel) -- every launch applies the
-    // previous iteration's update in its prologue, in every workgroup; one more update after the loop
-    const bool chained = km_use_filter(X, N, d, K, w.labels_u8) &&
-                         ceil_div(N, (int64_t)256) > (int64_t)kChainMinPasses;
+    // shards the matrix-core filter takes: the chained form (kmeans_lloyd_chain_kernel) -- every launch applies the
+    // previous iteration's update in its prologue, in every workgroup; one more update after the loop.  (A one-launch
+    // form with a ticketed fold + update in the last workgroup served shards <= 131072 points until its serial tail
+    // lost to this prologue: 19.8 against 16.8 us per iteration at N = 1e5.)
+    const bool chained = km_use_filter(X, N, d, K, w.labels_u8);
     if (chained) {
         const int threads = km_filter_threads(N);
         const size_t plen = km_plen(d, K), lds = km_filter_lds_bytes(d, K, threads);
