@@ -1417,7 +1417,9 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
             s2 += t * t;
             n2 += cj * cj;
         }
-        sDelta[j] = (float)(sqrt(s2) * (1.0 - 1e-6)) * (1.0f - 1e-6f);
+        // the SQUARE of a lower bound of the distance: the skip test below is delta >= 2 sqrt(E - b), evaluated as
+        // delta^2 >= 4 (E - b) with E - b >= 0 (no square root per point; both sides carry their margins)
+        sDelta[j] = (float)(s2 * (1.0 - 4e-6)) * (1.0f - 1e-6f);
         const float nj = (float)(sqrt(n2) * (1.0 + 1e-6)) * (1.0f + 1e-6f);
         atomicMax(&sCmax, nj == nj ? __float_as_uint(nj) : 0x7f800000u);  // NaN centroid: +inf, nothing is skipped
     }
@@ -1472,7 +1474,8 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             // (a NaN or +inf in b, E or Delta makes the comparison false: full evaluation)
-            const bool skip = sDelta[(l4 >> (8 * v)) & 0xffu] >= 2.0f * sqrtf(E - bb[v]) * 1.00001f;
+            const float w = E - bb[v];
+            const bool skip = w >= 0.0f && sDelta[(l4 >> (8 * v)) & 0xffu] >= 4.0001f * w;
             visit(4 * g + v, bb[v], skip);
         }
     }
@@ -1481,7 +1484,8 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
         bool skip = false;
         if (step > 1) {
             b = best[n];
-            skip = sDelta[(int)nearest[n]] >= 2.0f * sqrtf(E - b) * 1.00001f;
+            const float w = E - b;
+            skip = w >= 0.0f && sDelta[(int)nearest[n]] >= 4.0001f * w;
         }
         visit(n, b, skip);
     }
