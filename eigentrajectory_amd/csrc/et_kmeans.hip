@@ -1964,6 +1964,126 @@ extern "C" int et_kmeans_init_farthest(const float *X, int64_t N, int d, int K, 
     return rc;
 }
 
+// A collective the chained loop runs between two launches when the points are sharded over ranks: SUM over ranks of
+// `count` int64 values, in place, enqueued on `st` (csrc/et_sharded.hip binds it to ncclAllReduce).  Without one
+// (single GPU) the loop also polls the convergence flag opportunistically; with one, every rank must enqueue the same
+// collectives, so the flag is read by a blocking wait on a specific, long-arrived copy (et_hostring.h).
+struct ChainHook {
+    int (*reduce)(void *ctx, long long *buf, size_t count, hipStream_t st) = nullptr;
+    void *ctx = nullptr;
+};
+
+// The chained Lloyd loop (kmeans_lloyd_chain_kernel): `state` holds the initial state block (after scan / begin) on
+// entry and the final one on return, `centroids` the initial / final centroids, `partials` receives the final totals.
+// Ends with the update of the last assignment (finalize kernel) and, for trace-less fits, the inertia pass.
+static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, float tol, float *centroids,
+                        uint8_t *labels_u8, float *trace, et_kmeans_state *state, long long *partials, const KmWorkspace &w,
+                        hipStream_t st, ChainHook hook, std::vector<hipEvent_t> *events, int time_every, int *launched_out) {
+    constexpr int kEvery = 4;
+    auto timed = [&](int it) { return events && (it == 0 || it % time_every == 1); };
+    int rc = ET_OK;
+    StateRing *ring = StateRing::get(&rc);
+    if (!ring) return rc;
+    const bool want_sim = trace != nullptr;
+    const int threads = km_filter_threads(N);
+    const size_t plen = km_plen(d, K), lds = km_filter_lds_bytes(d, K, threads);
+    rc = km_fat_lds_attribute();
+    if (rc) return rc;
+    ET_HIP_TRY(hipMemcpyAsync(w.chain_state[0], state, sizeof(et_kmeans_state), hipMemcpyDeviceToDevice, st));
+    ET_HIP_TRY(hipMemcpyAsync(w.chain_cen[0], centroids, sizeof(float) * (size_t)d * K, hipMemcpyDeviceToDevice, st));
+    ET_HIP_TRY(hipMemsetAsync(w.chain_tot[0], 0, sizeof(long long) * plen, st));
+    for (int i = 0; i < 3; ++i) ET_HIP_TRY(hipMemsetAsync(w.chain_lanes[i], 0, sizeof(long long) * plen * 16, st));
+    auto chain_for = [&](int t) {
+        LloydChain ch;
+        ch.st_rd = w.chain_state[t & 1];
+        ch.st_wr = w.chain_state[(t + 1) & 1];
+        ch.cen_rd = w.chain_cen[t & 1];
+        ch.cen_wr = w.chain_cen[(t + 1) & 1];
+        ch.tot_rd = w.chain_tot[t & 1];
+        ch.tot_wr = w.chain_tot[(t + 1) & 1];
+        ch.lanes_rd = w.chain_lanes[t % 3];
+        ch.lanes_wr = w.chain_lanes[(t + 1) % 3];
+        ch.lanes_zero = w.chain_lanes[(t + 2) % 3];
+        ch.last = w.last;
+        return ch;
+    };
+    int grid = 0, launched = 0;
+    bool done = false;
+    for (int it = 0; it < max_iter && !done; ++it) {
+        const LloydChain ch = chain_for(it);
+        if (timed(it)) ET_HIP_TRY(hipEventRecord((*events)[2 * it], st));
+#define ET_LAUNCH_CHAIN(NR, SIM)                                                                                          \
+    do {                                                                                                                  \
+        if (!grid) grid = km_resident_grid(kmeans_lloyd_chain_kernel<NR, SIM>, lds, N / 4, threads);                      \
+        hipLaunchKernelGGL((kmeans_lloyd_chain_kernel<NR, SIM>), dim3(grid), dim3(threads), lds, st, X, N, K, ch,          \
+                           labels_u8, tol, trace, it > 0 ? 1 : 0);                                                        \
+    } while (0)
+        if (K <= 20) {
+            if (want_sim) ET_LAUNCH_CHAIN(10, true);
+            else ET_LAUNCH_CHAIN(10, false);
+        } else {
+            if (want_sim) ET_LAUNCH_CHAIN(16, true);
+            else ET_LAUNCH_CHAIN(16, false);
+        }
+#undef ET_LAUNCH_CHAIN
+        ET_LAUNCH_CHECK();
+        if (timed(it)) ET_HIP_TRY(hipEventRecord((*events)[2 * it + 1], st));
+        // sharded: the deltas this launch added onto its copy of the table become the sum over all ranks' before the
+        // next launch folds them (18 KB; the 16 copies are summed copy by copy, the fold adds them up as before)
+        if (hook.reduce) {
+            rc = hook.reduce(hook.ctx, ch.lanes_wr, plen * 16, st);
+            if (rc) return rc;
+        }
+        launched = it + 1;
+        if (launched % kEvery == 0) {
+            rc = ring->post(ch.st_wr, st, &done);
+            if (!rc && hook.reduce && ring->pending() > 1) rc = ring->wait_oldest(&done);  // the same copy on every rank
+            if (rc) return rc;
+        }
+        if (!hook.reduce) ring->poll(&done);
+    }
+    const LloydChain ch = chain_for(launched);
+    const size_t flds = 4096 + sizeof(long long) * plen;
+    hipLaunchKernelGGL(kmeans_chain_finalize_kernel, dim3(1), dim3(kKmThreads), flds, st, ch, state, partials, centroids, d,
+                       K, tol, trace, launched > 0 ? 1 : 0);
+    ET_LAUNCH_CHECK();
+    if (!want_sim) {  // inertia of the last assignment (over all ranks' points)
+        ET_HIP_TRY(hipMemsetAsync(w.sim_total, 0, 2 * sizeof(long long), st));
+        const size_t ilds = sizeof(float) * (size_t)K * cpitch_host(d);
+        hipLaunchKernelGGL((kmeans_inertia_kernel<6>), dim3(km_grid(N)), dim3(kKmThreads), ilds, st, X, N, d, K,
+                           (const float *)w.last, (const uint8_t *)labels_u8, w.sim_total);
+        ET_LAUNCH_CHECK();
+        if (hook.reduce) {
+            rc = hook.reduce(hook.ctx, w.sim_total, 2, st);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(kmeans_inertia_finish_kernel, dim3(1), dim3(64), 0, st, state, (const float *)w.last, d, K,
+                           (const long long *)w.sim_total);
+        ET_LAUNCH_CHECK();
+    }
+    if (launched_out) *launched_out = launched;
+    return ET_OK;
+}
+
+// Entry points for csrc/et_sharded.hip (not part of the public header): can this rank's shard run the chained loop,
+// and the loop itself with a reduction between the launches.  `workspace` as for et_kmeans_fit.
+extern "C" int et_internal_kmeans_chain_usable(const float *X, int64_t N, int d, int K, const uint8_t *labels_u8) {
+    return km_dims_ok(d, K) && N >= 1 && km_use_filter(X, N, d, K, labels_u8) ? 1 : 0;
+}
+extern "C" int et_internal_kmeans_chain_run(const float *X, int64_t N, int d, int K, int max_iter, float tol, float *centroids,
+                                            uint8_t *labels_u8, float *trace, et_kmeans_state *state, int64_t *partials,
+                                            void *workspace, size_t workspace_bytes,
+                                            int (*reduce)(void *, long long *, size_t, hipStream_t), void *ctx,
+                                            et_stream_t stream) {
+    if (!workspace || workspace_bytes < et_kmeans_workspace_bytes(N, d, K)) return ET_ERR_WORKSPACE;
+    const KmWorkspace w = km_carve(workspace, N, d, K);
+    ChainHook hook;
+    hook.reduce = reduce;
+    hook.ctx = ctx;
+    return km_chain_run(X, N, d, K, max_iter, tol, centroids, labels_u8, trace, state, (long long *)partials, w,
+                        (hipStream_t)stream, hook, nullptr, 8, nullptr);
+}
+
 extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_iter, float tol, float *centroids,
                              int64_t *labels, float *trace, et_kmeans_state *state_host,
                              et_kmeans_timing *timing_host, void *workspace, size_t workspace_bytes,
@@ -2015,60 +2135,9 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     // lost to this prologue: 19.8 against 16.8 us per iteration at N = 1e5.)
     const bool chained = km_use_filter(X, N, d, K, w.labels_u8);
     if (chained) {
-        const int threads = km_filter_threads(N);
-        const size_t plen = km_plen(d, K), lds = km_filter_lds_bytes(d, K, threads);
-        rc = km_fat_lds_attribute();
+        rc = km_chain_run(X, N, d, K, max_iter, tol, centroids, w.labels_u8, trace, w.state, (long long *)w.partials, w, st,
+                          ChainHook{}, timing_host ? &events : nullptr, kTimeEvery, &launched);
         if (rc) return rc;
-        ET_HIP_TRY(hipMemcpyAsync(w.chain_state[0], w.state, sizeof(et_kmeans_state), hipMemcpyDeviceToDevice, st));
-        ET_HIP_TRY(hipMemcpyAsync(w.chain_cen[0], centroids, sizeof(float) * (size_t)d * K, hipMemcpyDeviceToDevice, st));
-        ET_HIP_TRY(hipMemsetAsync(w.chain_tot[0], 0, sizeof(long long) * plen, st));
-        for (int i = 0; i < 3; ++i) ET_HIP_TRY(hipMemsetAsync(w.chain_lanes[i], 0, sizeof(long long) * plen * 16, st));
-        auto chain_for = [&](int t) {
-            LloydChain ch;
-            ch.st_rd = w.chain_state[t & 1];
-            ch.st_wr = w.chain_state[(t + 1) & 1];
-            ch.cen_rd = w.chain_cen[t & 1];
-            ch.cen_wr = w.chain_cen[(t + 1) & 1];
-            ch.tot_rd = w.chain_tot[t & 1];
-            ch.tot_wr = w.chain_tot[(t + 1) & 1];
-            ch.lanes_rd = w.chain_lanes[t % 3];
-            ch.lanes_wr = w.chain_lanes[(t + 1) % 3];
-            ch.lanes_zero = w.chain_lanes[(t + 2) % 3];
-            ch.last = w.last;
-            return ch;
-        };
-        int grid = 0;
-        for (int it = 0; it < max_iter && !done; ++it) {
-            const LloydChain ch = chain_for(it);
-            if (timed(it)) ET_HIP_TRY(hipEventRecord(events[2 * it], st));
-#define ET_LAUNCH_CHAIN(NR, SIM)                                                                                          \
-    do {                                                                                                                  \
-        if (!grid) grid = km_resident_grid(kmeans_lloyd_chain_kernel<NR, SIM>, lds, N / 4, threads);                      \
-        hipLaunchKernelGGL((kmeans_lloyd_chain_kernel<NR, SIM>), dim3(grid), dim3(threads), lds, st, X, N, K, ch,          \
-                           w.labels_u8, tol, trace, it > 0 ? 1 : 0);                                                      \
-    } while (0)
-            if (K <= 20) {
-                if (want_sim) ET_LAUNCH_CHAIN(10, true);
-                else ET_LAUNCH_CHAIN(10, false);
-            } else {
-                if (want_sim) ET_LAUNCH_CHAIN(16, true);
-                else ET_LAUNCH_CHAIN(16, false);
-            }
-#undef ET_LAUNCH_CHAIN
-            ET_LAUNCH_CHECK();
-            if (timed(it)) ET_HIP_TRY(hipEventRecord(events[2 * it + 1], st));
-            launched = it + 1;
-            if (launched % kEvery == 0) {
-                rc = ring->post(ch.st_wr, st, &done);
-                if (rc) return rc;
-            }
-            ring->poll(&done);
-        }
-        const LloydChain ch = chain_for(launched);
-        const size_t flds = 4096 + sizeof(long long) * plen;
-        hipLaunchKernelGGL(kmeans_chain_finalize_kernel, dim3(1), dim3(kKmThreads), flds, st, ch, w.state,
-                           (long long *)w.partials, centroids, d, K, tol, trace, launched > 0 ? 1 : 0);
-        ET_LAUNCH_CHECK();
     }
     for (int it = 0; !chained && it < max_iter && !done; ++it) {
         rc = assign_accumulate_impl(X, N, d, K, w.state, centroids, nullptr, w.labels_u8, (int64_t *)w.partials, workspace,
@@ -2082,7 +2151,7 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
         }
         ring->poll(&done);
     }
-    if (!want_sim) {
+    if (!want_sim && !chained) {
         ET_HIP_TRY(hipMemsetAsync(w.sim_total, 0, 2 * sizeof(long long), st));
         const size_t ilds = sizeof(float) * (size_t)K * cpitch_host(d);
         const int igrid = km_grid(N);

@@ -224,6 +224,22 @@ extern "C" int et_kmeans_init_farthest_sharded(const float *X, int64_t N_local, 
     return rc;
 }
 
+extern "C" int et_internal_kmeans_chain_usable(const float *X, int64_t N, int d, int K, const uint8_t *labels_u8);
+extern "C" int et_internal_kmeans_chain_run(const float *X, int64_t N, int d, int K, int max_iter, float tol, float *centroids,
+                                            uint8_t *labels_u8, float *trace, et_kmeans_state *state, int64_t *partials,
+                                            void *workspace, size_t workspace_bytes,
+                                            int (*reduce)(void *, long long *, size_t, hipStream_t), void *ctx,
+                                            et_stream_t stream);
+namespace {
+struct ReduceCtx {
+    ncclComm_t comm;
+};
+int sum_over_ranks(void *ctx, long long *buf, size_t count, hipStream_t st) {  // in place, int64 SUM
+    const ncclResult_t r = et::g_rccl.AllReduce(buf, buf, count, ncclInt64, ncclSum, static_cast<ReduceCtx *>(ctx)->comm, st);
+    return r == ncclSuccess ? ET_OK : ET_ERR_RCCL;
+}
+}  // namespace
+
 extern "C" int et_kmeans_fit_sharded(const float *X, int64_t N_local, int64_t N_total, int d, int K, int max_iter,
                                      float tol, float *centroids, int64_t *labels, float *trace,
                                      et_kmeans_state *state, uint8_t *labels_u8, int64_t *partials,
@@ -246,6 +262,30 @@ extern "C" int et_kmeans_fit_sharded(const float *X, int64_t N_local, int64_t N_
     }
     rc = et_kmeans_begin(state, N_total, centroids, d, K, stream);
     if (rc) return rc;
+    // The chained Lloyd loop (one launch per iteration, csrc/et_kmeans.hip: km_chain_run) when EVERY rank's shard can run
+    // it -- the two forms enqueue different collectives, so the choice is made together: MIN over ranks of a flag.
+    {
+        long long usable = et_internal_kmeans_chain_usable(X, N_local, d, K, labels_u8) ? 1 : 0;
+        if (comm) {
+            ET_HIP_TRY(hipMemcpyAsync(partials, &usable, sizeof usable, hipMemcpyHostToDevice, st));
+            ET_RCCL_TRY(g_rccl.AllReduce(partials, partials, 1, ncclInt64, ncclMin, c, st));
+            ET_HIP_TRY(hipMemcpyAsync(&usable, partials, sizeof usable, hipMemcpyDeviceToHost, st));
+            ET_HIP_TRY(hipStreamSynchronize(st));
+        }
+        if (usable) {
+            ReduceCtx ctx{c};
+            rc = et_internal_kmeans_chain_run(X, N_local, d, K, max_iter, tol, centroids, labels_u8, trace, state, partials,
+                                              workspace, workspace_bytes, comm ? &sum_over_ranks : nullptr, &ctx, stream);
+            if (rc) return rc;
+            if (labels) {
+                rc = et_kmeans_labels_i64(labels_u8, N_local, labels, stream);
+                if (rc) return rc;
+            }
+            ET_HIP_TRY(hipMemcpyAsync(state_host, state, sizeof(et_kmeans_state), hipMemcpyDeviceToHost, st));
+            ET_HIP_TRY(hipStreamSynchronize(st));
+            return state_host->bad_input ? ET_ERR_BAD_DATA : ET_OK;
+        }
+    }
     StateRing *ring = StateRing::get(&rc);
     if (!ring) return rc;
     const size_t plen = et_kmeans_partials_len(d, K);
