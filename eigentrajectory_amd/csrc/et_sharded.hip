@@ -8,11 +8,12 @@
 //                              deterministic eigensolver, so no broadcast of U is needed.
 //   et_kmeans_init_farthest_sharded   per new centroid: local candidate -> all-gather of one 8 + 4 d byte record per
 //                              rank -> the same arg-min on every rank.
-//   et_kmeans_fit_sharded      all-reduce MAX/MIN of the scale scan once; per Lloyd iteration: assignment kernels ->
-//                              all-reduce(SUM) of d K + K + 2 int64 (1.1 KB) in place -> update kernel, all enqueued
-//                              on one stream with no host round trip; convergence is decided on the device from
-//                              identical integers on every rank and looked at from the host a few iterations late
-//                              (et_hostring.h), so every rank enqueues the same collectives.
+//   et_kmeans_fit_sharded      all-reduce MAX/MIN of the scale scan once; per Lloyd iteration ONE launch of the chained
+//                              kernel (csrc/et_kmeans.hip) + ONE all-reduce(SUM) of its 18 KB delta table in place, all
+//                              enqueued on one stream with no host round trip (shards the chained kernel does not take:
+//                              assignment kernels -> all-reduce of d K + K + 2 int64 -> update kernel); convergence is
+//                              decided on the device from identical integers on every rank and looked at from the host a
+//                              few iterations late (et_hostring.h), so every rank enqueues the same collectives.
 // Exact 64-bit fixed-point sums make the k-means result bit-identical for any number of ranks / any partition.
 //
 // RCCL is bound at run time (dlopen + dlsym): libetamd.so has no link-time dependency on it, and a process that has

@@ -317,11 +317,14 @@ int et_kmeans_init_farthest_sharded(const float *X, int64_t N_local, int d, int 
                                     int64_t index_base, float *C0, float *best,
                                     void *workspace, size_t workspace_bytes, et_comm_t comm, et_stream_t stream);
 /* Lloyd iterations over all ranks' points from given centroids (identical on every rank; updated in place):
- * per iteration the assignment kernels, ONE in-place all-reduce(SUM) of the d K + K + 2 exact int64 partials and the
- * update kernel, all on `stream`, no host round trip inside the loop (the convergence flag is looked at a few
- * iterations late, on the same copy on every rank).  state / labels_u8 (N_local + 3) / partials
+ * per iteration ONE kernel launch (the previous iteration's update in its prologue, then the assignment) and ONE
+ * in-place all-reduce(SUM) of the exact int64 delta table (16 (d K + K + 2) values, 18 KB for d = 6, K = 20), all on
+ * `stream`, no host round trip inside the loop (the convergence flag is looked at a few iterations late, on the same
+ * copy on every rank).  Shards that form does not take (d != 6, K > 32, N_local < 1024 or not a multiple of 4 on ANY
+ * rank -- decided together, one all-reduce(MIN) and one stream synchronisation before the loop) run assignment kernels,
+ * an all-reduce of d K + K + 2 values and an update kernel instead.  state / labels_u8 (N_local + 3) / partials
  * (et_kmeans_partials_len) are caller-owned device buffers; labels (N_local) int64 may be NULL.  Synchronises the
- * stream once, at the end; *state_host receives the final state. */
+ * stream at the end; *state_host receives the final state. */
 int et_kmeans_fit_sharded(const float *X, int64_t N_local, int64_t N_total, int d, int K, int max_iter, float tol,
                           float *centroids, int64_t *labels, float *trace,
                           et_kmeans_state *state, uint8_t *labels_u8, int64_t *partials,
