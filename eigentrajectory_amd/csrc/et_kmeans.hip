@@ -1368,12 +1368,30 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
     __shared__ unsigned long long sKey[kKmThreads / 64];
     __shared__ unsigned sMax[kKmThreads / 64];
     __shared__ unsigned sCmax;  // fp32 bits of the largest centroid norm among columns 0 .. step-1
+    // the earlier centroids this thread will measure the new one against (columns < step - 1 are final): requested now,
+    // so that their round trip overlaps the key reduction and the gather of the new centroid
+    float cprev[D ? D : 1];
+    if constexpr (D != 0) {
+        const int jc = (int)threadIdx.x < step - 1 ? (int)threadIdx.x : 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) cprev[i] = C0[i * K + jc];
+    }
     if (prev_keys) {
         // Single-GPU path: centroid step-1 has not been stored yet -- every workgroup derives it from the previous
         // step's workgroup keys (the same minimum everywhere), workgroup 0 also stores it.  Two short round trips
         // in the prologue instead of a pick launch between two steps.
         unsigned long long key = ~0ull;
-        for (int b = threadIdx.x; b < n_prev; b += kKmThreads) key = prev_keys[b] < key ? prev_keys[b] : key;
+        for (int b0 = 0; b0 < n_prev; b0 += 4 * kKmThreads) {  // four keys per thread in flight (usually all there are)
+            unsigned long long k4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = b0 + u * kKmThreads + (int)threadIdx.x;
+                k4[u] = prev_keys[b < n_prev ? b : 0];
+                if (b >= n_prev) k4[u] = ~0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) key = k4[u] < key ? k4[u] : key;
+        }
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned long long other = __shfl_xor(key, o);
             key = other < key ? other : key;
@@ -1385,8 +1403,18 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
             const int64_t local = (int64_t)(unsigned)(key & 0xffffffffull) - index_base;
             sCmax = 0u;
             float bn = 0.f;
-            for (int i = 0; i < d; ++i) {
-                const float v = (key != ~0ull && local >= 0 && local < N) ? X[(int64_t)i * N + local] : __int_as_float(0x7fc00000);
+            const bool ok = key != ~0ull && local >= 0 && local < N;
+            float pt[D ? D : 1];
+            if constexpr (D != 0) {  // the winner's coordinates: all loads first (the stores below may alias for the compiler)
+#pragma unroll
+                for (int i = 0; i < D; ++i) pt[i] = X[(int64_t)i * N + (ok ? local : 0)];
+            }
+#pragma unroll
+            for (int i = 0; i < (D ? D : ET_KMEANS_MAX_D); ++i) {
+                if (i >= d) break;
+                float v;
+                if constexpr (D != 0) v = ok ? pt[i] : __int_as_float(0x7fc00000);
+                else v = ok ? X[(int64_t)i * N + local] : __int_as_float(0x7fc00000);
                 sc[i] = v;
                 bn = bn + v * v;
                 if (blockIdx.x == 0) {
@@ -1411,8 +1439,12 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
     // lower bounds of the distances from the new centroid to the earlier ones, upper bound of the centroid norms
     for (int j = threadIdx.x; j < step; j += kKmThreads) {
         double s2 = 0.0, n2 = 0.0;
-        for (int i = 0; i < d; ++i) {
-            const double cj = j == step - 1 ? (double)sc[i] : (double)C0[i * K + j];
+#pragma unroll
+        for (int i = 0; i < (D ? D : ET_KMEANS_MAX_D); ++i) {
+            if (i >= d) break;
+            double cj;
+            if constexpr (D != 0) cj = j == step - 1 ? (double)sc[i] : (double)cprev[i];  // step <= K < blockDim.x: j == threadIdx.x
+            else cj = j == step - 1 ? (double)sc[i] : (double)C0[i * K + j];
             const double t = (double)sc[i] - cj;
             s2 += t * t;
             n2 += cj * cj;
