@@ -5,7 +5,7 @@
 // query) is looked at; launches that were queued after convergence are no-ops on the device.
 //
 // This is the one place where the library keeps memory of its own (include/eigentraj.h, "Ownership"): per host
-// thread and device 4 x sizeof(et_kmeans_state) bytes of pinned host memory and 4 events, created on first use
+// thread and device 4 x sizeof(et_kmeans_state) + 64 bytes of pinned host memory and 4 events, created on first use
 // and kept for the life of the process.  No device memory is ever allocated by the library.
 #pragma once
 
@@ -30,11 +30,14 @@ class StateRing {
         if ((int)rings.size() <= dev) rings.resize(dev + 1, nullptr);
         if (!rings[dev]) {
             StateRing *r = new StateRing();
-            if (hipHostMalloc((void **)&r->slots_, sizeof(et_kmeans_state) * kSlots, hipHostMallocDefault) != hipSuccess) {
+            // (+ one cache line for the mailbox the chained Lloyd kernel writes its progress into, see mailbox())
+            if (hipHostMalloc((void **)&r->slots_, sizeof(et_kmeans_state) * kSlots + 64, hipHostMallocDefault) != hipSuccess) {
                 delete r;
                 *rc = ET_ERR_HIP;
                 return nullptr;
             }
+            r->mail_ = reinterpret_cast<volatile unsigned long long *>(r->slots_ + kSlots);
+            if (hipHostGetDevicePointer((void **)&r->mail_dev_, (void *)r->mail_, 0) != hipSuccess) r->mail_dev_ = nullptr;
             for (int i = 0; i < kSlots; ++i)
                 if (hipEventCreateWithFlags(&r->ev_[i], hipEventDisableTiming) != hipSuccess) {
                     *rc = ET_ERR_HIP;
@@ -81,7 +84,21 @@ class StateRing {
         }
     }
 
+    // Mailbox: 8 bytes of the pinned block that workgroup 0 of every chained Lloyd launch overwrites with
+    // (done << 63) | iterations applied -- a plain store over the host link, no copy packet and no event in the stream
+    // (a state copy every 4 launches cost a 4.6 us copy kernel and ~8 us of dispatch gaps each: 0.2 ms per 100
+    // iterations).  The single-GPU loop reads it to stop launching after convergence and to stay a bounded number of
+    // launches ahead of the device.  NOT for the sharded loop: what a rank sees here depends on timing.
+    unsigned long long *mailbox_device() const { return mail_dev_; }
+    void mailbox_reset() {
+        if (mail_) *mail_ = 0ull;
+    }
+    bool mailbox_done() const { return mail_ && (*mail_ >> 63) != 0; }
+    long long mailbox_iter() const { return mail_ ? (long long)(*mail_ & 0x7fffffffffffffffull) : 0; }
+
   private:
+    volatile unsigned long long *mail_ = nullptr;
+    unsigned long long *mail_dev_ = nullptr;
     et_kmeans_state *slots_ = nullptr;
     hipEvent_t ev_[kSlots];
     int posted_ = 0, seen_ = 0;

@@ -31,6 +31,8 @@
 #include <vector>
 
 #include "et_common.h"
+#include <sched.h>
+
 #include "et_hostring.h"
 
 namespace et {
@@ -1064,6 +1066,7 @@ struct LloydChain {
     long long *lanes_wr;
     long long *lanes_zero;
     float *last;
+    unsigned long long *mail;  // host-visible progress word (et_hostring.h: mailbox), or nullptr
 };
 
 // fold the 16 copies of every total (layout [entry][copy]: a linear, coalesced sweep, 16 adjacent lanes per entry) and
@@ -1164,7 +1167,12 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     }
     __syncthreads();
     if (wg0) {  // publish (read by the next launch, the host's convergence polling and the finalize kernel)
-        if (threadIdx.x == 0) *ch.st_wr = sSt;
+        if (threadIdx.x == 0) {
+            *ch.st_wr = sSt;
+            if (ch.mail)
+                __hip_atomic_store(ch.mail, ((unsigned long long)(sSt.done != 0) << 63) | (unsigned long long)sSt.iter,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         for (int e = threadIdx.x; e < d * K; e += (int)blockDim.x) ch.cen_wr[e] = sCen[e];
         if (has_pending)
             for (int e = threadIdx.x; e < plen; e += (int)blockDim.x) ch.tot_wr[e] = sTot[e];
@@ -2021,6 +2029,11 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
     const size_t plen = km_plen(d, K), lds = km_filter_lds_bytes(d, K, threads);
     rc = km_fat_lds_attribute();
     if (rc) return rc;
+    // single GPU: the kernel reports (done, iterations applied) into the ring's pinned mailbox and nothing is copied
+    // inside the loop; sharded: the lockstep state copies below (what a rank reads from a mailbox depends on timing)
+    unsigned long long *mail = hook.reduce ? nullptr : ring->mailbox_device();
+    if (mail) ring->mailbox_reset();
+    constexpr int kAhead = 16;  // launches the host may be ahead of the device's report
     ET_HIP_TRY(hipMemcpyAsync(w.chain_state[0], state, sizeof(et_kmeans_state), hipMemcpyDeviceToDevice, st));
     ET_HIP_TRY(hipMemcpyAsync(w.chain_cen[0], centroids, sizeof(float) * (size_t)d * K, hipMemcpyDeviceToDevice, st));
     ET_HIP_TRY(hipMemsetAsync(w.chain_tot[0], 0, sizeof(long long) * plen, st));
@@ -2037,6 +2050,7 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
         ch.lanes_wr = w.chain_lanes[(t + 1) % 3];
         ch.lanes_zero = w.chain_lanes[(t + 2) % 3];
         ch.last = w.last;
+        ch.mail = mail;
         return ch;
     };
     int grid = 0, launched = 0;
@@ -2067,12 +2081,28 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
             if (rc) return rc;
         }
         launched = it + 1;
-        if (launched % kEvery == 0) {
-            rc = ring->post(ch.st_wr, st, &done);
-            if (!rc && hook.reduce && ring->pending() > 1) rc = ring->wait_oldest(&done);  // the same copy on every rank
-            if (rc) return rc;
+        if (mail) {
+            // launch `it` reports iter = it (it applied the update of assignment it - 1); stay at most kAhead launches
+            // ahead of the last report, stop as soon as a report carries the flag
+            for (unsigned spins = 0;; ++spins) {
+                if (ring->mailbox_done()) {
+                    done = true;
+                    break;
+                }
+                if ((long long)launched - ring->mailbox_iter() <= kAhead) break;
+                // (a stream query puts a marker into the queue: only as the rare safety net against a lost report --
+                // if everything launched so far has finished, what the mailbox says is final)
+                if ((spins & 0xfffu) == 0xfffu && hipStreamQuery(st) == hipSuccess) break;
+                sched_yield();
+            }
+        } else {
+            if (launched % kEvery == 0) {
+                rc = ring->post(ch.st_wr, st, &done);
+                if (!rc && hook.reduce && ring->pending() > 1) rc = ring->wait_oldest(&done);  // the same copy on every rank
+                if (rc) return rc;
+            }
+            if (!hook.reduce) ring->poll(&done);
         }
-        if (!hook.reduce) ring->poll(&done);
     }
     const LloydChain ch = chain_for(launched);
     const size_t flds = 4096 + sizeof(long long) * plen;

@@ -23,7 +23,8 @@
  *    coefficients are k-major: C (k,N) and C (k,N,S); labels are int64;
  *  - the caller owns every buffer; the library never allocates device memory.
  *    Scratch is passed in as a workspace whose size comes from *_workspace_bytes().  The only memory the library
- *    keeps is host-side and private: per host thread and device a 4-slot pinned staging ring (4 x 96 B) + 4 events
+ *    keeps is host-side and private: per host thread and device a 4-slot pinned staging ring (4 x 96 B + a 64-byte
+ *    progress mailbox the single-GPU Lloyd kernel writes into) + 4 events
  *    for the non-blocking convergence polling of the Lloyd loops (csrc/et_hostring.h), and the timing events of
  *    et_kmeans_fit when timing is requested -- created on first use, kept for the life of the process;
  *  - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work and
