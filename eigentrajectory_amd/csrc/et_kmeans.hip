@@ -310,9 +310,15 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_scan_kernel(const float *__
             mn = sMn[w] < mn ? sMn[w] : mn;
             bad |= sBad[w];
         }
-        atomicMax(reinterpret_cast<unsigned long long *>(&state->max_abs_x),
-                  (unsigned long long)__double_as_longlong((double)m));
-        atomicMin(reinterpret_cast<unsigned long long *>(&state->min_nz_x_bits), (unsigned long long)mn);
+        // max / min only ever move one way: a workgroup whose value would not move them (by a possibly stale look at the
+        // current one -- the worst case is an unnecessary atomic) leaves them alone; ~1000 same-address device atomics
+        // at ~15 ns each were a third of this kernel
+        const unsigned long long mbits = (unsigned long long)__double_as_longlong((double)m);
+        unsigned long long *pmax = reinterpret_cast<unsigned long long *>(&state->max_abs_x);
+        unsigned long long *pmin = reinterpret_cast<unsigned long long *>(&state->min_nz_x_bits);
+        if (mbits > __hip_atomic_load(pmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(pmax, mbits);
+        if ((unsigned long long)mn < __hip_atomic_load(pmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMin(pmin, (unsigned long long)mn);
         if (bad) atomicMax(reinterpret_cast<unsigned long long *>(&state->bad_input), 1ull);
     }
 }
@@ -1186,7 +1192,9 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
 // After the loop: the update that belongs to the last assignment (if one is pending), into the caller's buffers.
 __global__ __launch_bounds__(kKmThreads) void kmeans_chain_finalize_kernel(const LloydChain ch, et_kmeans_state *state,
                                                                            long long *partials, float *cen, int d, int K,
-                                                                           float tol, float *trace, int has_pending) {
+                                                                           float tol, float *trace, int has_pending,
+                                                                           long long *sim_total) {
+    if (sim_total && threadIdx.x < 2) sim_total[threadIdx.x] = 0;  // for the inertia pass that follows a trace-less fit
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int plen = d * K + K + 2;
     long long *sTot = reinterpret_cast<long long *>(smem_raw) + 512;
@@ -1223,7 +1231,41 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_inertia_kernel(const float 
     const int sfrac = (int)*reinterpret_cast<const long long *>(last + ((d * K + 1) & ~1));
     const int pitch = cpitch(d);
     long long acc = 0, bad = 0;
-    for (int64_t n = (int64_t)blockIdx.x * kKmThreads + threadIdx.x; n < N; n += (int64_t)gridDim.x * kKmThreads) {
+    int64_t n_vec = 0;
+    if constexpr (D == 6) {
+        // four points per lane through 16-byte loads (one point per lane left the 250 MB pass at 3.6 TB/s)
+        const bool vec = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(labels) & 3u) == 0);
+        n_vec = vec ? N : 0;
+        for (int64_t g = (int64_t)blockIdx.x * kKmThreads + threadIdx.x; 4 * g < n_vec; g += (int64_t)gridDim.x * kKmThreads) {
+            float4 v[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[i] = *reinterpret_cast<const float4 *>(X + (int64_t)i * N + 4 * g);
+            const unsigned l4 = *reinterpret_cast<const unsigned *>(labels + 4 * g);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 *c4 = reinterpret_cast<const float4 *>(sC + (int)((l4 >> (8 * q)) & 0xffu) * 8);
+                const float4 c0 = c4[0], c1 = c4[1];
+                float x[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) x[i] = q == 0 ? v[i].x : (q == 1 ? v[i].y : (q == 2 ? v[i].z : v[i].w));
+                float an = 0.f;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) an = an + x[i] * x[i];  // kmeans.py:73
+                float y = fmaf(x[0], c0.x, 0.f);                     // :71
+                y = fmaf(x[1], c0.y, y);
+                y = fmaf(x[2], c0.z, y);
+                y = fmaf(x[3], c0.w, y);
+                y = fmaf(x[4], c1.x, y);
+                y = fmaf(x[5], c1.y, y);
+                y = y * 2.0f;
+                y = y - an;
+                y = y - c1.z;
+                if (isnan(y) || isinf(y)) bad += 1;
+                else acc += to_fixed(y, sfrac);
+            }
+        }
+    }
+    for (int64_t n = n_vec + (int64_t)blockIdx.x * kKmThreads + threadIdx.x; n < N; n += (int64_t)gridDim.x * kKmThreads) {
         const float *c = sC + (int)labels[n] * pitch;
         float an = 0.f, y = 0.f;
 #pragma unroll
@@ -1546,7 +1588,8 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
             mb = sMax[w] > mb ? sMax[w] : mb;
         }
         block_keys[blockIdx.x] = key;
-        if (step == 1) atomicMax(max_abs_bits, mb);  // non-negative floats order like their bits
+        // non-negative floats order like their bits; only a workgroup that would raise the maximum touches it
+        if (step == 1 && mb > __hip_atomic_load(max_abs_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_abs_bits, mb);
     }
 }
 
@@ -2004,6 +2047,23 @@ extern "C" int et_kmeans_init_farthest(const float *X, int64_t N, int d, int K, 
     return rc;
 }
 
+// Everything the chained loop's buffers need before its first launch, in ONE launch (the six separate copies / fills
+// it replaces were ~5 us packets each): state and centroids into copy 0, totals of copy 0 and the three delta tables zeroed.
+__global__ __launch_bounds__(kKmThreads) void kmeans_chain_prepare_kernel(const et_kmeans_state *__restrict__ state,
+                                                                          const float *__restrict__ cen, int dk, int plen,
+                                                                          LloydChain first, long long *lanes_b, long long *lanes_c) {
+    const int tid = blockIdx.x * kKmThreads + threadIdx.x, n_thr = gridDim.x * kKmThreads;
+    constexpr int kStateWords = (int)(sizeof(et_kmeans_state) / sizeof(unsigned));
+    if (tid < kStateWords) reinterpret_cast<unsigned *>(first.st_wr)[tid] = reinterpret_cast<const unsigned *>(state)[tid];
+    for (int e = tid; e < dk; e += n_thr) first.cen_wr[e] = cen[e];
+    for (int e = tid; e < plen; e += n_thr) first.tot_wr[e] = 0;
+    for (int e = tid; e < plen * kAccLanes; e += n_thr) {
+        first.lanes_wr[e] = 0;
+        lanes_b[e] = 0;
+        lanes_c[e] = 0;
+    }
+}
+
 // A collective the chained loop runs between two launches when the points are sharded over ranks: SUM over ranks of
 // `count` int64 values, in place, enqueued on `st` (csrc/et_sharded.hip binds it to ncclAllReduce).  Without one
 // (single GPU) the loop also polls the convergence flag opportunistically; with one, every rank must enqueue the same
@@ -2034,10 +2094,16 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
     unsigned long long *mail = hook.reduce ? nullptr : ring->mailbox_device();
     if (mail) ring->mailbox_reset();
     constexpr int kAhead = 16;  // launches the host may be ahead of the device's report
-    ET_HIP_TRY(hipMemcpyAsync(w.chain_state[0], state, sizeof(et_kmeans_state), hipMemcpyDeviceToDevice, st));
-    ET_HIP_TRY(hipMemcpyAsync(w.chain_cen[0], centroids, sizeof(float) * (size_t)d * K, hipMemcpyDeviceToDevice, st));
-    ET_HIP_TRY(hipMemsetAsync(w.chain_tot[0], 0, sizeof(long long) * plen, st));
-    for (int i = 0; i < 3; ++i) ET_HIP_TRY(hipMemsetAsync(w.chain_lanes[i], 0, sizeof(long long) * plen * 16, st));
+    {
+        LloydChain first{};  // the kernel writes through the *_wr fields: copy 0 of state / centroids / totals, table 0
+        first.st_wr = w.chain_state[0];
+        first.cen_wr = w.chain_cen[0];
+        first.tot_wr = w.chain_tot[0];
+        first.lanes_wr = w.chain_lanes[0];
+        hipLaunchKernelGGL(kmeans_chain_prepare_kernel, dim3(8), dim3(kKmThreads), 0, st, (const et_kmeans_state *)state,
+                           (const float *)centroids, d * K, (int)plen, first, w.chain_lanes[1], w.chain_lanes[2]);
+        ET_LAUNCH_CHECK();
+    }
     auto chain_for = [&](int t) {
         LloydChain ch;
         ch.st_rd = w.chain_state[t & 1];
@@ -2107,12 +2173,14 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
     const LloydChain ch = chain_for(launched);
     const size_t flds = 4096 + sizeof(long long) * plen;
     hipLaunchKernelGGL(kmeans_chain_finalize_kernel, dim3(1), dim3(kKmThreads), flds, st, ch, state, partials, centroids, d,
-                       K, tol, trace, launched > 0 ? 1 : 0);
+                       K, tol, trace, launched > 0 ? 1 : 0, want_sim ? (long long *)nullptr : w.sim_total);
     ET_LAUNCH_CHECK();
-    if (!want_sim) {  // inertia of the last assignment (over all ranks' points)
-        ET_HIP_TRY(hipMemsetAsync(w.sim_total, 0, 2 * sizeof(long long), st));
+    if (!want_sim) {  // inertia of the last assignment (over all ranks' points); the finalize kernel zeroed sim_total
         const size_t ilds = sizeof(float) * (size_t)K * cpitch_host(d);
-        hipLaunchKernelGGL((kmeans_inertia_kernel<6>), dim3(km_grid(N)), dim3(kKmThreads), ilds, st, X, N, d, K,
+        // (every workgroup ends with one device-scope atomic on the same address, ~15 ns each: 4096 workgroups made the
+        // pass atomic-bound at 64 us; four points per lane and 1024 workgroups stream instead)
+        const int igrid = min(km_grid(N / 4 + 1), 1024);
+        hipLaunchKernelGGL((kmeans_inertia_kernel<6>), dim3(igrid), dim3(kKmThreads), ilds, st, X, N, d, K,
                            (const float *)w.last, (const uint8_t *)labels_u8, w.sim_total);
         ET_LAUNCH_CHECK();
         if (hook.reduce) {
@@ -2183,8 +2251,6 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     rc = et_kmeans_scan(X, N, d, w.state, stream);
     if (!rc) rc = et_kmeans_begin(w.state, N, centroids, d, K, stream);
     if (rc) return rc;
-    ET_HIP_TRY(hipMemsetAsync(w.ticket, 0, sizeof(unsigned), st));
-    ET_HIP_TRY(hipMemsetAsync(w.acc_lanes, 0, sizeof(long long) * km_plen(d, K) * 16, st));
     // Without a trace the inertia of an iteration is not an output (kmeans.py:234 only prints it and keeps the last
     // one): the assignment kernels skip the fp64 similarity sums and the inertia of the LAST assignment is evaluated
     // by one extra pass after the loop -- the same bits as the per-iteration sum would have given.
@@ -2200,6 +2266,10 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
         rc = km_chain_run(X, N, d, K, max_iter, tol, centroids, w.labels_u8, trace, w.state, (long long *)w.partials, w, st,
                           ChainHook{}, timing_host ? &events : nullptr, kTimeEvery, &launched);
         if (rc) return rc;
+    }
+    if (!chained) {
+        ET_HIP_TRY(hipMemsetAsync(w.ticket, 0, sizeof(unsigned), st));
+        ET_HIP_TRY(hipMemsetAsync(w.acc_lanes, 0, sizeof(long long) * km_plen(d, K) * 16, st));
     }
     for (int it = 0; !chained && it < max_iter && !done; ++it) {
         rc = assign_accumulate_impl(X, N, d, K, w.state, centroids, nullptr, w.labels_u8, (int64_t *)w.partials, workspace,
