@@ -1964,7 +1964,7 @@ extern "C" int et_kmeans_predict(const float *X, int64_t N, int d, const float *
 // (= C0).  (Letting the last of the 4096 step workgroups do the pick was measured 3x SLOWER: 4096 device-scope
 // arrivals on one ticket serialise at ~25 ns each.)
 static int init_step_grid(int64_t N, int i) {
-    return i == 1 ? km_grid(N) : min(km_grid(N / 4 + 1), 1024);  // steps >= 2: four points per lane
+    return i == 1 ? min(km_grid(N), 1024) : min(km_grid(N / 4 + 1), 1024);  // steps >= 2: four points per lane
 }
 
 // fused != nullptr: single-GPU path.  Step i (>= 2) derives centroid i-1 itself from the keys step i-1 left in the other
