@@ -323,15 +323,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_scan_kernel(const float *__
     }
 }
 
-__device__ __forceinline__ double max_abs_centroid(const float *cen, int n) {  // NaN ignored
-    double m = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const double a = fabs((double)cen[i]);
-        if (a > m) m = a;
-    }
-    return m;
-}
-
+// state->fast_ok (set by kmeans_begin_kernel and by every update):
 // 0: similarities may be NaN/Inf -> NaN-aware scalar path.
 // 1: no similarity of the coming assignment can overflow or be NaN (every centroid finite, all
 //    magnitudes below 1e18: |2 a.b| + |a|^2 + |b|^2 <= 4 d 1e36 < FLT_MAX for d <= 32).
@@ -339,33 +331,48 @@ __device__ __forceinline__ double max_abs_centroid(const float *cen, int n) {  /
 //    a multiple of 2^-146, i.e. exactly representable even when subnormal, so scaling the chain by two
 //    commutes with every rounding: fl(2c.x) == 2 fl(c.x) bit for bit.  The matrix-core kernel relies
 //    on that to fold the reference's "y *= 2" (kmeans.py:72) into its A operand.
-__device__ __forceinline__ int64_t fast_ok_flag(const float *cen, int n, double mx, double mc, int64_t min_nz_x_bits) {
-    unsigned mn = 0x7f800000u;
-    for (int i = 0; i < n; ++i) {
-        const float a = fabsf(cen[i]);
-        if (!(a <= 3.402823466e+38f)) return 0;
-        const unsigned b = (unsigned)__float_as_int(a);
-        if (b != 0u && b < mn) mn = b;
-    }
-    if (!(mx < 1e18 && mc < 1e18)) return 0;
-    const unsigned lim = 0x26800000u;  // 2^-50
-    return (mn >= lim && (unsigned long long)min_nz_x_bits >= lim) ? 2 : 1;
-}
-
 __device__ __forceinline__ int sim_frac_bits(double mx, double mc, int d, int64_t n_total) {
     const double m = mx > mc ? mx : mc;
     return 62 - exponent_above(4.0 * d * m * m) - bits_for(n_total);
 }
 
+// One wavefront: the d K centroid values are looked at by the 64 lanes in parallel (maxima / minima / a flag: order
+// independent; a single lane used to walk through them with two dependent global loads per value -- 14 us of a
+// kernel that does almost nothing).
 __global__ void kmeans_begin_kernel(et_kmeans_state *state, int64_t n_total, const float *__restrict__ cen, int d,
                                     int K) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    const int lane = threadIdx.x, n = d * K;
+    double mc = 0.0;
+    unsigned mn = 0x7f800000u;
+    int bad = 0;
+    for (int i = lane; i < n; i += 64) {
+        const float a = fabsf(cen[i]);
+        if (!(a <= 3.402823466e+38f)) bad = 1;
+        const double ad = (double)a;
+        if (ad > mc) mc = ad;  // NaN ignored
+        const unsigned b = (unsigned)__float_as_int(a);
+        if (a <= 3.402823466e+38f && b != 0u && b < mn) mn = b;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double om = __shfl_xor(mc, o);
+        mc = om > mc ? om : mc;
+        const unsigned on = (unsigned)__shfl_xor((int)mn, o);
+        mn = on < mn ? on : mn;
+        bad |= __shfl_xor(bad, o);
+    }
+    if (lane != 0) return;
+    const double mx = state->max_abs_x;
     state->n_total = n_total;
-    state->frac = 62 - exponent_above(state->max_abs_x) - bits_for(n_total);
-    const double mc = max_abs_centroid(cen, d * K);
+    state->frac = 62 - exponent_above(mx) - bits_for(n_total);
     state->max_abs_c = mc;
-    state->sim_frac = sim_frac_bits(state->max_abs_x, mc, d, n_total);
-    state->fast_ok = fast_ok_flag(cen, d * K, state->max_abs_x, mc, state->min_nz_x_bits);
+    state->sim_frac = sim_frac_bits(mx, mc, d, n_total);
+    int64_t fast = 0;
+    if (!bad && mx < 1e18 && mc < 1e18) {
+        const unsigned lim = 0x26800000u;  // 2^-50, see the fast_ok levels above
+        fast = (mn >= lim && (unsigned long long)state->min_nz_x_bits >= lim) ? 2 : 1;
+    }
+    state->fast_ok = fast;
     state->iter = 0;
     state->done = state->bad_input ? 1 : 0;  // non-finite data: every later step is a no-op
     state->error = 0.0;
@@ -1025,7 +1032,7 @@ __device__ __forceinline__ void update_body(et_kmeans_state *state, const long l
         state->sim_frac = sim_frac_bits(mx, mc, d, n_total);
         int64_t fast = 0;
         if (sRed[2] == 0.f && mx < 1e18 && mc < 1e18) {
-            const unsigned lim = 0x26800000u;  // 2^-50, see fast_ok_flag()
+            const unsigned lim = 0x26800000u;  // 2^-50, see the fast_ok levels above
             fast = ((unsigned)__float_as_int(sRed[1]) >= lim && (unsigned long long)st.min_nz_x_bits >= lim) ? 2 : 1;
         }
         state->fast_ok = fast;
