@@ -385,6 +385,102 @@ def test_sharded_driver_on_one_gpu_matches_oracle(ops, oracle, dev):
     assert torch.equal(U_obs, ops.eigh_topk(g_obs, 6)[0]) and torch.equal(U_pred, ops.eigh_topk(g_pred, 6)[0])
 
 
+@pytest.mark.parametrize("cut,trace", [(8192, False), (20004, True), (1024, False)])
+def test_native_chained_loop_two_shards_one_gpu(ops, oracle, dev, cut, trace):
+    """The library's sharded Lloyd loop (csrc/et_kmeans.hip: km_chain_run with a reduction between two launches -- what
+    et_kmeans_fit_sharded runs with ncclAllReduce) on TWO shards of one GPU: two host threads, one stream each, and a
+    test reduction in place of RCCL (barrier, sum of the two shards' buffers).  Exercises what a one-rank run cannot:
+    the table being summed between the launches, the lockstep convergence polling, the final inertia reduction.
+    Centroids, labels, iteration count, error and inertia must be the oracle's on the whole data, bit for bit."""
+    import ctypes as C
+    import threading
+    from eigentrajectory_amd import _lib as L
+    from eigentrajectory_amd.synth import gaussian_points_np
+    n, K, max_iter, tol = 30000, 20, 40, 1e-4
+    x = gaussian_points_np(6, n, seed=31, n_blobs=9)
+    x[:, ::53] *= 40.0
+    c0, _ = oracle.kmeans_init_farthest(x, K, 77)
+    ref = oracle.kmeans_fit(x, c0, max_iter, tol)
+    lib = L.lib()
+    REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+    run = lib.et_internal_kmeans_chain_run
+    run.restype = C.c_int
+    run.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, REDUCE, C.c_void_p, C.c_void_p]
+    shards = [ops.KMeansShard(T(np.ascontiguousarray(x[:, :cut]), dev), K), ops.KMeansShard(T(np.ascontiguousarray(x[:, cut:]), dev), K)]
+    for sh in shards:
+        assert lib.et_internal_kmeans_chain_usable(L.ptr(sh.X), L.i64(sh.n), 6, K, L.ptr(sh.labels_u8)) == 1
+        sh.scan()
+    torch.cuda.synchronize()
+    # what the all-reduces of the scale scan do (dist.py / et_kmeans_fit_sharded): MAX, MAX, MIN
+    mx = torch.maximum(shards[0].state_f64[0], shards[1].state_f64[0])
+    bad = torch.maximum(shards[0].state[7], shards[1].state[7])
+    mn = torch.minimum(shards[0].state[11], shards[1].state[11])
+    cens, traces = [], []
+    for sh in shards:
+        sh.state_f64[0] = mx
+        sh.state[7] = bad
+        sh.state[11] = mn
+        cens.append(T(c0, dev).clone())
+        traces.append(torch.zeros((max_iter, 2), device=dev) if trace else None)
+        sh.begin(n, cens[-1])
+    torch.cuda.synchronize()
+    barrier = threading.Barrier(2)
+    streams = [torch.cuda.Stream(device=dev) for _ in shards]
+    errors = []
+
+    pending = [None, None]  # the buffer each shard's loop is asking to have reduced (a view into its own workspace)
+
+    def worker(r):
+        try:
+            sh = shards[r]
+
+            def reduce(ctx, buf, count, stream):
+                with torch.cuda.stream(streams[r]):
+                    streams[r].synchronize()
+                    off = buf - sh.ws.data_ptr()
+                    assert 0 <= off and off + 8 * count <= sh.ws.numel()
+                    mine = sh.ws[off:off + 8 * count].view(torch.int64)
+                    pending[r] = mine
+                    barrier.wait()  # both shards' buffers are complete and published
+                    theirs = pending[1 - r]
+                    assert theirs.numel() == count  # the same collective on both "ranks"
+                    total = mine + theirs
+                    streams[r].synchronize()
+                    barrier.wait()  # both have read both
+                    mine.copy_(total)
+                    streams[r].synchronize()
+                return 0
+
+            cb = REDUCE(reduce)
+            with torch.cuda.stream(streams[r]):
+                rc = run(L.ptr(sh.X), L.i64(sh.n), 6, K, max_iter, L.f32(tol), L.ptr(cens[r]), L.ptr(sh.labels_u8),
+                         L.ptr(traces[r]), L.ptr(sh.state), L.ptr(sh.partials), L.ptr(sh.ws), C.c_size_t(sh.ws.numel()), cb,
+                         None, C.c_void_p(streams[r].cuda_stream))
+                streams[r].synchronize()
+            assert rc == 0, rc
+        except BaseException as exc:  # noqa: BLE001
+            errors.append(exc)
+            barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    torch.cuda.synchronize()
+    for r, sh in enumerate(shards):
+        assert np.array_equal(N_(cens[r]), ref["centroids"]), r
+        st = L.KMeansState.from_buffer_copy(sh.state.cpu().numpy().tobytes())
+        assert int(st.iter) == ref["n_iter"]
+        assert np.float32(st.error) == np.float32(ref["error"]) and np.float32(st.inertia) == np.float32(ref["inertia"])
+        if trace:
+            assert np.array_equal(N_(traces[r])[:ref["n_iter"]], ref["trace"])
+    labels = np.concatenate([N_(shards[0].labels_u8)[:cut], N_(shards[1].labels_u8)[:n - cut]]).astype(np.int64)
+    assert np.array_equal(labels, ref["labels"])
+
+
 def _two_rank_gpu_worker(rank, world, port, cuts, out_dir):
     import os
     import torch.distributed as dist
