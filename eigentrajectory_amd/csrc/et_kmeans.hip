@@ -64,15 +64,11 @@ __device__ __forceinline__ int bits_for(int64_t n) {  // smallest b with 2^b > n
 // trunc(x * 2^frac) for finite x, by shifting the mantissa: bit-identical to the oracle's
 // (int64_t)ldexp((double)x, frac) and ~10 integer ops instead of an fp64 -> i64 emulation.
 __device__ __forceinline__ long long to_fixed(float x, int frac) {
-    const unsigned u = (unsigned)__float_as_int(x);
-    const int e = (int)((u >> 23) & 0xff);
-    const unsigned long long m = (u & 0x7fffffu) | (e ? 0x800000u : 0u);
-    const int sh = (e ? e : 1) - 150 + frac;  // x = m * 2^(e-150)
-    unsigned long long mag;
-    if (sh >= 0) mag = sh < 64 ? (m << sh) : 0ull;
-    else mag = sh > -64 ? (m >> (-sh)) : 0ull;
-    const long long v = (long long)mag;
-    return (u >> 31) ? -v : v;
+    // trunc(x 2^frac) as a 64-bit integer (|x 2^frac| < 2^62 by the choice of frac).  Through fp64: (double)x is exact, the
+    // scaling by a power of two is exact (the products stay far inside the fp64 range), and the conversion truncates
+    // toward zero -- the same integer as shifting the mantissa, without that version's data-dependent branches (six of
+    // these per accumulated point: every point in iteration 0, every queued point that changes its label later).
+    return (long long)ldexp((double)x, frac);
 }
 
 __device__ __forceinline__ bool gt_nanmax(float cand, float best) {  // torch.max: NaN beats everything
