@@ -143,10 +143,10 @@ def pmc_traffic(n):
             if f"N={n:.0e}".replace("+0", "") not in js.get("note", "").replace("+0", ""):
                 continue
             k = js["kernels"][DOMINANT_KERNEL]
-            return round(k["read_bytes_corrected"] + k["write_bytes"])
+            return round(k["read_bytes_corrected"] + k["write_bytes"]), os.path.relpath(path, ROOT)
         except Exception:
             continue
-    return None
+    return None, None
 
 
 def _cpu_model():
@@ -365,11 +365,41 @@ def extra_stages(ops, obs, pred, n, K, max_iter, first_index, dev):
     return out, sizes
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): start the N
+    ranks ourselves -- one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1 -- and hand their
+    output through.  Returns the exit code."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this machine has {n_dev}", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
+    if torch.cuda.device_count() <= local_rank:
+        print(f"bench.py: rank {rank} needs GPU {local_rank}, this machine has {torch.cuda.device_count()}", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     force_dist = os.environ.get("ET_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path on one GPU (testing aid)
@@ -379,7 +409,6 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or (args.gpus == 1 and world == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from eigentrajectory_amd import ops
     from eigentrajectory_amd.synth import synthetic_trajectories_torch
@@ -387,6 +416,7 @@ def main():
     K = 20
     obs, pred = synthetic_trajectories_torch(n, dev, seed=rank, min_disp=1e-3)
     km = comm = None
+    native_ranks = 0
     dist_path = "single"
     if world > 1 or force_dist:
         from eigentrajectory_amd.dist import Communicator, ShardedKMeans
@@ -395,7 +425,8 @@ def main():
         if os.environ.get("ET_BENCH_DIST", "native") == "native":
             try:
                 comm = Communicator(dev)
-                dist_path = "native (et_kmeans_fit_sharded, RCCL ranks seen by the library: %d)" % comm.info()[0]
+                native_ranks = comm.info()[0]  # ncclCommCount of the communicator the library enqueues its collectives on
+                dist_path = "native (et_kmeans_fit_sharded, RCCL ranks seen by the library: %d)" % native_ranks
             except Exception as exc:  # noqa: BLE001 -- fall back loudly, keep the run alive
                 print(f"[bench] native RCCL communicator unavailable ({exc!r}); using torch.distributed collectives",
                       file=sys.stderr, flush=True)
@@ -458,8 +489,11 @@ def main():
         else:  # sharded runs drive the step API from Python; fall back to the loop average
             avg_ms = stages["kmeans_lloyd"]["ms"] / max(n_it, 1.0)
         achieved = BYTES["kmeans_iter"] * n / avg_ms / 1e6
+        traffic, traffic_source = pmc_traffic(n)
+        # `traffic` is NOT measured in this run: it is the PMC figure of the committed rocprofv3 passes of the same
+        # workload (`traffic_source`); everything else on the line is measured live
         roofline = dict(bound="hbm", kernel=DOMINANT_KERNEL.replace("et::", ""), achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
-                        unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(n),
+                        unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
                         avg_launch_ms=round(avg_ms, 5), algorithmic_bytes_per_launch=BYTES["kmeans_iter"] * n)
         out = dict(metric="trajectories/sec fit+project+reconstruct+kmeans", value=total_traj / (elapsed / args.steps),
                    unit="trajectories/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -469,7 +503,8 @@ def main():
                                         f"fit + project(obs+pred) + reconstruct(S=1) + k-means(K=20, farthest-first, "
                                         f"max_iter={args.max_iter}, tol=1e-4)",
                                n_per_gpu=n, k=6, num_clusters=K, parallelism=f"shard{world}",
-                               rccl_ranks=dist.get_world_size() if dist.is_initialized() else 0, dist_path=dist_path),
+                               rccl_ranks=(native_ranks if comm is not None else
+                                           (dist.get_world_size() if dist.is_initialized() else 0)), dist_path=dist_path),
                    roofline=roofline, stages=stages)
         if world == 1 and not force_dist and not args.no_extras:
             more, sizes = extra_stages(ops, obs, pred, n, K, args.max_iter, first_index, dev)

@@ -74,12 +74,11 @@ class ETAnchor(nn.Module):
             C_anchor, self.inertia_, self.seed_indices_ = sklearn_style_kmeans(C_pred, self.s, random_state=seed)
         elif mode == "farthest":
             km = BatchKMeans(n_clusters=self.s, n_redo=n_redo, max_iter=max_iter, tol=tol, init_mode="kmeans++")
-            state = np.random.get_state()
-            try:
-                np.random.seed(seed)  # kmeans.py:92 draws the first centroid from numpy's global stream
-                km.fit(C_pred[None].contiguous())
-            finally:
-                np.random.set_state(state)
+            # kmeans.py:92 draws the first centroid from numpy's GLOBAL stream after the caller seeded it; here the same
+            # draws come from a private stream (the moving / static fits of calculate_parameters run in two threads:
+            # seeding and restoring the global state around a call that releases the GIL would race)
+            km.rng = np.random.RandomState(seed)
+            km.fit(C_pred[None].contiguous())
             C_anchor, self.inertia_ = km.centroids[0], km.inertia_
         else:
             raise ValueError(f"unknown anchor mode {mode!r}")

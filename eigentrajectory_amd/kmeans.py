@@ -42,6 +42,10 @@ class BatchKMeans(nn.Module):
         self.init_mode, self.verbose = init_mode, verbose
         self.inertia_ = None
         self.n_iter_ = None
+        # where the initial centroids are drawn from: None = numpy's global stream, exactly where the reference draws
+        # (kmeans.py:92,126); a caller that must not touch (or race on) the global stream sets a private
+        # numpy.random.RandomState here -- RandomState(s).randint(n) is the draw np.random.seed(s); np.random.randint(n) makes
+        self.rng = None
         self.register_buffer("centroids", None)  # filled by fit(); part of the state_dict like in the reference
 
     def load_state_dict(self, state_dict, **kwargs):
@@ -86,7 +90,7 @@ class BatchKMeans(nn.Module):
         r"""Farthest-first initialisation (kmeans.py:78-112): (..., d, n) -> (..., d, n_clusters)"""
         d3, lead = self._batched(data)
         n_data = d3.shape[-1]
-        first = np.random.randint(n_data)  # one draw for the whole batch, like kmeans.py:92
+        first = (self.rng or np.random).randint(n_data)  # one draw for the whole batch, like kmeans.py:92
         cen = torch.stack([ops.kmeans_init_farthest(d3[i], self.n_clusters, first) for i in range(d3.shape[0])], dim=0)
         return cen.reshape(tuple(lead) + tuple(cen.shape[-2:]))
 
@@ -96,7 +100,7 @@ class BatchKMeans(nn.Module):
         if self.init_mode == "kmeans++":
             centroids = self.kmeanspp(data).clone()
         elif self.init_mode == "random":
-            picks = np.random.choice(data.size(-1), size=[self.n_clusters], replace=False)
+            picks = (self.rng or np.random).choice(data.size(-1), size=[self.n_clusters], replace=False)
             centroids = data[:, :, picks].clone()  # 3-D data only, like the reference's indexing
         else:
             raise NotImplementedError(f"init_mode {self.init_mode!r}")
