@@ -550,7 +550,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //
 //  1. f16 MFMA (v_mfma_f32_32x32x16_f16, ~16x the fp32 rate) evaluates t'_j ~ G_j = 2 x.c_j - |c_j|^2 for
 //     all clusters: x and 2c, scaled by a power of two sg so that every magnitude is below 32, are split
-//     into f16 (hi, lo) pairs (round toward zero: 2^-20 relative, 2^-24 absolute on the denormal grid);
+//     into f16 (hi, lo) pairs (round to nearest: 2^-22 relative, 2^-25 absolute on the denormal grid -- the bounds
+//     below are derived with the looser 2^-20 / 2^-24 of a round-toward-zero split);
 //     the four partial products per coordinate and the split -|c|^2 occupy 26 of the 32 k-slots of two
 //     MFMAs, accumulation is fp32 (<= 28 additions, order unknown: 2^-18.2 of the sum of magnitudes).
 //     In scaled units, r = sg ||x||, C_j = sg ||c_j||:
@@ -585,14 +586,28 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// (a, b) * sg (a power of two) -> packed f16 {hi(a), hi(b)} and {lo(a), lo(b)} with sg a ~ hi + lo, round toward
-// zero.  The residual is a single fma (v_fma_mix_f32 reads the f16 halves directly) and exact.
+// (a, b) * sg (a power of two) -> packed f16 {hi(a), hi(b)} and {lo(a), lo(b)} with sg a ~ hi + lo, round to nearest:
+// |sg a - hi - lo| <= 2^-22 |sg a| + 2^-25 (inside the 2^-20 relative + 2^-24 absolute the bounds below are derived
+// with).  Four instructions per pair: v_fma_mixlo/mixhi_f16 scale and round in one step (a sg is exact in fp32, sg
+// being a power of two) and evaluate the residual a sg - hi exactly (it has at most 13 significant bits) before
+// rounding it to f16 -- no separate scaling multiplies and no pack instructions.  (Inline asm: from the C expression the
+// compiler rounds the second hi twice, five instructions; none of the operands is an MFMA result.)
 __device__ __forceinline__ void split_f16(float a, float b, float sg, unsigned &hi, unsigned &lo) {
-    const auto h = __builtin_amdgcn_cvt_pkrtz(a * sg, b * sg);
-    const float ra = __builtin_fmaf(a, sg, -(float)h[0]), rb = __builtin_fmaf(b, sg, -(float)h[1]);
-    const auto l = __builtin_amdgcn_cvt_pkrtz(ra, rb);
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
+    unsigned h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=&v"(h) : "v"(a), "v"(sg));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+&v"(h) : "v"(b), "v"(sg));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=&v"(l) : "v"(a), "v"(sg), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+&v"(l) : "v"(b), "v"(sg), "v"(h));
+    hi = h;
+    lo = l;
+}
+
+// max(|a|, |b|, |c|) in one instruction (from fmaxf(fmaxf(fabsf ...)) the compiler canonicalises two of the operands
+// with a v_max x,x each)
+__device__ __forceinline__ float max3_abs(float a, float b, float c) {
+    float m;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+    return m;
 }
 
 // max / min as v_med3_f32 against +-inf: fmaxf on a raw MFMA result would first be "canonicalised" by a
@@ -697,6 +712,7 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
     constexpr float kR2Slack = 1.57365e-5f;   // 2^-16 + 2^-21 (1 + 2^-10), rounded up: eps(r)'s r^2 term + the slack above
     constexpr float kCcSlack = 4.7731e-7f;    // 2^-21 (1 + 2^-10), rounded up
     const float sg = ldexpf(1.0f, 5 - e_max), sg2 = sg * sg;
+    const float sgk = sg * kSqrt6Up;  // exact (sg is a power of two, 2^-55 ... 2^45)
     const int n_thr = (int)blockDim.x, n_wav = n_thr >> 6;  // 768 or 1024 threads (host's choice)
     for (int i = threadIdx.x; i < plen; i += n_thr) sAcc[i] = 0;
     stage_centroids(cen, d, K, sC);
@@ -772,16 +788,13 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
         if (g >= n_groups) break;
         const int64_t n = g * 256 + 128 * half + 4 * col;
         const bool valid = n < N;  // N % 4 == 0
+        // lanes past the end (last pass only) read points 0..3 instead: finite data, results discarded through `valid`
+        // (unconditional loads: no exec-masked branch and no zero fill of 25 registers in every pass)
+        const int64_t nl = valid ? n : 0;
         float4 v[6];
-        unsigned old_packed = 0;
-        if (valid) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) v[i] = *reinterpret_cast<const float4 *>(X + (int64_t)i * N + n);
-            old_packed = *reinterpret_cast<const unsigned *>(labels + n);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int i = 0; i < 6; ++i) v[i] = *reinterpret_cast<const float4 *>(X + (int64_t)i * N + nl);
+        const unsigned old_packed = *reinterpret_cast<const unsigned *>(labels + nl);
         unsigned undecided = 0u;  // bit q: point q of this lane goes to the queue
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -794,9 +807,8 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
                 for (int i = 0; i < 6; ++i) an = an + x[i] * x[i];  // kmeans.py:73
                 rs = fmaf(__builtin_amdgcn_sqrtf(an) * sg, kUp, kTiny);  // >= sg ||x||
             } else {
-                const float m = fmaxf(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fabsf(x[2])),
-                                      fmaxf(fmaxf(fabsf(x[3]), fabsf(x[4])), fabsf(x[5])));
-                rs = fmaf(m * sg, kSqrt6Up, kTiny);  // >= sg ||x|| as well: ||x|| <= sqrt(6) max |x_i|
+                const float m = vmax(max3_abs(x[0], x[1], x[2]), max3_abs(x[3], x[4], x[5]));
+                rs = fmaf(m, sgk, kTiny);  // = fl(m sg kSqrt6Up + kTiny) >= sg ||x|| as well: ||x|| <= sqrt(6) max |x_i|
             }
             unsigned w[7];  // {xh01, xh23, xh45, xl01, xl23, xl45, (r, 1)}
 #pragma unroll
