@@ -116,7 +116,7 @@ def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None,
         sw.stop("kmeans_lloyd")
         # the first launch of a fit is the plain exact scan (kmeans_assign_kernel<6,4>, full accumulation); the
         # others are the filter kernel, the dominant kernel of the path, of which every 8th launch is timed
-        timing.append((res["assign_ms"], res["assign_launches"]))
+        timing.append((res["assign_ms"], res["assign_launches"], res["assign_iterations"]))
     else:
         skm = km(c_pred, K)
         sw.launched()
@@ -129,7 +129,10 @@ def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None,
     return res["n_iter"]
 
 
-DOMINANT_KERNEL = "et::kmeans_lloyd_chain_kernel<10, false>"  # one launch per Lloyd iteration (100 per step)
+# ONE launch per k-means fit runs all its Lloyd iterations (persistent workgroups, csrc/et_kmeans.hip);
+# ET_KMEANS_LOOP=chain selects one launch per iteration (kmeans_lloyd_chain_kernel<10, false>), the sharded loop's form
+DOMINANT_KERNEL = ("et::kmeans_lloyd_chain_kernel<10, false>" if os.environ.get("ET_KMEANS_LOOP", "")[:1] == "c"
+                   else "et::kmeans_lloyd_persist_kernel<10, false>")
 
 
 def pmc_traffic(n):
@@ -484,17 +487,24 @@ def main():
         # dominant kernel by time: the Lloyd assign kernel of iterations >= 1 (kmeans_assign_filter_kernel<10>),
         # timed with HIP events recorded on the launch stream around every launch inside the timed steps
         # (et_kmeans_fit)
-        if timing and sum(c for _, c in timing) > 0:
-            avg_ms = sum(m for m, _ in timing) / sum(c for _, c in timing)
-        else:  # sharded runs drive the step API from Python; fall back to the loop average
+        if timing and sum(c for _, c, _ in timing) > 0:
+            launches = sum(c for _, c, _ in timing)
+            avg_ms = sum(m for m, _, _ in timing) / launches
+            its_per_launch = sum(i for _, _, i in timing) / launches  # Lloyd iterations one launch covers (1 when chained)
+        else:  # sharded runs: the library enqueues launches and collectives itself; fall back to the loop average
             avg_ms = stages["kmeans_lloyd"]["ms"] / max(n_it, 1.0)
-        achieved = BYTES["kmeans_iter"] * n / avg_ms / 1e6
+            its_per_launch = 1.0
+        # algorithmic bytes of ONE launch of the dominant kernel: 24 B of coordinates per point and Lloyd iteration
+        #  x the iterations that launch runs
+        alg_bytes = BYTES["kmeans_iter"] * n * its_per_launch
+        achieved = alg_bytes / avg_ms / 1e6
         traffic, traffic_source = pmc_traffic(n)
         # `traffic` is NOT measured in this run: it is the PMC figure of the committed rocprofv3 passes of the same
         # workload (`traffic_source`); everything else on the line is measured live
         roofline = dict(bound="hbm", kernel=DOMINANT_KERNEL.replace("et::", ""), achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
-                        avg_launch_ms=round(avg_ms, 5), algorithmic_bytes_per_launch=BYTES["kmeans_iter"] * n)
+                        avg_launch_ms=round(avg_ms, 5), lloyd_iterations_per_launch=round(its_per_launch, 2),
+                        algorithmic_bytes_per_launch=alg_bytes)
         out = dict(metric="trajectories/sec fit+project+reconstruct+kmeans", value=total_traj / (elapsed / args.steps),
                    unit="trajectories/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="weak", vs_baseline=None,

@@ -46,7 +46,8 @@ class KMeansState(C.Structure):
 
 class KMeansTiming(C.Structure):
     """Mirror of ``et_kmeans_timing``."""
-    _fields_ = [("assign_ms", C.c_double), ("assign_launches", C.c_int64), ("first_assign_ms", C.c_double)]
+    _fields_ = [("assign_ms", C.c_double), ("assign_launches", C.c_int64), ("first_assign_ms", C.c_double),
+                ("iterations", C.c_int64)]
 
 
 STATE_BYTES = C.sizeof(KMeansState)

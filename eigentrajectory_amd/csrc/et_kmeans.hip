@@ -82,12 +82,24 @@ __device__ __forceinline__ unsigned orderable(float f) {  // ascending uint orde
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// threadIdx.x behind an empty asm.  The assignment bodies below run inside the iteration loop of the persistent kernel;
+// everything they derive from the thread index alone (lane, wavefront, queue and table addresses, the cluster a lane's
+// A operand belongs to, ...) is loop invariant there and would be hoisted in front of the loop and kept live across the
+// whole body -- measured: 128 VGPRs + 56 B of scratch memory against 116 and none for the same body as a kernel of its
+// own.  A volatile asm is never hoisted or merged, so each inlined call derives these values afresh.
+__device__ __forceinline__ unsigned thread_x() {
+    unsigned t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 // ---- centroids in LDS: row j = {c[0..d-1], |c_j|^2}, pitch = d+1 rounded up to 4 floats ------
 __device__ __forceinline__ int cpitch(int d) { return (d + 1 + 3) & ~3; }
 
 __device__ __forceinline__ void stage_centroids(const float *__restrict__ cen, int d, int K, float *sC) {
+    const unsigned tx = thread_x();  // (opaque per call: see thread_x)
     const int pitch = cpitch(d);
-    for (int j = threadIdx.x; j < K; j += blockDim.x) {
+    for (int j = tx; j < K; j += blockDim.x) {
         float bn = 0.f;
         for (int i = 0; i < d; ++i) {
             const float v = cen[i * K + j];
@@ -388,17 +400,19 @@ __global__ void kmeans_begin_kernel(et_kmeans_state *state, int64_t n_total, con
 constexpr int kAccLanes = 16;
 
 __device__ __forceinline__ void emit_partials(const long long *sAcc, int plen, int n_threads,
-                                              long long *__restrict__ block_partials, long long *__restrict__ lanes) {
+                                              long long *__restrict__ block_partials, long long *__restrict__ lanes,
+                                              int copy_mask = kAccLanes - 1) {
+    const unsigned tx = thread_x();  // (opaque per call: see thread_x)
     if (lanes) {
-        for (int i = threadIdx.x; i < plen; i += n_threads) {
+        for (int i = tx; i < plen; i += n_threads) {
             const long long v = sAcc[i];
             if (v != 0)
-                atomicAdd(reinterpret_cast<unsigned long long *>(&lanes[i * kAccLanes + (blockIdx.x & (kAccLanes - 1))]),
+                atomicAdd(reinterpret_cast<unsigned long long *>(&lanes[i * kAccLanes + (blockIdx.x & copy_mask)]),
                           (unsigned long long)v);
         }
     } else {
         // transposed [entry][workgroup] so that the reduction reads unit-stride
-        for (int i = threadIdx.x; i < plen; i += n_threads) block_partials[(size_t)i * gridDim.x + blockIdx.x] = sAcc[i];
+        for (int i = tx; i < plen; i += n_threads) block_partials[(size_t)i * gridDim.x + blockIdx.x] = sAcc[i];
     }
 }
 
@@ -406,7 +420,8 @@ template <int D, int VEC>
 __device__ __forceinline__ void assign_body_valu(
     const float *__restrict__ X, int64_t N, int d_rt, int K, const et_kmeans_state *__restrict__ state,
     const float *__restrict__ cen, const int64_t *__restrict__ given, uint8_t *__restrict__ labels,
-    long long *__restrict__ block_partials, long long *__restrict__ lanes = nullptr) {
+    long long *__restrict__ block_partials, long long *__restrict__ lanes = nullptr, int copy_mask = kAccLanes - 1) {
+    const unsigned tx = thread_x();  // (opaque per call: see thread_x)
     const int d = D ? D : d_rt;
     const int plen = d * K + K + 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -421,14 +436,14 @@ __device__ __forceinline__ void assign_body_valu(
     const bool incremental = (state->iter > 0) && (given == nullptr);
     const bool fast = state->fast_ok != 0;
     const int n_threads = (int)blockDim.x;  // 256, or the filter launch size (768 / 1024)
-    for (int i = threadIdx.x; i < plen; i += n_threads) sAcc[i] = 0;
+    for (int i = tx; i < plen; i += n_threads) sAcc[i] = 0;
     stage_centroids(cen, d, K, sC);
     __syncthreads();
 
     long long sim_acc = 0, nan_acc = 0;
     const int64_t n_groups = (N + VEC - 1) / VEC;
     const int64_t stride = (int64_t)gridDim.x * n_threads;
-    for (int64_t gidx = (int64_t)blockIdx.x * n_threads + threadIdx.x; gidx < n_groups; gidx += stride) {
+    for (int64_t gidx = (int64_t)blockIdx.x * n_threads + tx; gidx < n_groups; gidx += stride) {
         const int64_t n = gidx * VEC;
         float x[VEC][D ? D : ET_KMEANS_MAX_D];
         unsigned old_packed = 0xffffffffu;
@@ -472,10 +487,10 @@ __device__ __forceinline__ void assign_body_valu(
                         long long f = to_fixed(x[0][i], frac) + to_fixed(x[1 % VEC][i], frac) + to_fixed(x[2 % VEC][i], frac) +
                                       to_fixed(x[3 % VEC][i], frac);
                         for (int o = 32; o > 0; o >>= 1) f += __shfl_xor(f, o);
-                        if ((threadIdx.x & 63) == 0)
+                        if ((tx & 63) == 0)
                             atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[i * K + L0]), (unsigned long long)f);
                     }
-                    if ((threadIdx.x & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + L0]), 256ull);
+                    if ((tx & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + L0]), 256ull);
 #pragma unroll
                     for (int v = 0; v < 4; ++v) sim_acc += to_fixed(bests[v], sfrac);
                     *reinterpret_cast<unsigned *>(labels + n) = (unsigned)L0 * 0x01010101u;
@@ -521,12 +536,12 @@ __device__ __forceinline__ void assign_body_valu(
         sim_acc += __shfl_xor(sim_acc, o);
         nan_acc += __shfl_xor(nan_acc, o);
     }
-    if ((threadIdx.x & 63) == 0) {
+    if ((tx & 63) == 0) {
         atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K]), (unsigned long long)sim_acc);
         atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K + 1]), (unsigned long long)nan_acc);
     }
     __syncthreads();
-    emit_partials(sAcc, plen, n_threads, block_partials, lanes);
+    emit_partials(sAcc, plen, n_threads, block_partials, lanes, copy_mask);
 }
 
 template <int D, int VEC>
@@ -677,6 +692,61 @@ __device__ __forceinline__ void filter_drain(const unsigned *q, int cnt, int K, 
     if (SIM) sim_acc += to_fixed(best, sfrac);
 }
 
+#ifdef ET_PERSIST_STAMPS  // development aid (tools/persist_stamps.py): per workgroup and iteration, 10 ns ticks
+// kinds 0..5 (persistent kernel): top (own arrival done), go, folded, updated, body start, body end;
+// kinds 6..9 (inside the filter body): operands staged, passes done (wavefront 0), queue drained, deltas emitted
+constexpr int kStampIters = 104, kStampKinds = 10;
+__device__ unsigned long long g_persist_stamps[256 * kStampIters * kStampKinds];
+__device__ int g_stamp_it[256];
+#define ET_STAMP(kind)                                                                                              \
+    do {                                                                                                            \
+        if (threadIdx.x == 0 && blockIdx.x < 256 && it < kStampIters) {                                             \
+            g_stamp_it[blockIdx.x] = it;                                                                            \
+            g_persist_stamps[((size_t)blockIdx.x * kStampIters + it) * kStampKinds + (kind)] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                                                           \
+    } while (0)
+#define ET_BSTAMP(kind)                                                                                             \
+    do {                                                                                                            \
+        if (threadIdx.x == 0 && blockIdx.x < 256 && g_stamp_it[blockIdx.x] < kStampIters)                           \
+            g_persist_stamps[((size_t)blockIdx.x * kStampIters + g_stamp_it[blockIdx.x]) * kStampKinds + (kind)] =  \
+                __builtin_amdgcn_s_memrealtime();                                                                   \
+    } while (0)
+#else
+#define ET_STAMP(kind) do { } while (0)
+#define ET_BSTAMP(kind) do { } while (0)
+#endif
+
+// issue the loads of pass `gg` (256 points: lane (half, col) owns points 4 col .. 4 col + 3 of its 128-point half)
+__device__ __forceinline__ void pass_issue(const float *__restrict__ X, int64_t N, const uint8_t *__restrict__ labels, int64_t gg,
+                                           int half, int col, float4 (&vn)[6], unsigned &lpn) {
+    const int64_t n = gg * 256 + 128 * half + 4 * col;
+    // lanes past the end (last pass only) read points 0..3 instead: finite data, results discarded through `valid`
+    // (unconditional loads: no exec-masked branch and no zero fill of 25 registers in every pass)
+    const int64_t nl = n < N ? n : 0;  // N % 4 == 0
+#ifdef ET_EXP_NOLOAD  // measurement aid (tools/ab_lloyd.sh): the assignment without its memory traffic
+    const float f = (float)(nl & 1023) * 0.01f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) vn[i] = make_float4(f + i, f - i, f * 0.5f, 1.0f + i);
+    lpn = 0x01010101u * (unsigned)(nl & 7);
+#else
+#ifdef ET_EXP_NT_EVERY  // measurement aid: every ET_EXP_NT_EVERY-th pass bypasses the caches (does the rest then stay in the MALL?)
+    if ((gg / 12) % ET_EXP_NT_EVERY == ET_EXP_NT_EVERY - 1) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float4 *p = reinterpret_cast<const float4 *>(X + (int64_t)i * N + nl);
+            vn[i] = make_float4(__builtin_nontemporal_load(&p->x), __builtin_nontemporal_load(&p->y),
+                                __builtin_nontemporal_load(&p->z), __builtin_nontemporal_load(&p->w));
+        }
+        lpn = *reinterpret_cast<const unsigned *>(labels + nl);
+        return;
+    }
+#endif
+#pragma unroll
+    for (int i = 0; i < 6; ++i) vn[i] = *reinterpret_cast<const float4 *>(X + (int64_t)i * N + nl);
+    lpn = *reinterpret_cast<const unsigned *>(labels + nl);
+#endif
+}
+
 // SIM = false: the similarity sum (the inertia of THIS assignment, kmeans.py:234) is not accumulated -- a fit that
 // does not record the per-iteration trace evaluates the inertia once, after its last assignment
 // (kmeans_inertia_kernel); the labels and the cluster sums are the same either way.
@@ -684,7 +754,9 @@ template <int NREGS, bool SIM = true>
 __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, int64_t N, int K,
                                                    const et_kmeans_state *state, const float *cen,
                                                    uint8_t *__restrict__ labels, long long *__restrict__ block_partials,
-                                                   long long *__restrict__ lanes = nullptr) {
+                                                   long long *__restrict__ lanes = nullptr,
+                                                   int copy_mask = kAccLanes - 1) {
+    const unsigned tx = thread_x();  // (opaque per call: see thread_x)
     constexpr int d = 6;
     // power-of-two scale: every |x| sg, |c| sg < 32, so that |2c x| sg^2 < 6 * 2^11 and |c|^2 sg^2 < 6 * 2^10 fit
     // f16 and stay far above the -60000 that pads the rows of clusters >= K
@@ -692,14 +764,14 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
     // first iteration (no labels yet), possible NaN/Inf, or a scale whose square leaves the fp32 range:
     // the exact kernel decides
     if (state->iter <= 0 || !state->fast_ok || e_max < -40 || e_max > 60) {
-        assign_body_valu<6, 4>(X, N, d, K, state, cen, nullptr, labels, block_partials, lanes);
+        assign_body_valu<6, 4>(X, N, d, K, state, cen, nullptr, labels, block_partials, lanes, copy_mask);
         return;
     }
     const int plen = d * K + K + 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     long long *sAcc = reinterpret_cast<long long *>(smem_raw);                                 // plen
     float *sC = reinterpret_cast<float *>(smem_raw + sizeof(long long) * ((plen + 1) & ~1));  // K * 8
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+    const int lane = tx & 63, wave = tx >> 6, half = lane >> 5, col = lane & 31;
     unsigned *queue = reinterpret_cast<unsigned *>(sC + K * 8) + wave * kFilterQueue;
     const int frac = (int)state->frac, sfrac = (int)state->sim_frac;
     // threshold polynomial in rr, already multiplied by sg^2 (the MFMA works on scaled operands)
@@ -714,12 +786,12 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
     const float sg = ldexpf(1.0f, 5 - e_max), sg2 = sg * sg;
     const float sgk = sg * kSqrt6Up;  // exact (sg is a power of two, 2^-55 ... 2^45)
     const int n_thr = (int)blockDim.x, n_wav = n_thr >> 6;  // 768 or 1024 threads (host's choice)
-    for (int i = threadIdx.x; i < plen; i += n_thr) sAcc[i] = 0;
+    for (int i = tx; i < plen; i += n_thr) sAcc[i] = 0;
     stage_centroids(cen, d, K, sC);
     // slot 7 of a centroid row: the |c|^2 part of the rounding slack of the trace-less certification (below)
-    for (int j = threadIdx.x; j < K; j += n_thr) sC[j * 8 + 7] = fmaf(sC[j * 8 + 6] * sg2, kCcSlack, 2.3283064365386963e-10f);
+    for (int j = tx; j < K; j += n_thr) sC[j * 8 + 7] = fmaf(sC[j * 8 + 6] * sg2, kCcSlack, 2.3283064365386963e-10f);
     __shared__ int sNext;  // next of this workgroup's passes: the wavefronts take them as they come (see the loop)
-    if (threadIdx.x == 0) sNext = 0;
+    if (tx == 0) sNext = (int)(blockDim.x >> 6);  // a wavefront's first pass is its own (static), the others are handed out
     __syncthreads();
 
 
@@ -754,6 +826,7 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
         a2 = u32x4{cl[0], cl[1], cl[2], 0u};
     }
     const f16x8 A1 = __builtin_bit_cast(f16x8, a1), A2 = __builtin_bit_cast(f16x8, a2);
+    ET_BSTAMP(6);
     const float4 *s4 = reinterpret_cast<const float4 *>(sC);
 
     // Inertia: trunc(Y 2^sim_frac) is an integer below 2^(62 - bits(n_total)); a lane may add 2^(bits - 9) of them
@@ -773,28 +846,37 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
     // (shards with at most one pass per wavefront keep the fixed map: nothing to balance, and no counter round trip)
     const bool dynamic = n_groups > (int64_t)gridDim.x * n_wav;
     bool first = true;
-    for (;;) {
+    auto take = [&]() -> int64_t {  // this wavefront's next pass, or -1 (wave-uniform)
         int64_t g;
-        if (dynamic) {
+        if (first) {
+            first = false;
+            g = (int64_t)blockIdx.x * n_wav + wave;
+        } else if (dynamic) {
             int i = 0;
             if (lane == 0) i = atomicAdd(&sNext, 1);
             i = __builtin_amdgcn_readfirstlane(i);
             g = (int64_t)blockIdx.x * n_wav + (i % n_wav) + (int64_t)(i / n_wav) * gridDim.x * n_wav;
         } else {
-            if (!first) break;
-            first = false;
-            g = (int64_t)blockIdx.x * n_wav + wave;
+            g = n_groups;
         }
-        if (g >= n_groups) break;
+        return g < n_groups ? g : -1;
+    };
+    // (Requesting a pass's coordinates one pass ahead, or a wavefront's first pass before the persistent kernel's grid
+    // barrier -- 25 more VGPRs each, free at three wavefronts per SIMD -- was measured and dropped: 51.4 against 50.4 us
+    // per chained launch at N = 1e7 and no change of the persistent iteration; with the matrix-core work AND the top-2
+    // removed the launch still takes 49.5 us (tools/ab_lloyd.sh, profiles/r03e_ab_lloyd.txt): the passes run at what the
+    // memory side delivers for this access pattern, ~6 TB/s, and are neither latency nor issue bound.)
+    float4 vn[6];
+    unsigned lpn = 0u;
+    int64_t g = take();
+    if (g >= 0) pass_issue(X, N, labels, g, half, col, vn, lpn);
+    while (g >= 0) {
         const int64_t n = g * 256 + 128 * half + 4 * col;
-        const bool valid = n < N;  // N % 4 == 0
-        // lanes past the end (last pass only) read points 0..3 instead: finite data, results discarded through `valid`
-        // (unconditional loads: no exec-masked branch and no zero fill of 25 registers in every pass)
-        const int64_t nl = valid ? n : 0;
+        const bool valid = n < N;
         float4 v[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) v[i] = *reinterpret_cast<const float4 *>(X + (int64_t)i * N + nl);
-        const unsigned old_packed = *reinterpret_cast<const unsigned *>(labels + nl);
+        for (int i = 0; i < 6; ++i) v[i] = vn[i];
+        const unsigned old_packed = lpn;
         unsigned undecided = 0u;  // bit q: point q of this lane goes to the queue
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -831,13 +913,18 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
             f32x16 accL, accU;
 #pragma unroll
             for (int r = 0; r < 16; ++r) accL[r] = accU[r] = 0.f;
+            float bL, sL, bU, sU;
+#ifdef ET_EXP_NOMFMA  // measurement aid: no matrix-core work and no top-2 (every point is "kept")
+            bL = __uint_as_float(bLo[0]) * 1e-30f, sL = __uint_as_float(bLo[1]) * 1e-30f - 1e30f;
+            bU = __uint_as_float(bUp[2]) * 1e-30f, sU = __uint_as_float(bUp[3]) * 1e-30f - 1e30f;
+#else
             accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, BL, accL, 0, 0, 0);
             accU = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, BU, accU, 0, 0, 0);
             accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, BL, accL, 0, 0, 0);
             accU = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, BU, accU, 0, 0, 0);
-            float bL, sL, bU, sU;
             top2<NREGS>(accL, bL, sL);
             top2<NREGS>(accU, bU, sU);
+#endif
             // lower half-wave: both partials of its own points (tile L); upper half-wave: those of tile U
             const auto rb = __builtin_amdgcn_permlane32_swap(__float_as_uint(bL), __float_as_uint(bU), false, false);
             const auto rq = __builtin_amdgcn_permlane32_swap(__float_as_uint(sL), __float_as_uint(sU), false, false);
@@ -905,15 +992,20 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
                 terms = 0;
             }
         }
+        g = take();
+        if (g >= 0) pass_issue(X, N, labels, g, half, col, vn, lpn);
     }
     sim_acc += (long long)dsum;
+    ET_BSTAMP(7);
     if (qn) filter_drain<SIM>(queue, qn, K, sC, labels, sAcc, frac, sfrac, lane, sim_acc);
+    ET_BSTAMP(8);
     if (SIM) {
         for (int o = 32; o > 0; o >>= 1) sim_acc += __shfl_xor(sim_acc, o);
         if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K]), (unsigned long long)sim_acc);
     }
     __syncthreads();
-    emit_partials(sAcc, plen, n_thr, block_partials, lanes);
+    emit_partials(sAcc, plen, n_thr, block_partials, lanes, copy_mask);
+    ET_BSTAMP(9);
 }
 
 template <int NREGS>
@@ -959,6 +1051,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_reduce_partials_kernel(cons
 __device__ __forceinline__ void update_body(et_kmeans_state *state, const long long *partials, int d, int K, float tol,
                                             float *cen, float *trace, const et_kmeans_state *pre = nullptr,
                                             float *last = nullptr) {
+    const unsigned tx = thread_x();  // (opaque per call: see thread_x)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *sSq = reinterpret_cast<float *>(smem_raw);  // d*K squared differences
     float *sNew = sSq + d * K;
@@ -967,7 +1060,7 @@ __device__ __forceinline__ void update_body(et_kmeans_state *state, const long l
     const long long sim_sum = partials[d * K + K], nan_count = partials[d * K + K + 1];
     const int frac = (int)st.frac;
     const double inv_scale = ldexp(1.0, -frac);
-    for (int e = threadIdx.x; e < d * K; e += (int)blockDim.x) {
+    for (int e = tx; e < d * K; e += (int)blockDim.x) {
         const int j = e % K;
         const long long cnt = partials[d * K + j];
         float c;
@@ -980,18 +1073,18 @@ __device__ __forceinline__ void update_body(et_kmeans_state *state, const long l
         cen[e] = c;
         if (last) last[e] = prev;
     }
-    if (last && threadIdx.x == 0) *reinterpret_cast<long long *>(last + ((d * K + 1) & ~1)) = (long long)st.sim_frac;
+    if (last && tx == 0) *reinterpret_cast<long long *>(last + ((d * K + 1) & ~1)) = (long long)st.sim_frac;
     __syncthreads();
     // max |c| (NaN ignored), smallest non-zero |c| and a non-finite flag, reduced by the first wavefront
     __shared__ float sRed[3];
     __shared__ double sErr;
-    if (blockDim.x <= 64 || (threadIdx.x >> 6) == 1) {
+    if (blockDim.x <= 64 || (tx >> 6) == 1) {
         // kmeans.py:50 in the oracle's fixed order (oracle/et_oracle.c: eto_error_sum): fp64, blocks of 256 consecutive
         // terms, each a balanced tree x[i] += x[i + s], s = 1 ... 128, block results added in block order.  A lane holds
         // four consecutive terms (levels s = 1, 2), the lanes combine through shuffles (s = 4 ... 128): seven dependent
         // additions instead of the d K of a running sum (1.7 us of every Lloyd launch's prologue with d K = 120).
         // It runs on the second wavefront next to the reductions below.
-        const int l = threadIdx.x & 63, dk = d * K;
+        const int l = tx & 63, dk = d * K;
         double total = 0.0;
         for (int b0 = 0; b0 < dk; b0 += 256) {
             float f[4];
@@ -1004,11 +1097,11 @@ __device__ __forceinline__ void update_body(et_kmeans_state *state, const long l
         }
         if (l == 0) sErr = total;
     }
-    if (threadIdx.x < 64) {
+    if (tx < 64) {
         float mx = 0.f;
         unsigned mn = 0x7f800000u;
         int bad = 0;
-        for (int e = threadIdx.x; e < d * K; e += 64) {
+        for (int e = tx; e < d * K; e += 64) {
             const float a = fabsf(sNew[e]);
             if (!(a <= 3.402823466e+38f)) bad = 1;
             if (a > mx) mx = a;  // false for NaN: ignored, like the oracle
@@ -1021,14 +1114,14 @@ __device__ __forceinline__ void update_body(et_kmeans_state *state, const long l
             mn = other < mn ? other : mn;
             bad |= __shfl_xor(bad, o);
         }
-        if (threadIdx.x == 0) {
+        if (tx == 0) {
             sRed[0] = mx;
             sRed[1] = __int_as_float((int)mn);
             sRed[2] = bad ? 1.f : 0.f;
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tx == 0) {
         const float error = (float)sErr;
         const int64_t n_total = st.n_total;
         float inertia;
@@ -1225,6 +1318,153 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_chain_finalize_kernel(const
     if (threadIdx.x == 0) *state = *ch.st_rd;
     __syncthreads();
     update_body(state, sTot, d, K, tol, cen, trace, ch.st_rd, ch.last);
+}
+
+// ------------------------------------------------------------------------------------------
+// Single-GPU fit, shards the filter takes: ALL Lloyd iterations in ONE launch (persistent workgroups).
+//
+// What a kernel boundary costs between two iterations, measured on this chip (tools/exp_overlap*.hip,
+// profiles/r03b_overlap2.txt): ~7 us for a 256 x 768-thread grid -- ~1.5 us until the next launch's first workgroup
+// runs and ~5.5 us until its LAST one does (the dispatcher places ~3000 wavefronts one after the other), on the
+// critical path of every iteration.  Here the grid (one workgroup per CU, all co-resident) stays; iterations are
+// separated by a grid barrier that needs NO cache fence: everything that crosses workgroups -- the 16-copy delta
+// table -- is written with device-scope atomics and read with device-scope (sc1) loads, both served by the memory
+// side, so `buffer_wbl2` / `buffer_inv` (measured: 23 us per iteration for the pair at agent scope, the reason a first
+// cooperative version in round 2 lost) never appear; a workgroup's arrival is one relaxed atomic after an
+// `s_waitcnt vmcnt(0)` + workgroup barrier, the wait one lane polling that counter (~1.1 us from the last arrival to
+// everybody running).  Every workgroup then folds the table and applies the update ITSELF, as in the chained kernel
+// (identical integers in => identical centroids / error / convergence flag everywhere), but keeps state, centroids and
+// running totals in its own LDS across iterations -- nothing but the table travels through memory, and all workgroups
+// leave the loop in the same iteration.  Labels are only ever re-read by the workgroup that wrote them (the
+// chunk -> workgroup map is fixed and is the same in the exact first pass and in the filter passes).
+// Every spin carries a time-out: a workgroup that waits longer than kSpinTimeoutTicks sets *abort and everybody
+// leaves; the host then repeats the fit with the chained kernel (co-residency cannot be promised when another process
+// shares the GPU; inside this process et_kmeans_fit hands out the CUs, see PersistSlots).
+// ------------------------------------------------------------------------------------------
+struct LloydPersist {
+    const et_kmeans_state *st_in;  // state block after scan / begin
+    const float *cen_in;           // initial centroids (d, K)
+    et_kmeans_state *st_out;       // final state
+    float *cen_out;                // final centroids
+    long long *tot_out;            // final totals
+    long long *lanes0, *lanes1, *lanes2;  // three 16-copy delta tables, zeroed before the launch
+    unsigned *arrive;              // grid barrier: arrivals so far (zeroed before the launch)
+    unsigned *abort;               // set by a workgroup whose wait timed out (zeroed before the launch)
+    float *last;                   // centroids + sim_frac of the last assignment (for kmeans_inertia_kernel)
+};
+constexpr unsigned long long kSpinTimeoutTicks = 50000000ull;  // 0.5 s of the 100 MHz s_memrealtime clock
+
+
+template <int NREGS, bool SIM>
+__global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_persist_kernel(
+    const float *__restrict__ X, int64_t N, int K, const LloydPersist pa, uint8_t *__restrict__ labels, float tol,
+    float *trace, int max_iter) {
+    constexpr int d = 6;
+    constexpr int kMaxK = 32;  // the filter's limit (km_use_filter)
+    constexpr int kMaxPlen = d * kMaxK + kMaxK + 2;
+    const int plen = d * K + K + 2;
+    __shared__ et_kmeans_state sSt;
+    __shared__ long long sTot[(kMaxPlen + 1) & ~1];  // running totals of this fit (every workgroup holds the same)
+    __shared__ float sCen[d * kMaxK];
+    __shared__ int sAbort;
+    const bool wg0 = blockIdx.x == 0;
+    constexpr int kStateWords = (int)(sizeof(et_kmeans_state) / sizeof(unsigned));
+    if ((int)threadIdx.x < kStateWords)
+        reinterpret_cast<unsigned *>(&sSt)[threadIdx.x] = reinterpret_cast<const unsigned *>(pa.st_in)[threadIdx.x];
+    for (int e = threadIdx.x; e < d * K; e += (int)blockDim.x) sCen[e] = pa.cen_in[e];
+    for (int e = threadIdx.x; e < plen; e += (int)blockDim.x) sTot[e] = 0;
+    if (threadIdx.x == 0) sAbort = 0;
+    __syncthreads();
+    // copies of the delta table the workgroups spread their atomics over: 16 (as in the chained kernel) for a full grid,
+    // ONE for a small one (<= 64 arrivals per address are absorbed by the memory side while the workgroups finish, and
+    // the fold becomes a single load per entry)
+    const int copy_mask = gridDim.x <= 64 ? 0 : kAccLanes - 1;
+    int it = 0;
+    for (;; ++it) {
+        ET_STAMP(0);
+        if (it > 0) {
+            // ---- grid barrier: every workgroup has added the deltas of assignment it - 1 ----
+            if (threadIdx.x == 0) {
+                const unsigned want = (unsigned)it * gridDim.x;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                while (__hip_atomic_load(pa.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    if (__hip_atomic_load(pa.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                        __builtin_amdgcn_s_memrealtime() - t0 > kSpinTimeoutTicks) {
+                        __hip_atomic_store(pa.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sAbort = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __syncthreads();
+            if (sAbort) return;
+            ET_STAMP(1);
+            // ---- fold the 16 copies of the table this assignment filled (sc1 loads: the atomics were performed at the
+            //      memory side) onto the running totals, in place: one lane per entry reads and writes it ----
+            const long long *lanes = it % 3 == 0 ? pa.lanes0 : (it % 3 == 1 ? pa.lanes1 : pa.lanes2);
+            const int total = plen * kAccLanes, n_threads = (int)blockDim.x;
+            const bool have_prev = it > 1;
+            if (copy_mask == 0) {  // small grid: one copy, one load per entry, one memory round trip
+                for (int e = threadIdx.x; e < plen; e += n_threads) {
+                    const long long v = (long long)__hip_atomic_load(
+                        reinterpret_cast<const unsigned long long *>(lanes) + e * kAccLanes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sTot[e] = ((have_prev && e < plen - 2) ? sTot[e] : 0) + v;
+                }
+            } else {
+                for (int base = 0; base < total; base += n_threads) {
+                    const int idx = base + (int)threadIdx.x;
+                    long long v = 0;
+                    if (idx < total)
+                        v = (long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(lanes) + idx,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int o = kAccLanes / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                    if (idx < total && (idx & (kAccLanes - 1)) == 0) {
+                        const int e = idx / kAccLanes;
+                        sTot[e] = ((have_prev && e < plen - 2) ? sTot[e] : 0) + v;
+                    }
+                }
+            }
+            __syncthreads();
+            ET_STAMP(2);
+            update_body(&sSt, sTot, d, K, tol, sCen, wg0 ? trace : nullptr, nullptr, wg0 ? pa.last : nullptr);
+            __syncthreads();
+            ET_STAMP(3);
+            if (wg0) {  // the table launch it - 1 read becomes the one assignment it + 1 adds onto
+                long long *zero = (it + 2) % 3 == 0 ? pa.lanes0 : ((it + 2) % 3 == 1 ? pa.lanes1 : pa.lanes2);
+                for (int i = threadIdx.x; i < total; i += n_threads)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(zero) + i, 0ull, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (sSt.done || it >= max_iter) break;  // kmeans.py:239 / the iteration cap (uniform over the grid)
+        long long *wr = (it + 1) % 3 == 0 ? pa.lanes0 : ((it + 1) % 3 == 1 ? pa.lanes1 : pa.lanes2);
+        // The assignment is compiled as if it were a kernel of its own: its inputs pass through an empty asm, so nothing
+        // derived from them is loop invariant and hoisted out of the iteration loop (held live across the whole body,
+        // the hoisted values cost 12 VGPRs + 72 B of scratch memory: a private segment is paid for at every wavefront
+        // launch and the spills sit in the hot loop)
+        const float *Xi = X;
+        uint8_t *li = labels;
+        int64_t Ni = N;
+        int Ki = K;
+        asm volatile("" : "+s"(Xi), "+s"(li), "+s"(Ni), "+s"(Ki), "+s"(wr));
+        ET_STAMP(4);
+        filter_assign_body<NREGS, SIM>(Xi, Ni, Ki, &sSt, sCen, li, nullptr, wr, copy_mask);
+        ET_STAMP(5);
+        // arrival: this workgroup's atomics (and its table clear, workgroup 0) have been performed -- every wavefront
+        // waits for its own outstanding memory operations (s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0); a workgroup-scope
+        // release fence would omit the vmcnt), then the workgroup barrier, then one lane counts
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(pa.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wg0) {
+        if ((int)threadIdx.x < kStateWords)
+            reinterpret_cast<unsigned *>(pa.st_out)[threadIdx.x] = reinterpret_cast<const unsigned *>(&sSt)[threadIdx.x];
+        for (int e = threadIdx.x; e < d * K; e += (int)blockDim.x) pa.cen_out[e] = sCen[e];
+        for (int e = threadIdx.x; e < plen; e += (int)blockDim.x) pa.tot_out[e] = sTot[e];
+    }
 }
 
 // Inertia of the LAST assignment of a fit that did not track it per iteration (kmeans.py:234 of that iteration):
@@ -1680,16 +1920,22 @@ static int km_grid(int64_t work_items) {
 // per CU from the occupancy query): every workgroup then gets the same number of passes (+-1) and
 // there is no sparsely filled last round (4096 workgroups at 5 resident per CU would leave the
 // chip 80 % idle for its fourth round).
-template <typename Kernel>
-static int km_resident_grid(Kernel kernel, size_t lds_bytes, int64_t work_items, int threads = kKmThreads) {
-    // CU count of the CURRENT device (cached per device id; a process may drive several GPUs)
+// CU count of the CURRENT device (cached per device id; a process may drive several GPUs)
+static int km_cu_count(int *dev_out = nullptr) {
     static int cu_of_device[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev_out) *dev_out = dev;
     int &n_cu = cu_of_device[dev & 63];
     if (n_cu == 0) {
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
     }
+    return n_cu;
+}
+
+template <typename Kernel>
+static int km_resident_grid(Kernel kernel, size_t lds_bytes, int64_t work_items, int threads = kKmThreads) {
+    const int n_cu = km_cu_count();
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds_bytes) != hipSuccess || per_cu < 1)
         per_cu = threads > 256 ? 1 : 4;
@@ -1723,6 +1969,7 @@ struct KmWorkspace {
     float *chain_cen[2];              // three of the 16-copy delta table (see LloydChain)
     long long *chain_tot[2];
     long long *chain_lanes[3];
+    unsigned *persist_ctl;   // kmeans_lloyd_persist_kernel: {arrivals, abort flag}, a cache line of their own
     size_t bytes;
 };
 
@@ -1770,6 +2017,8 @@ static KmWorkspace km_carve(void *base, int64_t N, int d, int K) {
         w.chain_lanes[i] = (long long *)(p + off);
         off = align_up(off + sizeof(long long) * km_plen(d, K) * 16, 256);
     }
+    w.persist_ctl = (unsigned *)(p + off);
+    off = align_up(off + 2 * sizeof(unsigned), 256);
     w.bytes = off;
     return w;
 }
@@ -1845,12 +2094,13 @@ static int km_fat_lds_attribute() {
     ET_HIP_TRY(hipGetDevice(&dev_id));
     bool &lds_ok = lds_set[dev_id & 63];
     if (lds_ok) return ET_OK;
+#define ET_FAT4(KERNEL)                                                                                       \
+    reinterpret_cast<const void *>(KERNEL<10, true>), reinterpret_cast<const void *>(KERNEL<10, false>),           \
+        reinterpret_cast<const void *>(KERNEL<16, true>), reinterpret_cast<const void *>(KERNEL<16, false>)
     const void *fat[] = {reinterpret_cast<const void *>(kmeans_assign_filter_kernel<10>),
                          reinterpret_cast<const void *>(kmeans_assign_filter_kernel<16>),
-                         reinterpret_cast<const void *>(kmeans_lloyd_chain_kernel<10, true>),
-                         reinterpret_cast<const void *>(kmeans_lloyd_chain_kernel<10, false>),
-                         reinterpret_cast<const void *>(kmeans_lloyd_chain_kernel<16, true>),
-                         reinterpret_cast<const void *>(kmeans_lloyd_chain_kernel<16, false>)};
+                         ET_FAT4(kmeans_lloyd_chain_kernel), ET_FAT4(kmeans_lloyd_persist_kernel)};
+#undef ET_FAT4
     for (const void *f : fat) ET_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     lds_ok = true;
     return ET_OK;
@@ -2210,6 +2460,157 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
     return ET_OK;
 }
 
+// ---- the persistent loop (kmeans_lloyd_persist_kernel) ----
+// Its grid barrier needs every workgroup of the launch resident at once.  One launch alone always is (the grid is one
+// resident round, km_resident_grid); several fits running side by side in this process (the ten initialisations of the
+// sklearn recipe, the moving / static clusterings, BatchKMeans' problems -- one host thread and stream each) share the
+// CUs through this counter: a fit takes as many CU slots as its grid has workgroups before it launches and gives them
+// back after its final synchronisation, so the persistent grids in flight never need more CUs than the device has.
+// (Other kernels may occupy CUs for a while -- they end; another PROCESS on the same GPU can break the promise, which
+// is what the kernel's time-out and the chained fallback are for.)
+#include <condition_variable>
+#include <mutex>
+namespace et {
+class PersistSlots {
+  public:
+    static PersistSlots &of_device(int dev) {
+        static PersistSlots slots[64];
+        return slots[dev & 63];
+    }
+    void acquire(int n, int capacity) {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return used_ == 0 || used_ + n <= capacity; });
+        used_ += n;
+    }
+    void release(int n) {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            used_ -= n;
+        }
+        cv_.notify_all();
+    }
+
+  private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    int used_ = 0;
+};
+
+__global__ __launch_bounds__(kKmThreads) void kmeans_persist_prepare_kernel(int plen, long long *l0, long long *l1, long long *l2,
+                                                                            unsigned *ctl, long long *sim_total) {
+    const int tid = blockIdx.x * kKmThreads + threadIdx.x, n_thr = gridDim.x * kKmThreads;
+    for (int e = tid; e < plen * kAccLanes; e += n_thr) {
+        l0[e] = 0;
+        l1[e] = 0;
+        l2[e] = 0;
+    }
+    if (tid < 2) {
+        ctl[tid] = 0u;
+        sim_total[tid] = 0;
+    }
+}
+
+// Which loop form a single-GPU fit takes.  Measured per iteration (tools/ab_loop_sizes.py, profiles/r03f_loop_sizes.txt,
+// same box): N = 2e4 11.9 us persistent / 13.7 chained, 7e4 12.9 / 13.9, 1e5 13.6 / 14.0, 3e5 16.2 / 13.6,
+// 1e6 20.9 / 15.4, 1e7 56.1 / 49.7 -- the grid barrier + fold + update of the persistent form (~4 us for 33 workgroups,
+// ~7 us + the spread of 256 workgroups' finishing times for a full grid) beats a kernel boundary only while the grid is
+// small; for a full grid the staggered start of a new launch's workgroups happens to hide the uneven pass counts that
+// the barrier exposes.  Hence: persistent up to kPersistMaxPoints, chained above; ET_KMEANS_LOOP=persist / chain forces one.
+constexpr int64_t kPersistMaxPoints = 98304;  // 32 workgroups of 12 wavefronts, one 256-point pass each
+static bool km_persist_wanted(int64_t N) {
+    static const char mode = [] {
+        const char *e = getenv("ET_KMEANS_LOOP");
+        return e ? e[0] : 'a';
+    }();
+    if (mode == 'c') return false;
+    if (mode == 'p') return true;
+    return N <= kPersistMaxPoints;
+}
+
+// All Lloyd iterations of a single-GPU fit in one launch.  Same contract as km_chain_run; *aborted = true (and nothing
+// written to state / centroids / partials) when the grid barrier timed out -- the caller repeats the fit chained.
+static int km_persist_run(const float *X, int64_t N, int d, int K, int max_iter, float tol, float *centroids,
+                          uint8_t *labels_u8, float *trace, et_kmeans_state *state, long long *partials, const KmWorkspace &w,
+                          hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, bool *aborted, int *grid_out) {
+    const bool want_sim = trace != nullptr;
+    const int threads = km_filter_threads(N);
+    const size_t plen = km_plen(d, K), lds = km_filter_lds_bytes(d, K, threads);
+    int rc = km_fat_lds_attribute();
+    if (rc) return rc;
+    hipLaunchKernelGGL(kmeans_persist_prepare_kernel, dim3(8), dim3(kKmThreads), 0, st, (int)plen, w.chain_lanes[0],
+                       w.chain_lanes[1], w.chain_lanes[2], w.persist_ctl, w.sim_total);
+    ET_LAUNCH_CHECK();
+    LloydPersist pa;
+    pa.st_in = state;
+    pa.cen_in = centroids;
+    pa.st_out = w.chain_state[0];  // staged: the caller's buffers are only written once the loop is known to have run
+    pa.cen_out = w.chain_cen[0];
+    pa.tot_out = w.chain_tot[0];
+    pa.lanes0 = w.chain_lanes[0];
+    pa.lanes1 = w.chain_lanes[1];
+    pa.lanes2 = w.chain_lanes[2];
+    pa.arrive = w.persist_ctl;
+    pa.abort = w.persist_ctl + 1;
+    pa.last = w.last;
+    int grid = 0, dev = 0;
+    const int n_cu = km_cu_count(&dev);
+    // one resident round of workgroups of the instantiation that is launched
+    if (K <= 20) grid = want_sim ? km_resident_grid(kmeans_lloyd_persist_kernel<10, true>, lds, N / 4, threads)
+                                 : km_resident_grid(kmeans_lloyd_persist_kernel<10, false>, lds, N / 4, threads);
+    else grid = want_sim ? km_resident_grid(kmeans_lloyd_persist_kernel<16, true>, lds, N / 4, threads)
+                         : km_resident_grid(kmeans_lloyd_persist_kernel<16, false>, lds, N / 4, threads);
+    if (grid > n_cu) grid = n_cu;  // one fat workgroup per CU is what the co-residency accounting assumes
+    PersistSlots &slots = PersistSlots::of_device(dev);
+    slots.acquire(grid, n_cu);
+    struct Release {
+        PersistSlots &s;
+        int n;
+        ~Release() { s.release(n); }
+    } release_on_exit{slots, grid};
+    if (ev_begin) ET_HIP_TRY(hipEventRecord(ev_begin, st));
+#define ET_LAUNCH_PERSIST(NR, SIM)                                                                                \
+    hipLaunchKernelGGL((kmeans_lloyd_persist_kernel<NR, SIM>), dim3(grid), dim3(threads), lds, st, X, N, K, pa,      \
+                       labels_u8, tol, trace, max_iter)
+    if (K <= 20) {
+        if (want_sim) ET_LAUNCH_PERSIST(10, true);
+        else ET_LAUNCH_PERSIST(10, false);
+    } else {
+        if (want_sim) ET_LAUNCH_PERSIST(16, true);
+        else ET_LAUNCH_PERSIST(16, false);
+    }
+#undef ET_LAUNCH_PERSIST
+    ET_LAUNCH_CHECK();
+    if (ev_end) ET_HIP_TRY(hipEventRecord(ev_end, st));
+    if (grid_out) *grid_out = grid;
+    // the one host round trip of the fit that the chained loop does not have: did the barrier hold?  (pinned staging
+    // would save nothing here: the caller synchronises right after this anyway)
+    unsigned ctl[2] = {0u, 0u};
+    ET_HIP_TRY(hipMemcpyAsync(ctl, w.persist_ctl, sizeof ctl, hipMemcpyDeviceToHost, st));
+    ET_HIP_TRY(hipStreamSynchronize(st));
+    *aborted = ctl[1] != 0u;
+    if (*aborted) return ET_OK;
+    ET_HIP_TRY(hipMemcpyAsync(state, w.chain_state[0], sizeof(et_kmeans_state), hipMemcpyDeviceToDevice, st));
+    ET_HIP_TRY(hipMemcpyAsync(centroids, w.chain_cen[0], sizeof(float) * (size_t)d * K, hipMemcpyDeviceToDevice, st));
+    ET_HIP_TRY(hipMemcpyAsync(partials, w.chain_tot[0], sizeof(long long) * plen, hipMemcpyDeviceToDevice, st));
+    if (!want_sim) {  // inertia of the last assignment; the prepare kernel zeroed sim_total
+        const size_t ilds = sizeof(float) * (size_t)K * cpitch_host(d);
+        const int igrid = min(km_grid(N / 4 + 1), 1024);
+        hipLaunchKernelGGL((kmeans_inertia_kernel<6>), dim3(igrid), dim3(kKmThreads), ilds, st, X, N, d, K,
+                           (const float *)w.last, (const uint8_t *)labels_u8, w.sim_total);
+        hipLaunchKernelGGL(kmeans_inertia_finish_kernel, dim3(1), dim3(64), 0, st, state, (const float *)w.last, d, K,
+                           (const long long *)w.sim_total);
+        ET_LAUNCH_CHECK();
+    }
+    return ET_OK;
+}
+}  // namespace et
+
+#ifdef ET_PERSIST_STAMPS
+extern "C" int et_debug_persist_stamps(void *host, size_t bytes) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(et::g_persist_stamps), bytes) == hipSuccess ? 0 : 1;
+}
+#endif
+
 // Entry points for csrc/et_sharded.hip (not part of the public header): can this rank's shard run the chained loop,
 // and the loop itself with a reduction between the launches.  `workspace` as for et_kmeans_fit.
 extern "C" int et_internal_kmeans_chain_usable(const float *X, int64_t N, int d, int K, const uint8_t *labels_u8) {
@@ -2277,7 +2678,17 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     // form with a ticketed fold + update in the last workgroup served shards <= 131072 points until its serial tail
     // lost to this prologue: 19.8 against 16.8 us per iteration at N = 1e5.)
     const bool chained = km_use_filter(X, N, d, K, w.labels_u8);
-    if (chained) {
+    // ... as ONE persistent launch for all iterations (kmeans_lloyd_persist_kernel); one launch per iteration
+    // (km_chain_run, the form the sharded loop uses) if its grid barrier timed out or ET_KMEANS_LOOP=chain asks for it
+    bool persisted = false;
+    if (chained && km_persist_wanted(N)) {
+        bool aborted = false;
+        rc = km_persist_run(X, N, d, K, max_iter, tol, centroids, w.labels_u8, trace, w.state, (long long *)w.partials, w, st,
+                            timing_host ? events[0] : nullptr, timing_host ? events[1] : nullptr, &aborted, nullptr);
+        if (rc) return rc;
+        persisted = !aborted;
+    }
+    if (chained && !persisted) {
         rc = km_chain_run(X, N, d, K, max_iter, tol, centroids, w.labels_u8, trace, w.state, (long long *)w.partials, w, st,
                           ChainHook{}, timing_host ? &events : nullptr, kTimeEvery, &launched);
         if (rc) return rc;
@@ -2316,7 +2727,15 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     if (rc) return rc;
     ET_HIP_TRY(hipMemcpyAsync(state_host, w.state, sizeof(et_kmeans_state), hipMemcpyDeviceToHost, st));
     ET_HIP_TRY(hipStreamSynchronize(st));
-    if (timing_host) {
+    if (timing_host && persisted) {
+        // one launch ran every assignment (the exact first pass included) and every update of the fit
+        float ms = 0.f;
+        ET_HIP_TRY(hipEventElapsedTime(&ms, events[0], events[1]));
+        timing_host->assign_ms = (double)ms;
+        timing_host->assign_launches = 1;
+        timing_host->first_assign_ms = 0.0;
+        timing_host->iterations = state_host->iter;
+    } else if (timing_host) {
         // launches after convergence are no-ops (a few microseconds); count only the working ones.  The first
         // launch of a fit is the plain exact scan with full accumulation, the others the filter kernel.
         const int worked = (int)(state_host->iter < launched ? state_host->iter : launched);
@@ -2336,6 +2755,7 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
         timing_host->assign_ms = total;
         timing_host->assign_launches = samples;
         timing_host->first_assign_ms = first;
+        timing_host->iterations = samples;
     }
     return state_host->bad_input ? ET_ERR_BAD_DATA : ET_OK;
 }

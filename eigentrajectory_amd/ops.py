@@ -298,7 +298,7 @@ def kmeans_fit(X, centroids, max_iter=100, tol=1e-4, workspace=None, timing=Fals
                trace=trace_t[:int(st.iter)] if trace else None, done=bool(st.done))
     if timing:
         out["assign_ms"], out["assign_launches"] = float(tm.assign_ms), int(tm.assign_launches)
-        out["first_assign_ms"] = float(tm.first_assign_ms)
+        out["first_assign_ms"], out["assign_iterations"] = float(tm.first_assign_ms), int(tm.iterations)
     return out
 
 

@@ -243,14 +243,16 @@ int et_kmeans_update(et_kmeans_state *state, const int64_t *partials, int d, int
 /* widen the uint8 labels of the last assignment to the reference's int64 */
 int et_kmeans_labels_i64(const uint8_t *labels_u8, int64_t N, int64_t *labels, et_stream_t stream);
 
-/* optional kernel timing of et_kmeans_fit: HIP events recorded on `stream` around a sample of the
- * launches of the assign kernel (the dominant kernel of the path) -- the first launch and every 8th
- * of the others; timing every launch would put a dispatch gap around each of them.  Filled after
- * the final sync. */
+/* optional kernel timing of et_kmeans_fit: HIP events recorded on `stream` around the dominant kernel of the path.
+ * Default (all iterations of the fit in ONE persistent launch, kmeans_lloyd_persist_kernel): the duration of that
+ * launch, assign_launches = 1, iterations = the Lloyd iterations it ran.  One launch per iteration (ET_KMEANS_LOOP=chain,
+ * shapes the persistent kernel does not take): a sample of the launches -- the first one separately, then every 8th
+ * (an event record between two kernels costs a dispatch gap on both sides).  Filled after the final sync. */
 typedef struct et_kmeans_timing {
-    double assign_ms;        /* sum of the sampled durations of launches 1, 9, 17, ... (the filter kernel for d = 6) */
-    int64_t assign_launches; /* number of samples in assign_ms (only launches that did work count)               */
-    double first_assign_ms;  /* launch 0: plain exact scan + full accumulation                                    */
+    double assign_ms;        /* summed duration of the timed launches                                                 */
+    int64_t assign_launches; /* number of launches in assign_ms                                                       */
+    double first_assign_ms;  /* per-iteration form only: launch 0 (plain exact scan + full accumulation), else 0      */
+    int64_t iterations;      /* Lloyd iterations (24 B of coordinates per point each) that assign_ms covers           */
 } et_kmeans_timing;
 
 /* single-GPU fit of one batch element from given initial centroids (kmeans.py:228-240):
