@@ -129,13 +129,14 @@ def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None,
     return res["n_iter"]
 
 
-# ONE launch per k-means fit runs all its Lloyd iterations (persistent workgroups, csrc/et_kmeans.hip);
-# ET_KMEANS_LOOP=chain selects one launch per iteration (kmeans_lloyd_chain_kernel<10, false>), the sharded loop's form
-DOMINANT_KERNEL = ("et::kmeans_lloyd_chain_kernel<10, false>" if os.environ.get("ET_KMEANS_LOOP", "")[:1] == "c"
-                   else "et::kmeans_lloyd_persist_kernel<10, false>")
+# the dominant kernel of the step: one launch per Lloyd iteration for shards above 98304 points (the chained kernel),
+# ONE persistent launch for all iterations of a fit below that (csrc/et_kmeans.hip: km_persist_wanted; ET_KMEANS_LOOP
+# forces a form).  Which one ran is read off the timing record (iterations per launch).
+CHAIN_KERNEL = "et::kmeans_lloyd_chain_kernel<10, false>"
+PERSIST_KERNEL = "et::kmeans_lloyd_persist_kernel<10, false>"
 
 
-def pmc_traffic(n):
+def pmc_traffic(n, kernel):
     """HBM bytes per launch of the dominant kernel as measured by rocprofv3 PMC passes (FETCH_SIZE doubled
     as the gfx950 guide prescribes, + WRITE_SIZE); taken from the committed profile of the same workload
     size (profiles/*_pmc_hbm_traffic.json, made by tools/pmc_summary.py), else null."""
@@ -145,7 +146,7 @@ def pmc_traffic(n):
             js = json.load(open(path))
             if f"N={n:.0e}".replace("+0", "") not in js.get("note", "").replace("+0", ""):
                 continue
-            k = js["kernels"][DOMINANT_KERNEL]
+            k = js["kernels"][kernel]
             return round(k["read_bytes_corrected"] + k["write_bytes"]), os.path.relpath(path, ROOT)
         except Exception:
             continue
@@ -498,10 +499,11 @@ def main():
         #  x the iterations that launch runs
         alg_bytes = BYTES["kmeans_iter"] * n * its_per_launch
         achieved = alg_bytes / avg_ms / 1e6
-        traffic, traffic_source = pmc_traffic(n)
+        dominant = PERSIST_KERNEL if its_per_launch > 1.5 else CHAIN_KERNEL
+        traffic, traffic_source = pmc_traffic(n, dominant)
         # `traffic` is NOT measured in this run: it is the PMC figure of the committed rocprofv3 passes of the same
         # workload (`traffic_source`); everything else on the line is measured live
-        roofline = dict(bound="hbm", kernel=DOMINANT_KERNEL.replace("et::", ""), achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+        roofline = dict(bound="hbm", kernel=dominant.replace("et::", ""), achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
                         avg_launch_ms=round(avg_ms, 5), lloyd_iterations_per_launch=round(its_per_launch, 2),
                         algorithmic_bytes_per_launch=alg_bytes)

@@ -404,10 +404,13 @@ __device__ __forceinline__ void emit_partials(const long long *sAcc, int plen, i
                                               int copy_mask = kAccLanes - 1) {
     const unsigned tx = thread_x();  // (opaque per call: see thread_x)
     if (lanes) {
+        // copy_mask = 15: sixteen copies per entry, [entry][copy]; 0: one copy at the same stride (small persistent
+        // grids); -1: one copy, entries adjacent (the sharded loop's wire format)
+        const int stride = copy_mask < 0 ? 1 : kAccLanes, mask = copy_mask < 0 ? 0 : copy_mask;
         for (int i = tx; i < plen; i += n_threads) {
             const long long v = sAcc[i];
             if (v != 0)
-                atomicAdd(reinterpret_cast<unsigned long long *>(&lanes[i * kAccLanes + (blockIdx.x & copy_mask)]),
+                atomicAdd(reinterpret_cast<unsigned long long *>(&lanes[i * stride + (blockIdx.x & mask)]),
                           (unsigned long long)v);
         }
     } else {
@@ -1181,6 +1184,10 @@ struct LloydChain {
     long long *lanes_zero;
     float *last;
     unsigned long long *mail;  // host-visible progress word (et_hostring.h: mailbox), or nullptr
+    // sharded loop: ONE copy of the delta table, entries adjacent (what travels over the wire between two launches is
+    // then the d K + K + 2 int64 that carry the information, 1.1 KB, not the 16-copy table)
+    int compact;
+    int vec_ok;  // this shard's rows allow 16-byte loads (N % 4 == 0, aligned) and it has >= 1024 points: filter body
 };
 
 // fold the 16 copies of every total (layout [entry][copy]: a linear, coalesced sweep, 16 adjacent lanes per entry) and
@@ -1195,8 +1202,14 @@ struct FoldRegs {
 };
 __device__ __forceinline__ bool fold_fits(int plen) { return kFoldSweeps * (int)blockDim.x >= plen * kAccLanes; }
 __device__ __forceinline__ void fold_issue(const long long *__restrict__ lanes, const long long *__restrict__ tot_prev,
-                                           int plen, FoldRegs &r) {
+                                           int plen, FoldRegs &r, bool compact = false) {
     const int total = plen * kAccLanes, n_threads = (int)blockDim.x;
+    if (compact) {  // one copy, entries adjacent: one load per entry (plen <= 226 <= blockDim.x)
+        const int ci = (int)threadIdx.x < plen ? (int)threadIdx.x : 0;
+        r.v[0] = lanes[ci];
+        r.prev[0] = tot_prev[ci];
+        return;
+    }
 #pragma unroll
     for (int it = 0; it < kFoldSweeps; ++it) {
         const int idx = it * n_threads + (int)threadIdx.x;
@@ -1205,8 +1218,14 @@ __device__ __forceinline__ void fold_issue(const long long *__restrict__ lanes, 
         r.prev[it] = tot_prev[ci / kAccLanes];
     }
 }
-__device__ __forceinline__ void fold_combine(const FoldRegs &r, bool have_prev, int plen, long long *sTot) {
+__device__ __forceinline__ void fold_combine(const FoldRegs &r, bool have_prev, int plen, long long *sTot,
+                                             bool compact = false) {
     const int total = plen * kAccLanes, n_threads = (int)blockDim.x;
+    if (compact) {
+        const int e = (int)threadIdx.x;
+        if (e < plen) sTot[e] = ((have_prev && e < plen - 2) ? r.prev[0] : 0) + r.v[0];
+        return;
+    }
 #pragma unroll
     for (int it = 0; it < kFoldSweeps; ++it) {
         const int idx = it * n_threads + (int)threadIdx.x;
@@ -1221,7 +1240,12 @@ __device__ __forceinline__ void fold_combine(const FoldRegs &r, bool have_prev, 
     }
 }
 __device__ __forceinline__ void fold_lanes(const long long *__restrict__ lanes, const long long *__restrict__ tot_prev,
-                                           bool have_prev, int plen, long long *sTot) {
+                                           bool have_prev, int plen, long long *sTot, bool compact = false) {
+    if (compact) {
+        for (int e = threadIdx.x; e < plen; e += (int)blockDim.x)
+            sTot[e] = ((have_prev && e < plen - 2) ? tot_prev[e] : 0) + lanes[e];
+        return;
+    }
     if (fold_fits(plen)) {
         FoldRegs r;
         fold_issue(lanes, tot_prev, plen, r);
@@ -1263,7 +1287,7 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     const unsigned st_word = reinterpret_cast<const unsigned *>(ch.st_rd)[(int)threadIdx.x < kStateWords ? (int)threadIdx.x : 0];
     const float cen0 = ch.cen_rd[(int)threadIdx.x < d * K ? (int)threadIdx.x : 0];
     FoldRegs fr;
-    fold_issue(ch.lanes_rd, ch.tot_rd, plen, fr);  // (the filter kernels' launch sizes always fit: fold_fits())
+    fold_issue(ch.lanes_rd, ch.tot_rd, plen, fr, ch.compact != 0);  // (the filter kernels' launch sizes always fit: fold_fits())
     if (done0) {  // converged earlier: keep the published copies in step, nothing else to do
         if (wg0) {
             if (threadIdx.x == 0) *ch.st_wr = *ch.st_rd;
@@ -1275,7 +1299,7 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     if ((int)threadIdx.x < d * K) sCen[threadIdx.x] = cen0;
     if ((int)threadIdx.x < kStateWords) reinterpret_cast<unsigned *>(&sSt)[threadIdx.x] = st_word;  // the state block, word by word
     if (has_pending) {
-        fold_combine(fr, iter0 > 0, plen, sTot);
+        fold_combine(fr, iter0 > 0, plen, sTot, ch.compact != 0);
         __syncthreads();
         update_body(&sSt, sTot, d, K, tol, sCen, wg0 ? trace : nullptr, nullptr, wg0 ? ch.last : nullptr);  // reads its copy in LDS
     }
@@ -1294,7 +1318,12 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
         for (int i = threadIdx.x; i < total; i += (int)blockDim.x) ch.lanes_zero[i] = 0;
     }
     if (sSt.done) return;  // the update just applied met the tolerance: no further assignment (kmeans.py:239)
-    filter_assign_body<NREGS, SIM>(X, N, K, &sSt, sCen, labels, nullptr, ch.lanes_wr);
+    const int copy_mask = ch.compact ? -1 : kAccLanes - 1;
+    // a shard whose rows do not allow 16-byte loads (sharded runs cut the points anywhere), or a tiny one: the plain exact
+    // scan, one point per lane, inside the same launch -- which loop form a sharded fit takes then depends on (d, K)
+    // alone and every rank knows it without asking the others
+    if (ch.vec_ok) filter_assign_body<NREGS, SIM>(X, N, K, &sSt, sCen, labels, nullptr, ch.lanes_wr, copy_mask);
+    else assign_body_valu<6, 1>(X, N, d, K, &sSt, sCen, nullptr, labels, nullptr, ch.lanes_wr, copy_mask);
 }
 
 // After the loop: the update that belongs to the last assignment (if one is pending), into the caller's buffers.
@@ -1312,7 +1341,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_chain_finalize_kernel(const
         for (int e = threadIdx.x; e < plen; e += kKmThreads) partials[e] = ch.tot_rd[e];
         return;
     }
-    fold_lanes(ch.lanes_rd, ch.tot_rd, ch.st_rd->iter > 0, plen, sTot);
+    fold_lanes(ch.lanes_rd, ch.tot_rd, ch.st_rd->iter > 0, plen, sTot, ch.compact != 0);
     __syncthreads();
     for (int e = threadIdx.x; e < plen; e += kKmThreads) partials[e] = sTot[e];
     if (threadIdx.x == 0) *state = *ch.st_rd;
@@ -2352,6 +2381,10 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
     const bool want_sim = trace != nullptr;
     const int threads = km_filter_threads(N);
     const size_t plen = km_plen(d, K), lds = km_filter_lds_bytes(d, K, threads);
+    // rows that allow 16-byte loads and enough points: the filter body; any other shard of a sharded fit: the exact scan,
+    // one point per lane, inside the same kernel (a single-GPU fit only comes here with vec_ok)
+    const bool vec_ok = km_use_filter(X, N, d, K, labels_u8);
+    const int64_t work_items = vec_ok ? N / 4 : N;
     rc = km_fat_lds_attribute();
     if (rc) return rc;
     // single GPU: the kernel reports (done, iterations applied) into the ring's pinned mailbox and nothing is copied
@@ -2382,6 +2415,8 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
         ch.lanes_zero = w.chain_lanes[(t + 2) % 3];
         ch.last = w.last;
         ch.mail = mail;
+        ch.compact = hook.reduce ? 1 : 0;
+        ch.vec_ok = vec_ok ? 1 : 0;
         return ch;
     };
     int grid = 0, launched = 0;
@@ -2391,7 +2426,7 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
         if (timed(it)) ET_HIP_TRY(hipEventRecord((*events)[2 * it], st));
 #define ET_LAUNCH_CHAIN(NR, SIM)                                                                                          \
     do {                                                                                                                  \
-        if (!grid) grid = km_resident_grid(kmeans_lloyd_chain_kernel<NR, SIM>, lds, N / 4, threads);                      \
+        if (!grid) grid = km_resident_grid(kmeans_lloyd_chain_kernel<NR, SIM>, lds, work_items, threads);                 \
         hipLaunchKernelGGL((kmeans_lloyd_chain_kernel<NR, SIM>), dim3(grid), dim3(threads), lds, st, X, N, K, ch,          \
                            labels_u8, tol, trace, it > 0 ? 1 : 0);                                                        \
     } while (0)
@@ -2405,10 +2440,10 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
 #undef ET_LAUNCH_CHAIN
         ET_LAUNCH_CHECK();
         if (timed(it)) ET_HIP_TRY(hipEventRecord((*events)[2 * it + 1], st));
-        // sharded: the deltas this launch added onto its copy of the table become the sum over all ranks' before the
-        // next launch folds them (18 KB; the 16 copies are summed copy by copy, the fold adds them up as before)
+        // sharded: the deltas this launch added onto its (one-copy, compact) table become the sum over all ranks' before
+        // the next launch reads them: d K + K + 2 int64, 1.1 KB for d = 6, K = 20
         if (hook.reduce) {
-            rc = hook.reduce(hook.ctx, ch.lanes_wr, plen * 16, st);
+            rc = hook.reduce(hook.ctx, ch.lanes_wr, plen, st);
             if (rc) return rc;
         }
         launched = it + 1;
@@ -2613,8 +2648,10 @@ extern "C" int et_debug_persist_stamps(void *host, size_t bytes) {
 
 // Entry points for csrc/et_sharded.hip (not part of the public header): can this rank's shard run the chained loop,
 // and the loop itself with a reduction between the launches.  `workspace` as for et_kmeans_fit.
-extern "C" int et_internal_kmeans_chain_usable(const float *X, int64_t N, int d, int K, const uint8_t *labels_u8) {
-    return km_dims_ok(d, K) && N >= 1 && km_use_filter(X, N, d, K, labels_u8) ? 1 : 0;
+// (the choice depends on d, K and the process-wide ET_KMEANS_ARGMAX setting only -- never on a rank's own shard --, so the
+// ranks of a sharded fit agree on the loop form, i.e. on the collectives they enqueue, without exchanging anything)
+extern "C" int et_internal_kmeans_chain_usable(int d, int K) {
+    return km_dims_ok(d, K) && km_argmax_mode() == 'f' && d == 6 && K >= 3 && K <= 32 ? 1 : 0;
 }
 extern "C" int et_internal_kmeans_chain_run(const float *X, int64_t N, int d, int K, int max_iter, float tol, float *centroids,
                                             uint8_t *labels_u8, float *trace, et_kmeans_state *state, int64_t *partials,

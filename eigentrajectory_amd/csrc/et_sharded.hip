@@ -9,9 +9,9 @@
 //   et_kmeans_init_farthest_sharded   per new centroid: local candidate -> all-gather of one 8 + 4 d byte record per
 //                              rank -> the same arg-min on every rank.
 //   et_kmeans_fit_sharded      all-reduce MAX/MIN of the scale scan once; per Lloyd iteration ONE launch of the chained
-//                              kernel (csrc/et_kmeans.hip) + ONE all-reduce(SUM) of its 18 KB delta table in place, all
-//                              enqueued on one stream with no host round trip (shards the chained kernel does not take:
-//                              assignment kernels -> all-reduce of d K + K + 2 int64 -> update kernel); convergence is
+//                              kernel (csrc/et_kmeans.hip) + ONE all-reduce(SUM) of its d K + K + 2 int64 deltas (1.1 KB)
+//                              in place, all enqueued on one stream with no host round trip (shapes the chained kernel
+//                              does not take: assignment kernels -> the same all-reduce -> update kernel); convergence is
 //                              decided on the device from identical integers on every rank and looked at from the host a
 //                              few iterations late (et_hostring.h), so every rank enqueues the same collectives.
 // Exact 64-bit fixed-point sums make the k-means result bit-identical for any number of ranks / any partition.
@@ -225,7 +225,7 @@ extern "C" int et_kmeans_init_farthest_sharded(const float *X, int64_t N_local, 
     return rc;
 }
 
-extern "C" int et_internal_kmeans_chain_usable(const float *X, int64_t N, int d, int K, const uint8_t *labels_u8);
+extern "C" int et_internal_kmeans_chain_usable(int d, int K);
 extern "C" int et_internal_kmeans_chain_run(const float *X, int64_t N, int d, int K, int max_iter, float tol, float *centroids,
                                             uint8_t *labels_u8, float *trace, et_kmeans_state *state, int64_t *partials,
                                             void *workspace, size_t workspace_bytes,
@@ -263,16 +263,12 @@ extern "C" int et_kmeans_fit_sharded(const float *X, int64_t N_local, int64_t N_
     }
     rc = et_kmeans_begin(state, N_total, centroids, d, K, stream);
     if (rc) return rc;
-    // The chained Lloyd loop (one launch per iteration, csrc/et_kmeans.hip: km_chain_run) when EVERY rank's shard can run
-    // it -- the two forms enqueue different collectives, so the choice is made together: MIN over ranks of a flag.
+    // The chained Lloyd loop (one launch per iteration, csrc/et_kmeans.hip: km_chain_run) for the shapes it is built for
+    // (d = 6, 3 <= K <= 32).  The two loop forms enqueue different collectives, so every rank must take the same one: the
+    // choice depends on (d, K) alone -- a shard whose size or alignment rules out the 16-byte loads of the filter body
+    // runs the exact scan inside the same chained kernel -- and needs neither a collective nor a host round trip.
     {
-        long long usable = et_internal_kmeans_chain_usable(X, N_local, d, K, labels_u8) ? 1 : 0;
-        if (comm) {
-            ET_HIP_TRY(hipMemcpyAsync(partials, &usable, sizeof usable, hipMemcpyHostToDevice, st));
-            ET_RCCL_TRY(g_rccl.AllReduce(partials, partials, 1, ncclInt64, ncclMin, c, st));
-            ET_HIP_TRY(hipMemcpyAsync(&usable, partials, sizeof usable, hipMemcpyDeviceToHost, st));
-            ET_HIP_TRY(hipStreamSynchronize(st));
-        }
+        const bool usable = N_total <= 0xffffffffll && et_internal_kmeans_chain_usable(d, K) != 0;
         if (usable) {
             ReduceCtx ctx{c};
             rc = et_internal_kmeans_chain_run(X, N_local, d, K, max_iter, tol, centroids, labels_u8, trace, state, partials,

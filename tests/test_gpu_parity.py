@@ -385,7 +385,7 @@ def test_sharded_driver_on_one_gpu_matches_oracle(ops, oracle, dev):
     assert torch.equal(U_obs, ops.eigh_topk(g_obs, 6)[0]) and torch.equal(U_pred, ops.eigh_topk(g_pred, 6)[0])
 
 
-@pytest.mark.parametrize("cut,trace", [(8192, False), (20004, True), (1024, False)])
+@pytest.mark.parametrize("cut,trace", [(8192, False), (20004, True), (1024, False), (10001, False), (29501, True)])
 def test_native_chained_loop_two_shards_one_gpu(ops, oracle, dev, cut, trace):
     """The library's sharded Lloyd loop (csrc/et_kmeans.hip: km_chain_run with a reduction between two launches -- what
     et_kmeans_fit_sharded runs with ncclAllReduce) on TWO shards of one GPU: two host threads, one stream each, and a
@@ -409,7 +409,7 @@ def test_native_chained_loop_two_shards_one_gpu(ops, oracle, dev, cut, trace):
                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, REDUCE, C.c_void_p, C.c_void_p]
     shards = [ops.KMeansShard(T(np.ascontiguousarray(x[:, :cut]), dev), K), ops.KMeansShard(T(np.ascontiguousarray(x[:, cut:]), dev), K)]
     for sh in shards:
-        assert lib.et_internal_kmeans_chain_usable(L.ptr(sh.X), L.i64(sh.n), 6, K, L.ptr(sh.labels_u8)) == 1
+        assert lib.et_internal_kmeans_chain_usable(6, K) == 1
         sh.scan()
     torch.cuda.synchronize()
     # what the all-reduces of the scale scan do (dist.py / et_kmeans_fit_sharded): MAX, MAX, MIN
