@@ -1159,6 +1159,20 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_update_kernel(et_kmeans_sta
     update_body(state, partials, d, K, tol, cen, trace);
 }
 
+// BatchKMeans.fit on a batch of l > 1 problems (kmeans.py:228-240): ONE error -- the squared centroid movement summed
+// over all problems (kmeans.py:45-51 on the (l, d, K) tensors) -- is compared with the tolerance and all problems stop
+// together.  The step API runs the problems side by side with a tolerance no error can meet; this kernel, after their
+// updates, sums the per-problem errors (fp64, problem order; each is the fp32 value the update stored) and sets every
+// problem's convergence flag from the sum.  One wavefront.
+__global__ void kmeans_joint_done_kernel(et_kmeans_state *const *__restrict__ states, int n, float tol) {
+    if (threadIdx.x != 0) return;
+    if (states[0]->done) return;  // (the flags are only ever set together)
+    double sum = 0.0;
+    for (int b = 0; b < n; ++b) sum += states[b]->error;
+    const int64_t done = ((float)sum <= tol) ? 1 : 0;  // kmeans.py:239 (NaN -> keep going)
+    for (int b = 0; b < n; ++b) states[b]->done = done;
+}
+
 // Large shards, single-GPU fit: ONE launch per Lloyd iteration and NO serial section between two iterations.
 //
 // A launch first applies the update of the PREVIOUS iteration's assignment and then makes its own assignment:
@@ -2225,6 +2239,13 @@ extern "C" int et_kmeans_update(et_kmeans_state *state, const int64_t *partials,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kmeans_update_kernel, dim3(1), dim3(kKmThreads), lds, (hipStream_t)stream, state,
                        (const long long *)partials, d, K, tol, centroids, trace);
+    ET_LAUNCH_CHECK();
+    return ET_OK;
+}
+
+extern "C" int et_kmeans_joint_done(et_kmeans_state *const *states, int n_problems, float tol, et_stream_t stream) {
+    if (!states || n_problems < 1) return ET_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(kmeans_joint_done_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, states, n_problems, tol);
     ET_LAUNCH_CHECK();
     return ET_OK;
 }

@@ -8,8 +8,10 @@ n_data) d-major like the reference's.  Differences that a caller can observe:
   the launch geometry or the number of GPUs; the reference's fp32 sums carry
   ~1e-7 relative noise, which Lloyd iterations on unstructured data can amplify
   into a different local optimum (tests/test_oracle_golden.py, G7);
-* the convergence test runs on the device; the host looks at it every 8
-  iterations instead of synchronising every iteration (kmeans.py:239);
+* the convergence test runs on the device; the host looks at it a few
+  iterations late instead of synchronising every iteration (kmeans.py:239);
+  a batch of l > 1 problems stops together on the summed error, like the
+  reference's single loop over the batch (kmeans.py:228-240);
 * non-finite input raises instead of propagating.
 The only randomness is ``np.random.randint`` / ``np.random.choice`` on numpy's global
 RNG, drawn exactly where the reference draws it (kmeans.py:92,126).
@@ -180,25 +182,44 @@ class BatchKMeans(nn.Module):
         return best_labels
 
     def _fit_batch(self, data, centroids):
-        """One Lloyd fit per batch element (the reference iterates all `l` problems in one batched pass,
-        kmeans.py:228-240).  The problems are independent: with more than one, each runs on its own HIP stream from
-        its own host thread (``et_kmeans_fit`` blocks only the calling thread), side by side."""
+        """One Lloyd fit of the whole batch (kmeans.py:228-240).  One problem: ``et_kmeans_fit``.  Several: the reference
+        iterates them in ONE loop and stops them TOGETHER -- ``error`` (kmeans.py:232) is a single sum over the
+        (l, d, K) centroid tensors, so an easy problem keeps iterating until the hardest one has settled and all
+        problems run the same number of iterations.  Reproduced with the step API in lockstep: per iteration every
+        problem's assignment + update (with a tolerance no error meets), then ``et_kmeans_joint_done`` sums the errors on
+        the device and sets every problem's convergence flag; the host looks at the flag a few iterations late (the
+        steps enqueued meanwhile are no-ops)."""
         n_b = data.shape[0]
-        if n_b == 1 or not data.is_cuda:
-            return [ops.kmeans_fit(data[b], centroids[b], self.max_iter, self.tol, trace=self.verbose) for b in range(n_b)]
-        dev, main = data.device, torch.cuda.current_stream(data.device)
-        streams = [torch.cuda.Stream(device=dev) for _ in range(n_b)]
-
-        def run(b):
-            with torch.cuda.device(dev), torch.cuda.stream(streams[b]):
-                streams[b].wait_stream(main)
-                return ops.kmeans_fit(data[b], centroids[b], self.max_iter, self.tol, trace=self.verbose)
-
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=min(n_b, 16)) as pool:
-            runs = list(pool.map(run, range(n_b)))
-        for st in streams:
-            main.wait_stream(st)
+        if n_b == 1:
+            return [ops.kmeans_fit(data[0], centroids[0], self.max_iter, self.tol, trace=self.verbose)]
+        dev = ops.L.require_device(data)
+        K, n = int(centroids.shape[-1]), int(data.shape[-1])
+        shards = [ops.KMeansShard(data[b], K) for b in range(n_b)]
+        cens = [ops.L.on_device(centroids[b], dev).to(torch.float32).clone().contiguous() for b in range(n_b)]
+        traces = [torch.zeros((self.max_iter, 2), device=dev) if self.verbose else None for _ in range(n_b)]
+        for sh, cen in zip(shards, cens):
+            sh.scan()
+            sh.begin(n, cen)
+        ptrs = torch.tensor([sh.state.data_ptr() for sh in shards], dtype=torch.int64, device=dev)
+        every, handles, done = 4, [], False
+        for it in range(self.max_iter):
+            for sh, cen, tr in zip(shards, cens, traces):
+                sh.update(sh.assign(cen), cen, -1.0, tr)
+            ops.kmeans_joint_done(ptrs, n_b, self.tol)
+            if (it + 1) % every == 0:
+                handles.append(shards[0].post_state())
+                if len(handles) > 1:  # a copy posted `every` iterations ago: long since arrived
+                    done = bool(shards[0].wait_state(handles.pop(0)).done)
+            if done:
+                break
+        runs = []
+        for sh, cen, tr in zip(shards, cens, traces):
+            st = sh.read_state()
+            if st.bad_input:
+                raise ValueError("k-means input contains NaN/Inf")
+            runs.append(dict(centroids=cen, labels=sh.labels(), n_iter=int(st.iter), error=float(st.error),
+                             inertia=float(st.inertia), trace=tr[:int(st.iter)] if tr is not None else None,
+                             done=bool(st.done)))
         return runs
 
     def predict(self, query):

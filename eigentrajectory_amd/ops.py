@@ -302,6 +302,14 @@ def kmeans_fit(X, centroids, max_iter=100, tol=1e-4, workspace=None, timing=Fals
     return out
 
 
+def kmeans_joint_done(state_ptrs, n_problems, tol):
+    """kmeans.py:228-240 for a batch of problems run through the step API: ``state_ptrs`` = int64 device tensor of the
+    problems' state-block addresses; sets every state's ``done`` from the SUM of their errors."""
+    dev = L.require_device(state_ptrs)
+    L.check(L.lib().et_kmeans_joint_done(L.ptr(state_ptrs), int(n_problems), L.f32(tol), L.stream(dev)),
+            "et_kmeans_joint_done")
+
+
 def kmeans_predict(X, centroids, want_maxsims=True):
     """kmeans.py:143-158 / 261-272: labels (N,) int64 and max similarity (N,)."""
     dev = L.require_device(X)

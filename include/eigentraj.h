@@ -240,6 +240,11 @@ int et_kmeans_assign_accumulate(const float *X, int64_t N, int d, int K, const e
  * receives (error, inertia) at row state->iter when not NULL. */
 int et_kmeans_update(et_kmeans_state *state, const int64_t *partials, int d, int K, float tol,
                      float *centroids, float *trace, et_stream_t stream);
+/* BatchKMeans.fit with l > 1 problems stops them TOGETHER, on the sum of their errors (kmeans.py:228-240: `error` is one
+ * sum over the (l, d, K) centroid tensors).  Step-API driver: run et_kmeans_update of every problem with a negative
+ * tolerance (no error meets it), then this: states = device array of the n_problems state-block pointers; sets every
+ * state's `done` to (sum of the states' errors <= tol).  Later steps of all problems are then no-ops. */
+int et_kmeans_joint_done(et_kmeans_state *const *states, int n_problems, float tol, et_stream_t stream);
 /* widen the uint8 labels of the last assignment to the reference's int64 */
 int et_kmeans_labels_i64(const uint8_t *labels_u8, int64_t N, int64_t *labels, et_stream_t stream);
 

@@ -239,3 +239,22 @@ def kmeans_fit(X, C_init, max_iter=100, tol=1e-4):
                                 _p(trace, _f32p)), "kmeans_fit")
     return dict(centroids=cen, labels=labels, n_iter=it.value, error=err.value, inertia=ine.value,
                 trace=trace[:it.value].copy())
+
+
+def kmeans_fit_batch(Xs, C_inits, max_iter=100, tol=1e-4):
+    """BatchKMeans.fit on a batch of l problems (kmeans.py:228-240): ONE error -- the sum over all problems -- is
+    compared with ``tol`` (kmeans.py:239), so all problems stop in the same iteration.  Restated on the per-problem C
+    fit: every problem alone with a tolerance nothing meets gives its error trace; the joint loop stops at the first
+    iteration whose summed error (fp64 over the problems' fp32 errors, problem order, rounded to fp32) is <= tol; the
+    problems' results are their states after that many iterations.  -> list of kmeans_fit dicts."""
+    l = len(Xs)
+    full = [kmeans_fit(Xs[b], C_inits[b], max_iter, -1.0) for b in range(l)]
+    n_iter = max_iter
+    for t in range(max_iter):
+        s = 0.0
+        for b in range(l):
+            s += float(full[b]["trace"][t, 0])
+        if np.float32(s) <= np.float32(tol):  # NaN: keep going
+            n_iter = t + 1
+            break
+    return full if n_iter == max_iter else [kmeans_fit(Xs[b], C_inits[b], n_iter, -1.0) for b in range(l)]

@@ -102,3 +102,51 @@ def test_agentformer_end_to_end_replay_through_the_oracle_g12(oracle):
         np.testing.assert_allclose(W.batch_fde(out["recon_traj"], pred[s:e]), z[f"scene{j}.fde"], atol=1e-5)
         losses = [out["loss_eigentraj"], out["loss_euclidean_ade"], out["loss_euclidean_fde"]]
         np.testing.assert_allclose(losses, z[f"scene{j}.losses"], rtol=1e-5, atol=1e-5)
+
+
+class ReplaySGCN(torch.nn.Module):
+    """Stands in for the reference's SGCN (third-party predictor, not on the path): checks that the bridge hands it what
+    the reference's bridge handed the real network -- the graph `v` (1, k+2, N, 1) and the two identity stacks,
+    sgcn/bridge.py:4-12 -- and answers with the real network's recorded output (k, N, S)."""
+
+    def __init__(self, v, eye_shapes, net_out, tol):
+        super().__init__()
+        self.expect, self.eye_shapes, self.answer, self.tol = v, eye_shapes, net_out, tol
+
+    def forward(self, v, eyes):
+        assert v.shape == self.expect.shape and not v.requires_grad
+        assert torch.allclose(v.cpu(), self.expect, rtol=0, atol=self.tol), float((v.cpu() - self.expect).abs().max())
+        assert [list(e.shape) for e in eyes] == self.eye_shapes.tolist()
+        for e in eyes:
+            assert torch.equal(e.cpu(), torch.eye(e.size(-1)).expand_as(e))
+        return self.answer.to(v.device)
+
+
+@pytest.mark.parametrize("scene", G.SCENES)
+def test_sgcn_end_to_end_replay_through_the_oracle_g13(oracle, scene):
+    """Config 3's data path on CPU: reference-fitted descriptors -> oracle projection -> THIS build's sgcn bridge ->
+    the recorded output of the reference's SGCN -> oracle reconstruction == what the reference's wrapper + bridge +
+    network produced on the same test scenes (tools/make_golden_sgcn.py), ADE / FDE within 1e-5."""
+    from eigentrajectory_amd.bridges import get_hook_func
+    from oracle import wrapper_ref as W
+    z = G.load("g13_sgcn_all_scenes.npz")
+    g2 = G.load("g2_fit_all_scenes.npz")
+    params = {k[len(scene) + 1:]: g2[k] for k in g2.files if k.startswith(f"{scene}.ET_")}
+    obs, pred, sse = G.dataset(scene, "test")
+    hooks = get_hook_func("sgcn")
+    for j in range(3):
+        tag = f"{scene}.scene{j}"
+        s, e = sse[int(z[f"{tag}.index"])]
+        net = ReplaySGCN(torch.from_numpy(z[f"{tag}.v"]), z[f"{tag}.eye_shapes"], torch.from_numpy(z[f"{tag}.net_out"]), 2e-5)
+
+        def predictor(x):  # x = cat(C_obs, obs_ori) (k+2, N), the oracle wrapper's stand-in for the pre-hook input
+            xt = torch.from_numpy(x)
+            data = hooks.model_forward_pre_hook(xt[:6], xt[6:], None)
+            return hooks.model_forward_post_hook(hooks.model_forward(data, net), None).contiguous().numpy()
+        out = W.forward(params, obs[s:e], pred[s:e], predictor, float(z[f"{scene}.static_dist"]))
+        ref = z[f"{tag}.recon_traj"]
+        np.testing.assert_allclose(out["recon_traj"], ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+        np.testing.assert_allclose(W.batch_ade(out["recon_traj"], pred[s:e]), z[f"{tag}.ade"], atol=1e-5)
+        np.testing.assert_allclose(W.batch_fde(out["recon_traj"], pred[s:e]), z[f"{tag}.fde"], atol=1e-5)
+        losses = [out["loss_eigentraj"], out["loss_euclidean_ade"], out["loss_euclidean_fde"]]
+        np.testing.assert_allclose(losses, z[f"{tag}.losses"], rtol=1e-5, atol=1e-5)

@@ -931,7 +931,15 @@ def test_own_fit_ade_fde_all_scenes(dev, scene, anchor_init):
     ref_ade, ref_fde = G.manifest()["g6_ade_fde"][f"{scene}.zero"]
     print(f"own-fit {scene} {anchor_init or 'sklearn'}: ADE {ade:.5f} (ref {ref_ade:.5f})  FDE {fde:.5f} (ref {ref_fde:.5f})")
     if anchor_init is None:
-        assert abs(ade - ref_ade) < 5e-5 and abs(fde - ref_fde) < 5e-5, (ade, ref_ade, fde, ref_fde)
+        # north_star's 1e-5 on the four splits whose anchors come out the reference's to the last digit.  ETH: 5e-5 --
+        # its FDE is 0.64312 here against the reference's 0.64314; the anchors pair up one to one with inertia ratios
+        # within 1e-4 (test_wrapper_fit_calculate_parameters_all_scenes), the remaining difference is scikit-learn's own
+        # irreproducibility (its Lloyd sums are per-thread float32 partial sums in an unspecified order, here they are
+        # exact): one of the 20 anchors settles a few 1e-4 apart, which moves the best-of-20 FDE of a handful of
+        # pedestrians.  With the reference's OWN fitted parameters loaded all five splits hold 1e-5
+        # (test_wrapper_ade_fde_parity_g6).
+        bound = 5e-5 if scene == "eth" else 1e-5
+        assert abs(ade - ref_ade) < bound and abs(fde - ref_fde) < bound, (ade, ref_ade, fde, ref_fde)
     else:
         assert abs(ade / ref_ade - 1) < 0.05 and abs(fde / ref_fde - 1) < 0.10, (ade, ref_ade, fde, ref_fde)
 
@@ -1375,9 +1383,46 @@ def test_agentformer_bridge_end_to_end_replay_g12(dev):
         np.testing.assert_allclose(N_(fde), z[f"scene{j}.fde"], atol=1e-5)
 
 
-def test_batchkmeans_batch_of_problems_equals_single_fits(ops, oracle, dev):
-    """BatchKMeans.fit on (l, d, n) data (kmeans.py:200-259): the l problems run side by side (one stream / host thread
-    each) and give what l separate fits give, bit for bit -- and what the oracle gives."""
+@pytest.mark.parametrize("scene", G.SCENES)
+def test_sgcn_bridge_end_to_end_replay_g13(dev, scene):
+    """Config 3's data path through the PRODUCT on every split: wrapper (HIP projection) -> sgcn bridge contract -> the
+    recorded output of the reference's SGCN -> HIP reconstruction / fused metrics, against what the reference's
+    wrapper + bridge + network produced on the same test scenes (tools/make_golden_sgcn.py): trajectories 2e-5 of
+    scale, losses and best-of-20 ADE / FDE 1e-5."""
+    from eigentrajectory_amd import EigenTrajectory
+    from eigentrajectory_amd.bridges import get_hook_func
+    from eigentrajectory_amd.utils import default_hyper_params
+    from .test_bridges import ReplaySGCN
+    z = G.load("g13_sgcn_all_scenes.npz")
+    g2 = G.load("g2_fit_all_scenes.npz")
+    obs, pred, sse = G.dataset(scene, "test")
+    for j in range(3):
+        tag = f"{scene}.scene{j}"
+        s, e = sse[int(z[f"{tag}.index"])]
+        net = ReplaySGCN(torch.from_numpy(z[f"{tag}.v"]), z[f"{tag}.eye_shapes"], torch.from_numpy(z[f"{tag}.net_out"]), 2e-5)
+        model = EigenTrajectory(net, get_hook_func("sgcn"), default_hyper_params(static_dist=float(z[f"{scene}.static_dist"])))
+        sd = model.state_dict()
+        for key in list(sd):
+            if key.startswith("ET_"):
+                sd[key] = torch.from_numpy(g2[f"{scene}.{key}"])
+        model.load_state_dict(sd)
+        model = model.to(dev).eval()
+        o, p = T(obs[s:e], dev), T(pred[s:e], dev)
+        ref = z[f"{tag}.recon_traj"]
+        with torch.no_grad():
+            out = model(o, p)
+            close(N_(out["recon_traj"]), ref, tol=2e-5)
+            got = [float(out[k]) for k in ("loss_eigentraj", "loss_euclidean_ade", "loss_euclidean_fde")]
+            np.testing.assert_allclose(got, z[f"{tag}.losses"], rtol=1e-5, atol=1e-5)
+            close(N_(model(o)["recon_traj"]), ref, tol=2e-5)     # inference form (lean scene path)
+            ade, fde = model.evaluate(o, p)                        # fused metrics epilogue
+        np.testing.assert_allclose(N_(ade), z[f"{tag}.ade"], atol=1e-5)
+        np.testing.assert_allclose(N_(fde), z[f"{tag}.fde"], atol=1e-5)
+
+
+def test_batchkmeans_batch_of_problems_stops_together(ops, oracle, dev):
+    """BatchKMeans.fit on (l, d, n) data (kmeans.py:200-259): the l problems run in lockstep and stop TOGETHER, on the
+    error summed over the batch (kmeans.py:232, 239) -- bit for bit what the oracle's restatement of that loop gives."""
     from eigentrajectory_amd import BatchKMeans
     from eigentrajectory_amd.synth import gaussian_points_np
     xs = np.stack([gaussian_points_np(6, 3000, seed=60 + b, n_blobs=4 + b) for b in range(5)])
@@ -1387,8 +1432,25 @@ def test_batchkmeans_batch_of_problems_equals_single_fits(ops, oracle, dev):
     assert labels.shape == (5, 3000) and km.centroids.shape == (5, 6, 12)
     np.random.seed(3)
     first = np.random.randint(3000)
+    c0s = [oracle.kmeans_init_farthest(xs[b], 12, first)[0] for b in range(5)]
+    refs = oracle.kmeans_fit_batch(list(xs), c0s, 40, 1e-4)
+    alone = [oracle.kmeans_fit(xs[b], c0s[b], 40, 1e-4)["n_iter"] for b in range(5)]
+    assert len(set(alone)) > 1  # the problems would stop at different iterations on their own
     for b in range(5):
-        c0, _ = oracle.kmeans_init_farthest(xs[b], 12, first)
-        ref = oracle.kmeans_fit(xs[b], c0, 40, 1e-4)
-        assert np.array_equal(N_(labels[b]), ref["labels"]) and np.array_equal(N_(km.centroids[b]), ref["centroids"])
-        assert km.n_iter_[b] == ref["n_iter"]
+        assert np.array_equal(N_(labels[b]), refs[b]["labels"]) and np.array_equal(N_(km.centroids[b]), refs[b]["centroids"])
+        assert km.n_iter_[b] == refs[b]["n_iter"] == refs[0]["n_iter"]
+    np.testing.assert_allclose(km.inertia_, np.mean([r["inertia"] for r in refs]), rtol=1e-6)
+
+
+def test_batchkmeans_joint_stop_g7b(ops, dev):
+    """The reference's own l = 3 run (tests/golden/g7b, tools/make_golden_batchkmeans.py): alone the problems take
+    4 / 47 / 3 iterations, the batch takes 47 for all of them; labels equal, centroids to fp32 noise."""
+    from eigentrajectory_amd import BatchKMeans
+    z = G.load("g7b_batchkmeans_joint_stop.npz")
+    km = BatchKMeans(n_clusters=int(z["K"]), n_redo=1, max_iter=100, tol=1e-4, init_mode="kmeans++")
+    np.random.seed(0)
+    labels = km.fit(T(z["x"], dev))
+    assert km.n_iter_ == [len(z["trace"])] * 3
+    assert np.array_equal(N_(labels).astype(np.uint8), z["labels"])
+    np.testing.assert_allclose(N_(km.centroids), z["centroids"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(km.inertia_, z["trace"][-1, 1], rtol=1e-5)

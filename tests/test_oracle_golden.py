@@ -264,6 +264,27 @@ def test_g7_batchkmeans_whole_run(oracle, tag):
         assert (ql != z[f"{tag}.query_labels"]).sum() <= 1  # centroids differ in the last ulp
 
 
+def test_g7b_batch_of_problems_stops_on_the_summed_error(oracle):
+    """kmeans.py:228-240 with l = 3 problems (fixture from the imported reference, tools/make_golden_batchkmeans.py):
+    alone they stop after 4 / 47 / 3 iterations, together after 47 -- the error is ONE sum over the batch."""
+    z = G.load("g7b_batchkmeans_joint_stop.npz")
+    x, c0, K = z["x"], z["c0"], int(z["K"])
+    assert list(z["iterations_alone"]) != [len(z["trace"])] * 3  # the fixture does separate the two semantics
+    for b in range(3):
+        r0, _ = oracle.kmeans_init_farthest(x[b], K, int(z["first_index"]))
+        assert np.array_equal(r0, c0[b])
+    runs = oracle.kmeans_fit_batch(list(x), list(c0), 100, 1e-4)
+    assert [r["n_iter"] for r in runs] == [len(z["trace"])] * 3
+    for b in range(3):
+        assert np.array_equal(runs[b]["labels"], z["labels"][b].astype(np.int64))
+        np.testing.assert_allclose(runs[b]["centroids"], z["centroids"][b], rtol=2e-5, atol=2e-5)
+    # the reference's printed error of iteration t = the sum over the problems; its inertia = the mean over the batch
+    err = sum(r["trace"][:, 0].astype(np.float64) for r in runs)
+    np.testing.assert_allclose(err, z["trace"][:, 0], rtol=2e-3, atol=1e-7)
+    ine = np.mean([r["trace"][:, 1].astype(np.float64) for r in runs], axis=0)
+    np.testing.assert_allclose(ine, z["trace"][:, 1], rtol=1e-5)
+
+
 def test_g7_duplicate_points_nan_propagation(oracle):
     """kmeans.py:180-182: an empty cluster becomes NaN and poisons every later label (no re-seeding)."""
     z = G.load("g7_batchkmeans.npz")
