@@ -27,9 +27,9 @@ SYMBOLS = [
     "et_norm_params", "et_norm_params_from_nrm", "et_normalize", "et_denormalize",
     "et_norm_project", "et_scene_project", "et_anchor_reconstruct_fwd", "et_anchor_reconstruct_bwd", "et_anchor_reconstruct_metrics",
     "et_fit_gram_workspace_bytes", "et_fit_gram", "et_eigh_topk", "et_eigh_topk_batch",
-    "et_euc_sim", "et_kmeans_partials_len", "et_kmeans_workspace_bytes", "et_kmeans_scan", "et_kmeans_begin",
+    "et_euc_sim", "et_euc_sim_batch", "et_kmeans_partials_len", "et_kmeans_workspace_bytes", "et_kmeans_scan", "et_kmeans_begin",
     "et_kmeans_init_step", "et_kmeans_init_set", "et_kmeans_init_select", "et_kmeans_gather_point", "et_kmeans_init_farthest",
-    "et_kmeans_assign_accumulate", "et_kmeans_update", "et_kmeans_joint_done", "et_kmeans_labels_i64", "et_kmeans_fit", "et_kmeans_predict",
+    "et_kmeans_assign_accumulate", "et_kmeans_update", "et_kmeans_joint_done", "et_kmeans_labels_i64", "et_kmeans_fit", "et_kmeans_predict", "et_kmeans_predict_batch",
     "et_center_columns", "et_kmeanspp_workspace_bytes", "et_kmeanspp_seed",
     "et_comm_load", "et_comm_unique_id", "et_comm_init_rank", "et_comm_destroy", "et_comm_info",
     "et_fit_gram_sharded", "et_kmeans_sharded_workspace_bytes", "et_kmeans_init_farthest_sharded", "et_kmeans_fit_sharded",

@@ -6,7 +6,7 @@
 //
 // This is the one place where the library keeps memory of its own (include/eigentraj.h, "Ownership"): per host
 // thread and device 4 x sizeof(et_kmeans_state) + 64 bytes of pinned host memory and 4 events, created on first use
-// and kept for the life of the process.  No device memory is ever allocated by the library.
+// and released when that host thread ends.  No device memory is ever allocated by the library.
 #pragma once
 
 #include <vector>
@@ -26,7 +26,15 @@ class StateRing {
             *rc = ET_ERR_HIP;
             return nullptr;
         }
-        static thread_local std::vector<StateRing *> rings;
+        // per host thread: released when the thread ends (the Python side runs fits from short-lived pool threads)
+        struct Holder {
+            std::vector<StateRing *> v;
+            ~Holder() {
+                for (StateRing *r : v) delete r;
+            }
+        };
+        static thread_local Holder holder;
+        std::vector<StateRing *> &rings = holder.v;
         if ((int)rings.size() <= dev) rings.resize(dev + 1, nullptr);
         if (!rings[dev]) {
             StateRing *r = new StateRing();
@@ -38,11 +46,14 @@ class StateRing {
             }
             r->mail_ = reinterpret_cast<volatile unsigned long long *>(r->slots_ + kSlots);
             if (hipHostGetDevicePointer((void **)&r->mail_dev_, (void *)r->mail_, 0) != hipSuccess) r->mail_dev_ = nullptr;
-            for (int i = 0; i < kSlots; ++i)
+            for (int i = 0; i < kSlots; ++i) {
                 if (hipEventCreateWithFlags(&r->ev_[i], hipEventDisableTiming) != hipSuccess) {
+                    delete r;
                     *rc = ET_ERR_HIP;
                     return nullptr;
                 }
+                ++r->n_ev_;
+            }
             rings[dev] = r;
         }
         rings[dev]->posted_ = rings[dev]->seen_ = 0;
@@ -96,7 +107,15 @@ class StateRing {
     bool mailbox_done() const { return mail_ && (*mail_ >> 63) != 0; }
     long long mailbox_iter() const { return mail_ ? (long long)(*mail_ & 0x7fffffffffffffffull) : 0; }
 
+    // the pinned block and the events go back to the runtime with the owning thread (errors are ignored: at process
+    // exit the runtime may already be gone)
+    ~StateRing() {
+        for (int i = 0; i < n_ev_; ++i) (void)hipEventDestroy(ev_[i]);
+        if (slots_) (void)hipHostFree(slots_);
+    }
+
   private:
+    int n_ev_ = 0;
     volatile unsigned long long *mail_ = nullptr;
     unsigned long long *mail_dev_ = nullptr;
     et_kmeans_state *slots_ = nullptr;

@@ -1302,9 +1302,14 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     const float cen0 = ch.cen_rd[(int)threadIdx.x < d * K ? (int)threadIdx.x : 0];
     FoldRegs fr;
     fold_issue(ch.lanes_rd, ch.tot_rd, plen, fr, ch.compact != 0);  // (the filter kernels' launch sizes always fit: fold_fits())
-    if (done0) {  // converged earlier: keep the published copies in step, nothing else to do
+    if (done0) {  // converged earlier (or bad input flagged before the loop): keep the published copies in step
         if (wg0) {
-            if (threadIdx.x == 0) *ch.st_wr = *ch.st_rd;
+            if (threadIdx.x == 0) {
+                *ch.st_wr = *ch.st_rd;
+                if (ch.mail)  // the host stops launching as soon as it reads the flag (it would otherwise spin for it)
+                    __hip_atomic_store(ch.mail, (1ull << 63) | (unsigned long long)iter0, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             for (int e = threadIdx.x; e < d * K; e += (int)blockDim.x) ch.cen_wr[e] = ch.cen_rd[e];
             for (int e = threadIdx.x; e < plen; e += (int)blockDim.x) ch.tot_wr[e] = ch.tot_rd[e];
         }
@@ -1667,6 +1672,11 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_predict_kernel(const float 
                                                                     int64_t *__restrict__ labels,
                                                                     float *__restrict__ maxsims) {
     const int d = D ? D : d_rt;
+    // blockIdx.y = batch element: contiguous (B, d, N) data, (B, d, K) centroids -> (B, N) outputs
+    X += (int64_t)blockIdx.y * d * N;
+    cen += (int64_t)blockIdx.y * d * K;
+    if (labels) labels += (int64_t)blockIdx.y * N;
+    if (maxsims) maxsims += (int64_t)blockIdx.y * N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *sC = reinterpret_cast<float *>(smem_raw);
     stage_centroids(cen, d, K, sC);
@@ -2259,20 +2269,25 @@ extern "C" int et_kmeans_labels_i64(const uint8_t *labels_u8, int64_t N, int64_t
     return ET_OK;
 }
 
-extern "C" int et_kmeans_predict(const float *X, int64_t N, int d, const float *centroids, int K, int64_t *labels,
-                                 float *maxsims, et_stream_t stream) {
-    if (!km_dims_ok(d, K) || N < 0 || !centroids || (N > 0 && !X)) return ET_ERR_INVALID_ARG;
-    if (N == 0) return ET_OK;
+extern "C" int et_kmeans_predict_batch(const float *X, int64_t batch, int64_t N, int d, const float *centroids, int K,
+                                       int64_t *labels, float *maxsims, et_stream_t stream) {
+    if (!km_dims_ok(d, K) || N < 0 || batch < 0 || batch > 65535 || !centroids || (batch * N > 0 && !X))
+        return ET_ERR_INVALID_ARG;
+    if (batch * N == 0) return ET_OK;
     const size_t lds = sizeof(float) * (size_t)K * ((d + 1 + 3) & ~3);
     hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)km_grid(N), (unsigned)batch);
     if (d == 6)
-        hipLaunchKernelGGL((kmeans_predict_kernel<6>), dim3(km_grid(N)), dim3(kKmThreads), lds, st, X, N, d, centroids, K,
-                           labels, maxsims);
+        hipLaunchKernelGGL((kmeans_predict_kernel<6>), grid, dim3(kKmThreads), lds, st, X, N, d, centroids, K, labels, maxsims);
     else
-        hipLaunchKernelGGL((kmeans_predict_kernel<0>), dim3(km_grid(N)), dim3(kKmThreads), lds, st, X, N, d, centroids, K,
-                           labels, maxsims);
+        hipLaunchKernelGGL((kmeans_predict_kernel<0>), grid, dim3(kKmThreads), lds, st, X, N, d, centroids, K, labels, maxsims);
     ET_LAUNCH_CHECK();
     return ET_OK;
+}
+
+extern "C" int et_kmeans_predict(const float *X, int64_t N, int d, const float *centroids, int K, int64_t *labels,
+                                 float *maxsims, et_stream_t stream) {
+    return et_kmeans_predict_batch(X, 1, N, d, centroids, K, labels, maxsims, stream);
 }
 
 // fused != nullptr: single-GPU path, the one-workgroup pick launch also stores the candidate as centroid i of `fused`
@@ -2705,7 +2720,15 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
     // timing events belong to the device that is current when they are created: one cached set per (host thread, device)
     int dev_id = 0;
     ET_HIP_TRY(hipGetDevice(&dev_id));
-    static thread_local std::vector<std::vector<hipEvent_t>> per_device_events;
+    struct EventHolder {  // destroyed with the host thread
+        std::vector<std::vector<hipEvent_t>> v;
+        ~EventHolder() {
+            for (auto &dev_events : v)
+                for (hipEvent_t e : dev_events) (void)hipEventDestroy(e);
+        }
+    };
+    static thread_local EventHolder per_thread;
+    std::vector<std::vector<hipEvent_t>> &per_device_events = per_thread.v;
     if ((int)per_device_events.size() <= dev_id) per_device_events.resize(dev_id + 1);
     std::vector<hipEvent_t> &events = per_device_events[dev_id];
     if (timing_host) {

@@ -357,14 +357,15 @@ extern "C" int et_center_columns(float *X, int64_t N, int d, float rel_tol, floa
     if (d < 1 || d > ET_KMEANS_MAX_D || N < 1 || !X || !mean || !tol) return ET_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < 2 * sizeof(float) * ET_KMEANS_MAX_D) return ET_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    float *am = reinterpret_cast<float *>(workspace);  // np.var's own mean of the centred data
-    float *var = am + ET_KMEANS_MAX_D;
+    float *var = reinterpret_cast<float *>(workspace) + ET_KMEANS_MAX_D;
+    // sklearn's order (KMeans.fit): the tolerance from the variance of the data AS GIVEN (_check_params_vs_input ->
+    // _tolerance: mean(np.var(X, axis=0)) * tol; np.var's own column mean is the same sequential fp32 sum / n as
+    // X.mean(axis=0)), THEN X -= X.mean(axis=0)
     hipLaunchKernelGGL((colstats_kernel<0>), dim3(1), dim3(kPpThreads), 0, st, X, N, d, (const float *)nullptr, mean);
+    hipLaunchKernelGGL((colstats_kernel<1>), dim3(1), dim3(kPpThreads), 0, st, X, N, d, (const float *)mean, var);
     const int64_t blocks = ceil_div(N * d, (int64_t)kPpThreads);
     hipLaunchKernelGGL(center_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kPpThreads), 0, st, X, N, d,
                        (const float *)mean);
-    hipLaunchKernelGGL((colstats_kernel<0>), dim3(1), dim3(kPpThreads), 0, st, X, N, d, (const float *)nullptr, am);
-    hipLaunchKernelGGL((colstats_kernel<1>), dim3(1), dim3(kPpThreads), 0, st, X, N, d, (const float *)am, var);
     hipLaunchKernelGGL(tolerance_kernel, dim3(1), dim3(64), 0, st, (const float *)var, d, rel_tol, tol);
     ET_LAUNCH_CHECK();
     return ET_OK;

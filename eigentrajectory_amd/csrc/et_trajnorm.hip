@@ -99,9 +99,13 @@ __global__ __launch_bounds__(kTnThreads) void traj_transform_kernel(const float 
     reinterpret_cast<float2 *>(out)[i] = make_float2(x, y);
 }
 
-// kmeans.py:59-76 for one batch element; lane = (i, j) entry, j fastest (unit-stride stores).
+// kmeans.py:59-76; lane = (i, j) entry, j fastest (unit-stride stores); blockIdx.y = batch element (the reference's
+// leading dimensions: contiguous (B, d, m), (B, d, n) -> (B, m, n))
 __global__ __launch_bounds__(kTnThreads) void euc_sim_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                              int d, int64_t m, int64_t n, float *__restrict__ y) {
+    a += (int64_t)blockIdx.y * d * m;
+    b += (int64_t)blockIdx.y * d * n;
+    y += (int64_t)blockIdx.y * m * n;
     const int64_t e = (int64_t)blockIdx.x * kTnThreads + threadIdx.x;
     if (e >= m * n) return;
     const int64_t i = e / n, j = e - i * n;
@@ -168,11 +172,17 @@ extern "C" int et_denormalize(const float *traj, int64_t N, int T, const float *
     return traj_transform(true, traj, N, T, ori, rot, sca, out, stream);
 }
 
-extern "C" int et_euc_sim(const float *a, const float *b, int d, int64_t m, int64_t n, float *y, et_stream_t stream) {
-    if (d < 1 || m < 0 || n < 0 || (m * n > 0 && (!a || !b || !y))) return ET_ERR_INVALID_ARG;
-    if (m * n == 0) return ET_OK;
-    hipLaunchKernelGGL(euc_sim_kernel, dim3((unsigned)ceil_div(m * n, kTnThreads)), dim3(kTnThreads), 0,
+extern "C" int et_euc_sim_batch(const float *a, const float *b, int64_t batch, int d, int64_t m, int64_t n, float *y,
+                                et_stream_t stream) {
+    if (d < 1 || m < 0 || n < 0 || batch < 0 || batch > 65535 || (batch * m * n > 0 && (!a || !b || !y)))
+        return ET_ERR_INVALID_ARG;
+    if (batch * m * n == 0) return ET_OK;
+    hipLaunchKernelGGL(euc_sim_kernel, dim3((unsigned)ceil_div(m * n, kTnThreads), (unsigned)batch), dim3(kTnThreads), 0,
                        (hipStream_t)stream, a, b, d, m, n, y);
     ET_LAUNCH_CHECK();
     return ET_OK;
+}
+
+extern "C" int et_euc_sim(const float *a, const float *b, int d, int64_t m, int64_t n, float *y, et_stream_t stream) {
+    return et_euc_sim_batch(a, b, 1, d, m, n, y, stream);
 }

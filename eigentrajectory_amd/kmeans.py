@@ -85,7 +85,7 @@ class BatchKMeans(nn.Module):
         r"""Batched negative squared Euclidean distance (kmeans.py:59-76): (..., d, m), (..., d, n) -> (..., m, n)"""
         a3, lead = BatchKMeans._batched(a)
         b3, _ = BatchKMeans._batched(b)
-        out = torch.stack([ops.euc_sim(a3[i], b3[i]) for i in range(a3.shape[0])], dim=0)
+        out = ops.euc_sim(a3, b3)  # one launch for the whole batch
         return out.reshape(tuple(lead) + tuple(out.shape[-2:]))
 
     def kmeanspp(self, data):
@@ -115,10 +115,8 @@ class BatchKMeans(nn.Module):
         r"""maxsims (..., n), labels (..., n) int64 (kmeans.py:143-158)"""
         d3, lead = self._batched(data)
         c3, _ = self._batched(centroids)
-        outs = [ops.kmeans_predict(d3[i], c3[i]) for i in range(d3.shape[0])]
-        labels = torch.stack([o[0] for o in outs], dim=0).reshape(tuple(lead) + (d3.shape[-1],))
-        maxsims = torch.stack([o[1] for o in outs], dim=0).reshape(tuple(lead) + (d3.shape[-1],))
-        return maxsims, labels
+        labels, maxsims = ops.kmeans_predict(d3, c3)  # one launch for the whole batch
+        return maxsims.reshape(tuple(lead) + (d3.shape[-1],)), labels.reshape(tuple(lead) + (d3.shape[-1],))
 
     def compute_centroids(self, data, labels):
         r"""Per-cluster means (kmeans.py:160-198); an empty cluster gives NaN like the reference's 0/0."""

@@ -245,9 +245,16 @@ def eigh_topk_batch(mats, k):
 
 # -------------------------------------------------------------------------------- k-means
 def euc_sim(a, b):
-    """kmeans.py:59-76 for 2-D operands a (d,m), b (d,n) -> (m,n)."""
+    """kmeans.py:59-76: a (d,m), b (d,n) -> (m,n), or batched a (B,d,m), b (B,d,n) -> (B,m,n) in one launch."""
     dev = L.require_device(a, b)
     a, b = _dev_args(dev, a, b)
+    if a.dim() == 3:
+        B, d, m = a.shape
+        n = b.shape[2]
+        y = torch.empty((B, m, n), device=dev)
+        L.check(L.lib().et_euc_sim_batch(L.ptr(a), L.ptr(b), L.i64(B), d, L.i64(m), L.i64(n), L.ptr(y), L.stream(dev)),
+                "et_euc_sim_batch")
+        return y
     d, m = a.shape
     n = b.shape[1]
     y = torch.empty((m, n), device=dev)
@@ -311,9 +318,17 @@ def kmeans_joint_done(state_ptrs, n_problems, tol):
 
 
 def kmeans_predict(X, centroids, want_maxsims=True):
-    """kmeans.py:143-158 / 261-272: labels (N,) int64 and max similarity (N,)."""
+    """kmeans.py:143-158 / 261-272: labels (N,) int64 and max similarity (N,); batched (B,d,N), (B,d,K) -> (B,N) in one
+    launch."""
     dev = L.require_device(X)
     X, centroids = _dev_args(dev, X, centroids)
+    if X.dim() == 3:
+        B, d, n = X.shape
+        labels = torch.empty((B, n), device=dev, dtype=torch.int64)
+        maxsims = torch.empty((B, n), device=dev) if want_maxsims else None
+        L.check(L.lib().et_kmeans_predict_batch(L.ptr(X), L.i64(B), L.i64(n), d, L.ptr(centroids), centroids.shape[2],
+                                                L.ptr(labels), L.ptr(maxsims), L.stream(dev)), "et_kmeans_predict_batch")
+        return labels, maxsims
     d, n = X.shape
     labels = torch.empty((n,), device=dev, dtype=torch.int64)
     maxsims = torch.empty((n,), device=dev) if want_maxsims else None

@@ -26,7 +26,7 @@
  *    keeps is host-side and private: per host thread and device a 4-slot pinned staging ring (4 x 96 B + a 64-byte
  *    progress mailbox the single-GPU Lloyd kernel writes into) + 4 events
  *    for the non-blocking convergence polling of the Lloyd loops (csrc/et_hostring.h), and the timing events of
- *    et_kmeans_fit when timing is requested -- created on first use, kept for the life of the process;
+ *    et_kmeans_fit when timing is requested -- created on first use, released when that host thread ends;
  *  - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work and
  *    never synchronise unless documented;
  *  - return value: ET_OK or an ET_ERR_* code; no exceptions cross this boundary;
@@ -188,6 +188,9 @@ typedef struct et_kmeans_state {
 
 /* kmeans.py:59-76 euc_sim for one batch element: a (d,m), b (d,n) -> y (m,n) */
 int et_euc_sim(const float *a, const float *b, int d, int64_t m, int64_t n, float *y, et_stream_t stream);
+/* ... and for the reference's leading batch dimensions in one launch: contiguous a (B,d,m), b (B,d,n) -> y (B,m,n) */
+int et_euc_sim_batch(const float *a, const float *b, int64_t batch, int d, int64_t m, int64_t n, float *y,
+                     et_stream_t stream);
 
 /* number of int64 in a partials block: d*K sums (d-major), K counts, sim_sum, nan_count */
 size_t et_kmeans_partials_len(int d, int K);
@@ -275,6 +278,9 @@ int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_iter, float t
 /* kmeans.py:261-272 predict: labels int64 (N); maxsims (N) optional */
 int et_kmeans_predict(const float *X, int64_t N, int d, const float *centroids, int K, int64_t *labels,
                       float *maxsims, et_stream_t stream);
+/* kmeans.py:143-158 get_labels on a batch in one launch: X (B,d,N), centroids (B,d,K) -> labels / maxsims (B,N) */
+int et_kmeans_predict_batch(const float *X, int64_t batch, int64_t N, int d, const float *centroids, int K,
+                            int64_t *labels, float *maxsims, et_stream_t stream);
 
 /* ---- anchor clustering as the reference runs it: sklearn KMeans(init='k-means++', n_init=10) ----------
  * EigenTrajectory/anchor.py:65-71 hands the coefficients to sklearn.cluster.KMeans (third-party; its published

@@ -33,9 +33,9 @@ from . import et_oracle as eo
 def center_columns(C, rel_tol=1e-4):
     """C (d,N) float32 -> (Xc (d,N) float32, mean (d,), tol float32) like KMeans.fit's pre-processing."""
     X = np.ascontiguousarray(np.asarray(C, np.float32).T)  # (N,d) C-ordered like sklearn's validated copy
+    tol = np.float32(np.mean(np.var(X, axis=0)) * rel_tol)  # _check_params_vs_input: from the data AS GIVEN ...
     mean = X.mean(axis=0)          # sequential float32 adds over the rows
-    X = X - mean
-    tol = np.float32(np.mean(np.var(X, axis=0)) * rel_tol)
+    X = X - mean                   # ... then centred (KMeans.fit)
     return np.ascontiguousarray(X.T), mean, tol
 
 

@@ -1454,3 +1454,24 @@ def test_batchkmeans_joint_stop_g7b(ops, dev):
     assert np.array_equal(N_(labels).astype(np.uint8), z["labels"])
     np.testing.assert_allclose(N_(km.centroids), z["centroids"], rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(km.inertia_, z["trace"][-1, 1], rtol=1e-5)
+
+
+def test_batchkmeans_helpers_run_the_batch_in_one_launch(ops, oracle, dev):
+    """BatchKMeans.euc_sim / get_labels / predict on (l, d, n) operands (kmeans.py:59-76, 143-158): one launch for the
+    batch, bit for bit what the per-problem oracle gives."""
+    from eigentrajectory_amd import BatchKMeans
+    from eigentrajectory_amd.synth import gaussian_points_np
+    xs = np.stack([gaussian_points_np(6, 777, seed=90 + b, n_blobs=3 + b) for b in range(4)])
+    cs = np.stack([xs[b][:, 5:300:23].copy() for b in range(4)])  # (4, 6, 13)
+    sims = BatchKMeans.euc_sim(T(xs, dev), T(cs, dev))
+    assert sims.shape == (4, 777, 13)
+    km = BatchKMeans(n_clusters=13)
+    maxsims, labels = km.get_labels(T(xs, dev), T(cs, dev))
+    assert labels.shape == (4, 777) and labels.dtype == torch.int64
+    for b in range(4):
+        assert np.array_equal(N_(sims[b]), oracle.euc_sim(xs[b], cs[b]))
+        lb, ms = oracle.kmeans_assign(xs[b], cs[b])
+        assert np.array_equal(N_(labels[b]), lb) and np.array_equal(N_(maxsims[b]), ms)
+    # leading dimensions beyond one (the reference's "...")
+    sims2 = BatchKMeans.euc_sim(T(xs.reshape(2, 2, 6, 777), dev), T(cs.reshape(2, 2, 6, 13), dev))
+    assert torch.equal(sims2.reshape(4, 777, 13), sims)

@@ -53,7 +53,7 @@ def main():
         out[f"{tag}.inertia"] = np.float64(km.inertia_)
         out[f"{tag}.n_iter"] = np.int64(km.n_iter_)
         out[f"{tag}.mean"] = X.mean(axis=0)
-        out[f"{tag}.tol"] = np.float32(np.mean(np.var(Xc, axis=0)) * 1e-4)
+        out[f"{tag}.tol"] = np.float32(km._tol)  # sklearn's own: mean(var(X)) * 1e-4 of the data as given
         print(f"  {tag}: N={X.shape[0]} inertia={km.inertia_:.4f} n_iter={km.n_iter_}")
     path = os.path.join(args.out, "g11_sklearn_anchors.npz")
     np.savez_compressed(path, **out)
