@@ -308,6 +308,34 @@ def scene_latency(dev, U_obs, U_pred, n_peds=57, reps=2000):
                 fn()
             torch.cuda.synchronize()
             res[f"{name}_us_per_scene"] = round((time.perf_counter() - t0) / reps * 1e6, 2)
+    # the TRAINING form of a wrapper call (utils/trainer.py:126-152): forward with the ground truth -> the three loss terms
+    # -> backward into the predictor (here: into the refinement coefficients a one-parameter stub predictor emits, so
+    # that what is timed is the descriptor path, its autograd and the loss arithmetic)
+    class Bias(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.b = torch.nn.Parameter(torch.zeros((6, 1, 20)))
+
+        def forward(self, x):
+            return self.b.expand(6, x.size(1), 20) * 1.0
+
+    tmodel = EigenTrajectory(Bias(), hooks, default_hyper_params(static_dist=0.3)).to(dev)
+    tmodel.load_state_dict({**model.state_dict(), "baseline_model.b": tmodel.baseline_model.b.detach()})
+
+    def train_step():
+        with torch.enable_grad():  # (extra_stages runs under no_grad)
+            tmodel.baseline_model.b.grad = None
+            out = tmodel(obs, pred)
+            (out["loss_eigentraj"] + out["loss_euclidean_ade"] + out["loss_euclidean_fde"]).backward()
+    for _ in range(30):
+        train_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps // 4):
+        train_step()
+    torch.cuda.synchronize()
+    res["train_step_us_per_scene"] = round((time.perf_counter() - t0) / (reps // 4) * 1e6, 2)
+    with torch.no_grad():
         # W1 (model.py:34-56) at the size of the reference's own fit sets (ETH train+val+flip: 70 316 trajectories):
         # two descriptor fits + two anchor clusterings in the reference's sklearn recipe (k-means++, n_init = 10)
         o, p = synthetic_trajectories_torch(70_316, dev, seed=6)

@@ -107,51 +107,59 @@ def seeding_uniforms(rng, K, n_init):
     return U
 
 
+_UNIFORMS_CACHE = {}
+
+
 def sklearn_style_kmeans(C, K, *, random_state=0, n_init=10, max_iter=300, tol=1e-4, concurrent=True):
     """``KMeans(n_clusters=K, random_state=random_state, init='k-means++', n_init=n_init).fit(C.T)`` as a recipe on
     the device: -> (cluster centres (d,K) fp32 on C's device, inertia = mean squared distance to the final centres,
     seed indices (n_init,K) int64 of every initialisation).
 
-    The initialisations are independent problems: with ``concurrent`` each one (seeding + Lloyd + final inertia) runs
-    on its own HIP stream, driven by its own host thread (``et_kmeans_fit`` blocks only the calling thread, and the
-    library's polling state is per host thread) -- the ~1e5-point fits are launch-latency-bound, so ten of them side by
-    side take little longer than one.  The result does not depend on it: the best FINAL inertia wins, ties go to the
-    earlier initialisation, exactly as in the sequential order."""
+    The initialisations are independent problems on the same points.  ``concurrent`` (default): they are the batch
+    dimension of the library's batched entry points -- the 4K-1 seeding launches serve all of them
+    (``et_kmeanspp_seed_batch``), ONE persistent launch runs all their Lloyd loops (``et_kmeans_fit_batch``), one launch ranks them by the inertia of
+    their final centres -- from the calling thread, on the caller's stream (ten host threads with a stream each, the
+    round-2 form, scaled to barely 2x: stream / thread set-up and the fits slowing each other down).  ``concurrent=False``
+    runs them one after the other.  The result does not depend on it: the best FINAL inertia wins, ties go to the
+    earlier initialisation."""
     dev = ops.L.require_device(C)  # no CPU fallback: raises without a HIP device
     X, mean, tol_dev = ops.center_columns(C.to(device=dev, dtype=torch.float32), tol)
     d, n = X.shape
-    U = torch.from_numpy(seeding_uniforms(np.random.RandomState(random_state), K, n_init)).to(dev)
-    nbytes = ops.L.lib().et_kmeanspp_workspace_bytes(ops.L.i64(n), d, ops.kmeanspp_trials(K))
+    key = (int(random_state), int(K), int(n_init))
+    if key not in _UNIFORMS_CACHE:  # the draws of a seeding depend on (seed, K, n_init) only
+        _UNIFORMS_CACHE[key] = seeding_uniforms(np.random.RandomState(random_state), K, n_init)
+    U = torch.from_numpy(_UNIFORMS_CACHE[key]).to(dev)
     tol_ = float(tol_dev.item())
-    main = torch.cuda.current_stream(dev)
-
-    def one_init(i, stream):
-        with torch.cuda.device(dev), torch.cuda.stream(stream):
-            stream.wait_stream(main)  # X, U were produced on the caller's stream
-            ws_seed = torch.empty((max(nbytes, 8),), device=dev, dtype=torch.uint8)
-            c0, idx = ops.kmeanspp_seed(X, K, U[i], ws_seed)
-            res = ops.kmeans_fit(X, c0, max_iter, tol_, trace=False)
-            cen = res["centroids"]
-            if not bool(torch.isfinite(cen).all()):
-                # an empty cluster (kmeans.py:182 semantics): sklearn would re-seed it, here the run is dropped
-                return idx, None, float("nan")
-            _, maxsims = ops.kmeans_predict(X, cen)  # sklearn ranks by the inertia of the FINAL centres
-            return idx, cen, float((-maxsims.double()).sum())
 
     if concurrent and n_init > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        streams = [torch.cuda.Stream(device=dev) for _ in range(n_init)]
-        with ThreadPoolExecutor(max_workers=n_init) as pool:
-            runs = list(pool.map(one_init, range(n_init), streams))
-        for st in streams:
-            main.wait_stream(st)
-    else:
-        runs = [one_init(i, main) for i in range(n_init)]
-    best = None
-    for _, cen, inertia in runs:
-        if cen is not None and (best is None or inertia < best[0]):
+        c0, seeds = ops.kmeanspp_seed_batch(X, K, U)
+        res = ops.kmeans_fit_batch(X, c0, max_iter, tol_)
+        cens = res["centroids"]                                      # (n_init, d, K)
+        _, maxsims = ops.kmeans_predict(X, cens)                       # every set of centres on the same points
+        # sklearn ranks by the inertia of the FINAL centres; an initialisation with an empty cluster (NaN centre,
+        # kmeans.py:182 semantics -- sklearn would re-seed it) is dropped
+        inertia = (-maxsims.double()).sum(dim=1)
+        inertia = torch.where(torch.isfinite(cens).flatten(1).all(dim=1), inertia, torch.full_like(inertia, float("inf")))
+        best = int(torch.argmin(inertia))  # first minimum = the earlier initialisation on ties
+        best_inertia = float(inertia[best])
+        if not np.isfinite(best_inertia):
+            raise RuntimeError("every k-means initialisation produced an empty cluster")
+        return (cens[best] + mean[:, None]).contiguous(), best_inertia / n, seeds
+
+    nbytes = ops.L.lib().et_kmeanspp_workspace_bytes(ops.L.i64(n), d, ops.kmeanspp_trials(K))
+    ws_seed = torch.empty((max(nbytes, 8),), device=dev, dtype=torch.uint8)
+    best, seeds = None, []
+    for i in range(n_init):
+        c0, idx = ops.kmeanspp_seed(X, K, U[i], ws_seed)
+        res = ops.kmeans_fit(X, c0, max_iter, tol_, trace=False)
+        seeds.append(idx)
+        cen = res["centroids"]
+        if not bool(torch.isfinite(cen).all()):
+            continue  # an empty cluster (kmeans.py:182 semantics): sklearn would re-seed it, here the run is dropped
+        _, maxsims = ops.kmeans_predict(X, cen)  # sklearn ranks by the inertia of the FINAL centres
+        inertia = float((-maxsims.double()).sum())
+        if best is None or inertia < best[0]:
             best = (inertia, cen)
     if best is None:
         raise RuntimeError("every k-means initialisation produced an empty cluster")
-    seeds = torch.stack([idx for idx, _, _ in runs])
-    return (best[1] + mean[:, None]).contiguous(), best[0] / n, seeds
+    return (best[1] + mean[:, None]).contiguous(), best[0] / n, torch.stack(seeds)

@@ -28,6 +28,7 @@
 // result is independent of the order: the same bits for any workgroup schedule, grid size or
 // number of GPUs, and identical to the CPU oracle (oracle/et_oracle.c).
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "et_common.h"
@@ -347,9 +348,15 @@ __device__ __forceinline__ int sim_frac_bits(double mx, double mc, int d, int64_
 // One wavefront: the d K centroid values are looked at by the 64 lanes in parallel (maxima / minima / a flag: order
 // independent; a single lane used to walk through them with two dependent global loads per value -- 14 us of a
 // kernel that does almost nothing).
+// blockIdx.x = problem of a batch (et_kmeans_fit_batch): state blocks ws_stride bytes apart, centroids cen_stride floats
+// apart; shared_scan: the problems share their points, problem 0's state holds the scan results for all of them.
 __global__ void kmeans_begin_kernel(et_kmeans_state *state, int64_t n_total, const float *__restrict__ cen, int d,
-                                    int K) {
-    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+                                    int K, int64_t ws_stride = 0, int64_t cen_stride = 0, int shared_scan = 0) {
+    if (threadIdx.x >= 64) return;
+    const et_kmeans_state *scanned = state;
+    state = reinterpret_cast<et_kmeans_state *>(reinterpret_cast<char *>(state) + (int64_t)blockIdx.x * ws_stride);
+    cen += (int64_t)blockIdx.x * cen_stride;
+    if (!shared_scan) scanned = state;
     const int lane = threadIdx.x, n = d * K;
     double mc = 0.0;
     unsigned mn = 0x7f800000u;
@@ -370,7 +377,11 @@ __global__ void kmeans_begin_kernel(et_kmeans_state *state, int64_t n_total, con
         bad |= __shfl_xor(bad, o);
     }
     if (lane != 0) return;
-    const double mx = state->max_abs_x;
+    const double mx = scanned->max_abs_x;
+    const int64_t bad_input = scanned->bad_input, min_nz = scanned->min_nz_x_bits;
+    state->max_abs_x = mx;  // (the same values when the state is its own scan result)
+    state->bad_input = bad_input;
+    state->min_nz_x_bits = min_nz;
     state->n_total = n_total;
     state->frac = 62 - exponent_above(mx) - bits_for(n_total);
     state->max_abs_c = mc;
@@ -378,11 +389,11 @@ __global__ void kmeans_begin_kernel(et_kmeans_state *state, int64_t n_total, con
     int64_t fast = 0;
     if (!bad && mx < 1e18 && mc < 1e18) {
         const unsigned lim = 0x26800000u;  // 2^-50, see the fast_ok levels above
-        fast = (mn >= lim && (unsigned long long)state->min_nz_x_bits >= lim) ? 2 : 1;
+        fast = (mn >= lim && (unsigned long long)min_nz >= lim) ? 2 : 1;
     }
     state->fast_ok = fast;
     state->iter = 0;
-    state->done = state->bad_input ? 1 : 0;  // non-finite data: every later step is a no-op
+    state->done = bad_input ? 1 : 0;  // non-finite data: every later step is a no-op
     state->error = 0.0;
     state->inertia = 0.0;
 }
@@ -1389,6 +1400,11 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_chain_finalize_kernel(const
 // leaves; the host then repeats the fit with the chained kernel (co-residency cannot be promised when another process
 // shares the GPU; inside this process et_kmeans_fit hands out the CUs, see PersistSlots).
 // ------------------------------------------------------------------------------------------
+template <typename T>
+__host__ __device__ __forceinline__ T *byte_shift(T *p, int64_t bytes) {
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(const_cast<std::remove_const_t<T> *>(p)) + bytes);
+}
+
 struct LloydPersist {
     const et_kmeans_state *st_in;  // state block after scan / begin
     const float *cen_in;           // initial centroids (d, K)
@@ -1399,15 +1415,37 @@ struct LloydPersist {
     unsigned *arrive;              // grid barrier: arrivals so far (zeroed before the launch)
     unsigned *abort;               // set by a workgroup whose wait timed out (zeroed before the launch)
     float *last;                   // centroids + sim_frac of the last assignment (for kmeans_inertia_kernel)
+    // blockIdx.y = one of several problems run side by side in one launch (et_kmeans_fit_batch: the n_init fits of the
+    // sklearn recipe), each with its own workspace of identical layout: byte distance between two problems' workspaces
+    // (every pointer above except cen_in lives there, and so does `labels`), element distances of their points (0: the
+    // same points) and of their initial centroids
+    int64_t ws_stride, x_stride, cen_stride;
 };
 constexpr unsigned long long kSpinTimeoutTicks = 50000000ull;  // 0.5 s of the 100 MHz s_memrealtime clock
 
 
 template <int NREGS, bool SIM>
 __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_persist_kernel(
-    const float *__restrict__ X, int64_t N, int K, const LloydPersist pa, uint8_t *__restrict__ labels, float tol,
+    const float *__restrict__ X, int64_t N, int K, LloydPersist pa, uint8_t *__restrict__ labels, float tol,
     float *trace, int max_iter) {
     constexpr int d = 6;
+    if (blockIdx.y) {  // this problem's points, initial centroids and workspace
+        const int64_t y = blockIdx.y;
+        const int64_t off = y * pa.ws_stride;
+        X += y * pa.x_stride;
+        pa.cen_in += y * pa.cen_stride;
+        pa.st_in = byte_shift(pa.st_in, off);
+        pa.st_out = byte_shift(pa.st_out, off);
+        pa.cen_out = byte_shift(pa.cen_out, off);
+        pa.tot_out = byte_shift(pa.tot_out, off);
+        pa.lanes0 = byte_shift(pa.lanes0, off);
+        pa.lanes1 = byte_shift(pa.lanes1, off);
+        pa.lanes2 = byte_shift(pa.lanes2, off);
+        pa.arrive = byte_shift(pa.arrive, off);
+        pa.abort = byte_shift(pa.abort, off);
+        pa.last = byte_shift(pa.last, off);
+        labels = byte_shift(labels, off);
+    }
     constexpr int kMaxK = 32;  // the filter's limit (km_use_filter)
     constexpr int kMaxPlen = d * kMaxK + kMaxK + 2;
     const int plen = d * K + K + 2;
@@ -1523,8 +1561,15 @@ template <int D>
 __global__ __launch_bounds__(kKmThreads) void kmeans_inertia_kernel(const float *__restrict__ X, int64_t N, int d_rt, int K,
                                                                      const float *__restrict__ last,
                                                                      const uint8_t *__restrict__ labels,
-                                                                     long long *__restrict__ sim_total) {
+                                                                     long long *__restrict__ sim_total,
+                                                                     int64_t ws_stride = 0, int64_t x_stride = 0) {
     const int d = D ? D : d_rt;
+    if (blockIdx.y) {  // problem of a batch: last / labels / sim_total live in workspaces ws_stride bytes apart
+        X += (int64_t)blockIdx.y * x_stride;
+        last = byte_shift(last, (int64_t)blockIdx.y * ws_stride);
+        labels = byte_shift(labels, (int64_t)blockIdx.y * ws_stride);
+        sim_total = byte_shift(sim_total, (int64_t)blockIdx.y * ws_stride);
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *sC = reinterpret_cast<float *>(smem_raw);
     __shared__ long long sSum[2];
@@ -1598,8 +1643,13 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_inertia_kernel(const float 
 }
 
 __global__ void kmeans_inertia_finish_kernel(et_kmeans_state *state, const float *__restrict__ last, int d, int K,
-                                             const long long *__restrict__ sim_total) {
+                                             const long long *__restrict__ sim_total, int64_t ws_stride = 0) {
     if (threadIdx.x != 0) return;
+    if (blockIdx.x) {  // problem of a batch
+        state = byte_shift(state, (int64_t)blockIdx.x * ws_stride);
+        last = byte_shift(last, (int64_t)blockIdx.x * ws_stride);
+        sim_total = byte_shift(sim_total, (int64_t)blockIdx.x * ws_stride);
+    }
     const int sfrac = (int)*reinterpret_cast<const long long *>(last + ((d * K + 1) & ~1));
     float inertia;
     if (sim_total[1] > 0) inertia = __int_as_float(0x7fc00000);
@@ -1646,7 +1696,11 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_reduce_update_kernel(const 
 }
 
 __global__ __launch_bounds__(kKmThreads) void kmeans_labels_i64_kernel(const uint8_t *__restrict__ lb, int64_t N,
-                                                                       int64_t *__restrict__ out) {
+                                                                       int64_t *__restrict__ out, int64_t ws_stride = 0) {
+    if (blockIdx.y) {  // problem of a batch: uint8 labels in workspaces ws_stride bytes apart, int64 rows of N
+        lb = byte_shift(lb, (int64_t)blockIdx.y * ws_stride);
+        out += (int64_t)blockIdx.y * N;
+    }
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // four labels per lane: one 4-B load, two 16-B stores (both buffers come 16-B aligned from the allocator)
@@ -1670,10 +1724,11 @@ template <int D>
 __global__ __launch_bounds__(kKmThreads) void kmeans_predict_kernel(const float *__restrict__ X, int64_t N, int d_rt,
                                                                     const float *__restrict__ cen, int K,
                                                                     int64_t *__restrict__ labels,
-                                                                    float *__restrict__ maxsims) {
+                                                                    float *__restrict__ maxsims, int64_t x_stride) {
     const int d = D ? D : d_rt;
-    // blockIdx.y = batch element: contiguous (B, d, N) data, (B, d, K) centroids -> (B, N) outputs
-    X += (int64_t)blockIdx.y * d * N;
+    // blockIdx.y = batch element: data x_stride floats apart (d N: contiguous (B, d, N); 0: the same points for every
+    // element), (B, d, K) centroids -> (B, N) outputs
+    X += (int64_t)blockIdx.y * x_stride;
     cen += (int64_t)blockIdx.y * d * K;
     if (labels) labels += (int64_t)blockIdx.y * N;
     if (maxsims) maxsims += (int64_t)blockIdx.y * N;
@@ -2269,25 +2324,27 @@ extern "C" int et_kmeans_labels_i64(const uint8_t *labels_u8, int64_t N, int64_t
     return ET_OK;
 }
 
-extern "C" int et_kmeans_predict_batch(const float *X, int64_t batch, int64_t N, int d, const float *centroids, int K,
-                                       int64_t *labels, float *maxsims, et_stream_t stream) {
-    if (!km_dims_ok(d, K) || N < 0 || batch < 0 || batch > 65535 || !centroids || (batch * N > 0 && !X))
+extern "C" int et_kmeans_predict_batch(const float *X, int64_t x_stride, int64_t batch, int64_t N, int d,
+                                       const float *centroids, int K, int64_t *labels, float *maxsims, et_stream_t stream) {
+    if (!km_dims_ok(d, K) || N < 0 || batch < 0 || batch > 65535 || x_stride < 0 || !centroids || (batch * N > 0 && !X))
         return ET_ERR_INVALID_ARG;
     if (batch * N == 0) return ET_OK;
     const size_t lds = sizeof(float) * (size_t)K * ((d + 1 + 3) & ~3);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)km_grid(N), (unsigned)batch);
     if (d == 6)
-        hipLaunchKernelGGL((kmeans_predict_kernel<6>), grid, dim3(kKmThreads), lds, st, X, N, d, centroids, K, labels, maxsims);
+        hipLaunchKernelGGL((kmeans_predict_kernel<6>), grid, dim3(kKmThreads), lds, st, X, N, d, centroids, K, labels, maxsims,
+                           x_stride);
     else
-        hipLaunchKernelGGL((kmeans_predict_kernel<0>), grid, dim3(kKmThreads), lds, st, X, N, d, centroids, K, labels, maxsims);
+        hipLaunchKernelGGL((kmeans_predict_kernel<0>), grid, dim3(kKmThreads), lds, st, X, N, d, centroids, K, labels, maxsims,
+                           x_stride);
     ET_LAUNCH_CHECK();
     return ET_OK;
 }
 
 extern "C" int et_kmeans_predict(const float *X, int64_t N, int d, const float *centroids, int K, int64_t *labels,
                                  float *maxsims, et_stream_t stream) {
-    return et_kmeans_predict_batch(X, 1, N, d, centroids, K, labels, maxsims, stream);
+    return et_kmeans_predict_batch(X, 0, 1, N, d, centroids, K, labels, maxsims, stream);
 }
 
 // fused != nullptr: single-GPU path, the one-workgroup pick launch also stores the candidate as centroid i of `fused`
@@ -2568,7 +2625,16 @@ class PersistSlots {
 };
 
 __global__ __launch_bounds__(kKmThreads) void kmeans_persist_prepare_kernel(int plen, long long *l0, long long *l1, long long *l2,
-                                                                            unsigned *ctl, long long *sim_total) {
+                                                                            unsigned *ctl, long long *sim_total,
+                                                                            int64_t ws_stride) {
+    {   // blockIdx.y: problem of a batch (workspaces of identical layout, ws_stride bytes apart)
+        const int64_t off = (int64_t)blockIdx.y * ws_stride;
+        l0 = reinterpret_cast<long long *>(reinterpret_cast<char *>(l0) + off);
+        l1 = reinterpret_cast<long long *>(reinterpret_cast<char *>(l1) + off);
+        l2 = reinterpret_cast<long long *>(reinterpret_cast<char *>(l2) + off);
+        ctl = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(ctl) + off);
+        sim_total = reinterpret_cast<long long *>(reinterpret_cast<char *>(sim_total) + off);
+    }
     const int tid = blockIdx.x * kKmThreads + threadIdx.x, n_thr = gridDim.x * kKmThreads;
     for (int e = tid; e < plen * kAccLanes; e += n_thr) {
         l0[e] = 0;
@@ -2588,11 +2654,15 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_persist_prepare_kernel(int 
 // small; for a full grid the staggered start of a new launch's workgroups happens to hide the uneven pass counts that
 // the barrier exposes.  Hence: persistent up to kPersistMaxPoints, chained above; ET_KMEANS_LOOP=persist / chain forces one.
 constexpr int64_t kPersistMaxPoints = 98304;  // 32 workgroups of 12 wavefronts, one 256-point pass each
-static bool km_persist_wanted(int64_t N) {
+static char km_persist_mode() {  // 'a'uto, 'c'hain, 'p'ersist
     static const char mode = [] {
         const char *e = getenv("ET_KMEANS_LOOP");
         return e ? e[0] : 'a';
     }();
+    return mode;
+}
+static bool km_persist_wanted(int64_t N) {
+    const char mode = km_persist_mode();
     if (mode == 'c') return false;
     if (mode == 'p') return true;
     return N <= kPersistMaxPoints;
@@ -2609,7 +2679,7 @@ static int km_persist_run(const float *X, int64_t N, int d, int K, int max_iter,
     int rc = km_fat_lds_attribute();
     if (rc) return rc;
     hipLaunchKernelGGL(kmeans_persist_prepare_kernel, dim3(8), dim3(kKmThreads), 0, st, (int)plen, w.chain_lanes[0],
-                       w.chain_lanes[1], w.chain_lanes[2], w.persist_ctl, w.sim_total);
+                       w.chain_lanes[1], w.chain_lanes[2], w.persist_ctl, w.sim_total, (int64_t)0);
     ET_LAUNCH_CHECK();
     LloydPersist pa;
     pa.st_in = state;
@@ -2623,6 +2693,7 @@ static int km_persist_run(const float *X, int64_t N, int d, int K, int max_iter,
     pa.arrive = w.persist_ctl;
     pa.abort = w.persist_ctl + 1;
     pa.last = w.last;
+    pa.ws_stride = pa.x_stride = pa.cen_stride = 0;
     int grid = 0, dev = 0;
     const int n_cu = km_cu_count(&dev);
     // one resident round of workgroups of the instantiation that is launched
@@ -2703,12 +2774,164 @@ extern "C" int et_internal_kmeans_chain_run(const float *X, int64_t N, int d, in
                         (hipStream_t)stream, hook, nullptr, 8, nullptr);
 }
 
+// ---- several fits side by side in ONE persistent launch (blockIdx.y = problem) ----
+// The reference's anchor clustering is ten independent small fits (sklearn's n_init = 10, anchor.py:65-71) on the same
+// points; at dataset sizes each is latency bound and driving them from ten host threads / streams scaled to barely 2x
+// (profiles/r03g_concurrent_inits.txt: 3.4 ms of stream / thread set-up, fits slowed down by each other).  Here the
+// problems are the y dimension of ONE persistent grid: each has its own workspace (same layout, ws_stride apart), its
+// own barrier counter and stops on its own error; problems whose workgroups do not all fit on the device at once are
+// launched in chunks.
+namespace et {
+__global__ __launch_bounds__(kKmThreads) void kmeans_batch_collect_kernel(const float *cen_staged, const et_kmeans_state *st_staged,
+                                                                          et_kmeans_state *st_final, int64_t ws_stride,
+                                                                          float *centroids, int dk) {
+    const int64_t off = (int64_t)blockIdx.x * ws_stride;
+    const float *src = byte_shift(cen_staged, off);
+    for (int e = threadIdx.x; e < dk; e += kKmThreads) centroids[(int64_t)blockIdx.x * dk + e] = src[e];
+    constexpr int kStateWords = (int)(sizeof(et_kmeans_state) / sizeof(unsigned));
+    if ((int)threadIdx.x < kStateWords)
+        reinterpret_cast<unsigned *>(byte_shift(st_final, off))[threadIdx.x] =
+            reinterpret_cast<const unsigned *>(byte_shift(st_staged, off))[threadIdx.x];
+}
+}  // namespace et
+
+extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_iter, float tol, float *centroids,
+                             int64_t *labels, float *trace, et_kmeans_state *state_host,
+                             et_kmeans_timing *timing_host, void *workspace, size_t workspace_bytes,
+                             et_stream_t stream);
+
+extern "C" size_t et_kmeans_batch_workspace_bytes(int64_t N, int d, int K, int64_t batch) {
+    const size_t one = et_kmeans_workspace_bytes(N, d, K);
+    return one == 0 || batch < 1 ? 0 : one * (size_t)batch;
+}
+
+extern "C" int et_kmeans_fit_batch(const float *X, int64_t x_stride, int64_t N, int d, int K, int64_t batch, int max_iter,
+                                   float tol, float *centroids, int64_t *labels, et_kmeans_state *states_host,
+                                   void *workspace, size_t workspace_bytes, et_stream_t stream) {
+    if (!km_dims_ok(d, K) || N < 1 || !X || !centroids || !states_host || max_iter < 1 || batch < 1 || batch > 65535 ||
+        x_stride < 0)
+        return ET_ERR_INVALID_ARG;
+    const size_t one = et_kmeans_workspace_bytes(N, d, K);
+    if (!workspace || workspace_bytes < one * (size_t)batch) return ET_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const KmWorkspace w = km_carve(workspace, N, d, K);  // problem 0's; problem b's is the same layout, b * one bytes on
+    const int64_t dk = (int64_t)d * K;
+    // every problem alone through et_kmeans_fit: shapes the persistent kernel does not take, or when it is switched off
+    auto one_by_one = [&](int64_t from, int64_t to) -> int {
+        for (int64_t b = from; b < to; ++b) {
+            const int rc = et_kmeans_fit(X + b * x_stride, N, d, K, max_iter, tol, centroids + b * dk,
+                                         labels ? labels + b * N : nullptr, nullptr,
+                                         &states_host[b], nullptr, byte_shift((char *)workspace, b * (int64_t)one), one, stream);
+            if (rc && rc != ET_ERR_BAD_DATA) return rc;
+        }
+        return ET_OK;
+    };
+    bool takes = km_persist_mode() != 'c' && x_stride % 4 == 0;
+    for (int64_t b = 0; takes && b < batch; ++b) takes = km_use_filter(X + b * x_stride, N, d, K, w.labels_u8);
+    const int threads = km_filter_threads(N);
+    const size_t plen = km_plen(d, K), lds = km_filter_lds_bytes(d, K, threads);
+    int dev = 0;
+    const int n_cu = km_cu_count(&dev);
+    int grid = 0;
+    if (takes) {
+        int rc = km_fat_lds_attribute();
+        if (rc) return rc;
+        grid = K <= 20 ? km_resident_grid(kmeans_lloyd_persist_kernel<10, false>, lds, N / 4, threads)
+                       : km_resident_grid(kmeans_lloyd_persist_kernel<16, false>, lds, N / 4, threads);
+        if (grid > n_cu / 2) takes = false;  // a shard that fills the device by itself: nothing to put side by side
+    }
+    if (!takes) {
+        return one_by_one(0, batch);
+    }
+    const bool shared = x_stride == 0;
+    // scale scan: once when the problems share their points, else per problem; then every problem's begin in one launch
+    for (int64_t b = 0; b < (shared ? 1 : batch); ++b) {
+        const int rc = et_kmeans_scan(X + b * x_stride, N, d, byte_shift(w.state, b * (int64_t)one), stream);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(kmeans_begin_kernel, dim3((unsigned)batch), dim3(64), 0, st, w.state, N, (const float *)centroids, d, K,
+                       (int64_t)one, dk, shared ? 1 : 0);
+    ET_LAUNCH_CHECK();
+    const int per_launch = n_cu / grid;  // problems whose workgroups are resident together (one fat workgroup per CU)
+    PersistSlots &slots = PersistSlots::of_device(dev);
+    std::vector<unsigned> ctl((size_t)batch * 2, 0u);
+    for (int64_t b0 = 0; b0 < batch; b0 += per_launch) {
+        const int64_t nb = batch - b0 < per_launch ? batch - b0 : per_launch;
+        const int64_t off = b0 * (int64_t)one;
+        hipLaunchKernelGGL(kmeans_persist_prepare_kernel, dim3(8, (unsigned)nb), dim3(kKmThreads), 0, st, (int)plen,
+                           byte_shift(w.chain_lanes[0], off), byte_shift(w.chain_lanes[1], off),
+                           byte_shift(w.chain_lanes[2], off), byte_shift(w.persist_ctl, off), byte_shift(w.sim_total, off),
+                           (int64_t)one);
+        ET_LAUNCH_CHECK();
+        LloydPersist pa;
+        pa.st_in = byte_shift(w.state, off);
+        pa.cen_in = centroids + b0 * dk;
+        pa.st_out = byte_shift(w.chain_state[0], off);
+        pa.cen_out = byte_shift(w.chain_cen[0], off);
+        pa.tot_out = byte_shift(w.chain_tot[0], off);
+        pa.lanes0 = byte_shift(w.chain_lanes[0], off);
+        pa.lanes1 = byte_shift(w.chain_lanes[1], off);
+        pa.lanes2 = byte_shift(w.chain_lanes[2], off);
+        pa.arrive = byte_shift(w.persist_ctl, off);
+        pa.abort = byte_shift(w.persist_ctl, off) + 1;
+        pa.last = byte_shift(w.last, off);
+        pa.ws_stride = (int64_t)one;
+        pa.x_stride = x_stride;
+        pa.cen_stride = dk;
+        slots.acquire(grid * (int)nb, n_cu);
+        struct Release {
+            PersistSlots &s;
+            int n;
+            ~Release() { s.release(n); }
+        } release_on_exit{slots, grid * (int)nb};
+        const dim3 g((unsigned)grid, (unsigned)nb);
+        if (K <= 20)
+            hipLaunchKernelGGL((kmeans_lloyd_persist_kernel<10, false>), g, dim3(threads), lds, st, X + b0 * x_stride, N, K, pa,
+                               byte_shift(w.labels_u8, off), tol, (float *)nullptr, max_iter);
+        else
+            hipLaunchKernelGGL((kmeans_lloyd_persist_kernel<16, false>), g, dim3(threads), lds, st, X + b0 * x_stride, N, K, pa,
+                               byte_shift(w.labels_u8, off), tol, (float *)nullptr, max_iter);
+        ET_LAUNCH_CHECK();
+        // did every problem's barrier hold?  (the slots go back when this chunk has run)
+        ET_HIP_TRY(hipMemcpy2DAsync(ctl.data() + 2 * b0, 2 * sizeof(unsigned), byte_shift(w.persist_ctl, off), one,
+                                    2 * sizeof(unsigned), (size_t)nb, hipMemcpyDeviceToHost, st));
+        ET_HIP_TRY(hipStreamSynchronize(st));
+    }
+    // results: staged centroids / state -> the caller's (B, d, K) array and the problems' state blocks; the inertia of the
+    // last assignment; the labels when asked for
+    hipLaunchKernelGGL(kmeans_batch_collect_kernel, dim3((unsigned)batch), dim3(kKmThreads), 0, st, (const float *)w.chain_cen[0],
+                       (const et_kmeans_state *)w.chain_state[0], w.state, (int64_t)one, centroids, (int)dk);
+    {
+        const size_t ilds = sizeof(float) * (size_t)K * cpitch_host(d);
+        const int igrid = min(km_grid(N / 4 + 1), 1024);
+        hipLaunchKernelGGL((kmeans_inertia_kernel<6>), dim3(igrid, (unsigned)batch), dim3(kKmThreads), ilds, st, X, N, d, K,
+                           (const float *)w.last, (const uint8_t *)w.labels_u8, w.sim_total, (int64_t)one, x_stride);
+        hipLaunchKernelGGL(kmeans_inertia_finish_kernel, dim3((unsigned)batch), dim3(64), 0, st, w.state, (const float *)w.last, d,
+                           K, (const long long *)w.sim_total, (int64_t)one);
+    }
+    if (labels)
+        hipLaunchKernelGGL(kmeans_labels_i64_kernel, dim3(km_grid(N / 4 + 1), (unsigned)batch), dim3(kKmThreads), 0, st,
+                           (const uint8_t *)w.labels_u8, N, labels, (int64_t)one);
+    ET_LAUNCH_CHECK();
+    ET_HIP_TRY(hipMemcpy2DAsync(states_host, sizeof(et_kmeans_state), w.state, one, sizeof(et_kmeans_state), (size_t)batch,
+                                hipMemcpyDeviceToHost, st));
+    ET_HIP_TRY(hipStreamSynchronize(st));
+    // a problem whose grid barrier timed out (another process on the GPU): that fit again, alone, with the chained loop
+    for (int64_t b = 0; b < batch; ++b) {
+        if (ctl[2 * b + 1] == 0u) continue;
+        const int rc = one_by_one(b, b + 1);
+        if (rc) return rc;
+    }
+    for (int64_t b = 0; b < batch; ++b)
+        if (states_host[b].bad_input) return ET_ERR_BAD_DATA;
+    return ET_OK;
+}
+
 extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_iter, float tol, float *centroids,
                              int64_t *labels, float *trace, et_kmeans_state *state_host,
                              et_kmeans_timing *timing_host, void *workspace, size_t workspace_bytes,
                              et_stream_t stream) {
-    if (!km_dims_ok(d, K) || N < 1 || !X || !centroids || !labels || !state_host || max_iter < 1)
-        return ET_ERR_INVALID_ARG;
+    if (!km_dims_ok(d, K) || N < 1 || !X || !centroids || !state_host || max_iter < 1) return ET_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < et_kmeans_workspace_bytes(N, d, K)) return ET_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const KmWorkspace w = km_carve(workspace, N, d, K);
@@ -2804,8 +3027,10 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
                            (const long long *)w.sim_total);
         ET_LAUNCH_CHECK();
     }
-    rc = et_kmeans_labels_i64(w.labels_u8, N, labels, stream);
-    if (rc) return rc;
+    if (labels) {  // (NULL: the caller only wants the centroids)
+        rc = et_kmeans_labels_i64(w.labels_u8, N, labels, stream);
+        if (rc) return rc;
+    }
     ET_HIP_TRY(hipMemcpyAsync(state_host, w.state, sizeof(et_kmeans_state), hipMemcpyDeviceToHost, st));
     ET_HIP_TRY(hipStreamSynchronize(st));
     if (timing_host && persisted) {

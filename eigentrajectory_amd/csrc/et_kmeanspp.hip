@@ -32,6 +32,9 @@
 //   kpp_locate_kernel      block prefix + in-block search of every threshold -> candidate indices
 //   kpp_dist_kernel        float64 distances to the candidates, min with closest, potentials
 //   kpp_select_kernel      arg-min potential -> new centre, its index, the new potential
+#include <cstdlib>
+#include <type_traits>
+
 #include "et_common.h"
 
 namespace et {
@@ -39,32 +42,67 @@ namespace et {
 constexpr int kPpThreads = 256;
 constexpr int kPpBlock = 4096;    // elements per block of the running-sum search
 constexpr int kPpMaxTrials = 8;   // 2 + log(255) = 7
-constexpr int kColChunk = 512;    // rows staged per LDS tile in colstats_kernel
+__host__ __device__ static inline int colstats_chunk(int d) {  // rows staged per LDS tile in colstats_kernel
+    const int c = (6144 / d) & ~3;
+    return c > 1024 ? 1024 : c;
+}
+static inline size_t colstats_lds_bytes(int d) { return sizeof(float) * 2 * (size_t)d * (colstats_chunk(d) + 4); }
 
 // ------------------------------------------------------------------------------------------
 // numpy's add.reduce(axis=0) on a C-ordered (N,d) float32 array: out[j] += x[i][j], i ascending.
 // OP 0: sum of x;  OP 1: sum of (x - shift[j])^2   (np.var's second pass).  X is d-major (d,N).
 // out[j] = sum / N (float32 division, like umr_sum / true_divide in np.mean / np.var).
+// The sum is inherently serial (every fp32 addition rounds), so what can be fast is everything around the one dependent
+// v_add_f32 per row: wavefront 0 (one lane per coordinate) adds chunk i from LDS, four rows per ds_read_b128, while
+// wavefronts 1..3 stage chunk i + 1 into the other half of the LDS tile -- one barrier per 2048 rows.  (The first
+// version staged 512 rows per barrier pair with all threads and added them with scalar LDS reads: 0.8 ms per pass at
+// N = 6e4, a third of an anchor clustering once its ten initialisations ran side by side.)
 template <int OP>
 __global__ __launch_bounds__(kPpThreads) void colstats_kernel(const float *__restrict__ X, int64_t N, int d,
                                                                const float *__restrict__ shift,
                                                                float *__restrict__ out) {
-    __shared__ float tile[ET_KMEANS_MAX_D * (kColChunk + 1)];
+    // rows per tile: 1024 for d <= 6, fewer for wider points (two tiles of d x (rows + 4) floats in ~48 KB of LDS)
+    const int kColChunk = colstats_chunk(d), kPitch = kColChunk + 4;  // (16-byte aligned rows, a different bank per coordinate)
+    extern __shared__ __attribute__((aligned(16))) float colstats_lds[];
+    float *tile[2] = {colstats_lds, colstats_lds + d * kPitch};
     const int tid = threadIdx.x;
     float acc = 0.0f;
     const float a = (OP == 1 && tid < d) ? shift[tid] : 0.0f;
-    for (int64_t base = 0; base < N; base += kColChunk) {
+    const int64_t n_chunks = (N + kColChunk - 1) / kColChunk;
+    auto stage = [&](int64_t chunk, int first, int step) {  // rows of `chunk` -> tile[chunk & 1], by threads first, first + step, ...
+        const int64_t base = chunk * kColChunk;
         const int cnt = (int)((N - base) < kColChunk ? (N - base) : kColChunk);
-        for (int idx = tid; idx < d * kColChunk; idx += kPpThreads) {
+        float *dst = tile[chunk & 1];
+        for (int idx = first; idx < d * kColChunk; idx += step) {
             const int r = idx / kColChunk, c = idx - r * kColChunk;
-            if (c < cnt) tile[r * (kColChunk + 1) + c] = X[(int64_t)r * N + base + c];
+            dst[r * kPitch + c] = c < cnt ? X[(int64_t)r * N + base + c] : 0.0f;
         }
-        __syncthreads();
-        if (tid < d) {
-            const float *row = tile + tid * (kColChunk + 1);
+    };
+    stage(0, tid, kPpThreads);
+    __syncthreads();
+    for (int64_t chunk = 0; chunk < n_chunks; ++chunk) {
+        if (tid >= kWave) {
+            if (chunk + 1 < n_chunks) stage(chunk + 1, tid - kWave, kPpThreads - kWave);
+        } else if (tid < d) {
+            const int64_t base = chunk * kColChunk;
+            const int cnt = (int)((N - base) < kColChunk ? (N - base) : kColChunk);
+            const float4 *row = reinterpret_cast<const float4 *>(tile[chunk & 1] + tid * kPitch);
+            const int full = cnt / 4;
 #pragma unroll 8
-            for (int c = 0; c < cnt; ++c) {
-                float v = row[c];
+            for (int q = 0; q < full; ++q) {
+                float4 v = row[q];
+                if (OP == 1) {
+                    const float t0 = v.x - a, t1 = v.y - a, t2 = v.z - a, t3 = v.w - a;
+                    v = make_float4(t0 * t0, t1 * t1, t2 * t2, t3 * t3);
+                }
+                acc = acc + v.x;
+                acc = acc + v.y;
+                acc = acc + v.z;
+                acc = acc + v.w;
+            }
+            const float *tail = tile[chunk & 1] + tid * kPitch;
+            for (int c = 4 * full; c < cnt; ++c) {
+                float v = tail[c];
                 if (OP == 1) {
                     const float t = v - a;
                     v = t * t;
@@ -101,10 +139,25 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// blockIdx.y of the four kernels below = one of several seedings of the SAME points run side by side (the n_init
+// initialisations of the sklearn recipe): every scratch pointer moves on by y * ws bytes, the draws / outputs by their
+// element strides.  {0, 0, 0, 0} for a single seeding.
+struct PpBatch {
+    int64_t ws, uniforms, centers, indices;
+};
+template <typename T>
+__device__ __forceinline__ T *pp_shift(T *p, int64_t bytes) {
+    return p ? reinterpret_cast<T *>(reinterpret_cast<char *>(const_cast<typename std::remove_const<T>::type *>(p)) + bytes) : p;
+}
+
 // closest[n] <- D[best][n] (when D != nullptr), blocksums[b] = float64 sum of the block's closest values.
 __global__ __launch_bounds__(kPpThreads) void kpp_blocksum_kernel(const float *__restrict__ D, const int *__restrict__ best,
                                                                    float *__restrict__ closest, int64_t N,
-                                                                   double *__restrict__ blocksums) {
+                                                                   double *__restrict__ blocksums, PpBatch bt) {
+    {
+        const int64_t off = (int64_t)blockIdx.y * bt.ws;
+        D = pp_shift(D, off), best = pp_shift(best, off), closest = pp_shift(closest, off), blocksums = pp_shift(blocksums, off);
+    }
     __shared__ double part[kPpThreads / kWave];
     const float *src = D ? D + (int64_t)best[0] * N : closest;
     const int64_t base = (int64_t)blockIdx.x * kPpBlock;
@@ -133,7 +186,14 @@ __global__ __launch_bounds__(kPpThreads) void kpp_locate_kernel(const float *__r
                                                                  const double *__restrict__ blocksums, int64_t nb,
                                                                  double *__restrict__ prefix,
                                                                  const double *__restrict__ uniforms, int n_trials, int c,
-                                                                 const float *__restrict__ pot, int64_t *__restrict__ cand) {
+                                                                 const float *__restrict__ pot, int64_t *__restrict__ cand,
+                                                                 PpBatch bt) {
+    {
+        const int64_t off = (int64_t)blockIdx.y * bt.ws;
+        closest = pp_shift(closest, off), blocksums = pp_shift(blocksums, off), prefix = pp_shift(prefix, off);
+        pot = pp_shift(pot, off), cand = pp_shift(cand, off);
+        uniforms += (int64_t)blockIdx.y * bt.uniforms;
+    }
     if (c == 0) {
         if (threadIdx.x == 0) {
             int64_t f = (int64_t)(uniforms[0] * (double)N);
@@ -213,7 +273,11 @@ template <int DIM>
 __global__ __launch_bounds__(kPpThreads) void kpp_dist_kernel(const float *__restrict__ X, int64_t N, int d_rt,
                                                                const int64_t *__restrict__ cand, int n_trials,
                                                                const float *__restrict__ closest, float *__restrict__ D,
-                                                               double *__restrict__ partials, int64_t n_blocks) {
+                                                               double *__restrict__ partials, int64_t n_blocks, PpBatch bt) {
+    {
+        const int64_t off = (int64_t)blockIdx.y * bt.ws;
+        cand = pp_shift(cand, off), closest = pp_shift(closest, off), D = pp_shift(D, off), partials = pp_shift(partials, off);
+    }
     constexpr int DM = DIM ? DIM : ET_KMEANS_MAX_D;
     const int d = DIM ? DIM : d_rt;
     __shared__ double cen[kPpMaxTrials][ET_KMEANS_MAX_D + 1];  // [j][r], [j][d] = |c_j|^2
@@ -290,7 +354,14 @@ __global__ __launch_bounds__(kPpThreads) void kpp_select_kernel(const double *__
                                                                  int n_trials, const int64_t *__restrict__ cand,
                                                                  const float *__restrict__ X, int64_t N, int d, int K, int c,
                                                                  float *__restrict__ pot, int *__restrict__ best,
-                                                                 float *__restrict__ centers, int64_t *__restrict__ indices) {
+                                                                 float *__restrict__ centers, int64_t *__restrict__ indices,
+                                                                 PpBatch bt) {
+    {
+        const int64_t off = (int64_t)blockIdx.y * bt.ws;
+        partials = pp_shift(partials, off), cand = pp_shift(cand, off), pot = pp_shift(pot, off), best = pp_shift(best, off);
+        centers += (int64_t)blockIdx.y * bt.centers;
+        indices += (int64_t)blockIdx.y * bt.indices;
+    }
     __shared__ float pots[kPpMaxTrials];
     __shared__ int best_s;
     const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
@@ -361,8 +432,10 @@ extern "C" int et_center_columns(float *X, int64_t N, int d, float rel_tol, floa
     // sklearn's order (KMeans.fit): the tolerance from the variance of the data AS GIVEN (_check_params_vs_input ->
     // _tolerance: mean(np.var(X, axis=0)) * tol; np.var's own column mean is the same sequential fp32 sum / n as
     // X.mean(axis=0)), THEN X -= X.mean(axis=0)
-    hipLaunchKernelGGL((colstats_kernel<0>), dim3(1), dim3(kPpThreads), 0, st, X, N, d, (const float *)nullptr, mean);
-    hipLaunchKernelGGL((colstats_kernel<1>), dim3(1), dim3(kPpThreads), 0, st, X, N, d, (const float *)mean, var);
+    hipLaunchKernelGGL((colstats_kernel<0>), dim3(1), dim3(kPpThreads), colstats_lds_bytes(d), st, X, N, d, (const float *)nullptr,
+                       mean);
+    hipLaunchKernelGGL((colstats_kernel<1>), dim3(1), dim3(kPpThreads), colstats_lds_bytes(d), st, X, N, d, (const float *)mean,
+                       var);
     const int64_t blocks = ceil_div(N * d, (int64_t)kPpThreads);
     hipLaunchKernelGGL(center_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kPpThreads), 0, st, X, N, d,
                        (const float *)mean);
@@ -376,42 +449,74 @@ extern "C" size_t et_kmeanspp_workspace_bytes(int64_t N, int d, int n_trials) {
     return pp_carve(nullptr, N, n_trials).bytes;
 }
 
-extern "C" int et_kmeanspp_seed(const float *X, int64_t N, int d, int K, int n_trials, const double *uniforms,
-                                float *centers, int64_t *indices, void *workspace, size_t workspace_bytes,
-                                et_stream_t stream) {
+static int pp_seed_launches(const float *X, int64_t N, int d, int K, int n_trials, const double *uniforms, float *centers,
+                            int64_t *indices, const PpWorkspace &w, hipStream_t st, int64_t batch, size_t ws_stride);
+
+extern "C" size_t et_kmeanspp_batch_workspace_bytes(int64_t N, int d, int n_trials, int64_t batch) {
+    const size_t one = et_kmeanspp_workspace_bytes(N, d, n_trials);
+    return one == 0 || batch < 1 ? 0 : one * (size_t)batch;
+}
+
+// `batch` seedings of the SAME points side by side: the y dimension of every launch (the n_init initialisations of the
+// sklearn recipe: 4K - 1 launches for all of them together instead of per initialisation -- at dataset sizes a seeding is
+// nothing but launch latency.  A one-launch form with a fence-free grid barrier between the phases was built and
+// measured too: 1.3 ms against 0.8 ms, its ~15 dependent sc1 round trips to the memory side per centre cost more than
+// the kernel boundaries they replace; profiles/r03g_calc_params_profile.txt)
+extern "C" int et_kmeanspp_seed_batch(const float *X, int64_t N, int d, int K, int n_trials, const double *uniforms,
+                                      int64_t batch, float *centers, int64_t *indices, void *workspace,
+                                      size_t workspace_bytes, et_stream_t stream) {
     if (!X || !uniforms || !centers || !indices || N < 1 || d < 1 || d > ET_KMEANS_MAX_D || K < 1 ||
-        K > ET_KMEANS_MAX_CLUSTERS || n_trials < 1 || n_trials > kPpMaxTrials || n_trials * d > kPpThreads)
+        K > ET_KMEANS_MAX_CLUSTERS || n_trials < 1 || n_trials > kPpMaxTrials || n_trials * d > kPpThreads || batch < 1 ||
+        batch > 65535)
         return ET_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < et_kmeanspp_workspace_bytes(N, d, n_trials)) return ET_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
+    const size_t one = et_kmeanspp_workspace_bytes(N, d, n_trials);
+    if (!workspace || workspace_bytes < one * (size_t)batch) return ET_ERR_WORKSPACE;
     const PpWorkspace w = pp_carve(workspace, N, n_trials);
+    return pp_seed_launches(X, N, d, K, n_trials, uniforms, centers, indices, w, (hipStream_t)stream, batch, one);
+}
+
+// the 4K - 1 launches of `batch` seedings of the same points (grid.y = seeding)
+static int pp_seed_launches(const float *X, int64_t N, int d, int K, int n_trials, const double *uniforms, float *centers,
+                            int64_t *indices, const PpWorkspace &w, hipStream_t st, int64_t batch, size_t ws_stride) {
     const int64_t nb = ceil_div(N, (int64_t)kPpBlock);
+    const unsigned B = (unsigned)batch;
+    PpBatch bt;
+    bt.ws = (int64_t)ws_stride;
+    bt.uniforms = 1 + (int64_t)(K - 1) * n_trials;
+    bt.centers = (int64_t)d * K;
+    bt.indices = K;
     // first centre: index floor(u0 * N); closest = its distances (no min), potential = their sum
-    hipLaunchKernelGGL(kpp_locate_kernel, dim3(1), dim3(kPpThreads), 0, st, (const float *)nullptr, N,
-                       (const double *)nullptr, nb, w.prefix, uniforms, 1, 0, (const float *)nullptr, w.cand);
+    hipLaunchKernelGGL(kpp_locate_kernel, dim3(1, B), dim3(kPpThreads), 0, st, (const float *)nullptr, N,
+                       (const double *)nullptr, nb, w.prefix, uniforms, 1, 0, (const float *)nullptr, w.cand, bt);
     if (d == 6)
-        hipLaunchKernelGGL(kpp_dist_kernel<6>, dim3((unsigned)nb), dim3(kPpThreads), 0, st, X, N, d, (const int64_t *)w.cand, 1,
-                           (const float *)nullptr, w.D, w.partials, nb);
+        hipLaunchKernelGGL(kpp_dist_kernel<6>, dim3((unsigned)nb, B), dim3(kPpThreads), 0, st, X, N, d, (const int64_t *)w.cand, 1,
+                           (const float *)nullptr, w.D, w.partials, nb, bt);
     else
-        hipLaunchKernelGGL(kpp_dist_kernel<0>, dim3((unsigned)nb), dim3(kPpThreads), 0, st, X, N, d, (const int64_t *)w.cand, 1,
-                           (const float *)nullptr, w.D, w.partials, nb);
-    hipLaunchKernelGGL(kpp_select_kernel, dim3(1), dim3(kPpThreads), 0, st, (const double *)w.partials, nb, 1,
-                       (const int64_t *)w.cand, X, N, d, K, 0, w.pot, w.best, centers, indices);
+        hipLaunchKernelGGL(kpp_dist_kernel<0>, dim3((unsigned)nb, B), dim3(kPpThreads), 0, st, X, N, d, (const int64_t *)w.cand, 1,
+                           (const float *)nullptr, w.D, w.partials, nb, bt);
+    hipLaunchKernelGGL(kpp_select_kernel, dim3(1, B), dim3(kPpThreads), 0, st, (const double *)w.partials, nb, 1,
+                       (const int64_t *)w.cand, X, N, d, K, 0, w.pot, w.best, centers, indices, bt);
     for (int c = 1; c < K; ++c) {
-        hipLaunchKernelGGL(kpp_blocksum_kernel, dim3((unsigned)nb), dim3(kPpThreads), 0, st, (const float *)w.D,
-                           (const int *)w.best, w.closest, N, w.blocksums);
-        hipLaunchKernelGGL(kpp_locate_kernel, dim3(1), dim3(kPpThreads), 0, st, (const float *)w.closest, N,
+        hipLaunchKernelGGL(kpp_blocksum_kernel, dim3((unsigned)nb, B), dim3(kPpThreads), 0, st, (const float *)w.D,
+                           (const int *)w.best, w.closest, N, w.blocksums, bt);
+        hipLaunchKernelGGL(kpp_locate_kernel, dim3(1, B), dim3(kPpThreads), 0, st, (const float *)w.closest, N,
                            (const double *)w.blocksums, nb, w.prefix, uniforms + 1 + (size_t)(c - 1) * n_trials, n_trials, c,
-                           (const float *)w.pot, w.cand);
+                           (const float *)w.pot, w.cand, bt);
         if (d == 6)
-            hipLaunchKernelGGL(kpp_dist_kernel<6>, dim3((unsigned)nb), dim3(kPpThreads), 0, st, X, N, d, (const int64_t *)w.cand,
-                               n_trials, (const float *)w.closest, w.D, w.partials, nb);
+            hipLaunchKernelGGL(kpp_dist_kernel<6>, dim3((unsigned)nb, B), dim3(kPpThreads), 0, st, X, N, d, (const int64_t *)w.cand,
+                               n_trials, (const float *)w.closest, w.D, w.partials, nb, bt);
         else
-            hipLaunchKernelGGL(kpp_dist_kernel<0>, dim3((unsigned)nb), dim3(kPpThreads), 0, st, X, N, d, (const int64_t *)w.cand,
-                               n_trials, (const float *)w.closest, w.D, w.partials, nb);
-        hipLaunchKernelGGL(kpp_select_kernel, dim3(1), dim3(kPpThreads), 0, st, (const double *)w.partials, nb, n_trials,
-                           (const int64_t *)w.cand, X, N, d, K, c, w.pot, w.best, centers, indices);
+            hipLaunchKernelGGL(kpp_dist_kernel<0>, dim3((unsigned)nb, B), dim3(kPpThreads), 0, st, X, N, d, (const int64_t *)w.cand,
+                               n_trials, (const float *)w.closest, w.D, w.partials, nb, bt);
+        hipLaunchKernelGGL(kpp_select_kernel, dim3(1, B), dim3(kPpThreads), 0, st, (const double *)w.partials, nb, n_trials,
+                           (const int64_t *)w.cand, X, N, d, K, c, w.pot, w.best, centers, indices, bt);
     }
     ET_LAUNCH_CHECK();
     return ET_OK;
+}
+
+extern "C" int et_kmeanspp_seed(const float *X, int64_t N, int d, int K, int n_trials, const double *uniforms,
+                                float *centers, int64_t *indices, void *workspace, size_t workspace_bytes,
+                                et_stream_t stream) {
+    return et_kmeanspp_seed_batch(X, N, d, K, n_trials, uniforms, 1, centers, indices, workspace, workspace_bytes, stream);
 }

@@ -309,6 +309,52 @@ def kmeans_fit(X, centroids, max_iter=100, tol=1e-4, workspace=None, timing=Fals
     return out
 
 
+def kmeans_fit_batch(X, centroids, max_iter=100, tol=1e-4, want_labels=False):
+    """``B`` independent Lloyd fits in one call, each stopping on its own error (the n_init initialisations of the
+    sklearn recipe, anchor.py:65-71): X (d,N) shared by all problems or (B,d,N); centroids (B,d,K) initial -> final.
+    Returns dict(centroids (B,d,K), labels (B,N) int64 | None, n_iter [B], error [B], inertia [B], done [B])."""
+    dev = L.require_device(X)
+    X, centroids = _dev_args(dev, X, centroids)
+    B, d, K = centroids.shape
+    n = X.shape[-1]
+    x_stride = 0 if X.dim() == 2 else d * n
+    nbytes = L.lib().et_kmeans_batch_workspace_bytes(L.i64(n), int(d), int(K), L.i64(B))
+    if nbytes == 0:
+        raise ValueError(f"k-means dimensions out of range: d={d}, K={K}")
+    ws = torch.empty((nbytes,), device=dev, dtype=torch.uint8)
+    cen = centroids.clone()
+    labels = torch.empty((B, n), device=dev, dtype=torch.int64) if want_labels else None
+    states = (L.KMeansState * B)()
+    L.check(L.lib().et_kmeans_fit_batch(L.ptr(X), L.i64(x_stride), L.i64(n), int(d), int(K), L.i64(B), int(max_iter), L.f32(tol),
+                                        L.ptr(cen), L.ptr(labels), states, L.ptr(ws), C.c_size_t(ws.numel()), L.stream(dev)),
+            "et_kmeans_fit_batch")
+    return dict(centroids=cen, labels=labels, n_iter=[int(s_.iter) for s_ in states], error=[float(s_.error) for s_ in states],
+                inertia=[float(s_.inertia) for s_ in states], done=[bool(s_.done) for s_ in states])
+
+
+def kmeanspp_seed_batch(X, K, uniforms):
+    """``B`` greedy k-means++ seedings of the same X (d,N) side by side (the y dimension of the same 4K-1 launches):
+    uniforms (B, 1 + (K-1)*n_trials) float64 -> (centers (B,d,K), indices (B,K) int64).  No host synchronisation."""
+    dev = L.require_device(X)
+    (X,) = _dev_args(dev, X)
+    uniforms = L.on_device(uniforms, dev, torch.float64)
+    d, n = X.shape
+    nt = kmeanspp_trials(K)
+    B = uniforms.shape[0]
+    if uniforms.dim() != 2 or uniforms.shape[1] != 1 + (K - 1) * nt:
+        raise ValueError(f"k-means++ seeding of {K} centres consumes {1 + (K - 1) * nt} draws per initialisation")
+    nbytes = L.lib().et_kmeanspp_batch_workspace_bytes(L.i64(n), d, nt, L.i64(B))
+    if nbytes == 0:
+        raise ValueError(f"k-means++ dimensions out of range: N={n}, d={d}, K={K}")
+    ws = torch.empty((nbytes,), device=dev, dtype=torch.uint8)
+    centers = torch.empty((B, d, K), device=dev)
+    indices = torch.empty((B, K), device=dev, dtype=torch.int64)
+    L.check(L.lib().et_kmeanspp_seed_batch(L.ptr(X), L.i64(n), d, int(K), nt, L.ptr(uniforms), L.i64(B), L.ptr(centers),
+                                           L.ptr(indices), L.ptr(ws), C.c_size_t(ws.numel()), L.stream(dev)),
+            "et_kmeanspp_seed_batch")
+    return centers, indices
+
+
 def kmeans_joint_done(state_ptrs, n_problems, tol):
     """kmeans.py:228-240 for a batch of problems run through the step API: ``state_ptrs`` = int64 device tensor of the
     problems' state-block addresses; sets every state's ``done`` from the SUM of their errors."""
@@ -322,12 +368,14 @@ def kmeans_predict(X, centroids, want_maxsims=True):
     launch."""
     dev = L.require_device(X)
     X, centroids = _dev_args(dev, X, centroids)
-    if X.dim() == 3:
-        B, d, n = X.shape
+    if centroids.dim() == 3:  # a batch of centroid sets: on their own points (B,d,N) or all on the same points (d,N)
+        B = centroids.shape[0]
+        d, n = X.shape[-2], X.shape[-1]
         labels = torch.empty((B, n), device=dev, dtype=torch.int64)
         maxsims = torch.empty((B, n), device=dev) if want_maxsims else None
-        L.check(L.lib().et_kmeans_predict_batch(L.ptr(X), L.i64(B), L.i64(n), d, L.ptr(centroids), centroids.shape[2],
-                                                L.ptr(labels), L.ptr(maxsims), L.stream(dev)), "et_kmeans_predict_batch")
+        L.check(L.lib().et_kmeans_predict_batch(L.ptr(X), L.i64(d * n if X.dim() == 3 else 0), L.i64(B), L.i64(n), d,
+                                                L.ptr(centroids), centroids.shape[2], L.ptr(labels), L.ptr(maxsims),
+                                                L.stream(dev)), "et_kmeans_predict_batch")
         return labels, maxsims
     d, n = X.shape
     labels = torch.empty((n,), device=dev, dtype=torch.int64)

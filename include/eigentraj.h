@@ -264,7 +264,7 @@ typedef struct et_kmeans_timing {
 } et_kmeans_timing;
 
 /* single-GPU fit of one batch element from given initial centroids (kmeans.py:228-240):
- * centroids (d,K) in/out, labels int64 (N) out, trace (max_iter,2) fp32 (error, inertia) per iteration or NULL:
+ * centroids (d,K) in/out, labels int64 (N) out (NULL: not wanted), trace (max_iter,2) fp32 (error, inertia) per iteration or NULL:
  * without a trace the per-iteration inertia is not evaluated (the reference only prints it, kmeans.py:236) and
  * state.inertia -- the inertia of the last assignment -- comes from one extra pass after the loop (same bits).
  * *state_host receives the final state,
@@ -275,12 +275,25 @@ int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_iter, float t
                   int64_t *labels, float *trace, et_kmeans_state *state_host, et_kmeans_timing *timing_host,
                   void *workspace, size_t workspace_bytes, et_stream_t stream);
 
+/* `batch` independent fits in one call (each stops on its own error, unlike BatchKMeans' joint stop): the n_init
+ * initialisations of the reference's sklearn anchor clustering (anchor.py:65-71).  X: problem b's points at X + b *
+ * x_stride floats (x_stride = 0: all problems cluster the same points); centroids (batch,d,K) in/out; labels
+ * (batch,N) int64 or NULL; states_host[batch].  For d = 6, 3 <= K <= 32 and shards that leave room for at least two
+ * problems on the device the problems run side by side as the y dimension of ONE persistent launch
+ * (csrc/et_kmeans.hip), in chunks when they do not all fit; any other shape: one et_kmeans_fit after the other.
+ * workspace: et_kmeans_batch_workspace_bytes (= batch x et_kmeans_workspace_bytes).  Synchronises the stream. */
+size_t et_kmeans_batch_workspace_bytes(int64_t N, int d, int K, int64_t batch);
+int et_kmeans_fit_batch(const float *X, int64_t x_stride, int64_t N, int d, int K, int64_t batch, int max_iter, float tol,
+                        float *centroids, int64_t *labels, et_kmeans_state *states_host, void *workspace,
+                        size_t workspace_bytes, et_stream_t stream);
+
 /* kmeans.py:261-272 predict: labels int64 (N); maxsims (N) optional */
 int et_kmeans_predict(const float *X, int64_t N, int d, const float *centroids, int K, int64_t *labels,
                       float *maxsims, et_stream_t stream);
-/* kmeans.py:143-158 get_labels on a batch in one launch: X (B,d,N), centroids (B,d,K) -> labels / maxsims (B,N) */
-int et_kmeans_predict_batch(const float *X, int64_t batch, int64_t N, int d, const float *centroids, int K,
-                            int64_t *labels, float *maxsims, et_stream_t stream);
+/* kmeans.py:143-158 get_labels on a batch in one launch: element b's points at X + b * x_stride floats (d N for a
+ * contiguous (B,d,N) tensor, 0: the same points for every element), centroids (B,d,K) -> labels / maxsims (B,N) */
+int et_kmeans_predict_batch(const float *X, int64_t x_stride, int64_t batch, int64_t N, int d, const float *centroids,
+                            int K, int64_t *labels, float *maxsims, et_stream_t stream);
 
 /* ---- anchor clustering as the reference runs it: sklearn KMeans(init='k-means++', n_init=10) ----------
  * EigenTrajectory/anchor.py:65-71 hands the coefficients to sklearn.cluster.KMeans (third-party; its published
@@ -301,6 +314,12 @@ int et_center_columns(float *X, int64_t N, int d, float rel_tol, float *mean, fl
 size_t et_kmeanspp_workspace_bytes(int64_t N, int d, int n_trials);
 int et_kmeanspp_seed(const float *X, int64_t N, int d, int K, int n_trials, const double *uniforms,
                      float *centers, int64_t *indices, void *workspace, size_t workspace_bytes, et_stream_t stream);
+/* `batch` seedings of the SAME points side by side (the n_init initialisations), as the y dimension of the same 4K-1
+ * launches: uniforms (batch, 1+(K-1)*n_trials), centers (batch,d,K), indices (batch,K);
+ * workspace = batch x et_kmeanspp_workspace_bytes. */
+size_t et_kmeanspp_batch_workspace_bytes(int64_t N, int d, int n_trials, int64_t batch);
+int et_kmeanspp_seed_batch(const float *X, int64_t N, int d, int K, int n_trials, const double *uniforms, int64_t batch,
+                           float *centers, int64_t *indices, void *workspace, size_t workspace_bytes, et_stream_t stream);
 
 /* ---- data-sharded fit and k-means: one process per GPU, RCCL over xGMI (csrc/et_sharded.hip) ------------------------
  * The reference has no distributed code; these are the entry points of SURVEY.md §8(b) "with an optional

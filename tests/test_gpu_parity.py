@@ -1475,3 +1475,53 @@ def test_batchkmeans_helpers_run_the_batch_in_one_launch(ops, oracle, dev):
     # leading dimensions beyond one (the reference's "...")
     sims2 = BatchKMeans.euc_sim(T(xs.reshape(2, 2, 6, 777), dev), T(cs.reshape(2, 2, 6, 13), dev))
     assert torch.equal(sims2.reshape(4, 777, 13), sims)
+
+
+@pytest.mark.parametrize("n,K,B,shared", [(2048, 20, 10, True), (14456, 20, 10, True), (61896, 20, 10, True), (98304, 20, 10, True),
+                                          (5000, 8, 3, False), (30000, 32, 4, False), (1000, 20, 5, True), (30002, 20, 3, True)])
+def test_kmeans_fit_batch_equals_single_fits(ops, oracle, dev, n, K, B, shared):
+    """et_kmeans_fit_batch (the problems as the y dimension of one persistent launch, in chunks when they do not fit on
+    the device together; shapes it does not take run one after the other): every problem's centroids, iteration count,
+    error, inertia and labels are bit for bit those of its own et_kmeans_fit -- i.e. the oracle's."""
+    from eigentrajectory_amd.synth import gaussian_points_np
+    xs = [gaussian_points_np(6, n, seed=70 + (0 if shared else b), n_blobs=6) for b in range(B)]
+    for x in xs:
+        x[:, ::89] *= 20.0
+    rng = np.random.RandomState(n)
+    c0 = np.stack([xs[b][:, rng.choice(n, K, replace=False)] for b in range(B)])
+    X = T(xs[0], dev) if shared else T(np.stack(xs), dev)
+    res = ops.kmeans_fit_batch(X, T(c0, dev), 60, 1e-4, want_labels=True)
+    for b in range(B):
+        one = ops.kmeans_fit(T(xs[b], dev), T(c0[b], dev), 60, 1e-4, trace=False)
+        assert res["n_iter"][b] == one["n_iter"] and res["done"][b] == one["done"]
+        # (an empty cluster is NaN in both, kmeans.py:182)
+        assert np.array_equal(N_(res["centroids"][b]), N_(one["centroids"]), equal_nan=True)
+        assert torch.equal(res["labels"][b], one["labels"])
+        assert np.array_equal(np.float32([res["error"][b], res["inertia"][b]]), np.float32([one["error"], one["inertia"]]),
+                              equal_nan=True)
+    ref = oracle.kmeans_fit(xs[B - 1], c0[B - 1], 60, 1e-4)
+    assert res["n_iter"][B - 1] == ref["n_iter"]
+    assert np.array_equal(N_(res["centroids"][B - 1]), ref["centroids"], equal_nan=True)
+    assert np.array_equal(N_(res["labels"][B - 1]), ref["labels"])
+    no_labels = ops.kmeans_fit_batch(X, T(c0, dev), 60, 1e-4)
+    assert no_labels["labels"] is None
+    assert np.array_equal(N_(no_labels["centroids"]), N_(res["centroids"]), equal_nan=True)
+
+
+@pytest.mark.parametrize("n,d,K", [(257, 6, 20), (4097, 6, 3), (20011, 6, 20), (70001, 4, 12), (5000, 9, 33)])
+def test_kmeanspp_seed_batch_equals_single_seedings(ops, dev, n, d, K):
+    """The batched seeding (seedings = the y dimension of every launch) draws, for every initialisation, the same seed
+    indices and centres, bit for bit, as that initialisation alone -- which is pinned against scikit-learn's own
+    kmeans_plusplus (G11)."""
+    from eigentrajectory_amd.synth import gaussian_points_np
+    import eigentrajectory_amd.anchor as A
+    rng = np.random.RandomState(n + K)
+    x = gaussian_points_np(d, n, seed=n % 97, n_blobs=7) if d == 6 else rng.standard_normal((d, n)).astype(np.float32)
+    x[:, ::101] *= 30.0
+    X = T(x, dev)
+    U = torch.from_numpy(A.seeding_uniforms(np.random.RandomState(0), K, 10)).to(dev)
+    cb, ib = ops.kmeanspp_seed_batch(X, K, U)
+    for i in range(10):
+        c1, i1 = ops.kmeanspp_seed(X, K, U[i])
+        assert torch.equal(cb[i], c1) and torch.equal(ib[i], i1)
+        assert np.array_equal(N_(c1), x[:, N_(i1)])
