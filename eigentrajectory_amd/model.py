@@ -22,6 +22,18 @@ from .anchor import ETAnchor
 from .descriptor import ETDescriptor
 
 
+_SIDE = {}
+
+
+def _side_lane(dev):
+    """(one-thread executor, side stream) of a device for work that runs next to the caller's stream."""
+    key = (dev.type, dev.index)
+    if key not in _SIDE:
+        from concurrent.futures import ThreadPoolExecutor
+        _SIDE[key] = (ThreadPoolExecutor(max_workers=1, thread_name_prefix="et-side"), torch.cuda.Stream(device=dev))
+    return _SIDE[key]
+
+
 class EigenTrajectory(nn.Module):
     r"""Wrapper that runs any trajectory predictor in the ET coefficient space (model.py:9-32 of the reference).
 
@@ -106,24 +118,23 @@ class EigenTrajectory(nn.Module):
                                               want_nrm=False, want_obs=False)
         moving = flag.bool()
         C_m, C_s = C_pred[:, moving].contiguous(), C_pred[:, ~moving].contiguous()
-        # the two clusterings are independent (model.py:55-56 runs them one after the other): side by side, each
-        # from its own host thread on its own HIP stream -- they are launch-latency-bound at dataset sizes
+        # the two clusterings are independent (model.py:55-56 runs them one after the other): side by side -- the static
+        # one from a helper thread on a side stream (both kept for the life of the process: creating them costs more
+        # than they save at these sizes), the moving one from this thread on the current stream
         dev, main = C_pred.device, torch.cuda.current_stream(C_pred.device)
-        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        pool, side = _side_lane(dev)
+        side.wait_stream(main)
 
-        def run(anchor, coeff, stream):
-            with torch.cuda.device(dev), torch.cuda.stream(stream):
-                stream.wait_stream(main)
-                anchor.generate_from_coefficients(coeff)
+        def run_static():
+            with torch.cuda.device(dev), torch.cuda.stream(side):
+                self.ET_s_anchor.generate_from_coefficients(C_s)
 
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=2) as pool:
-            jobs = [pool.submit(run, a, c, st) for a, c, st in ((self.ET_m_anchor, C_m, streams[0]),
-                                                                 (self.ET_s_anchor, C_s, streams[1]))]
-            for j in jobs:
-                j.result()  # re-raises what a worker raised
-        for st in streams:
-            main.wait_stream(st)
+        job = pool.submit(run_static)
+        try:
+            self.ET_m_anchor.generate_from_coefficients(C_m)
+        finally:
+            job.result()  # re-raises what the helper raised
+            main.wait_stream(side)
 
     @torch.no_grad()
     def evaluate(self, obs_traj, pred_traj, addl_info=None):
