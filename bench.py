@@ -362,30 +362,7 @@ def extra_stages(ops, obs, pred, n, K, max_iter, first_index, dev):
     with torch.no_grad():
         g_obs, g_pred, _ = ops.fit_gram(obs, pred, mode, 0.0, 1)
         (U_obs, _), (U_pred, _) = ops.eigh_topk_batch([g_obs, g_pred], 6)
-        _, c_pred1, nrm, _ = ops.norm_project(obs, pred, U_obs, U_pred, None, None, mode, want_flag=False)
-
-        def back_to_back(fn, inner=4, reps=5):
-            """ms per call when `inner` calls are enqueued back to back (dispatch gaps between them overlap with the
-            previous call's tail: the kernels' own throughput; every call streams far more than the 256 MB MALL)"""
-            fn()
-            ts = []
-            for _ in range(reps):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                for _ in range(inner):
-                    fn()
-                b.record()
-                torch.cuda.synchronize()
-                ts.append(a.elapsed_time(b) / inner)
-            return float(np.median(ts))
-        # the two north-star kernels by themselves: in the headline step each is ONE launch between two stage events, so
-        # its stage time carries the dispatch latency of a lone launch (~10-20 us); this is the same launch repeated
-        kp = back_to_back(lambda: ops.norm_project(obs, pred, U_obs, U_pred, None, None, mode, want_flag=False))
-        kr = back_to_back(lambda: ops.anchor_reconstruct(c_pred1.view(6, n, 1), None, None, U_pred, None, mode, nrm=nrm))
-        out["project+reconstruct_back_to_back"] = dict(
-            project_ms=round(kp, 4), reconstruct_ms=round(kr, 4), ms=round(kp + kr, 4),
-            GBs=round(344.0 * n / (kp + kr) / 1e6, 1), frac_of_peak=round(344.0 * n / (kp + kr) / 1e6 / HBM_PEAK_GBS, 4))
-        del c_pred1
+        _, _, nrm, _ = ops.norm_project(obs, pred, U_obs, U_pred, None, None, mode, want_flag=False)
         S = 20
         C20 = torch.randn((6, n, S), device=dev) * 0.1
         A = torch.randn((6, S), device=dev)

@@ -25,7 +25,8 @@ SCENE_MAX_N = 16384  # ET_SCENE_MAX_N
 SYMBOLS = [
     "et_abi_version", "et_status_string", "et_compiled_arch",
     "et_norm_params", "et_norm_params_from_nrm", "et_normalize", "et_denormalize",
-    "et_norm_project", "et_scene_project", "et_anchor_reconstruct_fwd", "et_anchor_reconstruct_bwd", "et_anchor_reconstruct_metrics",
+    "et_norm_project", "et_scene_project", "et_scene_project_train", "et_wrapper_losses_fwd", "et_wrapper_losses_bwd",
+    "et_anchor_reconstruct_fwd", "et_anchor_reconstruct_bwd", "et_anchor_reconstruct_metrics",
     "et_fit_gram_workspace_bytes", "et_fit_gram", "et_eigh_topk", "et_eigh_topk_batch",
     "et_euc_sim", "et_euc_sim_batch", "et_kmeans_partials_len", "et_kmeans_workspace_bytes", "et_kmeans_scan", "et_kmeans_begin",
     "et_kmeans_init_step", "et_kmeans_init_set", "et_kmeans_init_select", "et_kmeans_gather_point", "et_kmeans_init_farthest",
@@ -130,6 +131,9 @@ _FAST_SIGNATURES = {
     "et_scene_project": [_P, _I64, _I, _I, _P, _P, _I, _F, _P, _P, _P, _P, _P],
     "et_anchor_reconstruct_fwd": [_P, _I64, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P],
     "et_anchor_reconstruct_metrics": [_P, _I64, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P],
+    "et_scene_project_train": [_P, _P, _I64, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P],
+    "et_wrapper_losses_fwd": [_P, _I64, _I, _I, _I, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P],
+    "et_wrapper_losses_bwd": [_P, _P, _P, _P, _I64, _I, _I, _I, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P],
 }
 _fast = {}
 

@@ -22,6 +22,56 @@ from .anchor import ETAnchor
 from .descriptor import ETDescriptor
 
 
+class _SceneLosses(torch.autograd.Function):
+    """Anchor refinement + reconstruction + the three loss terms of model.py:119-123 for one scene in ONE launch, their
+    gradient w.r.t. the predictor's output in one more (csrc/et_train.hip).  Differentiable w.r.t. C only, like the
+    reference (anchors, U and the normaliser state are detached there too: anchor.py:87, descriptor.py:72,87)."""
+
+    @staticmethod
+    def forward(ctx, Cc, model, nrm, C_gt, gt, t_obs):
+        k, n, s = Cc.shape
+        t_pred = gt.shape[1]
+        dev = Cc.device
+        recon = torch.empty((s, n, t_pred, 2), device=dev)
+        small = torch.empty((3 * n + 3,), device=dev)           # best (3,N) | losses (3)
+        arg = torch.empty((3, n), device=dev, dtype=torch.int32)
+        ptrs = (nrm.data_ptr(), model.ET_m_anchor.C_anchor.data_ptr(), model.ET_s_anchor.C_anchor.data_ptr(),
+                model.ET_m_descriptor.U_pred_trunc.data_ptr(), model.ET_s_descriptor.U_pred_trunc.data_ptr())
+        rc = ops.L.fast("et_wrapper_losses_fwd")(
+            Cc.data_ptr(), n, s, k, t_pred, *ptrs, ops.MODE_SPLIT, model.static_dist, C_gt.data_ptr(), gt.data_ptr(),
+            recon.data_ptr(), small.data_ptr(), arg.data_ptr(), small.data_ptr() + 12 * n, ops.L.raw_stream(dev.index))
+        if rc:
+            ops.L.check(rc, "et_wrapper_losses_fwd")
+        ctx.save_for_backward(Cc, nrm, C_gt, gt, recon, arg)
+        ctx.ptrs, ctx.static_dist, ctx.t_obs = ptrs, model.static_dist, t_obs
+        ctx.U = (model.ET_m_descriptor.U_pred_trunc.detach(), model.ET_s_descriptor.U_pred_trunc.detach())
+        return recon, small[3 * n], small[3 * n + 1], small[3 * n + 2]
+
+    @staticmethod
+    def backward(ctx, g_recon, g_e, g_ade, g_fde):
+        Cc, nrm, C_gt, gt, recon, arg = ctx.saved_tensors
+        k, n, s = Cc.shape
+        dC = torch.empty_like(Cc)
+
+        def scalar(g):  # the upstream gradient of one loss term: a 0-dim fp32 tensor on the device, or nothing
+            if g is None:
+                return None
+            if g.dtype != torch.float32 or not g.is_cuda:
+                g = g.to(device=Cc.device, dtype=torch.float32)
+            return g
+        gs = [scalar(g) for g in (g_e, g_ade, g_fde)]
+        rc = ops.L.fast("et_wrapper_losses_bwd")(
+            *(None if g is None else g.data_ptr() for g in gs), Cc.data_ptr(), n, s, k, gt.shape[1], *ctx.ptrs, ops.MODE_SPLIT,
+            ctx.static_dist, C_gt.data_ptr(), gt.data_ptr(), recon.data_ptr(), arg.data_ptr(), dC.data_ptr(),
+            ops.L.raw_stream(Cc.device.index))
+        if rc:
+            ops.L.check(rc, "et_wrapper_losses_bwd")
+        if g_recon is not None:  # somebody also differentiates through recon_traj itself
+            dC = dC + ops._reconstruct_bwd(g_recon.contiguous().float(), None, nrm, ctx.U[0], ctx.U[1], ops.MODE_SPLIT,
+                                           ctx.static_dist, ctx.t_obs)
+        return dC, None, None, None, None, None
+
+
 _SIDE = {}
 
 
@@ -83,6 +133,21 @@ class EigenTrajectory(nn.Module):
         if rc:
             ops.L.check(rc, "et_scene_project")
         return block[:k], block[k:k + 2], block[k + 2:]
+
+    def _scene_project_train(self, obs_traj, pred_traj):
+        """-> C_obs (k,N), obs_ori (2,N), nrm (4,N), C_gt (k,N): views of one fresh (2k+6,N) block (one launch)."""
+        n, k = obs_traj.shape[0], self.k
+        block = torch.empty((2 * k + 6, n), device=obs_traj.device)
+        base = block.data_ptr()
+        rc = ops.L.fast("et_scene_project_train")(
+            obs_traj.data_ptr(), pred_traj.data_ptr(), n, obs_traj.shape[1], pred_traj.shape[1], k,
+            self.ET_m_descriptor.U_obs_trunc.data_ptr(), self.ET_s_descriptor.U_obs_trunc.data_ptr(),
+            self.ET_m_descriptor.U_pred_trunc.data_ptr(), self.ET_s_descriptor.U_pred_trunc.data_ptr(), ops.MODE_SPLIT,
+            self.static_dist, base, base + 4 * (k + 2) * n, base + 4 * k * n, base + 4 * (k + 6) * n, None,
+            ops.L.raw_stream(obs_traj.device.index))
+        if rc:
+            ops.L.check(rc, "et_scene_project_train")
+        return block[:k], block[k:k + 2], block[k + 2:k + 6], block[k + 6:]
 
     def _predict(self, C_obs, obs_ori, addl_info):
         """bridge protocol of baseline/<name>/bridge.py: pre-hook -> predictor -> post-hook; returns the refinement
@@ -200,6 +265,22 @@ class EigenTrajectory(nn.Module):
             recon = ops.anchor_reconstruct(C_pred_refine, A_m, A_s, U_pred_m, U_pred_s, ops.MODE_SPLIT, sd, nrm=nrm,
                                            t_obs=obs_traj.shape[1])
             return {"recon_traj": recon.to(obs_traj.device)}
+        if (pred_traj is not None and self._scene_ok(obs_traj) and self._scene_ok(pred_traj)
+                and pred_traj.shape[0] == obs_traj.shape[0] and self.ET_m_anchor.C_anchor.device == obs_traj.device):
+            # training on one scene (utils/trainer.py:126-152): projection of obs and ground truth in one launch,
+            # reconstruction + the three losses in one more, one launch for their gradient (csrc/et_train.hip)
+            C_obs, obs_ori, nrm, C_gt = self._scene_project_train(obs_traj, pred_traj)
+            C_pred_refine = self._predict(C_obs, obs_ori, addl_info)
+            if C_pred_refine.is_cuda and C_pred_refine.dtype == torch.float32 and C_pred_refine.dim() == 3:
+                Cc = C_pred_refine if C_pred_refine.is_contiguous() else C_pred_refine.contiguous()
+                recon, l_e, l_ade, l_fde = _SceneLosses.apply(Cc, self, nrm, C_gt, pred_traj, obs_traj.shape[1])
+                return {"recon_traj": recon, "loss_eigentraj": l_e, "loss_euclidean_ade": l_ade, "loss_euclidean_fde": l_fde}
+        return self._forward_composite(obs_traj, pred_traj, addl_info)
+
+    def _forward_composite(self, obs_traj, pred_traj=None, addl_info=None):
+        """:meth:`forward` out of the general kernels and framework operators: any batch size, tensors on any device
+        (they are moved), predictors that answer in another dtype.  What the scene paths above are checked against."""
+        sd = self.static_dist
         U_obs_m, U_pred_m, U_obs_s, U_pred_s = self._U()
         A_m, A_s = self.ET_m_anchor.C_anchor.detach(), self.ET_s_anchor.C_anchor.detach()
 

@@ -115,6 +115,33 @@ int et_scene_project(const float *obs, int64_t N, int T_obs, int k, const float 
                      int mode, float static_dist, float *C_obs, float *nrm, float *obs_ori, uint8_t *flag,
                      et_stream_t stream);
 
+/* ---- training form of a wrapper call on one scene (model.py:58-125 with pred_traj; utils/trainer.py:126-152) ----------
+ * N <= ET_SCENE_MAX_N, single-workgroup launches (the work is microseconds; what costs is launches and framework
+ * operators).  mode: ET_MODE_STATIC / MOVING / SPLIT.
+ *   et_scene_project_train  et_scene_project + C_gt (k,N): the ground truth `pred` (N,T_pred,2) projected with the
+ *                           observation's normaliser and its row's U_pred (descriptor.py:144-160, model.py:73-83).
+ *   et_wrapper_losses_fwd   recon (S,N,T_pred,2) as et_anchor_reconstruct_fwd, and in the same launch
+ *                             losses[0] loss_eigentraj     = mean_n min_s ||A[:,s] + C[:,n,s] - C_gt[:,n]||   (model.py:119)
+ *                             losses[1] loss_euclidean_ade = mean_n min_s mean_t ||recon[s,n,t] - gt[n,t]||   (model.py:120-121)
+ *                             losses[2] loss_euclidean_fde = mean_n min_s ||recon[s,n,-1] - gt[n,-1]||        (model.py:122-123)
+ *                           best (3,N): the per-pedestrian minima, arg (3,N) int32: the sample attaining each.
+ *   et_wrapper_losses_bwd   dC (k,N,S) = sum_i g_i * d losses[i] / d C (g_*: the upstream gradient of each loss, a device
+ *                           scalar, NULL = not differentiated); each term reaches only its arg-min sample (torch.amin's
+ *                           gradient). */
+int et_scene_project_train(const float *obs, const float *pred, int64_t N, int T_obs, int T_pred, int k,
+                           const float *U_obs_m, const float *U_obs_s, const float *U_pred_m, const float *U_pred_s,
+                           int mode, float static_dist, float *C_obs, float *nrm, float *obs_ori, float *C_gt,
+                           uint8_t *flag, et_stream_t stream);
+int et_wrapper_losses_fwd(const float *C, int64_t N, int S, int k, int T_pred, const float *nrm, const float *A_m,
+                          const float *A_s, const float *U_pred_m, const float *U_pred_s, int mode, float static_dist,
+                          const float *C_gt, const float *gt, float *recon, float *best, int32_t *arg, float *losses,
+                          et_stream_t stream);
+int et_wrapper_losses_bwd(const float *g_eigentraj, const float *g_ade, const float *g_fde, const float *C, int64_t N, int S,
+                          int k, int T_pred, const float *nrm,
+                          const float *A_m, const float *A_s, const float *U_pred_m, const float *U_pred_s, int mode,
+                          float static_dist, const float *C_gt, const float *gt, const float *recon, const int32_t *arg,
+                          float *dC, et_stream_t stream);
+
 /* ---- anchor refinement + reconstruction -------------------------------------------
  * out[s][n] = denormalize( reshape( U_pred . (C[:,n,s] + A[:,s]) ) )      (S,N,T_pred,2)
  * C (k,N,S); A_m/A_s (k,S) or NULL (no anchor add); normaliser state comes from `nrm`

@@ -1525,3 +1525,61 @@ def test_kmeanspp_seed_batch_equals_single_seedings(ops, dev, n, d, K):
         c1, i1 = ops.kmeanspp_seed(X, K, U[i])
         assert torch.equal(cb[i], c1) and torch.equal(ib[i], i1)
         assert np.array_equal(N_(c1), x[:, N_(i1)])
+
+
+@pytest.mark.parametrize("scene,n_max", [("eth", 60), ("univ", 300)])
+def test_scene_training_form_fused_equals_composite(dev, scene, n_max):
+    """The training form of a wrapper call on a scene (model.py:58-125 with pred_traj; csrc/et_train.hip: projection of
+    obs + ground truth, reconstruction + the three losses, their gradient -- three launches) against the same call made
+    of the general kernels and framework operators (`_forward_composite`, itself checked against the reference's losses
+    by the G6 / G12 / G13 tests): trajectories, losses and the gradient that reaches the predictor's parameters."""
+    from eigentrajectory_amd import EigenTrajectory
+    from eigentrajectory_amd.utils import DotDict, default_hyper_params
+    g2 = G.load("g2_fit_all_scenes.npz")
+
+    class Net(torch.nn.Module):  # a predictor with parameters: (k+2, N) -> (k, N, S)
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(5)
+            self.w = torch.nn.Parameter(torch.randn(6, 8, 20) * 0.3)
+            self.b = torch.nn.Parameter(torch.randn(6, 1, 20) * 0.5)
+
+        def forward(self, x):
+            return torch.einsum("jis,in->jns", self.w, x) + self.b
+
+    hooks = DotDict(model_forward_pre_hook=lambda c, o, a=None: torch.cat([c, o], dim=0),
+                    model_forward=lambda x, m: m(x), model_forward_post_hook=lambda y, a=None: y)
+    model = EigenTrajectory(Net(), hooks, default_hyper_params(static_dist=0.4))
+    sd = model.state_dict()
+    for key in list(sd):
+        if key.startswith("ET_"):
+            sd[key] = torch.from_numpy(g2[f"{scene}.{key}"])
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    obs, pred, sse = G.dataset(scene, "test")
+    picks = [(s, e) for s, e in sse if e - s <= n_max][:4]
+    for weights in ((1.0, 1.0, 1.0), (0.3, 0.0, 2.0)):
+        for s, e in picks:
+            o, p = T(obs[s:e], dev), T(pred[s:e], dev)
+            grads, outs = [], []
+            for fn in (model, model._forward_composite):
+                model.zero_grad(set_to_none=True)
+                out = fn(o, p)
+                loss = sum(w * out[k] for w, k in zip(weights, ("loss_eigentraj", "loss_euclidean_ade", "loss_euclidean_fde")))
+                loss.backward()
+                grads.append([model.baseline_model.w.grad.clone(), model.baseline_model.b.grad.clone()])
+                outs.append(out)
+            close(N_(outs[0]["recon_traj"]), N_(outs[1]["recon_traj"]), tol=2e-6)
+            for k in ("loss_eigentraj", "loss_euclidean_ade", "loss_euclidean_fde"):
+                np.testing.assert_allclose(float(outs[0][k].detach()), float(outs[1][k].detach()), rtol=2e-6, atol=1e-7)
+            for a, b in zip(*grads):
+                close(N_(a), N_(b), tol=2e-5)
+    # differentiating through recon_traj itself (not only the losses) still works
+    o, p = T(obs[picks[0][0]:picks[0][1]], dev), T(pred[picks[0][0]:picks[0][1]], dev)
+    got = []
+    for fn in (model, model._forward_composite):
+        model.zero_grad(set_to_none=True)
+        out = fn(o, p)
+        (out["recon_traj"].square().mean() + out["loss_euclidean_fde"]).backward()
+        got.append(model.baseline_model.b.grad.clone())
+    close(N_(got[0]), N_(got[1]), tol=2e-5)
