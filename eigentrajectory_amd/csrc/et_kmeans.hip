@@ -859,6 +859,11 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
     // and labels per point, so who processes a pass does not matter.
     // (shards with at most one pass per wavefront keep the fixed map: nothing to balance, and no counter round trip)
     const bool dynamic = n_groups > (int64_t)gridDim.x * n_wav;
+    // (Spreading the passes of the last, partial round evenly over all workgroups -- 152.6 each instead of 156 for
+    // workgroups 0..182 and 144 for the rest at N = 1e7 -- was measured and dropped: +0.9 us per launch.  A launch's
+    // workgroups start over ~5.7 us in index order, so the ones with the extra round are the ones that start first.
+    // Leaning into that -- run lengths of the last rounds falling linearly with the workgroup index, 0.04 ... 0.16 passes
+    // per index -- lost as well: 50.7 / 50.6 / 51.5 / 52.2 against 50.2 us.)
     bool first = true;
     auto take = [&]() -> int64_t {  // this wavefront's next pass, or -1 (wave-uniform)
         int64_t g;
@@ -2508,7 +2513,11 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
         ch.lanes_zero = w.chain_lanes[(t + 2) % 3];
         ch.last = w.last;
         ch.mail = mail;
-        ch.compact = hook.reduce ? 1 : 0;
+        // ONE compact copy of the delta table in every form of the chained loop: measured against the 16-copy table on one
+        // GPU it is 1.0 us per launch FASTER (50.0 against 51.0 us, three alternating runs: the prologue reads 142 values
+        // instead of folding 2272, and <= 256 arrivals per address spread over the launch's tail are absorbed by the
+        // memory side), and it is what a sharded fit puts on the wire
+        ch.compact = 1;
         ch.vec_ok = vec_ok ? 1 : 0;
         return ch;
     };
