@@ -761,6 +761,72 @@ __device__ __forceinline__ void pass_issue(const float *__restrict__ X, int64_t 
 #endif
 }
 
+// The same for a HANDFUL of queued points (what a wavefront of a small shard holds at the end of its one pass: ~1 % of
+// 256 points): one point per LANE leaves 60 lanes idle for a serial walk through the K centroids (2.1 us -- a sixth of a
+// small shard's whole Lloyd iteration, profiles/r03f_persist_stamps_7e4.txt).  Here a half-wave takes one point and its
+// lane j the similarity to centroid j -- the reference's operations in the reference's order, so the same bits --, the
+// arg-max is a butterfly over the 32 lanes with torch.max's rule (first maximum wins; the filter body only runs when no
+// similarity can be NaN / Inf, fast_ok), lanes 0..5 of the half-wave add the coordinate deltas.  Two points per step.
+constexpr int kSmallDrain = 8;
+template <bool SIM>
+__device__ __forceinline__ void filter_drain_small(const unsigned *q, int cnt, int K, const float *sC,
+                                                   uint8_t *__restrict__ labels, long long *sAcc, int frac, int sfrac, int lane,
+                                                   long long &sim_acc) {
+    constexpr int d = 6;
+    const int j = lane & 31, hw = lane >> 5;
+    const float4 *s4 = reinterpret_cast<const float4 *>(sC);  // rows of 8 floats: c[0..5], |c|^2, -
+    const int jr = j < K ? j : 0;
+    const float4 c0 = s4[2 * jr], c1 = s4[2 * jr + 1];
+    for (int p0 = 0; p0 < cnt; p0 += 2) {
+        const int p = p0 + hw;
+        const bool live = p < cnt;
+        const int ps = live ? p : 0;
+        float x[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) x[i] = __uint_as_float(q[i * kFilterSlots + ps]);
+        float an = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) an = an + x[i] * x[i];  // kmeans.py:73 |a|^2
+        float y = fmaf(x[0], c0.x, 0.f);                     // :71
+        y = fmaf(x[1], c0.y, y);
+        y = fmaf(x[2], c0.z, y);
+        y = fmaf(x[3], c0.w, y);
+        y = fmaf(x[4], c1.x, y);
+        y = fmaf(x[5], c1.y, y);
+        y = y * 2.0f;   // :72
+        y = y - an;     // :73
+        y = y - c1.z;   // :74
+        int lb = j;
+        if (j >= K) y = -__int_as_float(0x7f800000);  // no such centroid: loses to every finite similarity
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            const float oy = __shfl_xor(y, o);
+            const int ol = __shfl_xor(lb, o);
+            if (oy > y || (oy == y && ol < lb)) {  // first maximum wins (kmeans.py:156: torch.max)
+                y = oy;
+                lb = ol;
+            }
+        }
+        if (live) {
+            const int old = (int)q[7 * kFilterSlots + p];
+            if (lb != old) {
+                if (j == 0) {
+                    labels[(int64_t)q[6 * kFilterSlots + p]] = (uint8_t)lb;
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + lb]), 1ull);
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + old]), ~0ull);
+                }
+                if (j < d) {
+                    const float xi = j == 0 ? x[0] : (j == 1 ? x[1] : (j == 2 ? x[2] : (j == 3 ? x[3] : (j == 4 ? x[4] : x[5]))));
+                    const unsigned long long f = (unsigned long long)to_fixed(xi, frac);
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[j * K + lb]), f);
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[j * K + old]), 0ull - f);
+                }
+            }
+            if (SIM && j == 0) sim_acc += to_fixed(y, sfrac);
+        }
+    }
+}
+
 // SIM = false: the similarity sum (the inertia of THIS assignment, kmeans.py:234) is not accumulated -- a fit that
 // does not record the per-iteration trace evaluates the inertia once, after its last assignment
 // (kmeans_inertia_kernel); the labels and the cluster sums are the same either way.
@@ -1016,7 +1082,8 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
     }
     sim_acc += (long long)dsum;
     ET_BSTAMP(7);
-    if (qn) filter_drain<SIM>(queue, qn, K, sC, labels, sAcc, frac, sfrac, lane, sim_acc);
+    if (qn > kSmallDrain) filter_drain<SIM>(queue, qn, K, sC, labels, sAcc, frac, sfrac, lane, sim_acc);
+    else if (qn) filter_drain_small<SIM>(queue, qn, K, sC, labels, sAcc, frac, sfrac, lane, sim_acc);
     ET_BSTAMP(8);
     if (SIM) {
         for (int o = 32; o > 0; o >>= 1) sim_acc += __shfl_xor(sim_acc, o);
