@@ -320,6 +320,9 @@ __global__ __launch_bounds__(kFitThreads) void gram_generic_finish_kernel(const 
 // (and V its column rotation): two barriers per round instead of four per rotation.  Same pairing, same formulas and the same per-element
 // operation order as the CPU oracle (oracle/et_oracle.c: eto_jacobi) => bit-identical output.
 // 24 x 24 converges in ~8 sweeps (23 rounds each).
+// (Round 3 tried ONE barrier per round: every work item derives its rotations itself from a double-buffered copy of the
+// matrix, no parameter phase -- the same bits, but 239 against 221 us: the fp64 sqrt -> sqrt -> divide chains then run in
+// every wavefront instead of one, and that costs more than the barrier and the LDS hand-off it removes.)
 // ------------------------------------------------------------------------------------------
 constexpr int kJacobiMaxSweeps = 30;
 #ifndef ET_EIGH_THREADS
@@ -327,72 +330,32 @@ constexpr int kJacobiMaxSweeps = 30;
 #endif
 constexpr int kEighThreads = ET_EIGH_THREADS;  // 16 wavefronts share the element updates of a round: 290 us (256 threads) -> 245 us for 24 x 24; 64 threads: 630 us
 
-// rotation of the pair (p, q) from the matrix entries at the start of a round (oracle/et_oracle.c: eto_jacobi, same
-// formulas and operation order): c = D / g, s = sgn |beta| / g; returns false (no rotation) for a_pq == 0 or a padding index
-__device__ __forceinline__ bool jacobi_pair(const double *__restrict__ A, int n, int p, int q, double &c, double &sn) {
-    c = 1.0;
-    sn = 0.0;
-    if (q >= n) return false;
-    const double apq = A[p * n + q], app = A[p * n + p], aqq = A[q * n + q];
-    if (apq == 0.0) return false;
-    const double alpha = aqq - app, beta = 2.0 * apq;
-    const double h = sqrt(alpha * alpha + beta * beta);
-    const double D = fabs(alpha) + h;
-    const double g = sqrt(D * D + beta * beta);
-    const double sgn = (alpha == 0.0 || ((alpha > 0.0) == (beta > 0.0))) ? 1.0 : -1.0;
-    c = D / g;
-    sn = sgn * fabs(beta) / g;
-    return true;
-}
-
-// pair i of round r of the round-robin schedule on m (even) players -> (p, q), p < q
-__device__ __forceinline__ void jacobi_schedule(int m, int r, int i, int &p, int &q) {
-    int a, b;
-    if (i == 0) {
-        a = m - 1;
-        b = r;
-    } else {
-        a = r + i;
-        a = a >= m - 1 ? a - (m - 1) : a;          // (r + i) % (m - 1), both < m - 1
-        b = r + (m - 1) - i;
-        b = b >= m - 1 ? b - (m - 1) : b;
-    }
-    p = a < b ? a : b;
-    q = a < b ? b : a;
-}
-
-// One barrier per round.  Every work item derives the rotation(s) it applies ITSELF from the matrix as it stood at the
-// start of the round -- the same inputs, formulas and operation order in every lane, hence the same bits as one lane
-// computing them for all (and as the oracle) -- instead of waiting for a parameter phase (12 lanes, an LDS hand-off and a
-// second barrier: 1.0 us per round, of which the fp64 sqrt -> sqrt -> divide chain is 0.35).  For that the matrix is
-// double-buffered: a round reads A[cur] and writes every entry of A[cur ^ 1] (an item whose pairs do not rotate copies
-// its 2 x 2 block), so no lane can overwrite what another still has to read; V is updated in place (an item reads and
-// writes only its own two entries).
 __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int n, int k, float *__restrict__ U,
                                                float *__restrict__ sigma) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *A0 = sm;                 // n*n  (A[0])
-    double *A1 = sm + n * n;         // n*n  (A[1])
-    double *V = A1 + n * n;          // n*n
-    double *sMax = V + n * n;        // 2 * (kEighThreads / 64) partial maxima
-    int *sUsed = reinterpret_cast<int *>(sMax + 2 * (kEighThreads / 64));  // 64 ranks, 1 flag
+    double *A = sm;                  // n*n
+    double *V = sm + n * n;          // n*n
+    double *sC = V + n * n;          // 32 cosines
+    double *sS = sC + 32;            // 32 sines
+    int *sP = reinterpret_cast<int *>(sS + 32 + 2 * (kEighThreads / 64));  // 32 p, 32 q, 32 active, 64 used, 1 flag
+    int *sQ = sP + 32, *sAct = sQ + 32, *sUsed = sAct + 32;
     int &sFlag = sUsed[64];
     const int lane = threadIdx.x;
     const int m = (n + 1) & ~1, half = m / 2;
     for (int i = lane; i < n * n; i += kEighThreads) {
-        A0[i] = G[i];
+        A[i] = G[i];
         V[i] = (i / n == i % n) ? 1.0 : 0.0;
     }
     __syncthreads();
-    // work items of this thread in a round:
-    //   V: e = lane + t * threads - shift -> (pair i, row j): columns p_i, q_i of row j
-    //   A: b = lane                       -> (pair i1, pair i2): the 2 x 2 block rows {p1, q1} x columns {p2, q2}
+    // work items of this thread in the update phase:
+    //   V: e = lane + t*256 -> (pair i, row j): columns p_i, q_i of row j
+    //   A: b = lane + t*256 -> (pair i1, pair i2): the 2 x 2 block rows {p1, q1} x columns {p2, q2}
     // (the V items start half a workgroup away from the A blocks: for the usual small n the two kinds of work land on
     // different wavefronts and a round's critical path is the longer of the two, not their sum)
     constexpr int kVShift = kEighThreads / 2;
     constexpr int kSlots = (32 * 64 + kVShift + kEighThreads - 1) / kEighThreads;
-    static_assert(32 * 32 <= kEighThreads, "one 2 x 2 block per thread");
-    int slot_i[kSlots], slot_j[kSlots];
+    constexpr int kBlkSlots = (32 * 32 + kEighThreads - 1) / kEighThreads;
+    int slot_i[kSlots], slot_j[kSlots], blk_1[kBlkSlots], blk_2[kBlkSlots];
 #pragma unroll
     for (int t = 0; t < kSlots; ++t) {
         const int e = lane + t * kEighThreads - kVShift;
@@ -400,10 +363,14 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
         slot_i[t] = ok ? e / n : -1;
         slot_j[t] = ok ? e % n : 0;
     }
-    const int blk_1 = lane < half * half ? lane / half : -1, blk_2 = lane < half * half ? lane % half : 0;
-    int cur = 0;
+#pragma unroll
+    for (int t = 0; t < kBlkSlots; ++t) {
+        const int b = lane + t * kEighThreads;
+        blk_1[t] = b < half * half ? b / half : -1;
+        blk_2[t] = b < half * half ? b % half : 0;
+    }
+    double *sMax = sS + 32;  // 2 * (kEighThreads / 64) partial maxima
     for (int sweep = 0; sweep < kJacobiMaxSweeps; ++sweep) {
-        const double *A = cur ? A1 : A0;
         // converged when max |off-diagonal| <= 1e-15 max |diagonal| (maxima: order independent)
         double off = 0.0, diag = 0.0;
         for (int e = lane; e < n * n; e += kEighThreads) {
@@ -432,21 +399,52 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
         __syncthreads();
         if (sFlag) break;
         for (int r = 0; r < m - 1; ++r) {
-            const double *Ac = cur ? A1 : A0;
-            double *An = cur ? A0 : A1;
-            if (blk_1 >= 0) {
-                // A' = J^T A J for the round's disjoint rotations, one 2 x 2 block per work item: the row rotation of pair
-                // i1 followed by the column rotation of pair i2 touches exactly these four entries, so "all row updates,
-                // then all column updates" (the oracle's order, with its intermediate roundings) needs no barrier in
-                // between.  Inactive pairs (a_pq == 0, or the padding index of an odd n) leave their side untouched.
-                int p1, q1, p2, q2;
-                jacobi_schedule(m, r, blk_1, p1, q1);
-                jacobi_schedule(m, r, blk_2, p2, q2);
+            if (lane < half) {
+                int a, b;
+                if (lane == 0) {
+                    a = m - 1;
+                    b = r;
+                } else {
+                    a = (r + lane) % (m - 1);
+                    b = (r + (m - 1) - lane) % (m - 1);
+                }
+                const int p = a < b ? a : b, q = a < b ? b : a;
+                int act = 0;
+                if (q < n) {
+                    const double apq = A[p * n + q], app = A[p * n + p], aqq = A[q * n + q];
+                    if (apq != 0.0) {
+                        // c = D / g, s = sgn |beta| / g (see the oracle): sqrt -> sqrt -> one level of divisions
+                        const double alpha = aqq - app, beta = 2.0 * apq;
+                        const double h = sqrt(alpha * alpha + beta * beta);
+                        const double D = fabs(alpha) + h;
+                        const double g = sqrt(D * D + beta * beta);
+                        const double sgn = (alpha == 0.0 || ((alpha > 0.0) == (beta > 0.0))) ? 1.0 : -1.0;
+                        sC[lane] = D / g;
+                        sS[lane] = sgn * fabs(beta) / g;
+                        act = 1;
+                    }
+                }
+                sP[lane] = p;
+                sQ[lane] = q;
+                sAct[lane] = act;
+            }
+            __syncthreads();
+            // A' = J^T A J for the round's disjoint rotations, one 2 x 2 block per work item: the row rotation of pair
+            // i1 followed by the column rotation of pair i2 touches exactly these four entries, so "all row updates,
+            // then all column updates" (the oracle's order, with its intermediate roundings) needs no barrier in
+            // between.  Inactive pairs (a_pq == 0, or the padding index of an odd n) leave their side untouched.
+#pragma unroll
+            for (int t = 0; t < kBlkSlots; ++t) {
+                const int i1 = blk_1[t], i2 = blk_2[t];
+                if (i1 < 0) continue;
+                // (all pair records are fetched before the first one is looked at: one LDS round trip, not three)
+                const int a1 = sAct[i1], a2 = sAct[i2];
+                const int p1 = sP[i1], q1 = sQ[i1], p2 = sP[i2], q2 = sQ[i2];
+                const double c1 = sC[i1], s1 = sS[i1], c2 = sC[i2], s2 = sS[i2];
+                if (!a1 && !a2) continue;
                 const bool hq1 = q1 < n, hq2 = q2 < n;  // an active pair always has q < n
-                double x_pp = Ac[p1 * n + p2], x_pq = hq2 ? Ac[p1 * n + q2] : 0.0;
-                double x_qp = hq1 ? Ac[q1 * n + p2] : 0.0, x_qq = (hq1 && hq2) ? Ac[q1 * n + q2] : 0.0;
-                double c1, s1, c2, s2;
-                const bool a1 = jacobi_pair(Ac, n, p1, q1, c1, s1), a2 = jacobi_pair(Ac, n, p2, q2, c2, s2);
+                double x_pp = A[p1 * n + p2], x_pq = hq2 ? A[p1 * n + q2] : 0.0;
+                double x_qp = hq1 ? A[q1 * n + p2] : 0.0, x_qq = (hq1 && hq2) ? A[q1 * n + q2] : 0.0;
                 if (a1) {  // rows p1, q1 (columns p2 and q2)
                     const double c = c1, sn = s1;
                     const double t_pp = c * x_pp - sn * x_qp, t_qp = sn * x_pp + c * x_qp;
@@ -465,36 +463,33 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
                     x_qp = r_qp;
                     x_qq = r_qq;
                 }
-                if (blk_1 == blk_2 && a1) {  // the rotated pair entries are exactly zero, like in the oracle
+                if (i1 == i2) {  // (active) the rotated pair entries are exactly zero, like in the oracle
                     x_pq = 0.0;
                     x_qp = 0.0;
                 }
-                An[p1 * n + p2] = x_pp;
-                if (hq2) An[p1 * n + q2] = x_pq;
-                if (hq1) An[q1 * n + p2] = x_qp;
-                if (hq1 && hq2) An[q1 * n + q2] = x_qq;
+                A[p1 * n + p2] = x_pp;
+                if (hq2) A[p1 * n + q2] = x_pq;
+                if (hq1) A[q1 * n + p2] = x_qp;
+                if (hq1 && hq2) A[q1 * n + q2] = x_qq;
             }
 #pragma unroll
             for (int t = 0; t < kSlots; ++t) {  // V' = V J: columns p, q of every row
                 const int i = slot_i[t], j = slot_j[t];
                 if (i < 0) continue;
-                int p, q;
-                jacobi_schedule(m, r, i, p, q);
-                double c, sn;
-                if (jacobi_pair(Ac, n, p, q, c, sn)) {
+                const int act = sAct[i], p = sP[i], q = sQ[i];
+                const double c = sC[i], sn = sS[i];
+                if (act) {
                     const double vjp = V[j * n + p], vjq = V[j * n + q];
                     V[j * n + p] = c * vjp - sn * vjq;
                     V[j * n + q] = sn * vjp + c * vjq;
                 }
             }
-            cur ^= 1;
             __syncthreads();
         }
     }
-    double *A = cur ? A1 : A0;
     __syncthreads();
     // Top-k extraction, all columns at once (a single lane walking through n diagonal entries and n vector entries per
-    // column cost ~5 us per column: 30 us of a 230 us solve).  Rank of eigenvalue i = number of eigenvalues that come before
+    // column cost ~4 us per column: 22 us of a 243 us solve).  Rank of eigenvalue i = number of eigenvalues that come before
     // it in "largest first, lower index first on ties" order -- the order the serial selection (strict `>`) produces; the
     // sign makes the first entry of largest magnitude positive.
     if (lane < n) {
@@ -504,13 +499,11 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
             const double dj = A[i * n + i];
             rank += (dj > di || (dj == di && i < lane)) ? 1 : 0;
         }
-        // (a NaN eigenvalue compares false both ways: it ranks first among equals like in the serial walk's `!(>)`; the
-        // Gram matrices of finite data have none)
         sUsed[lane] = rank;
     }
     __syncthreads();
     for (int e = lane; e < n * k; e += kEighThreads) {
-        const int col = e / k, j = e - col * k;  // work item: eigenvector index `col` if its rank is j
+        const int col = e / k, j = e - col * k;  // work item: eigenvector `col`, if its rank is j
         if (sUsed[col] != j) continue;
         int im = 0;
         for (int i = 1; i < n; ++i)
@@ -602,8 +595,8 @@ extern "C" int et_fit_gram(const float *obs, const float *pred, int64_t N, int T
     return ET_OK;
 }
 
-static size_t eigh_lds_bytes(int n) {  // A (two copies), V, the partial maxima, ranks + flag
-    return sizeof(double) * (3 * (size_t)n * n + 2 * (kEighThreads / 64)) + sizeof(int) * (64 + 2);
+static size_t eigh_lds_bytes(int n) {
+    return sizeof(double) * (2 * (size_t)n * n + 64 + 2 * (kEighThreads / 64)) + sizeof(int) * (32 * 3 + 64 + 2);
 }
 
 extern "C" int et_eigh_topk_batch(int batch, const double *const *G, const int *n, const int *k, float *const *U,
