@@ -330,6 +330,38 @@ constexpr int kJacobiMaxSweeps = 30;
 #endif
 constexpr int kEighThreads = ET_EIGH_THREADS;  // 16 wavefronts share the element updates of a round: 290 us (256 threads) -> 245 us for 24 x 24; 64 threads: 630 us
 
+// sqrt(x) and 1 / sqrt(x) of a normal positive double to full precision (not correctly rounded): hardware estimate
+// (v_rsq_f64) + two coupled Goldschmidt steps, ~10 dependent fp64 operations instead of two ~25-operation IEEE sequences.
+// No range scaling: the arguments here are sums of squares of Gram-matrix entries (1e-40 ... 1e+30).
+__device__ __forceinline__ void sqrt_rsqrt(double x, double &root, double &rroot) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    root = g;
+    rroot = h + h;
+}
+
+// pair i of round r of the round-robin schedule on m (even) players -> (p, q), p < q  (oracle/et_oracle.c: eto_jacobi)
+__device__ __forceinline__ void jacobi_schedule(int m, int r, int i, int &p, int &q) {
+    int a, b;
+    if (i == 0) {
+        a = m - 1;
+        b = r;
+    } else {
+        a = r + i;  // (r + i) % (m - 1) with r, i < m - 1
+        a = a >= m - 1 ? a - (m - 1) : a;
+        b = r + (m - 1) - i;
+        b = b >= m - 1 ? b - (m - 1) : b;
+    }
+    p = a < b ? a : b;
+    q = a < b ? b : a;
+}
+
 __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int n, int k, float *__restrict__ U,
                                                float *__restrict__ sigma) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -400,32 +432,39 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
         if (sFlag) break;
         for (int r = 0; r < m - 1; ++r) {
             if (lane < half) {
-                int a, b;
-                if (lane == 0) {
-                    a = m - 1;
-                    b = r;
-                } else {
-                    a = (r + lane) % (m - 1);
-                    b = (r + (m - 1) - lane) % (m - 1);
-                }
-                const int p = a < b ? a : b, q = a < b ? b : a;
+                int p, q;
+                jacobi_schedule(m, r, lane, p, q);
                 int act = 0;
                 if (q < n) {
                     const double apq = A[p * n + q], app = A[p * n + p], aqq = A[q * n + q];
                     if (apq != 0.0) {
-                        // c = D / g, s = sgn |beta| / g (see the oracle): sqrt -> sqrt -> one level of divisions
+                        // c = D / g, s = sgn |beta| / g with D = |alpha| + sqrt(alpha^2 + beta^2), g = sqrt(D^2 + beta^2)
+                        // (the oracle's formulas).  This chain -- sqrt -> sqrt -> divide, each a ~100-150 ns correctly
+                        // rounded software sequence in fp64 -- is on the critical path of every one of the ~200 rounds
+                        // while 15 of the 16 wavefronts wait at the barrier; here both roots come from v_rsq_f64 + two
+                        // Goldschmidt steps (sqrt_rsqrt: full double precision, not correctly rounded) and the divisions
+                        // become multiplications by 1 / g.  c^2 + s^2 = 1 to a few 1e-16 as before; the result is no
+                        // longer bit-identical to the oracle's correctly rounded chain (U agrees to ~1e-14, i.e. to the
+                        // last bit of its fp32 value except on a rounding boundary) but is the same on every GPU / rank.
                         const double alpha = aqq - app, beta = 2.0 * apq;
+#ifdef ET_EIGH_IEEE_PARAMS
                         const double h = sqrt(alpha * alpha + beta * beta);
                         const double D = fabs(alpha) + h;
                         const double g = sqrt(D * D + beta * beta);
+                        const double rg = 1.0 / g;
+#else
+                        double h, rh;
+                        sqrt_rsqrt(alpha * alpha + beta * beta, h, rh);
+                        const double D = fabs(alpha) + h;
+                        double g, rg;
+                        sqrt_rsqrt(D * D + beta * beta, g, rg);
+#endif
                         const double sgn = (alpha == 0.0 || ((alpha > 0.0) == (beta > 0.0))) ? 1.0 : -1.0;
-                        sC[lane] = D / g;
-                        sS[lane] = sgn * fabs(beta) / g;
+                        sC[lane] = D * rg;
+                        sS[lane] = sgn * fabs(beta) * rg;
                         act = 1;
                     }
                 }
-                sP[lane] = p;
-                sQ[lane] = q;
                 sAct[lane] = act;
             }
             __syncthreads();
@@ -437,14 +476,17 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
             for (int t = 0; t < kBlkSlots; ++t) {
                 const int i1 = blk_1[t], i2 = blk_2[t];
                 if (i1 < 0) continue;
-                // (all pair records are fetched before the first one is looked at: one LDS round trip, not three)
-                const int a1 = sAct[i1], a2 = sAct[i2];
-                const int p1 = sP[i1], q1 = sQ[i1], p2 = sP[i2], q2 = sQ[i2];
-                const double c1 = sC[i1], s1 = sS[i1], c2 = sC[i2], s2 = sS[i2];
-                if (!a1 && !a2) continue;
+                // (the pairs follow from the round number, so the rotations AND the four matrix entries are requested from
+                // LDS together: one round trip after the barrier, not two)
+                int p1, q1, p2, q2;
+                jacobi_schedule(m, r, i1, p1, q1);
+                jacobi_schedule(m, r, i2, p2, q2);
                 const bool hq1 = q1 < n, hq2 = q2 < n;  // an active pair always has q < n
+                const int a1 = sAct[i1], a2 = sAct[i2];
+                const double c1 = sC[i1], s1 = sS[i1], c2 = sC[i2], s2 = sS[i2];
                 double x_pp = A[p1 * n + p2], x_pq = hq2 ? A[p1 * n + q2] : 0.0;
                 double x_qp = hq1 ? A[q1 * n + p2] : 0.0, x_qq = (hq1 && hq2) ? A[q1 * n + q2] : 0.0;
+                if (!a1 && !a2) continue;
                 if (a1) {  // rows p1, q1 (columns p2 and q2)
                     const double c = c1, sn = s1;
                     const double t_pp = c * x_pp - sn * x_qp, t_qp = sn * x_pp + c * x_qp;
@@ -476,10 +518,13 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
             for (int t = 0; t < kSlots; ++t) {  // V' = V J: columns p, q of every row
                 const int i = slot_i[t], j = slot_j[t];
                 if (i < 0) continue;
-                const int act = sAct[i], p = sP[i], q = sQ[i];
+                int p, q;
+                jacobi_schedule(m, r, i, p, q);
+                const int act = sAct[i];
                 const double c = sC[i], sn = sS[i];
+                const int qs = q < n ? q : p;  // (an inactive padding pair: any valid address)
+                const double vjp = V[j * n + p], vjq = V[j * n + qs];
                 if (act) {
-                    const double vjp = V[j * n + p], vjq = V[j * n + q];
                     V[j * n + p] = c * vjp - sn * vjq;
                     V[j * n + q] = sn * vjp + c * vjq;
                 }
