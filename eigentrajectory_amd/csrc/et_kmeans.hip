@@ -27,6 +27,7 @@
 // fixed-point integer (truncation, power-of-two scale => exact) and integers are summed, so the
 // result is independent of the order: the same bits for any workgroup schedule, grid size or
 // number of GPUs, and identical to the CPU oracle (oracle/et_oracle.c).
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 #include <vector>
@@ -1094,6 +1095,383 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
     ET_BSTAMP(9);
 }
 
+// ------------------------------------------------------------------------------------------
+// Trace-less Lloyd iterations on a PACKED copy of the points (d = 6, K <= 32, big shards).
+//
+// The filter above reads 24 B per point and iteration to certify that a label did not change, and an iteration takes as
+// long as the memory side needs to stream them.  The certification does not need the exact coordinates:
+// kmeans_pack_kernel writes, once per fit,
+//   xh   three rows of N dwords: the coordinate pairs (0,1), (2,3), (4,5) of  s (x - mu)  rounded to f16 (nearest);
+//        mu = the mean of 1024 evenly spaced points (any vector would do: arg-max_j -|x - c_j|^2 does not depend on the
+//        origin), s = the power of two that brings every |s (x - mu)| below 16
+//   rr   N f16: an upper bound R of  s ||x - mu||
+//   xa   N rows of 32 B: the exact coordinates of a point side by side, for the few points the test cannot decide
+// = 14 B per point and iteration instead of 24, and the 1-3 % of undecided points cost one 64-B sector each instead of
+// six.  The rounding of x is now by far the largest error of the matrix-core estimate, so the bounds are re-derived
+// (scaled units; p = s (x - mu), q_j = s (c_j - mu) exact, R >= ||p||, Q_j >= ||q_j||; r = s ||x|| <= R + m with
+// m >= s ||mu||, C_j = s ||c_j||, M_j = m + C_j;  G_j = 2 p.q_j - |q_j|^2, and G_j - G_l = s^2 (Y_j - Y_l) in exact
+// arithmetic whatever mu is):
+//   |xh_i - p_i|  <= (2^-11 + 2^-23) |p_i| + 2^-25          (x - mu in fp32, then f16 to nearest / denormal grid)
+//   the MFMA's  t'_j = sum_i xh_i (ch + cl)_ji - |q_j|^2  (2 q_j split into f16 hi + lo as before, fp32 accumulation
+//   of 16 terms):   |t'_j - G_j| <= E2 = 2^-9.99 R Q_j + 2^-17.5 (R + Q_j)^2 + 2^-21 (R + Q_j) + 2^-34
+//   the reference's fp32 chain (kmeans.py:71-74):  |s^2 (Y_j + |x|^2) - (G_j + |p|^2 ... )| -- only differences
+//   matter --  is within E1_j = 2^-20.99 (R + M_j)^2 of the exact value (the 2^-21 (r + C_j)^2 of the filter above)
+//   so  s^2 Y_j - const <= u_j := t'_j + E2_j + E1_j,  and  u_j - epsR(R)  is linear in (R, 1) per cluster: the slope
+//   rides in a k-slot against R, the constant is folded into the -|q_j|^2 slots (rounded up).
+//   The old label l:  w' = sum_i xh_i (2 s c~_li) - s^2 |c~_l|^2  as an fp32 chain on the f16 values (v_fma_mix_f32),
+//   G_l >= w' - Ew_l,  Ew_l = 2^-9.99 R Q_l + 2^-20 (R + Q_l)^2 + 2^-22 Q_l + 2^-40.
+//   keep  <=>  w' - second > epsR(R) + Ew_l + E1_l (+ the rounding of the comparison):  then l owns the largest u (were it
+//   not, u_l <= second would give w' <= second + epsR + Ew_l) and every other cluster j has  s^2 Y_j - const <= second +
+//   epsR < w' - Ew_l - E1_l <= s^2 Y_l - const:  l is the reference's arg-max, strictly.
+// Everything else -- the queue, the exact scan of the queued points (now on coordinates fetched from xa), the
+// incremental integer sums -- is the filter's; labels, sums and iteration counts stay bit-identical.  Falls back to the
+// fp32 filter for an iteration whose centroids leave the packed range (|s (c - mu)| >= 31: cannot happen for means of
+// the points, can for caller-provided initial centroids) or when the scale is out of range.
+// ------------------------------------------------------------------------------------------
+struct PackedHeader {  // written by kmeans_pack_kernel
+    float mu[6];
+    float s;        // power of two
+    float mu_norm;  // >= s ||mu||
+    int ok;         // 0: scale out of range / non-finite sample: the fp32 filter decides
+    int pad[7];
+};
+struct LloydPacked {
+    const unsigned *xh;
+    const unsigned short *rr;
+    const float4 *xa;
+    const PackedHeader *hdr;
+};
+constexpr int kPackSamples = 1024;
+
+__global__ __launch_bounds__(kKmThreads) void kmeans_pack_kernel(const float *__restrict__ X, int64_t N,
+                                                                 const et_kmeans_state *__restrict__ state,
+                                                                 PackedHeader *__restrict__ hdr, unsigned *__restrict__ xh,
+                                                                 unsigned short *__restrict__ rr, float4 *__restrict__ xa) {
+    constexpr int d = 6;
+    __shared__ double sSum[kKmThreads / 64][d];
+    __shared__ float sMu[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {   // the same sample mean in every workgroup (fixed order: reproducible)
+        double acc[d] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int k = 0; k < kPackSamples / kKmThreads; ++k) {
+            const int64_t idx = ((int64_t)(tid + kKmThreads * k) * N) / kPackSamples;
+#pragma unroll
+            for (int i = 0; i < d; ++i) acc[i] += (double)X[(int64_t)i * N + idx];
+        }
+#pragma unroll
+        for (int i = 0; i < d; ++i) {
+            for (int o = 32; o > 0; o >>= 1) acc[i] += __shfl_xor(acc[i], o);
+            if (lane == 0) sSum[wave][i] = acc[i];
+        }
+        __syncthreads();
+        if (tid < d) {
+            double t = 0.0;
+            for (int w = 0; w < kKmThreads / 64; ++w) t += sSum[w][tid];
+            sMu[tid] = (float)(t / (double)kPackSamples);
+        }
+        __syncthreads();
+    }
+    float mu[d];
+    double mu_max = 0.0, mu_sq = 0.0;
+#pragma unroll
+    for (int i = 0; i < d; ++i) {
+        mu[i] = sMu[i];
+        mu_max = fmax(mu_max, fabs((double)mu[i]));
+        mu_sq += (double)mu[i] * (double)mu[i];
+    }
+    const double bound = state->max_abs_x + mu_max;  // >= every |x_i - mu_i|
+    const int e = exponent_above(bound);
+    const bool ok = state->fast_ok && !state->bad_input && bound == bound && bound < 1e30 && e >= -40 && e <= 60;
+    const float s = ldexpf(1.0f, 4 - e);
+    if (blockIdx.x == 0 && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < d; ++i) hdr->mu[i] = mu[i];
+        hdr->s = s;
+        hdr->mu_norm = (float)(sqrt(mu_sq) * (double)s * 1.001) + 1e-30f;
+        hdr->ok = ok ? 1 : 0;
+    }
+    if (!ok) return;
+    constexpr float kUp = 1.001953125f, kTiny = 1.1920928955078125e-7f;
+    const int64_t n_quads = N / 4;  // N % 4 == 0 (the caller's vec_ok)
+    for (int64_t g = (int64_t)blockIdx.x * kKmThreads + tid; g < n_quads; g += (int64_t)gridDim.x * kKmThreads) {
+        const int64_t n = 4 * g;
+        float4 v[d];
+#pragma unroll
+        for (int i = 0; i < d; ++i) v[i] = *reinterpret_cast<const float4 *>(X + (int64_t)i * N + n);
+        unsigned hw[3][4];
+        unsigned short rh[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x[d], xc[d];
+#pragma unroll
+            for (int i = 0; i < d; ++i) {
+                x[i] = q == 0 ? v[i].x : (q == 1 ? v[i].y : (q == 2 ? v[i].z : v[i].w));
+                xc[i] = x[i] - mu[i];
+            }
+            float an = 0.f;
+#pragma unroll
+            for (int i = 0; i < d; ++i) an = fmaf(xc[i], xc[i], an);
+            const float rs = fmaf(__builtin_amdgcn_sqrtf(an) * s, kUp, kTiny);
+            const auto rp = __builtin_amdgcn_cvt_pkrtz(fmaf(rs, kUp, kTiny), 0.f);  // survives the rounding toward zero
+            rh[q] = (unsigned short)(__builtin_bit_cast(unsigned, rp) & 0xffffu);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                unsigned h;
+                asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=&v"(h) : "v"(xc[2 * p]), "v"(s));
+                asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+&v"(h) : "v"(xc[2 * p + 1]), "v"(s));
+                hw[p][q] = h;
+            }
+            xa[2 * (n + q)] = make_float4(x[0], x[1], x[2], x[3]);
+            xa[2 * (n + q) + 1] = make_float4(x[4], x[5], 0.f, 0.f);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<uint4 *>(xh + (int64_t)p * N + n) = make_uint4(hw[p][0], hw[p][1], hw[p][2], hw[p][3]);
+        *reinterpret_cast<uint2 *>(rr + n) =
+            make_uint2((unsigned)rh[0] | ((unsigned)rh[1] << 16), (unsigned)rh[2] | ((unsigned)rh[3] << 16));
+    }
+}
+
+// a += f16(w.lo or w.hi) * b, one v_fma_mix_f32 (the f16 operand is converted exactly)
+__device__ __forceinline__ float fma_mix_lo(unsigned w, float b, float a) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(b), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float fma_mix_hi(unsigned w, float b, float a) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(b), "v"(a));
+    return r;
+}
+
+constexpr int kPkQueue = 2 * kFilterSlots;  // per wavefront: point index, old label
+constexpr int kPkRow = 12;                  // floats per cluster in the label table
+
+// full exact scan of `cnt` (<= 64) queued points, one per lane, on coordinates fetched from the side-by-side copy
+__device__ __forceinline__ void packed_drain(const unsigned *q, int cnt, int K, const float *sC, const float4 *__restrict__ xa,
+                                             uint8_t *__restrict__ labels, long long *sAcc, int frac, int lane) {
+    constexpr int d = 6;
+    if (lane >= cnt) return;
+    const int64_t n = (int64_t)q[lane];
+    const int old = (int)q[kFilterSlots + lane];
+    const float4 a = xa[2 * n], b = xa[2 * n + 1];
+    const float x[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+    int lb;
+    float best;
+    best_centroid6_drain(x, sC, K, lb, best);
+    if (lb != old) {
+        labels[n] = (uint8_t)lb;
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + lb]), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + old]), ~0ull);
+#pragma unroll
+        for (int i = 0; i < d; ++i) {
+            const unsigned long long f = (unsigned long long)to_fixed(x[i], frac);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[i * K + lb]), f);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[i * K + old]), 0ull - f);
+        }
+    }
+}
+
+__device__ __forceinline__ void packed_issue(const LloydPacked &pk, int64_t N, const uint8_t *__restrict__ labels, int64_t gg,
+                                             int half, int col, uint4 (&vn)[3], uint2 &rn, unsigned &lpn) {
+    const int64_t n = gg * 256 + 128 * half + 4 * col;
+    const int64_t nl = n < N ? n : 0;  // lanes past the end read points 0..3: finite data, discarded through `valid`
+#pragma unroll
+    for (int p = 0; p < 3; ++p) vn[p] = *reinterpret_cast<const uint4 *>(pk.xh + (int64_t)p * N + nl);
+    rn = *reinterpret_cast<const uint2 *>(pk.rr + nl);
+    lpn = *reinterpret_cast<const unsigned *>(labels + nl);
+}
+
+template <int NREGS>
+__device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const float *__restrict__ X, int64_t N, int K,
+                                                   const et_kmeans_state *state, const float *cen,
+                                                   uint8_t *__restrict__ labels, long long *__restrict__ lanes,
+                                                   int copy_mask) {
+    const unsigned tx = thread_x();  // (opaque per call: see thread_x)
+    constexpr int d = 6;
+    const int n_thr = (int)blockDim.x, n_wav = n_thr >> 6;
+    const float s = pk.hdr->s;
+    bool fallback = state->iter <= 0 || !state->fast_ok || !pk.hdr->ok;
+    if (!fallback) {  // every |s (c - mu)| inside the packed range?  (cen: d x K floats in LDS, the same in every workgroup)
+        int bad = 0;
+        for (int e = tx; e < d * K; e += n_thr) bad |= !(fabsf((cen[e] - pk.hdr->mu[e / K]) * s) < 31.0f);
+        fallback = __syncthreads_or(bad) != 0;
+    }
+    if (fallback) {
+        filter_assign_body<NREGS, false>(X, N, K, state, cen, labels, nullptr, lanes, copy_mask);
+        return;
+    }
+    const int plen = d * K + K + 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    long long *sAcc = reinterpret_cast<long long *>(smem_raw);                                 // plen
+    float *sC = reinterpret_cast<float *>(smem_raw + sizeof(long long) * ((plen + 1) & ~1));  // K * 8: exact rows (drain)
+    float *sL = sC + K * 8;                                                                    // K * kPkRow: label table
+    const int lane = tx & 63, wave = tx >> 6, half = lane >> 5, col = lane & 31;
+    unsigned *queue = reinterpret_cast<unsigned *>(sL + K * kPkRow) + wave * kPkQueue;
+    const int frac = (int)state->frac;
+    constexpr float kUp = 1.001953125f, kTiny = 1.1920928955078125e-7f;  // (1 + 2^-9) v + 2^-23 survives the rtz to f16
+    const float s2 = s * s, m_up = pk.hdr->mu_norm;
+    for (int i = tx; i < plen; i += n_thr) sAcc[i] = 0;
+    stage_centroids(cen, d, K, sC);
+    __shared__ int sNext;
+    if (tx == 0) sNext = n_wav;
+    __syncthreads();
+    // per cluster: the centred, scaled row for the old-label chain and the two threshold coefficients
+    for (int j = tx; j < K; j += n_thr) {
+        float qq = 0.f;
+#pragma unroll
+        for (int i = 0; i < d; ++i) {
+            const float ct = sC[j * 8 + i] - pk.hdr->mu[i];
+            qq = fmaf(ct, ct, qq);
+            sL[j * kPkRow + i] = 2.0f * s * ct;
+        }
+        const float Q = sqrtf(qq) * s * 1.001f + 1e-30f, M = m_up + sqrtf(sC[j * 8 + 6]) * s * 1.001f;
+        sL[j * kPkRow + 6] = qq * s2;
+        // th(R) = R^2 k1 + R thr_r + thr_1:  epsR + Ew_l + E1_l  (header comment), coefficients rounded up
+        sL[j * kPkRow + 7] = fmaf(9.86e-4f, Q, 9.7e-7f * M) * kUp + 1e-30f;
+        sL[j * kPkRow + 8] = (fmaf(9.6e-7f * Q, Q, 2.4e-7f * Q) + fmaf(4.85e-7f * M, M, 1e-12f)) * kUp;
+    }
+
+    // A operand of this lane's cluster (layout as in filter_assign_body): lower half-wave lanes carry k-slots 0..7 =
+    // {hi(2 q)_0..5, -|q|^2 + const as hi, lo * 2^10}, upper half-wave lanes k-slots 8..15 = {lo(2 q)_0..5, slope, 0}
+    u32x4 a1 = {0u, 0u, 0u, 0u};
+    {
+        const int j = 2 * (4 * (col >> 3) + (col & 3)) + ((col >> 2) & 1);
+        unsigned ch[3] = {0u, 0u, 0u}, cl[3] = {0u, 0u, 0u};
+        float nb = -60000.0f;
+        unsigned ebd = 0u;
+        if (j < K) {
+            float ct[d], qq = 0.f;
+#pragma unroll
+            for (int i = 0; i < d; ++i) {
+                ct[i] = sC[j * 8 + i] - pk.hdr->mu[i];
+                qq = fmaf(ct[i], ct[i], qq);
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) split_f16(ct[2 * p], ct[2 * p + 1], 2.0f * s, ch[p], cl[p]);
+            const float Q = sqrtf(qq) * s * 1.001f + 1e-30f, M = m_up + sqrtf(sC[j * 8 + 6]) * s * 1.001f;
+            // u_j - epsR(R) = t'_j + R ebd_r + ebd_1
+            const float ebd_r = fmaf(9.95e-4f, Q, fmaf(9.7e-7f, M, 4.8e-7f));
+            const float ebd_1 = fmaf(5.4e-6f * Q, Q, 4.8e-7f * Q) + fmaf(4.85e-7f * M, M, 6e-11f);
+            nb = fmaf(-qq, s2, ebd_1 * kUp);
+            nb = fmaf(fabsf(nb), 3.814697265625e-6f, nb) + 1e-12f;  // + 2^-18 |nb|: the hi / lo pair below never rounds it down
+            ebd = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(fmaf(ebd_r, kUp, kTiny), 0.f));
+        }
+        const auto nh = __builtin_amdgcn_cvt_pkrtz(nb, 0.f);
+        const unsigned bnd = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(nb, (nb - (float)nh[0]) * 1024.0f));
+        a1 = half == 0 ? u32x4{ch[0], ch[1], ch[2], bnd} : u32x4{cl[0], cl[1], cl[2], ebd};
+    }
+    const f16x8 A1 = __builtin_bit_cast(f16x8, a1);
+    __syncthreads();  // sL complete
+    const float4 *l4 = reinterpret_cast<const float4 *>(sL);
+
+    int qn = 0;  // wave-uniform number of queued points
+    const int64_t n_groups = (N + 255) / 256;
+    const bool dynamic = n_groups > (int64_t)gridDim.x * n_wav;
+    bool first = true;
+    auto take = [&]() -> int64_t {  // this wavefront's next pass, or -1 (wave-uniform); see filter_assign_body
+        int64_t g;
+        if (first) {
+            first = false;
+            g = (int64_t)blockIdx.x * n_wav + wave;
+        } else if (dynamic) {
+            int i = 0;
+            if (lane == 0) i = atomicAdd(&sNext, 1);
+            i = __builtin_amdgcn_readfirstlane(i);
+            g = (int64_t)blockIdx.x * n_wav + (i % n_wav) + (int64_t)(i / n_wav) * gridDim.x * n_wav;
+        } else {
+            g = n_groups;
+        }
+        return g < n_groups ? g : -1;
+    };
+    uint4 vn[3];
+    uint2 rn = make_uint2(0u, 0u);
+    unsigned lpn = 0u;
+    int64_t g = take();
+    if (g >= 0) packed_issue(pk, N, labels, g, half, col, vn, rn, lpn);
+    while (g >= 0) {
+        const int64_t n = g * 256 + 128 * half + 4 * col;
+        const bool valid = n < N;
+        uint4 v[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) v[p] = vn[p];
+        const uint2 rv = rn;
+        const unsigned old_packed = lpn;
+        // the next pass's rows are in flight during this pass's arithmetic and its queue drain
+        g = take();
+        if (g >= 0) packed_issue(pk, N, labels, g, half, col, vn, rn, lpn);
+        unsigned undecided = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned w[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) w[p] = q == 0 ? v[p].x : (q == 1 ? v[p].y : (q == 2 ? v[p].z : v[p].w));
+            const unsigned rpair = q < 2 ? rv.x : rv.y;
+            const unsigned r16 = (q & 1) ? (rpair >> 16) : rpair;  // low half: this point's R (the high half meets a zero)
+            const float R = (float)__builtin_bit_cast(_Float16, (unsigned short)(r16 & 0xffffu));
+            const unsigned ones = 0x14003c00u;  // {1, 2^-10}: partners of {hi, lo * 2^10} of -|q|^2 + const
+            u32x4 bLo, bUp;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const auto r = p < 3 ? __builtin_amdgcn_permlane32_swap(w[p], w[p], false, false)
+                                     : __builtin_amdgcn_permlane32_swap(ones, r16, false, false);
+                bLo[p] = r[0];
+                bUp[p] = r[1];
+            }
+            const f16x8 BL = __builtin_bit_cast(f16x8, bLo), BU = __builtin_bit_cast(f16x8, bUp);
+            f32x16 accL, accU;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accL[r] = accU[r] = 0.f;
+            accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, BL, accL, 0, 0, 0);
+            accU = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, BU, accU, 0, 0, 0);
+            float bL, sL_, bU, sU;
+            top2<NREGS>(accL, bL, sL_);
+            top2<NREGS>(accU, bU, sU);
+            const auto rb = __builtin_amdgcn_permlane32_swap(__float_as_uint(bL), __float_as_uint(bU), false, false);
+            const auto rq = __builtin_amdgcn_permlane32_swap(__float_as_uint(sL_), __float_as_uint(sU), false, false);
+            const float b0 = __uint_as_float(rb[0]), b1 = __uint_as_float(rb[1]);
+            const float s0 = __uint_as_float(rq[0]), s1 = __uint_as_float(rq[1]);
+            const float second = vmed3(b0, b1, vmax(s0, s1));  // second largest upper bound
+            // certified lower bound of the old label's value: fp32 chain on the f16 coordinates
+            const int ol = (int)((old_packed >> (8 * q)) & 0xffu);
+            const float4 r0 = l4[3 * ol], r1 = l4[3 * ol + 1], r2 = l4[3 * ol + 2];
+            float y = -r1.z;
+            y = fma_mix_lo(w[0], r0.x, y);
+            y = fma_mix_hi(w[0], r0.y, y);
+            y = fma_mix_lo(w[1], r0.z, y);
+            y = fma_mix_hi(w[1], r0.w, y);
+            y = fma_mix_lo(w[2], r1.x, y);
+            y = fma_mix_hi(w[2], r1.y, y);
+            const float th = fmaf(fabsf(y), 2.384185791015625e-7f, fmaf(R, fmaf(R, 7.4e-6f, r1.w), r2.x)) * kUp;
+            const bool keep = y - second > th;
+            undecided |= (valid && !keep) ? (1u << q) : 0u;
+        }
+        if (__ballot(undecided != 0u)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool push = (undecided >> q) & 1u;
+                const unsigned long long m = __ballot(push);
+                if (push) {
+                    unsigned *e = queue + qn + __popcll(m & ((1ull << lane) - 1ull));
+                    e[0] = (unsigned)(n + q);
+                    e[kFilterSlots] = (old_packed >> (8 * q)) & 0xffu;
+                }
+                qn += __popcll(m);
+#ifdef ET_FILTER_DEBUG
+                if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + K + 1]), (unsigned long long)__popcll(m));
+#endif
+                if (qn >= 64) {
+                    qn -= 64;
+                    packed_drain(queue + qn, 64, K, sC, pk.xa, labels, sAcc, frac, lane);
+                }
+            }
+        }
+    }
+    if (qn) packed_drain(queue, qn, K, sC, pk.xa, labels, sAcc, frac, lane);
+    __syncthreads();
+    emit_partials(sAcc, plen, n_thr, nullptr, lanes, copy_mask);
+}
+
 template <int NREGS>
 __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_assign_filter_kernel(
     const float *__restrict__ X, int64_t N, int K, const et_kmeans_state *__restrict__ state,
@@ -1285,6 +1663,7 @@ struct LloydChain {
     // then the d K + K + 2 int64 that carry the information, 1.1 KB, not the 16-copy table)
     int compact;
     int vec_ok;  // this shard's rows allow 16-byte loads (N % 4 == 0, aligned) and it has >= 1024 points: filter body
+    LloydPacked pk;  // pk.xh != nullptr: trace-less iterations run on the packed copy (packed_assign_body)
 };
 
 // fold the 16 copies of every total (layout [entry][copy]: a linear, coalesced sweep, 16 adjacent lanes per entry) and
@@ -1424,8 +1803,17 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     // a shard whose rows do not allow 16-byte loads (sharded runs cut the points anywhere), or a tiny one: the plain exact
     // scan, one point per lane, inside the same launch -- which loop form a sharded fit takes then depends on (d, K)
     // alone and every rank knows it without asking the others
-    if (ch.vec_ok) filter_assign_body<NREGS, SIM>(X, N, K, &sSt, sCen, labels, nullptr, ch.lanes_wr, copy_mask);
-    else assign_body_valu<6, 1>(X, N, d, K, &sSt, sCen, nullptr, labels, nullptr, ch.lanes_wr, copy_mask);
+    if (ch.vec_ok) {
+        if constexpr (!SIM) {
+            if (ch.pk.xh) {
+                packed_assign_body<NREGS>(ch.pk, X, N, K, &sSt, sCen, labels, ch.lanes_wr, copy_mask);
+                return;
+            }
+        }
+        filter_assign_body<NREGS, SIM>(X, N, K, &sSt, sCen, labels, nullptr, ch.lanes_wr, copy_mask);
+    } else {
+        assign_body_valu<6, 1>(X, N, d, K, &sSt, sCen, nullptr, labels, nullptr, ch.lanes_wr, copy_mask);
+    }
 }
 
 // After the loop: the update that belongs to the last assignment (if one is pending), into the caller's buffers.
@@ -2150,10 +2538,20 @@ struct KmWorkspace {
     long long *chain_tot[2];
     long long *chain_lanes[3];
     unsigned *persist_ctl;   // kmeans_lloyd_persist_kernel: {arrivals, abort flag}, a cache line of their own
+    // packed copy of the points for the trace-less chained loop (kmeans_pack_kernel); nullptr when the shape has none
+    PackedHeader *pk_hdr;
+    unsigned *pk_xh;
+    unsigned short *pk_rr;
+    float4 *pk_xa;
     size_t bytes;
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// shards the packed copy is kept for: the filter's shape (d = 6, 3 <= K <= 32) and enough points for the one-off packing
+// pass (~0.13 ms at 1e7 points) to pay within a few iterations
+constexpr int64_t kPackedMinPoints = 262144;
+static bool km_packed_shape(int64_t N, int d, int K) { return d == 6 && K >= 3 && K <= 32 && N >= kPackedMinPoints && N % 4 == 0; }
 
 static KmWorkspace km_carve(void *base, int64_t N, int d, int K) {
     KmWorkspace w;
@@ -2199,6 +2597,20 @@ static KmWorkspace km_carve(void *base, int64_t N, int d, int K) {
     }
     w.persist_ctl = (unsigned *)(p + off);
     off = align_up(off + 2 * sizeof(unsigned), 256);
+    w.pk_hdr = nullptr;
+    w.pk_xh = nullptr;
+    w.pk_rr = nullptr;
+    w.pk_xa = nullptr;
+    if (km_packed_shape(N, d, K)) {  // 46 B per point
+        w.pk_hdr = (PackedHeader *)(p + off);
+        off = align_up(off + sizeof(PackedHeader), 256);
+        w.pk_xh = (unsigned *)(p + off);
+        off = align_up(off + 12 * (size_t)N, 256);
+        w.pk_rr = (unsigned short *)(p + off);
+        off = align_up(off + 2 * (size_t)N, 256);
+        w.pk_xa = (float4 *)(p + off);
+        off = align_up(off + 32 * (size_t)N, 256);
+    }
     w.bytes = off;
     return w;
 }
@@ -2260,6 +2672,13 @@ static char km_argmax_mode() {
     }();
     return mode;
 }
+
+// ET_KMEANS_PACKED=0: trace-less fits keep the fp32 filter (read per fit: same-process A/B runs and tests)
+static bool km_packed_mode() {
+    const char *e = getenv("ET_KMEANS_PACKED");
+    return !(e && e[0] == '0');
+}
+static std::atomic<long long> g_packed_fits{0};  // fits that iterated on the packed copy (tests: the path under test ran)
 
 // matrix-core filter + exact certification (default; ET_KMEANS_ARGMAX=valu disables it)
 static bool km_use_filter(const float *X, int64_t N, int d, int K, const uint8_t *labels_u8) {
@@ -2567,6 +2986,16 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
                            (const float *)centroids, d * K, (int)plen, first, w.chain_lanes[1], w.chain_lanes[2]);
         ET_LAUNCH_CHECK();
     }
+    // trace-less fits of big shards iterate on the packed copy (ET_KMEANS_PACKED=0: the fp32 filter, for A/B runs)
+    const bool packed = vec_ok && !want_sim && w.pk_xh && km_packed_mode();
+    if (packed) {
+        const int64_t quads = N / 4;
+        const int pgrid = (int)std::min<int64_t>((quads + kKmThreads - 1) / kKmThreads, 1024);
+        hipLaunchKernelGGL(kmeans_pack_kernel, dim3(pgrid), dim3(kKmThreads), 0, st, X, N, (const et_kmeans_state *)state,
+                           w.pk_hdr, w.pk_xh, w.pk_rr, w.pk_xa);
+        ET_LAUNCH_CHECK();
+        g_packed_fits.fetch_add(1, std::memory_order_relaxed);
+    }
     auto chain_for = [&](int t) {
         LloydChain ch;
         ch.st_rd = w.chain_state[t & 1];
@@ -2586,6 +3015,7 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
         // memory side), and it is what a sharded fit puts on the wire
         ch.compact = 1;
         ch.vec_ok = vec_ok ? 1 : 0;
+        ch.pk = packed ? LloydPacked{w.pk_xh, w.pk_rr, w.pk_xa, w.pk_hdr} : LloydPacked{nullptr, nullptr, nullptr, nullptr};
         return ch;
     };
     int grid = 0, launched = 0;
@@ -2833,6 +3263,8 @@ extern "C" int et_debug_persist_stamps(void *host, size_t bytes) {
 // and the loop itself with a reduction between the launches.  `workspace` as for et_kmeans_fit.
 // (the choice depends on d, K and the process-wide ET_KMEANS_ARGMAX setting only -- never on a rank's own shard --, so the
 // ranks of a sharded fit agree on the loop form, i.e. on the collectives they enqueue, without exchanging anything)
+extern "C" long long et_internal_kmeans_packed_fits(void) { return g_packed_fits.load(std::memory_order_relaxed); }
+
 extern "C" int et_internal_kmeans_chain_usable(int d, int K) {
     return km_dims_ok(d, K) && km_argmax_mode() == 'f' && d == 6 && K >= 3 && K <= 32 ? 1 : 0;
 }

@@ -392,8 +392,9 @@ def test_sharded_driver_on_one_gpu_matches_oracle(ops, oracle, dev):
     assert torch.equal(U_obs, ops.eigh_topk(g_obs, 6)[0]) and torch.equal(U_pred, ops.eigh_topk(g_pred, 6)[0])
 
 
-@pytest.mark.parametrize("cut,trace", [(8192, False), (20004, True), (1024, False), (10001, False), (29501, True)])
-def test_native_chained_loop_two_shards_one_gpu(ops, oracle, dev, cut, trace):
+@pytest.mark.parametrize("n,cut,trace", [(30000, 8192, False), (30000, 20004, True), (30000, 1024, False), (30000, 10001, False),
+                                         (30000, 29501, True), (560000, 280000, False)])
+def test_native_chained_loop_two_shards_one_gpu(ops, oracle, dev, n, cut, trace):
     """The library's sharded Lloyd loop (csrc/et_kmeans.hip: km_chain_run with a reduction between two launches -- what
     et_kmeans_fit_sharded runs with ncclAllReduce) on TWO shards of one GPU: two host threads, one stream each, and a
     test reduction in place of RCCL (barrier, sum of the two shards' buffers).  Exercises what a one-rank run cannot:
@@ -403,7 +404,8 @@ def test_native_chained_loop_two_shards_one_gpu(ops, oracle, dev, cut, trace):
     import threading
     from eigentrajectory_amd import _lib as L
     from eigentrajectory_amd.synth import gaussian_points_np
-    n, K, max_iter, tol = 30000, 20, 40, 1e-4
+    # (the last case: both shards big enough for the PACKED copy of the points, each with its own origin and scale)
+    K, max_iter, tol = 20, 40 if n <= 30000 else 16, 1e-4
     x = gaussian_points_np(6, n, seed=31, n_blobs=9)
     x[:, ::53] *= 40.0
     c0, _ = oracle.kmeans_init_farthest(x, K, 77)
@@ -651,6 +653,71 @@ def test_kmeans_filter_kernel_bit_exact_on_adversarial_data(ops, oracle, dev, ki
     assert np.array_equal(N_(res["labels"]), ref["labels"])
     assert np.array_equal(N_(res["centroids"]), ref["centroids"], equal_nan=True)
     np.testing.assert_array_equal(N_(res["trace"]), ref["trace"])
+
+
+def packed_case(tag, oracle):
+    """(6, n) point sets for the packed-copy path (csrc/et_kmeans.hip: packed_assign_body), n % 4 == 0, n >= 262144."""
+    from eigentrajectory_amd.synth import gaussian_points_np, synthetic_trajectories_np
+    n = 300000
+    if tag == "bench":  # what bench.py clusters: coefficients of normalised synthetic trajectories (outliers up to ~2000)
+        obs, pred = synthetic_trajectories_np(n, seed=0, min_disp=1e-3)
+        pn = oracle.normalize(obs, pred, True).reshape(n, 24).astype(np.float64)
+        _, vec = np.linalg.eigh(pn.T @ pn)
+        return np.ascontiguousarray((pn @ vec[:, ::-1][:, :6]).T.astype(np.float32)), 20
+    if tag == "blobs":
+        return gaussian_points_np(6, n, seed=5, n_blobs=20), 20
+    if tag == "offset":  # far from the origin: the reference's fp32 chain is noisy there, the packed copy is centred
+        return gaussian_points_np(6, n, seed=6, n_blobs=12) + np.float32(1000.0), 20
+    if tag == "outliers":
+        x = gaussian_points_np(6, n, seed=7, n_blobs=0)
+        x[:, ::15013] *= 1.0e4
+        return x, 20
+    if tag == "k3":
+        return gaussian_points_np(6, 262144, seed=8, n_blobs=3), 3
+    if tag == "k32":
+        return gaussian_points_np(6, n, seed=9, n_blobs=40), 32
+    if tag == "tiny":
+        return gaussian_points_np(6, n, seed=10, n_blobs=10) * np.float32(1e-12), 20, 1e-28
+    if tag == "huge":
+        return gaussian_points_np(6, n, seed=12, n_blobs=10) * np.float32(1e12), 20, 1e20
+    if tag == "lattice":  # many exact ties between similarities: the filter must hand them to the exact scan
+        return np.round(gaussian_points_np(6, n, seed=13, n_blobs=0) * 2.0).astype(np.float32), 20
+    raise KeyError(tag)
+
+
+@pytest.mark.parametrize("tag", ["bench", "blobs", "offset", "outliers", "k3", "k32", "tiny", "huge", "lattice"])
+def test_kmeans_packed_copy_equals_fp32_filter(ops, oracle, dev, tag, monkeypatch):
+    """Trace-less fits of big shards iterate on a packed copy of the points (f16 coordinates about a sample mean + a norm
+    bound, 14 B per point; exact coordinates only for the points the test cannot decide).  Labels, centroids, iteration
+    count, error and inertia must be those of the fp32 filter (and of the traced fit, which never uses the copy), bit for
+    bit; the counter says which path ran."""
+    import ctypes as C
+    from eigentrajectory_amd import _lib as L
+    fits = L.lib().et_internal_kmeans_packed_fits
+    fits.restype = C.c_longlong
+    x, K, *rest = packed_case(tag, oracle)
+    tol = rest[0] if rest else 1e-4
+    x_dev = T(x, dev)
+    c0 = ops.kmeans_init_farthest(x_dev, K, 4242 % x.shape[1])
+    before = fits()
+    res = fit_and_check_traceless(ops, x_dev, c0, 30, tol)  # traced fit == trace-less fit (packed)
+    assert fits() == before + 1
+    monkeypatch.setenv("ET_KMEANS_PACKED", "0")
+    plain = ops.kmeans_fit(x_dev, c0, 30, tol, trace=False)
+    assert fits() == before + 1
+    assert plain["n_iter"] == res["n_iter"] and torch.equal(plain["labels"], res["labels"])
+    assert np.array_equal(N_(plain["centroids"]), N_(res["centroids"]), equal_nan=True)
+
+
+def test_kmeans_packed_copy_vs_oracle(ops, oracle, dev):
+    """the packed path against the CPU oracle itself (one case: the oracle needs ~1 s per iteration at this size)"""
+    x, K = packed_case("blobs", oracle)[:2]
+    c0, _ = oracle.kmeans_init_farthest(x, K, 99)
+    ref = oracle.kmeans_fit(x, c0, 12, 1e-4)
+    res = ops.kmeans_fit(T(x, dev), T(c0, dev), 12, 1e-4, trace=False)
+    assert res["n_iter"] == ref["n_iter"]
+    assert np.array_equal(N_(res["labels"]), ref["labels"])
+    assert np.array_equal(N_(res["centroids"]), ref["centroids"])
 
 
 def test_kmeans_fit_randomized_stress_vs_oracle(ops, oracle, dev):
