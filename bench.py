@@ -134,6 +134,17 @@ def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None,
 # forces a form).  Which one ran is read off the timing record (iterations per launch).
 CHAIN_KERNEL = "et::kmeans_lloyd_chain_kernel<10, false>"
 PERSIST_KERNEL = "et::kmeans_lloyd_persist_kernel<10, false>"
+# trace-less fits of shards >= 262144 points iterate on a packed copy of the points (16 B per point instead of 24)
+PACKED_KERNEL = CHAIN_KERNEL  # (the same kernel: the packed body is a branch of it)
+
+
+def packed_fits():
+    """fits that iterated on the packed copy so far (a counter inside the library)"""
+    import ctypes
+    from eigentrajectory_amd import _lib as L
+    fn = L.lib().et_internal_kmeans_packed_fits
+    fn.restype = ctypes.c_longlong
+    return int(fn())
 
 
 def pmc_traffic(n, kernel):
@@ -484,6 +495,7 @@ def main():
         one_step(ops, obs, pred, K, args.max_iter, first_index, warm, km, [], comm)
     sw = Stage()
     timing = []
+    packed_before = packed_fits()
     barrier()
     t0 = time.perf_counter()
     iters = []
@@ -527,14 +539,16 @@ def main():
         #  x the iterations that launch runs
         alg_bytes = BYTES["kmeans_iter"] * n * its_per_launch
         achieved = alg_bytes / avg_ms / 1e6
-        dominant = PERSIST_KERNEL if its_per_launch > 1.5 else CHAIN_KERNEL
+        dominant = PERSIST_KERNEL if its_per_launch > 1.5 else (PACKED_KERNEL if packed_fits() > packed_before else CHAIN_KERNEL)
         traffic, traffic_source = pmc_traffic(n, dominant)
         # `traffic` is NOT measured in this run: it is the PMC figure of the committed rocprofv3 passes of the same
         # workload (`traffic_source`); everything else on the line is measured live
         roofline = dict(bound="hbm", kernel=dominant.replace("et::", ""), achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
                         avg_launch_ms=round(avg_ms, 5), lloyd_iterations_per_launch=round(its_per_launch, 2),
-                        algorithmic_bytes_per_launch=alg_bytes)
+                        algorithmic_bytes_per_launch=alg_bytes,
+                        points_read_as=("packed f16 rows, 14 B per point" if its_per_launch <= 1.5 and packed_fits() > packed_before
+                                        else "fp32 rows, 24 B per point"))
         out = dict(metric="trajectories/sec fit+project+reconstruct+kmeans", value=total_traj / (elapsed / args.steps),
                    unit="trajectories/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="weak", vs_baseline=None,

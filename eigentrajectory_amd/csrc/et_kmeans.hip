@@ -2714,6 +2714,10 @@ static size_t km_filter_lds_bytes(int d, int K, int threads) {
 // 12 or 16 wavefronts per CU for a shard of N points (one workgroup per CU, 256 points per wavefront pass): the
 // launch ends with its slowest wavefront, a pass costs 0.73x as much with three wavefronts per SIMD as with four.
 static int km_filter_threads(int64_t N) {
+    if (const char *e = getenv("ET_KMEANS_FILTER_THREADS")) {  // measurement aid (tools/ab_threads.sh)
+        const int t = atoi(e);
+        if (t >= 256 && t <= kFilterMaxThreads && t % 64 == 0) return t;
+    }
     int dev = 0, n_cu = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
         n_cu <= 0)
