@@ -1247,6 +1247,12 @@ __device__ __forceinline__ float fma_mix_hi(unsigned w, float b, float a) {
 constexpr int kPkQueue = 2 * kFilterSlots;  // per wavefront: point index, old label
 constexpr int kPkRow = 12;                  // floats per cluster in the label table
 
+#ifndef ET_PK_ACC_COPIES
+#define ET_PK_ACC_COPIES 4
+#endif
+constexpr int kPkAccCopies = ET_PK_ACC_COPIES;  // copies of the workgroup's accumulators in LDS (packed_drain); a power of two
+constexpr int kPkAccPitch = 228;   // int64 per copy: >= d K + K + 2 = 226 for K = 32; 456 words = 8 mod 64: eight different banks
+
 // full exact scan of `cnt` (<= 64) queued points, one per lane, on coordinates fetched from the side-by-side copy
 __device__ __forceinline__ void packed_drain(const unsigned *q, int cnt, int K, const float *sC, const float4 *__restrict__ xa,
                                              uint8_t *__restrict__ labels, long long *sAcc, int frac, int lane) {
@@ -1261,13 +1267,19 @@ __device__ __forceinline__ void packed_drain(const unsigned *q, int cnt, int K, 
     best_centroid6_drain(x, sC, K, lb, best);
     if (lb != old) {
         labels[n] = (uint8_t)lb;
-        atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + lb]), 1ull);
-        atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[d * K + old]), ~0ull);
+        // kPkAccCopies copies of the accumulators, a lane adds onto copy lane % kPkAccCopies: the points that change in
+        // one iteration move between a handful of clusters, so the 64 lanes of a drain hit a few addresses each, and LDS
+        // atomics of one instruction on the same address are executed one after the other.  Same-box rocprofv3 averages
+        // over the bench's 100 iterations: 1 copy 40.3 / 40.5 us, 2: 39.8 / 40.2, 4: 39.7 / 39.8, 8: 39.7 / 40.1 (the
+        // iterations in which 3 % of the points move gain 4 us, the quiet ones pay 0.5 us for clearing and folding)
+        long long *acc = sAcc + (lane & (kPkAccCopies - 1)) * kPkAccPitch;
+        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[d * K + lb]), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[d * K + old]), ~0ull);
 #pragma unroll
         for (int i = 0; i < d; ++i) {
             const unsigned long long f = (unsigned long long)to_fixed(x[i], frac);
-            atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[i * K + lb]), f);
-            atomicAdd(reinterpret_cast<unsigned long long *>(&sAcc[i * K + old]), 0ull - f);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&acc[i * K + lb]), f);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&acc[i * K + old]), 0ull - f);
         }
     }
 }
@@ -1303,19 +1315,19 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
     }
     const int plen = d * K + K + 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    long long *sAcc = reinterpret_cast<long long *>(smem_raw);                                 // plen
-    float *sC = reinterpret_cast<float *>(smem_raw + sizeof(long long) * ((plen + 1) & ~1));  // K * 8: exact rows (drain)
+    long long *sAcc = reinterpret_cast<long long *>(smem_raw);                                 // kPkAccCopies x kPkAccPitch
+    float *sC = reinterpret_cast<float *>(smem_raw + sizeof(long long) * kPkAccCopies * kPkAccPitch);  // K * 8: exact rows (drain)
     float *sL = sC + K * 8;                                                                    // K * kPkRow: label table
     const int lane = tx & 63, wave = tx >> 6, half = lane >> 5, col = lane & 31;
     unsigned *queue = reinterpret_cast<unsigned *>(sL + K * kPkRow) + wave * kPkQueue;
     const int frac = (int)state->frac;
     constexpr float kUp = 1.001953125f, kTiny = 1.1920928955078125e-7f;  // (1 + 2^-9) v + 2^-23 survives the rtz to f16
     const float s2 = s * s, m_up = pk.hdr->mu_norm;
-    for (int i = tx; i < plen; i += n_thr) sAcc[i] = 0;
     stage_centroids(cen, d, K, sC);
     __shared__ int sNext;
     if (tx == 0) sNext = n_wav;
-    __syncthreads();
+    __syncthreads();  // (`cen` -- the chained kernel's prologue scratch -- lies inside the accumulator copies: cleared only now)
+    for (int i = tx; i < kPkAccCopies * kPkAccPitch; i += n_thr) sAcc[i] = 0;
     // per cluster: the centred, scaled row for the old-label chain and the two threshold coefficients
     for (int j = tx; j < K; j += n_thr) {
         float qq = 0.f;
@@ -1468,6 +1480,13 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
         }
     }
     if (qn) packed_drain(queue, qn, K, sC, pk.xa, labels, sAcc, frac, lane);
+    __syncthreads();
+    for (int i = tx; i < plen; i += n_thr) {  // the copies -> copy 0
+        long long v = sAcc[i];
+#pragma unroll
+        for (int c = 1; c < kPkAccCopies; ++c) v += sAcc[c * kPkAccPitch + i];
+        sAcc[i] = v;
+    }
     __syncthreads();
     emit_partials(sAcc, plen, n_thr, nullptr, lanes, copy_mask);
 }
