@@ -221,6 +221,9 @@ int et_euc_sim_batch(const float *a, const float *b, int64_t batch, int d, int64
 
 /* number of int64 in a partials block: d*K sums (d-major), K counts, sim_sum, nan_count */
 size_t et_kmeans_partials_len(int d, int K);
+/* scratch of every k-means call on a shard of N points: ~5 B per point (labels, running best similarity) + O(d K); for
+ * d = 6, 3 <= K <= 32, N >= 262144 and N % 4 == 0 another 46 B per point: the packed copy of the points that the trace-less
+ * Lloyd iterations of et_kmeans_fit / et_kmeans_fit_sharded read instead of X (csrc/et_kmeans.hip: kmeans_pack_kernel) */
 size_t et_kmeans_workspace_bytes(int64_t N, int d, int K);
 
 /* max |x| and non-finite flag of this shard -> state->max_abs_x, state->bad_input
