@@ -1295,18 +1295,21 @@ __device__ __forceinline__ void packed_issue(const LloydPacked &pk, int64_t N, c
 }
 
 template <int NREGS>
-__device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const float *__restrict__ X, int64_t N, int K,
+__device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const float *hdr,
+                                                   const float *__restrict__ X, int64_t N, int K,
                                                    const et_kmeans_state *state, const float *cen,
                                                    uint8_t *__restrict__ labels, long long *__restrict__ lanes,
                                                    int copy_mask) {
     const unsigned tx = thread_x();  // (opaque per call: see thread_x)
     constexpr int d = 6;
     const int n_thr = (int)blockDim.x, n_wav = n_thr >> 6;
-    const float s = pk.hdr->s;
-    bool fallback = state->iter <= 0 || !state->fast_ok || !pk.hdr->ok;
+    // (hdr: the caller's copy of *pk.hdr in LDS -- mu[6], s, mu_norm, ok --, requested together with the kernel's other
+    // prologue loads: read here, it would be one more dependent round trip to memory in every launch)
+    const float s = hdr[6];
+    bool fallback = state->iter <= 0 || !state->fast_ok || __float_as_uint(hdr[8]) == 0u;
     if (!fallback) {  // every |s (c - mu)| inside the packed range?  (cen: d x K floats in LDS, the same in every workgroup)
         int bad = 0;
-        for (int e = tx; e < d * K; e += n_thr) bad |= !(fabsf((cen[e] - pk.hdr->mu[e / K]) * s) < 31.0f);
+        for (int e = tx; e < d * K; e += n_thr) bad |= !(fabsf((cen[e] - hdr[e / K]) * s) < 31.0f);
         fallback = __syncthreads_or(bad) != 0;
     }
     if (fallback) {
@@ -1322,7 +1325,7 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
     unsigned *queue = reinterpret_cast<unsigned *>(sL + K * kPkRow) + wave * kPkQueue;
     const int frac = (int)state->frac;
     constexpr float kUp = 1.001953125f, kTiny = 1.1920928955078125e-7f;  // (1 + 2^-9) v + 2^-23 survives the rtz to f16
-    const float s2 = s * s, m_up = pk.hdr->mu_norm;
+    const float s2 = s * s, m_up = hdr[7];
     stage_centroids(cen, d, K, sC);
     __shared__ int sNext;
     if (tx == 0) sNext = n_wav;
@@ -1333,7 +1336,7 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
         float qq = 0.f;
 #pragma unroll
         for (int i = 0; i < d; ++i) {
-            const float ct = sC[j * 8 + i] - pk.hdr->mu[i];
+            const float ct = sC[j * 8 + i] - hdr[i];
             qq = fmaf(ct, ct, qq);
             sL[j * kPkRow + i] = 2.0f * s * ct;
         }
@@ -1356,7 +1359,7 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
             float ct[d], qq = 0.f;
 #pragma unroll
             for (int i = 0; i < d; ++i) {
-                ct[i] = sC[j * 8 + i] - pk.hdr->mu[i];
+                ct[i] = sC[j * 8 + i] - hdr[i];
                 qq = fmaf(ct[i], ct[i], qq);
             }
 #pragma unroll
@@ -1778,6 +1781,11 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     // Everything the prologue needs from memory is requested at once -- the convergence flag, the centroids (d K <= 192
     // <= blockDim.x values), the delta table and the previous totals: one round trip, not three dependent ones.
     const int64_t done0 = ch.st_rd->done, iter0 = ch.st_rd->iter;
+    __shared__ float sPkHdr[12];
+    float pk_word = 0.f;
+    if constexpr (!SIM) {  // the packed copy's header (9 words), with the other prologue loads
+        if (ch.pk.xh && threadIdx.x < 9) pk_word = reinterpret_cast<const float *>(ch.pk.hdr)[threadIdx.x];
+    }
     constexpr int kStateWords = (int)(sizeof(et_kmeans_state) / sizeof(unsigned));
     const unsigned st_word = reinterpret_cast<const unsigned *>(ch.st_rd)[(int)threadIdx.x < kStateWords ? (int)threadIdx.x : 0];
     const float cen0 = ch.cen_rd[(int)threadIdx.x < d * K ? (int)threadIdx.x : 0];
@@ -1797,6 +1805,7 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
         return;
     }
     if ((int)threadIdx.x < d * K) sCen[threadIdx.x] = cen0;
+    if (!SIM && threadIdx.x < 9) sPkHdr[threadIdx.x] = pk_word;
     if ((int)threadIdx.x < kStateWords) reinterpret_cast<unsigned *>(&sSt)[threadIdx.x] = st_word;  // the state block, word by word
     if (has_pending) {
         fold_combine(fr, iter0 > 0, plen, sTot, ch.compact != 0);
@@ -1825,7 +1834,7 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     if (ch.vec_ok) {
         if constexpr (!SIM) {
             if (ch.pk.xh) {
-                packed_assign_body<NREGS>(ch.pk, X, N, K, &sSt, sCen, labels, ch.lanes_wr, copy_mask);
+                packed_assign_body<NREGS>(ch.pk, sPkHdr, X, N, K, &sSt, sCen, labels, ch.lanes_wr, copy_mask);
                 return;
             }
         }
@@ -2567,10 +2576,17 @@ struct KmWorkspace {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// shards the packed copy is kept for: the filter's shape (d = 6, 3 <= K <= 32) and enough points for the one-off packing
-// pass (~0.13 ms at 1e7 points) to pay within a few iterations
-constexpr int64_t kPackedMinPoints = 262144;
-static bool km_packed_shape(int64_t N, int d, int K) { return d == 6 && K >= 3 && K <= 32 && N >= kPackedMinPoints && N % 4 == 0; }
+// shards the packed copy is kept for: the filter's shape (d = 6, 3 <= K <= 32) and enough points.  Same-box A/B of the
+// bench step over shard sizes (tools/ab_packed_sizes.sh, 100 iterations): 3e5 1.41 against 1.28 ms with the fp32 filter,
+// 5e5 1.60 / 1.46, 1e6 1.85 / 1.70, 2e6 2.19 / 2.19, 4e6 2.77 / 2.90, 1e7 4.40 / 5.05 -- the packed body's longer set-up
+// (label table, accumulator copies) costs ~1.4 us per launch, the bytes it saves only count once a launch streams for longer
+constexpr int64_t kPackedMinPoints = (int64_t)1 << 21;
+static int64_t km_packed_min_points() {  // ET_KMEANS_PACKED_MIN: tests run the packed path on small shards
+    const char *e = getenv("ET_KMEANS_PACKED_MIN");
+    const long long v = e ? atoll(e) : 0;
+    return v >= 1024 ? (int64_t)v : kPackedMinPoints;
+}
+static bool km_packed_shape(int64_t N, int d, int K) { return d == 6 && K >= 3 && K <= 32 && N >= km_packed_min_points() && N % 4 == 0; }
 
 static KmWorkspace km_carve(void *base, int64_t N, int d, int K) {
     KmWorkspace w;

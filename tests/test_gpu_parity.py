@@ -394,7 +394,7 @@ def test_sharded_driver_on_one_gpu_matches_oracle(ops, oracle, dev):
 
 @pytest.mark.parametrize("n,cut,trace", [(30000, 8192, False), (30000, 20004, True), (30000, 1024, False), (30000, 10001, False),
                                          (30000, 29501, True), (560000, 280000, False)])
-def test_native_chained_loop_two_shards_one_gpu(ops, oracle, dev, n, cut, trace):
+def test_native_chained_loop_two_shards_one_gpu(ops, oracle, dev, n, cut, trace, monkeypatch):
     """The library's sharded Lloyd loop (csrc/et_kmeans.hip: km_chain_run with a reduction between two launches -- what
     et_kmeans_fit_sharded runs with ncclAllReduce) on TWO shards of one GPU: two host threads, one stream each, and a
     test reduction in place of RCCL (barrier, sum of the two shards' buffers).  Exercises what a one-rank run cannot:
@@ -405,7 +405,11 @@ def test_native_chained_loop_two_shards_one_gpu(ops, oracle, dev, n, cut, trace)
     from eigentrajectory_amd import _lib as L
     from eigentrajectory_amd.synth import gaussian_points_np
     # (the last case: both shards big enough for the PACKED copy of the points, each with its own origin and scale)
+    monkeypatch.setenv("ET_KMEANS_PACKED_MIN", "262144")
     K, max_iter, tol = 20, 40 if n <= 30000 else 16, 1e-4
+    packed_fits = L.lib().et_internal_kmeans_packed_fits
+    packed_fits.restype = C.c_longlong
+    packed_before = packed_fits()
     x = gaussian_points_np(6, n, seed=31, n_blobs=9)
     x[:, ::53] *= 40.0
     c0, _ = oracle.kmeans_init_farthest(x, K, 77)
@@ -479,6 +483,7 @@ def test_native_chained_loop_two_shards_one_gpu(ops, oracle, dev, n, cut, trace)
         t.join(timeout=120)
     assert not errors, errors
     torch.cuda.synchronize()
+    assert packed_fits() == packed_before + (2 if n > 30000 and not trace else 0)
     for r, sh in enumerate(shards):
         assert np.array_equal(N_(cens[r]), ref["centroids"]), r
         st = L.KMeansState.from_buffer_copy(sh.state.cpu().numpy().tobytes())
@@ -695,6 +700,7 @@ def test_kmeans_packed_copy_equals_fp32_filter(ops, oracle, dev, tag, monkeypatc
     from eigentrajectory_amd import _lib as L
     fits = L.lib().et_internal_kmeans_packed_fits
     fits.restype = C.c_longlong
+    monkeypatch.setenv("ET_KMEANS_PACKED_MIN", "262144")  # (the library's own threshold is 2^21 points: where the copy pays)
     x, K, *rest = packed_case(tag, oracle)
     tol = rest[0] if rest else 1e-4
     x_dev = T(x, dev)
@@ -709,12 +715,19 @@ def test_kmeans_packed_copy_equals_fp32_filter(ops, oracle, dev, tag, monkeypatc
     assert np.array_equal(N_(plain["centroids"]), N_(res["centroids"]), equal_nan=True)
 
 
-def test_kmeans_packed_copy_vs_oracle(ops, oracle, dev):
+def test_kmeans_packed_copy_vs_oracle(ops, oracle, dev, monkeypatch):
     """the packed path against the CPU oracle itself (one case: the oracle needs ~1 s per iteration at this size)"""
+    import ctypes as C
+    from eigentrajectory_amd import _lib as L
+    monkeypatch.setenv("ET_KMEANS_PACKED_MIN", "262144")
+    fits = L.lib().et_internal_kmeans_packed_fits
+    fits.restype = C.c_longlong
+    before = fits()
     x, K = packed_case("blobs", oracle)[:2]
     c0, _ = oracle.kmeans_init_farthest(x, K, 99)
     ref = oracle.kmeans_fit(x, c0, 12, 1e-4)
     res = ops.kmeans_fit(T(x, dev), T(c0, dev), 12, 1e-4, trace=False)
+    assert fits() == before + 1
     assert res["n_iter"] == ref["n_iter"]
     assert np.array_equal(N_(res["labels"]), ref["labels"])
     assert np.array_equal(N_(res["centroids"]), ref["centroids"])
