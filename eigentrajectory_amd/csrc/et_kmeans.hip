@@ -1367,7 +1367,9 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
             const float Q = sqrtf(qq) * s * 1.001f + 1e-30f, M = m_up + sqrtf(sC[j * 8 + 6]) * s * 1.001f;
             // u_j - epsR(R) = t'_j + R ebd_r + ebd_1
             const float ebd_r = fmaf(9.95e-4f, Q, fmaf(9.7e-7f, M, 4.8e-7f));
-            const float ebd_1 = fmaf(5.4e-6f * Q, Q, 4.8e-7f * Q) + fmaf(4.85e-7f * M, M, 6e-11f);
+            // (+ 2e-10: the 2^-34 of E2 and, for a cluster so close to mu that -|q|^2 + const is positive, what the
+            // round-toward-zero hi / lo pair below can fall short of it: < 2^-24 / 1024 = 5.8e-11)
+            const float ebd_1 = fmaf(5.4e-6f * Q, Q, 4.8e-7f * Q) + fmaf(4.85e-7f * M, M, 2e-10f);
             nb = fmaf(-qq, s2, ebd_1 * kUp);
             nb = fmaf(fabsf(nb), 3.814697265625e-6f, nb) + 1e-12f;  // + 2^-18 |nb|: the hi / lo pair below never rounds it down
             ebd = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(fmaf(ebd_r, kUp, kTiny), 0.f));

@@ -715,6 +715,25 @@ def test_kmeans_packed_copy_equals_fp32_filter(ops, oracle, dev, tag, monkeypatc
     assert np.array_equal(N_(plain["centroids"]), N_(res["centroids"]), equal_nan=True)
 
 
+@pytest.mark.parametrize("max_iter", [1, 2, 3, 7])
+def test_kmeans_packed_copy_short_fits(ops, oracle, dev, monkeypatch, max_iter):
+    """the first launch of a fit is the exact scan, the packed body starts with the second: fits that end after one, two,
+    three iterations, and one that converges before max_iter (well separated blobs), against the fp32 filter"""
+    from eigentrajectory_amd.synth import gaussian_points_np
+    monkeypatch.setenv("ET_KMEANS_PACKED_MIN", "262144")
+    x = gaussian_points_np(6, 262144 + 4 * 37, seed=21, n_blobs=20) * np.float32(1.0 if max_iter < 7 else 0.05)
+    if max_iter == 7:  # 20 tight blobs, centres ~ N(0, 4^2): the farthest-first start is already near the fixed point
+        x = x + gaussian_points_np(6, 1, seed=3)[:, :1] * 0.0
+    x_dev = T(x, dev)
+    c0 = ops.kmeans_init_farthest(x_dev, 20, 5)
+    tol = 1e-4 if max_iter < 7 else 1e-2
+    res = fit_and_check_traceless(ops, x_dev, c0, max_iter if max_iter < 7 else 60, tol)
+    monkeypatch.setenv("ET_KMEANS_PACKED", "0")
+    plain = ops.kmeans_fit(x_dev, c0, max_iter if max_iter < 7 else 60, tol, trace=False)
+    assert plain["n_iter"] == res["n_iter"] and plain["done"] == res["done"] and torch.equal(plain["labels"], res["labels"])
+    assert np.array_equal(N_(plain["centroids"]), N_(res["centroids"]), equal_nan=True)
+
+
 def test_kmeans_packed_copy_vs_oracle(ops, oracle, dev, monkeypatch):
     """the packed path against the CPU oracle itself (one case: the oracle needs ~1 s per iteration at this size)"""
     import ctypes as C
