@@ -431,11 +431,120 @@ __device__ __forceinline__ void emit_partials(const long long *sAcc, int plen, i
     }
 }
 
+struct PackedHeader {  // written by kmeans_pack_kernel
+    float mu[6];
+    float s;        // power of two
+    float mu_norm;  // >= s ||mu||
+    int ok;         // 0: scale out of range / non-finite sample: the fp32 filter decides
+    int pad[7];
+};
+struct LloydPacked {
+    const unsigned *xh;
+    const unsigned short *rr;
+    const float4 *xa;
+    const PackedHeader *hdr;
+    int fused;  // the exact first iteration of the fit writes the copy (default); 0: kmeans_pack_kernel did, before the loop
+};
+constexpr int kPackSamples = 1024;
+
+// where the exact first iteration of a fit (assign_body_valu<6, 4>) writes the packed copy of the points it reads anyway
+struct PackOut {
+    unsigned *xh;
+    unsigned short *rr;
+    float4 *xa;
+    float mu[6];
+    float s;
+};
+
+// mu (the mean of kPackSamples evenly spaced points, the same in every workgroup: fixed order) and the scale of the packed
+// copy; every thread of the workgroup calls (two barriers), the first kKmThreads do the work.  -> usable?
+__device__ __forceinline__ bool packed_header(const float *__restrict__ X, int64_t N, const et_kmeans_state *__restrict__ state,
+                                              PackedHeader *__restrict__ hdr, float (&mu)[6], float &s) {
+    constexpr int d = 6;
+    __shared__ double sSum[kKmThreads / 64][d];
+    __shared__ float sMu[8];
+    const unsigned tid = thread_x();
+    const int lane = (int)(tid & 63), wave = (int)(tid >> 6);
+    if (tid < kKmThreads) {
+        double acc[d] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int k = 0; k < kPackSamples / kKmThreads; ++k) {
+            const int64_t idx = ((int64_t)(tid + kKmThreads * k) * N) / kPackSamples;
+#pragma unroll
+            for (int i = 0; i < d; ++i) acc[i] += (double)X[(int64_t)i * N + idx];
+        }
+#pragma unroll
+        for (int i = 0; i < d; ++i) {
+            for (int o = 32; o > 0; o >>= 1) acc[i] += __shfl_xor(acc[i], o);
+            if (lane == 0) sSum[wave][i] = acc[i];
+        }
+    }
+    __syncthreads();
+    if (tid < d) {
+        double t = 0.0;
+        for (int w = 0; w < kKmThreads / 64; ++w) t += sSum[w][tid];
+        sMu[tid] = (float)(t / (double)kPackSamples);
+    }
+    __syncthreads();
+    double mu_max = 0.0, mu_sq = 0.0;
+#pragma unroll
+    for (int i = 0; i < d; ++i) {
+        mu[i] = sMu[i];
+        mu_max = fmax(mu_max, fabs((double)mu[i]));
+        mu_sq += (double)mu[i] * (double)mu[i];
+    }
+    const double bound = state->max_abs_x + mu_max;  // >= every |x_i - mu_i|
+    const int e = exponent_above(bound);
+    const bool ok = state->fast_ok && !state->bad_input && bound == bound && bound < 1e30 && e >= -40 && e <= 60;
+    s = ldexpf(1.0f, 4 - e);
+    if (blockIdx.x == 0 && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < d; ++i) hdr->mu[i] = mu[i];
+        hdr->s = s;
+        hdr->mu_norm = (float)(sqrt(mu_sq) * (double)s * 1.001) + 1e-30f;
+        hdr->ok = ok ? 1 : 0;
+    }
+    return ok;
+}
+
+// the packed form of the four points n .. n + 3 (x[v][i]: coordinate i of point n + v)
+__device__ __forceinline__ void pack_quad(const float (&x)[4][6], int64_t n, int64_t N, const PackOut &po) {
+    constexpr float kUp = 1.001953125f, kTiny = 1.1920928955078125e-7f;
+    unsigned hw[3][4];
+    unsigned short rh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float xc[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) xc[i] = x[q][i] - po.mu[i];
+        float an = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) an = fmaf(xc[i], xc[i], an);
+        const float rs = fmaf(__builtin_amdgcn_sqrtf(an) * po.s, kUp, kTiny);
+        const auto rp = __builtin_amdgcn_cvt_pkrtz(fmaf(rs, kUp, kTiny), 0.f);  // survives the rounding toward zero
+        rh[q] = (unsigned short)(__builtin_bit_cast(unsigned, rp) & 0xffffu);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            unsigned h;
+            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=&v"(h) : "v"(xc[2 * p]), "v"(po.s));
+            asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+&v"(h) : "v"(xc[2 * p + 1]), "v"(po.s));
+            hw[p][q] = h;
+        }
+        po.xa[2 * (n + q)] = make_float4(x[q][0], x[q][1], x[q][2], x[q][3]);
+        po.xa[2 * (n + q) + 1] = make_float4(x[q][4], x[q][5], 0.f, 0.f);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+        *reinterpret_cast<uint4 *>(po.xh + (int64_t)p * N + n) = make_uint4(hw[p][0], hw[p][1], hw[p][2], hw[p][3]);
+    *reinterpret_cast<uint2 *>(po.rr + n) =
+        make_uint2((unsigned)rh[0] | ((unsigned)rh[1] << 16), (unsigned)rh[2] | ((unsigned)rh[3] << 16));
+}
+
 template <int D, int VEC>
 __device__ __forceinline__ void assign_body_valu(
     const float *__restrict__ X, int64_t N, int d_rt, int K, const et_kmeans_state *__restrict__ state,
     const float *__restrict__ cen, const int64_t *__restrict__ given, uint8_t *__restrict__ labels,
-    long long *__restrict__ block_partials, long long *__restrict__ lanes = nullptr, int copy_mask = kAccLanes - 1) {
+    long long *__restrict__ block_partials, long long *__restrict__ lanes = nullptr, int copy_mask = kAccLanes - 1,
+    const PackOut pack = PackOut{nullptr, nullptr, nullptr, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0.f}) {
     const unsigned tx = thread_x();  // (opaque per call: see thread_x)
     const int d = D ? D : d_rt;
     const int plen = d * K + K + 2;
@@ -473,6 +582,10 @@ __device__ __forceinline__ void assign_body_valu(
                     x[3 % VEC][i] = v.w;
                 }
             if (incremental) old_packed = *reinterpret_cast<const unsigned *>(labels + n);
+            // the first iteration of a fit that will iterate on the packed copy writes it, from the rows it has just read
+            if constexpr (D == 6 && VEC == 4) {
+                if (pack.xh) pack_quad(x, n, N, pack);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < (D ? D : ET_KMEANS_MAX_D); ++i)
@@ -1128,107 +1241,31 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
 // fp32 filter for an iteration whose centroids leave the packed range (|s (c - mu)| >= 31: cannot happen for means of
 // the points, can for caller-provided initial centroids) or when the scale is out of range.
 // ------------------------------------------------------------------------------------------
-struct PackedHeader {  // written by kmeans_pack_kernel
-    float mu[6];
-    float s;        // power of two
-    float mu_norm;  // >= s ||mu||
-    int ok;         // 0: scale out of range / non-finite sample: the fp32 filter decides
-    int pad[7];
-};
-struct LloydPacked {
-    const unsigned *xh;
-    const unsigned short *rr;
-    const float4 *xa;
-    const PackedHeader *hdr;
-};
-constexpr int kPackSamples = 1024;
-
 __global__ __launch_bounds__(kKmThreads) void kmeans_pack_kernel(const float *__restrict__ X, int64_t N,
                                                                  const et_kmeans_state *__restrict__ state,
                                                                  PackedHeader *__restrict__ hdr, unsigned *__restrict__ xh,
                                                                  unsigned short *__restrict__ rr, float4 *__restrict__ xa) {
+    // (stand-alone form, ET_KMEANS_PACK_FUSED=0: by default the exact first iteration of the fit writes the copy)
     constexpr int d = 6;
-    __shared__ double sSum[kKmThreads / 64][d];
-    __shared__ float sMu[8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    {   // the same sample mean in every workgroup (fixed order: reproducible)
-        double acc[d] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        for (int k = 0; k < kPackSamples / kKmThreads; ++k) {
-            const int64_t idx = ((int64_t)(tid + kKmThreads * k) * N) / kPackSamples;
-#pragma unroll
-            for (int i = 0; i < d; ++i) acc[i] += (double)X[(int64_t)i * N + idx];
-        }
-#pragma unroll
-        for (int i = 0; i < d; ++i) {
-            for (int o = 32; o > 0; o >>= 1) acc[i] += __shfl_xor(acc[i], o);
-            if (lane == 0) sSum[wave][i] = acc[i];
-        }
-        __syncthreads();
-        if (tid < d) {
-            double t = 0.0;
-            for (int w = 0; w < kKmThreads / 64; ++w) t += sSum[w][tid];
-            sMu[tid] = (float)(t / (double)kPackSamples);
-        }
-        __syncthreads();
-    }
-    float mu[d];
-    double mu_max = 0.0, mu_sq = 0.0;
-#pragma unroll
-    for (int i = 0; i < d; ++i) {
-        mu[i] = sMu[i];
-        mu_max = fmax(mu_max, fabs((double)mu[i]));
-        mu_sq += (double)mu[i] * (double)mu[i];
-    }
-    const double bound = state->max_abs_x + mu_max;  // >= every |x_i - mu_i|
-    const int e = exponent_above(bound);
-    const bool ok = state->fast_ok && !state->bad_input && bound == bound && bound < 1e30 && e >= -40 && e <= 60;
-    const float s = ldexpf(1.0f, 4 - e);
-    if (blockIdx.x == 0 && tid == 0) {
-#pragma unroll
-        for (int i = 0; i < d; ++i) hdr->mu[i] = mu[i];
-        hdr->s = s;
-        hdr->mu_norm = (float)(sqrt(mu_sq) * (double)s * 1.001) + 1e-30f;
-        hdr->ok = ok ? 1 : 0;
-    }
-    if (!ok) return;
-    constexpr float kUp = 1.001953125f, kTiny = 1.1920928955078125e-7f;
+    PackOut po;
+    po.xh = xh;
+    po.rr = rr;
+    po.xa = xa;
+    if (!packed_header(X, N, state, hdr, po.mu, po.s)) return;
+    const int tid = threadIdx.x;
     const int64_t n_quads = N / 4;  // N % 4 == 0 (the caller's vec_ok)
     for (int64_t g = (int64_t)blockIdx.x * kKmThreads + tid; g < n_quads; g += (int64_t)gridDim.x * kKmThreads) {
         const int64_t n = 4 * g;
-        float4 v[d];
+        float x[4][d];
 #pragma unroll
-        for (int i = 0; i < d; ++i) v[i] = *reinterpret_cast<const float4 *>(X + (int64_t)i * N + n);
-        unsigned hw[3][4];
-        unsigned short rh[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float x[d], xc[d];
-#pragma unroll
-            for (int i = 0; i < d; ++i) {
-                x[i] = q == 0 ? v[i].x : (q == 1 ? v[i].y : (q == 2 ? v[i].z : v[i].w));
-                xc[i] = x[i] - mu[i];
-            }
-            float an = 0.f;
-#pragma unroll
-            for (int i = 0; i < d; ++i) an = fmaf(xc[i], xc[i], an);
-            const float rs = fmaf(__builtin_amdgcn_sqrtf(an) * s, kUp, kTiny);
-            const auto rp = __builtin_amdgcn_cvt_pkrtz(fmaf(rs, kUp, kTiny), 0.f);  // survives the rounding toward zero
-            rh[q] = (unsigned short)(__builtin_bit_cast(unsigned, rp) & 0xffffu);
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                unsigned h;
-                asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=&v"(h) : "v"(xc[2 * p]), "v"(s));
-                asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+&v"(h) : "v"(xc[2 * p + 1]), "v"(s));
-                hw[p][q] = h;
-            }
-            xa[2 * (n + q)] = make_float4(x[0], x[1], x[2], x[3]);
-            xa[2 * (n + q) + 1] = make_float4(x[4], x[5], 0.f, 0.f);
+        for (int i = 0; i < d; ++i) {
+            const float4 v = *reinterpret_cast<const float4 *>(X + (int64_t)i * N + n);
+            x[0][i] = v.x;
+            x[1][i] = v.y;
+            x[2][i] = v.z;
+            x[3][i] = v.w;
         }
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-            *reinterpret_cast<uint4 *>(xh + (int64_t)p * N + n) = make_uint4(hw[p][0], hw[p][1], hw[p][2], hw[p][3]);
-        *reinterpret_cast<uint2 *>(rr + n) =
-            make_uint2((unsigned)rh[0] | ((unsigned)rh[1] << 16), (unsigned)rh[2] | ((unsigned)rh[3] << 16));
+        pack_quad(x, n, N, po);
     }
 }
 
@@ -1305,6 +1342,18 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
     const int n_thr = (int)blockDim.x, n_wav = n_thr >> 6;
     // (hdr: the caller's copy of *pk.hdr in LDS -- mu[6], s, mu_norm, ok --, requested together with the kernel's other
     // prologue loads: read here, it would be one more dependent round trip to memory in every launch)
+    if (state->iter <= 0 && pk.fused) {
+        // the fit's first launch: the exact scan of every point -- which also writes the packed copy, from the rows it reads
+        // anyway (the scan is bound by its arithmetic, ~130 us at 1e7 points, and has the memory side to spare: a pass of
+        // its own over X, kmeans_pack_kernel, costs 175-190 us)
+        PackOut po;
+        po.xh = const_cast<unsigned *>(pk.xh);
+        po.rr = const_cast<unsigned short *>(pk.rr);
+        po.xa = const_cast<float4 *>(pk.xa);
+        if (!packed_header(X, N, state, const_cast<PackedHeader *>(pk.hdr), po.mu, po.s)) po.xh = nullptr;
+        assign_body_valu<6, 4>(X, N, d, K, state, cen, nullptr, labels, nullptr, lanes, copy_mask, po);
+        return;
+    }
     const float s = hdr[6];
     bool fallback = state->iter <= 0 || !state->fast_ok || __float_as_uint(hdr[8]) == 0u;
     if (!fallback) {  // every |s (c - mu)| inside the packed range?  (cen: d x K floats in LDS, the same in every workgroup)
@@ -2715,6 +2764,11 @@ static bool km_packed_mode() {
     const char *e = getenv("ET_KMEANS_PACKED");
     return !(e && e[0] == '0');
 }
+// ET_KMEANS_PACK_FUSED=0: the packed copy is written by a pass of its own before the loop (A/B runs)
+static bool km_pack_fused_mode() {
+    const char *e = getenv("ET_KMEANS_PACK_FUSED");
+    return !(e && e[0] == '0');
+}
 static std::atomic<long long> g_packed_fits{0};  // fits that iterated on the packed copy (tests: the path under test ran)
 
 // matrix-core filter + exact certification (default; ET_KMEANS_ARGMAX=valu disables it)
@@ -3029,13 +3083,14 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
     }
     // trace-less fits of big shards iterate on the packed copy (ET_KMEANS_PACKED=0: the fp32 filter, for A/B runs)
     const bool packed = vec_ok && !want_sim && w.pk_xh && km_packed_mode();
-    if (packed) {
+    const bool pack_fused = km_pack_fused_mode();
+    if (packed) g_packed_fits.fetch_add(1, std::memory_order_relaxed);
+    if (packed && !pack_fused) {
         const int64_t quads = N / 4;
         const int pgrid = (int)std::min<int64_t>((quads + kKmThreads - 1) / kKmThreads, 1024);
         hipLaunchKernelGGL(kmeans_pack_kernel, dim3(pgrid), dim3(kKmThreads), 0, st, X, N, (const et_kmeans_state *)state,
                            w.pk_hdr, w.pk_xh, w.pk_rr, w.pk_xa);
         ET_LAUNCH_CHECK();
-        g_packed_fits.fetch_add(1, std::memory_order_relaxed);
     }
     auto chain_for = [&](int t) {
         LloydChain ch;
@@ -3056,7 +3111,7 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
         // memory side), and it is what a sharded fit puts on the wire
         ch.compact = 1;
         ch.vec_ok = vec_ok ? 1 : 0;
-        ch.pk = packed ? LloydPacked{w.pk_xh, w.pk_rr, w.pk_xa, w.pk_hdr} : LloydPacked{nullptr, nullptr, nullptr, nullptr};
+        ch.pk = packed ? LloydPacked{w.pk_xh, w.pk_rr, w.pk_xa, w.pk_hdr, pack_fused ? 1 : 0} : LloydPacked{nullptr, nullptr, nullptr, nullptr, 0};
         return ch;
     };
     int grid = 0, launched = 0;

@@ -715,6 +715,20 @@ def test_kmeans_packed_copy_equals_fp32_filter(ops, oracle, dev, tag, monkeypatc
     assert np.array_equal(N_(plain["centroids"]), N_(res["centroids"]), equal_nan=True)
 
 
+def test_kmeans_packed_copy_written_by_its_own_pass(ops, oracle, dev, monkeypatch):
+    """ET_KMEANS_PACK_FUSED=0: the copy is written by kmeans_pack_kernel before the loop instead of by the fit's first
+    iteration -- same results"""
+    monkeypatch.setenv("ET_KMEANS_PACKED_MIN", "262144")
+    x, K = packed_case("bench", oracle)[:2]
+    x_dev = T(x, dev)
+    c0 = ops.kmeans_init_farthest(x_dev, K, 17)
+    fused = ops.kmeans_fit(x_dev, c0, 25, 1e-4, trace=False)
+    monkeypatch.setenv("ET_KMEANS_PACK_FUSED", "0")
+    own = ops.kmeans_fit(x_dev, c0, 25, 1e-4, trace=False)
+    assert own["n_iter"] == fused["n_iter"] and torch.equal(own["labels"], fused["labels"])
+    assert np.array_equal(N_(own["centroids"]), N_(fused["centroids"]), equal_nan=True)
+
+
 @pytest.mark.parametrize("max_iter", [1, 2, 3, 7])
 def test_kmeans_packed_copy_short_fits(ops, oracle, dev, monkeypatch, max_iter):
     """the first launch of a fit is the exact scan, the packed body starts with the second: fits that end after one, two,
