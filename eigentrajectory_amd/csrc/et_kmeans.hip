@@ -2313,7 +2313,8 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
                                                                       int64_t index_base,
                                                                       unsigned long long *__restrict__ block_keys,
                                                                       const unsigned long long *__restrict__ prev_keys,
-                                                                      int n_prev, float *C0_rw, unsigned char *cand) {
+                                                                      int n_prev, float *C0_rw, unsigned char *cand,
+                                                                      uint4 *__restrict__ meta, int meta_valid) {
     const int d = D ? D : d_rt;
     __shared__ float sc[ET_KMEANS_MAX_D + 1];
     __shared__ float sDelta[ET_KMEANS_MAX_CLUSTERS + 1];
@@ -2423,7 +2424,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
     unsigned long long key = ~0ull;
     float mabs = 0.f;
     // one point: full evaluation unless `skip`; returns the (possibly updated) running maximum
-    auto visit = [&](int64_t n, float b, bool skip) {
+    auto visit = [&](int64_t n, float b, bool skip, float &b_out, int &lab_out) {
         if (!skip) {
             float an = 0.f, y = 0.f;
 #pragma unroll
@@ -2441,8 +2442,10 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
                 b = y;
                 best[n] = b;
                 nearest[n] = (uint8_t)(step - 1);
+                lab_out = step - 1;
             }
         }
+        b_out = b;
         const unsigned long long k = ((unsigned long long)orderable(b) << 32) | (unsigned)(index_base + n);
         key = k < key ? k : key;
     };
@@ -2451,16 +2454,91 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
     // steps >= 2 look at four points per lane through one 16-B load of best[] and one 4-B load of nearest[]
     const bool vec = step > 1 && ((reinterpret_cast<uintptr_t>(best) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(nearest) & 3u) == 0);
     const int64_t n4 = vec ? N / 4 : 0;
-    for (int64_t g = tid; g < n4; g += stride) {
-        const float4 b4 = reinterpret_cast<const float4 *>(best)[g];
-        const unsigned l4 = reinterpret_cast<const unsigned *>(nearest)[g];
-        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+    // Steps >= 3 first look at a 16-byte summary of each tile of 256 points (the smallest key, the largest running
+    // similarity, the set of nearest centroids -- written by the step before): if the skip test holds for the tile's
+    // WORST values it holds for every point in it (E - b and the product are monotone in b, the distance bound is the
+    // smallest over the labels present), nothing in the tile changes, and its smallest key is the stored one -- the tile
+    // costs 16 bytes instead of 1280.  A wavefront owns a contiguous run of tiles; its LANES test up to 64 of them at once
+    // (one summary each: one round trip for the whole run, not one per tile), then the whole wavefront goes through the
+    // tiles that failed, point by point as before.  After a farthest-first pick almost every tile passes: the sweep of a
+    // step was 9 of its 18 us, all of it reading best[] and nearest[].
+    const int lane = (int)(threadIdx.x & 63);
+    auto sweep_tile = [&](int64_t tile) {  // the whole wavefront: four points per lane, and the tile's new summary
+        const int64_t g = tile * 64 + lane;
+        const bool act = g < n4;
+        unsigned long long tkey = ~0ull;
+        float tmax = -__int_as_float(0x7f800000);
+        unsigned tmask = 0u;
+        if (act) {
+            const float4 b4 = reinterpret_cast<const float4 *>(best)[g];
+            const unsigned l4 = reinterpret_cast<const unsigned *>(nearest)[g];
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+            const unsigned long long before = key;
+            key = ~0ull;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            // (a NaN or +inf in b, E or Delta makes the comparison false: full evaluation)
-            const float w = E - bb[v];
-            const bool skip = w >= 0.0f && sDelta[(l4 >> (8 * v)) & 0xffu] >= 4.0001f * w;
-            visit(4 * g + v, bb[v], skip);
+            for (int v = 0; v < 4; ++v) {
+                // (a NaN or +inf in b, E or Delta makes the comparison false: full evaluation)
+                const float w = E - bb[v];
+                const int lab = (int)((l4 >> (8 * v)) & 0xffu);
+                const bool skip = w >= 0.0f && sDelta[lab] >= 4.0001f * w;
+                float b_after = bb[v];
+                int lab_after = lab;
+                visit(4 * g + v, bb[v], skip, b_after, lab_after);
+                tmax = b_after != b_after ? __int_as_float(0x7f800000) : fmaxf(tmax, b_after);
+                tmask |= 1u << (lab_after & 31);
+            }
+            tkey = key;
+            key = tkey < before ? tkey : before;
+        }
+        if (meta) {
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long ok = __shfl_xor(tkey, o);
+                tkey = ok < tkey ? ok : tkey;
+                tmax = fmaxf(tmax, __shfl_xor(tmax, o));
+                tmask |= (unsigned)__shfl_xor((int)tmask, o);
+            }
+            if (lane == 0)
+                meta[tile] = make_uint4((unsigned)(tkey & 0xffffffffull), (unsigned)(tkey >> 32), __float_as_uint(tmax), tmask);
+        }
+    };
+    if (meta && vec) {
+        const int64_t n_tiles = (n4 + 63) >> 6, n_waves = (int64_t)gridDim.x * (kKmThreads / 64);
+        const int64_t per = (n_tiles + n_waves - 1) / n_waves;
+        const int64_t t_begin = ((int64_t)blockIdx.x * (kKmThreads / 64) + (threadIdx.x >> 6)) * per;
+        const int64_t t_end = t_begin + per < n_tiles ? t_begin + per : n_tiles;
+        for (int64_t tb = t_begin; tb < t_end; tb += 64) {  // (wave-uniform)
+            const int64_t mine = tb + lane;
+            bool todo_mine = mine < t_end;
+            if (meta_valid && todo_mine) {
+                const uint4 m = meta[mine];
+                const unsigned ob = m.y;  // orderable(b_min) -> b_min
+                const float b_min = __uint_as_float((ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob), b_max = __uint_as_float(m.z);
+                float dmin = __int_as_float(0x7f800000);
+                for (unsigned bits = m.w; bits; bits &= bits - 1u) dmin = fminf(dmin, sDelta[__builtin_ctz(bits)]);
+                // (a NaN anywhere makes a comparison false: the tile is looked at point by point)
+                if (m.w != 0u && E - b_max >= 0.0f && dmin >= 4.0001f * (E - b_min)) {
+                    const unsigned long long k = ((unsigned long long)m.y << 32) | m.x;
+                    key = k < key ? k : key;
+                    todo_mine = false;
+                }
+            }
+            for (unsigned long long todo = __ballot(todo_mine); todo; todo &= todo - 1ull)
+                sweep_tile(tb + __builtin_ctzll(todo));
+        }
+    } else {
+        for (int64_t g = tid; g < n4; g += stride) {
+            const float4 b4 = reinterpret_cast<const float4 *>(best)[g];
+            const unsigned l4 = reinterpret_cast<const unsigned *>(nearest)[g];
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                // (a NaN or +inf in b, E or Delta makes the comparison false: full evaluation)
+                const float w = E - bb[v];
+                const bool skip = w >= 0.0f && sDelta[(l4 >> (8 * v)) & 0xffu] >= 4.0001f * w;
+                float b_after;
+                int lab_after = 0;
+                visit(4 * g + v, bb[v], skip, b_after, lab_after);
+            }
         }
     }
     for (int64_t n = 4 * n4 + tid; n < N; n += stride) {
@@ -2471,7 +2549,9 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
             const float w = E - b;
             skip = w >= 0.0f && sDelta[(int)nearest[n]] >= 4.0001f * w;
         }
-        visit(n, b, skip);
+        float b_after;
+        int lab_after;
+        visit(n, b, skip, b_after, lab_after);
     }
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned long long other = __shfl_xor(key, o);
@@ -2609,6 +2689,7 @@ struct KmWorkspace {
     uint8_t *labels_u8;
     unsigned *ticket;        // arrival counter of the fused reduce + update kernel
     unsigned *init_maxabs;   // farthest-first: fp32 bits of max|x| of this shard (collected by step 1)
+    uint4 *init_meta;        // farthest-first: one 16-byte summary per 256 points (kmeans_init_step_kernel)
     long long *acc_lanes;    // single-GPU fit: kAccLanes copies of every total, the assignment kernel's atomics land here
     float *last;             // single-GPU fit: centroids (d*K floats) + sim_frac (int64) of the last assignment
     long long *sim_total;    // kmeans_inertia_kernel: the exact similarity sum and the non-finite count
@@ -2663,6 +2744,8 @@ static KmWorkspace km_carve(void *base, int64_t N, int d, int K) {
     off = align_up(off + sizeof(unsigned), 256);
     w.init_maxabs = (unsigned *)(p + off);
     off = align_up(off + sizeof(unsigned), 256);
+    w.init_meta = (uint4 *)(p + off);
+    off = align_up(off + sizeof(uint4) * (size_t)((N > 0 ? N : 1) / 256 + 2), 256);
     w.acc_lanes = (long long *)(p + off);
     off = align_up(off + sizeof(long long) * km_plen(d, K) * 16, 256);
     w.last = (float *)(p + off);
@@ -2762,6 +2845,11 @@ static char km_argmax_mode() {
 // ET_KMEANS_PACKED=0: trace-less fits keep the fp32 filter (read per fit: same-process A/B runs and tests)
 static bool km_packed_mode() {
     const char *e = getenv("ET_KMEANS_PACKED");
+    return !(e && e[0] == '0');
+}
+// ET_KMEANS_INIT_TILES=0: farthest-first steps look at every point's running similarity (A/B runs)
+static bool km_init_tiles_mode() {
+    const char *e = getenv("ET_KMEANS_INIT_TILES");
     return !(e && e[0] == '0');
 }
 // ET_KMEANS_PACK_FUSED=0: the packed copy is written by a pass of its own before the loop (A/B runs)
@@ -2957,12 +3045,16 @@ static int init_step_impl(const float *X, int64_t N, int d, int K, int i, const 
     unsigned long long *keys = (fused && (i & 1)) ? w.block_keys2 : w.block_keys;
     const unsigned long long *prev = (fused && i > 1) ? ((i & 1) ? w.block_keys : w.block_keys2) : nullptr;
     const int n_prev = i > 1 ? init_step_grid(N, i - 1) : 0;
+    // tile summaries: written by step 2 and every later one, used from step 3 on (K <= 32: the label set is a 32-bit mask)
+    uint4 *meta = (K <= 32 && km_init_tiles_mode()) ? w.init_meta : nullptr;
     if (d == 6)
         hipLaunchKernelGGL((kmeans_init_step_kernel<6>), dim3(grid), dim3(kKmThreads), 0, st, X, N, d, K, i, C0, best,
-                           w.labels_u8, w.init_maxabs, index_base, keys, prev, n_prev, fused, (unsigned char *)cand);
+                           w.labels_u8, w.init_maxabs, index_base, keys, prev, n_prev, fused, (unsigned char *)cand, meta,
+                           i > 2 ? 1 : 0);
     else
         hipLaunchKernelGGL((kmeans_init_step_kernel<0>), dim3(grid), dim3(kKmThreads), 0, st, X, N, d, K, i, C0, best,
-                           w.labels_u8, w.init_maxabs, index_base, keys, prev, n_prev, fused, (unsigned char *)cand);
+                           w.labels_u8, w.init_maxabs, index_base, keys, prev, n_prev, fused, (unsigned char *)cand, meta,
+                           i > 2 ? 1 : 0);
     ET_LAUNCH_CHECK();
     if (!fused || last) {
         hipLaunchKernelGGL(kmeans_init_pick_kernel, dim3(1), dim3(kKmThreads), 0, st, X, N, d, keys, grid, index_base,
