@@ -310,7 +310,10 @@ def scene_latency(dev, U_obs, U_pred, n_peds=57, reps=2000):
         model.ET_s_anchor.C_anchor.normal_()
         obs, pred = synthetic_trajectories_torch(n_peds, dev, seed=5)
         res = {}
-        for name, fn in (("evaluate", lambda: model.evaluate(obs, pred)), ("forward", lambda: model(obs))):
+        # (..._replayed: the same call captured once per scene size in a HIP graph and replayed -- model.py)
+        for name, fn in (("evaluate", lambda: model.evaluate(obs, pred)), ("forward", lambda: model(obs)),
+                         ("evaluate_replayed", lambda: model.evaluate_replayed(obs, pred)),
+                         ("forward_replayed", lambda: model.forward_replayed(obs))):
             for _ in range(50):
                 fn()
             torch.cuda.synchronize()

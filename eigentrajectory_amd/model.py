@@ -236,6 +236,65 @@ class EigenTrajectory(nn.Module):
         return ops.anchor_reconstruct_metrics(C_pred_refine.contiguous(), pred_traj, A_m, A_s, U_pred_m, U_pred_s,
                                               ops.MODE_SPLIT, sd, nrm=nrm, t_obs=obs_traj.shape[1])
 
+    # ---- replayed scene calls ---------------------------------------------------------------------------------------
+    # A scene call is four to five small launches and ~35 us of host work around them.  For loops that see the same scene
+    # sizes again and again (the reference's test loop walks the same ~70 scenes per split every epoch,
+    # utils/trainer.py:170-190) the whole call -- projection, the bridge's hooks, the predictor, reconstruction --
+    # is captured ONCE per scene size in a HIP graph (torch.cuda.CUDAGraph; the library's launches go to the capturing
+    # stream like any other kernel) and then replayed: two input copies + one graph launch per call.
+    def _graph_for(self, kind, obs_traj, pred_traj, run):
+        params = (self.ET_m_descriptor.U_obs_trunc, self.ET_m_descriptor.U_pred_trunc, self.ET_s_descriptor.U_obs_trunc,
+                  self.ET_s_descriptor.U_pred_trunc, self.ET_m_anchor.C_anchor, self.ET_s_anchor.C_anchor)
+        key = (kind, obs_traj.device.index, tuple(obs_traj.shape), None if pred_traj is None else tuple(pred_traj.shape))
+        # (calculate_parameters / load_state_dict may re-register the parameters: a graph holds raw pointers)
+        stamp = tuple(p.data_ptr() for p in params)
+        cache = self.__dict__.setdefault("_scene_graphs", {})
+        entry = cache.get(key)
+        if entry is None or entry["stamp"] != stamp:
+            dev = obs_traj.device
+            ins = [torch.empty_like(obs_traj), None if pred_traj is None else torch.empty_like(pred_traj)]
+            ins[0].copy_(obs_traj)
+            if pred_traj is not None:
+                ins[1].copy_(pred_traj)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):  # lazy initialisation (allocator pools, the predictor's own) outside the capture
+                for _ in range(2):
+                    run(*ins)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = run(*ins)
+            entry = cache[key] = dict(stamp=stamp, graph=graph, ins=ins, outs=outs)
+        return entry
+
+    @torch.no_grad()
+    def evaluate_replayed(self, obs_traj, pred_traj):
+        r""":meth:`evaluate` through a HIP graph captured per scene size.
+
+        Needs contiguous fp32 tensors on the device, a predictor and hooks that are plain tensor code (no host
+        synchronisation, no data-dependent Python control flow -- the ten bridges of the reference qualify) and no
+        ``addl_info``.  The returned tensors are the graph's own output buffers: valid until the next replayed call with
+        the same scene size (``.clone()`` to keep them)."""
+        if not (self._scene_ok(obs_traj) and self._scene_ok(pred_traj)):
+            return self.evaluate(obs_traj, pred_traj)
+        entry = self._graph_for("evaluate", obs_traj, pred_traj, lambda o, p: self.evaluate(o, p))
+        entry["ins"][0].copy_(obs_traj)
+        entry["ins"][1].copy_(pred_traj)
+        entry["graph"].replay()
+        return entry["outs"]
+
+    @torch.no_grad()
+    def forward_replayed(self, obs_traj):
+        r"""The inference form of :meth:`forward` (``pred_traj=None``) through a HIP graph captured per scene size; same
+        conditions and the same ownership of the returned ``recon_traj`` as :meth:`evaluate_replayed`."""
+        if not self._scene_ok(obs_traj):
+            return self.forward(obs_traj)
+        entry = self._graph_for("forward", obs_traj, None, lambda o, p: self.forward(o))
+        entry["ins"][0].copy_(obs_traj)
+        entry["graph"].replay()
+        return entry["outs"]
+
     def forward(self, obs_traj, pred_traj=None, addl_info=None):
         r"""One scene through projection -> predictor -> anchor refinement -> reconstruction (model.py:58-125).
 

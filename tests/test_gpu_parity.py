@@ -1647,6 +1647,44 @@ def test_kmeanspp_seed_batch_equals_single_seedings(ops, dev, n, d, K):
         assert np.array_equal(N_(c1), x[:, N_(i1)])
 
 
+def test_scene_calls_replayed_from_a_graph(dev):
+    """evaluate_replayed / forward_replayed (one HIP graph per scene size, captured on first use) return what the eager
+    calls return, for several scene sizes in turn, again after the inputs changed, and again after the parameters were
+    re-registered (calculate_parameters): the graph holds raw pointers and must be re-captured."""
+    from eigentrajectory_amd import EigenTrajectory
+    from eigentrajectory_amd.synth import synthetic_trajectories_torch
+    from eigentrajectory_amd.utils import DotDict, default_hyper_params
+
+    class Lin(torch.nn.Module):  # a predictor with weights: (k + 2, N) -> (k, N, S)
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.randn(6 * 20, 8) * 0.05)
+
+        def forward(self, x):
+            return (self.w @ x).view(6, 20, -1).permute(0, 2, 1).contiguous()
+
+    hooks = DotDict(model_forward_pre_hook=lambda c, o, a=None: torch.cat([c, o], dim=0), model_forward=lambda x, m: m(x),
+                    model_forward_post_hook=lambda y, a=None: y)
+    torch.manual_seed(0)
+    model = EigenTrajectory(Lin(), hooks, default_hyper_params(static_dist=0.3)).to(dev)
+    obs_fit, pred_fit = synthetic_trajectories_torch(4000, dev, seed=1)
+    model.calculate_parameters(obs_fit, pred_fit)
+    scenes = [synthetic_trajectories_torch(n, dev, seed=10 + n) for n in (2, 57, 13, 57, 2)]
+    for rnd in range(3):
+        for obs, pred in scenes:
+            if rnd == 1:  # other inputs of the same size: the captured graph is replayed on them
+                obs, pred = obs + 0.25, pred + 0.25
+            ade, fde = model.evaluate(obs, pred)
+            ade_r, fde_r = model.evaluate_replayed(obs, pred)
+            assert torch.equal(ade, ade_r) and torch.equal(fde, fde_r)
+            rec = model(obs)["recon_traj"]
+            assert torch.equal(rec, model.forward_replayed(obs)["recon_traj"])
+        if rnd == 1:
+            obs_fit2, pred_fit2 = synthetic_trajectories_torch(3000, dev, seed=2)
+            model.calculate_parameters(obs_fit2, pred_fit2)  # new parameter tensors
+    assert len(model._scene_graphs) == 6  # three sizes x two kinds
+
+
 @pytest.mark.parametrize("scene,n_max", [("eth", 60), ("univ", 300)])
 def test_scene_training_form_fused_equals_composite(dev, scene, n_max):
     """The training form of a wrapper call on a scene (model.py:58-125 with pred_traj; csrc/et_train.hip: projection of
