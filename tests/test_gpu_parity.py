@@ -715,6 +715,22 @@ def test_kmeans_packed_copy_equals_fp32_filter(ops, oracle, dev, tag, monkeypatc
     assert np.array_equal(N_(plain["centroids"]), N_(res["centroids"]), equal_nan=True)
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_kmeans_packed_copy_unusable_scale(ops, oracle, dev, monkeypatch, fused):
+    """magnitudes whose square leaves the fp32 range (the exact kernel decides every iteration): the packed copy reports
+    itself unusable and the fit falls back -- the traced fit, the trace-less one and the oracle agree"""
+    from eigentrajectory_amd.synth import gaussian_points_np
+    monkeypatch.setenv("ET_KMEANS_PACKED_MIN", "262144")
+    monkeypatch.setenv("ET_KMEANS_PACK_FUSED", fused)
+    x = gaussian_points_np(6, 262144, seed=33, n_blobs=6) * np.float32(1e24)
+    x_dev = T(x, dev)
+    c0 = ops.kmeans_init_farthest(x_dev, 20, 3)
+    res = fit_and_check_traceless(ops, x_dev, c0, 6, 0.0)
+    ref = oracle.kmeans_fit(x, N_(c0), 6, 0.0)
+    assert res["n_iter"] == ref["n_iter"] and np.array_equal(N_(res["labels"]), ref["labels"])
+    assert np.array_equal(N_(res["centroids"]), ref["centroids"], equal_nan=True)
+
+
 def test_kmeans_packed_copy_written_by_its_own_pass(ops, oracle, dev, monkeypatch):
     """ET_KMEANS_PACK_FUSED=0: the copy is written by kmeans_pack_kernel before the loop instead of by the fit's first
     iteration -- same results"""
