@@ -2907,6 +2907,25 @@ static int km_filter_threads(int64_t N) {
     return (double)p12 * 0.73 < (double)p16 ? kFilterMinThreads : kFilterMaxThreads;
 }
 
+// The loops of a single-GPU fit (chained / persistent kernel) on small shards: a launch of 256 x 12 wavefronts for a
+// shard that has one or two 256-point passes per CU spends its time placing wavefronts.  Same-box sweep of the bench step
+// (tools/ab_threads_sizes.sh, 100 Lloyd iterations, ms): chained 256 / 512 / 768 threads per workgroup at N = 2e4
+// 1.01 / 1.10 / 1.19, 7e4 1.07 / 1.14 / 1.23, 1e5 1.09 / 1.16 / 1.24, 2e5 1.25 / 1.20 / 1.29, 3e5 1.37 / 1.24 / 1.27,
+// 1e6 2.65 / 1.97 / 1.65 (1024: 1.69); persistent at 2e4 0.96 / 0.99 / 1.07, at 7e4 1.50 / 1.11 / 1.17.
+// -> the fewest wavefronts that still give every 256-point pass a wavefront of its own twice over.
+static int km_loop_threads(int64_t N, bool persistent) {
+    if (const char *e = getenv("ET_KMEANS_FILTER_THREADS")) {  // measurement aid
+        const int t = atoi(e);
+        if (t >= 256 && t <= kFilterMaxThreads && t % 64 == 0) return t;
+    }
+    const int n_cu = km_cu_count();
+    const int64_t groups = ceil_div(N, (int64_t)256);
+    if (persistent) return N <= 32768 ? 256 : 512;
+    for (int t = 256; t < kFilterMinThreads; t += 256)
+        if ((int64_t)n_cu * (t / 64) >= 2 * groups) return t;
+    return kFilterMinThreads;
+}
+
 static int assign_accumulate_impl(const float *X, int64_t N, int d, int K, et_kmeans_state *state,
                                   const float *centroids, const int64_t *given_labels, uint8_t *labels_u8,
                                   int64_t *partials, void *workspace, size_t workspace_bytes, hipStream_t st,
@@ -3150,7 +3169,7 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
     StateRing *ring = StateRing::get(&rc);
     if (!ring) return rc;
     const bool want_sim = trace != nullptr;
-    const int threads = km_filter_threads(N);
+    const int threads = km_loop_threads(N, false);
     const size_t plen = km_plen(d, K), lds = km_filter_lds_bytes(d, K, threads);
     // rows that allow 16-byte loads and enough points: the filter body; any other shard of a sharded fit: the exact scan,
     // one point per lane, inside the same kernel (a single-GPU fit only comes here with vec_ok)
@@ -3347,7 +3366,9 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_persist_prepare_kernel(int 
 // ~7 us + the spread of 256 workgroups' finishing times for a full grid) beats a kernel boundary only while the grid is
 // small; for a full grid the staggered start of a new launch's workgroups happens to hide the uneven pass counts that
 // the barrier exposes.  Hence: persistent up to kPersistMaxPoints, chained above; ET_KMEANS_LOOP=persist / chain forces one.
-constexpr int64_t kPersistMaxPoints = 98304;  // 32 workgroups of 12 wavefronts, one 256-point pass each
+// (round 3, later: with 256-thread workgroups the chained loop is ahead from ~3e4 points on -- the table above
+// km_loop_threads; et_kmeans_fit_batch keeps the persistent form for its side-by-side problems at any size it takes)
+constexpr int64_t kPersistMaxPoints = 32768;
 static char km_persist_mode() {  // 'a'uto, 'c'hain, 'p'ersist
     static const char mode = [] {
         const char *e = getenv("ET_KMEANS_LOOP");
@@ -3368,7 +3389,7 @@ static int km_persist_run(const float *X, int64_t N, int d, int K, int max_iter,
                           uint8_t *labels_u8, float *trace, et_kmeans_state *state, long long *partials, const KmWorkspace &w,
                           hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, bool *aborted, int *grid_out) {
     const bool want_sim = trace != nullptr;
-    const int threads = km_filter_threads(N);
+    const int threads = km_loop_threads(N, true);
     const size_t plen = km_plen(d, K), lds = km_filter_lds_bytes(d, K, threads);
     int rc = km_fat_lds_attribute();
     if (rc) return rc;
