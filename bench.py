@@ -129,7 +129,7 @@ def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None,
     return res["n_iter"]
 
 
-# the dominant kernel of the step: one launch per Lloyd iteration for shards above 98304 points (the chained kernel),
+# the dominant kernel of the step: one launch per Lloyd iteration for shards above 32768 points (the chained kernel),
 # ONE persistent launch for all iterations of a fit below that (csrc/et_kmeans.hip: km_persist_wanted; ET_KMEANS_LOOP
 # forces a form).  Which one ran is read off the timing record (iterations per launch).
 CHAIN_KERNEL = "et::kmeans_lloyd_chain_kernel<10, false>"
