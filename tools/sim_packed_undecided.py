@@ -2,12 +2,16 @@
 per Lloyd iteration, on the data bench.py clusters?  A CPU estimate in fp64 with the error terms of the kernel: the current
 fp32 filter, f16 coordinates about the origin, f16 coordinates about the mean (adopted), f16 for point AND centroid.
 Run here (no GPU): python tools/sim_packed_undecided.py [N]"""
-sys.path.insert(0, "/root/repo")
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eigentrajectory_amd.synth import synthetic_trajectories_np
 from oracle import et_oracle as O
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 400000
 obs, pred = synthetic_trajectories_np(N, seed=0, min_disp=1e-3)
-G_obs, G_pred, cnt = O.fit_gram(obs, pred, 1, 0.0, 1)[:3] if False else (None, None, None)
 # simple: normalise (sca on), SVD via numpy
 on, pn = O.normalize(obs, obs, True), O.normalize(obs, pred, True)
 M = pn.reshape(N, 24).astype(np.float64)
