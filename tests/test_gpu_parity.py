@@ -1664,9 +1664,9 @@ def test_kmeanspp_seed_batch_equals_single_seedings(ops, dev, n, d, K):
 
 
 def test_scene_calls_replayed_from_a_graph(dev):
-    """evaluate_replayed / forward_replayed (one HIP graph per scene size, captured on first use) return what the eager
-    calls return, for several scene sizes in turn, again after the inputs changed, and again after the parameters were
-    re-registered (calculate_parameters): the graph holds raw pointers and must be re-captured."""
+    """evaluate_replayed / forward_replayed (one HIP graph per device-resident scene, captured on first use) return what
+    the eager calls return, for several scenes in turn, again after their contents changed in place, and again after the
+    parameters were re-registered (calculate_parameters): the graph holds raw pointers and must be re-captured."""
     from eigentrajectory_amd import EigenTrajectory
     from eigentrajectory_amd.synth import synthetic_trajectories_torch
     from eigentrajectory_amd.utils import DotDict, default_hyper_params
@@ -1685,11 +1685,12 @@ def test_scene_calls_replayed_from_a_graph(dev):
     model = EigenTrajectory(Lin(), hooks, default_hyper_params(static_dist=0.3)).to(dev)
     obs_fit, pred_fit = synthetic_trajectories_torch(4000, dev, seed=1)
     model.calculate_parameters(obs_fit, pred_fit)
-    scenes = [synthetic_trajectories_torch(n, dev, seed=10 + n) for n in (2, 57, 13, 57, 2)]
+    scenes = [synthetic_trajectories_torch(n, dev, seed=10 + n) for n in (2, 57, 13)]
     for rnd in range(3):
         for obs, pred in scenes:
-            if rnd == 1:  # other inputs of the same size: the captured graph is replayed on them
-                obs, pred = obs + 0.25, pred + 0.25
+            if rnd == 1:  # other contents at the same addresses: the captured graph is replayed on them
+                obs.add_(0.25)
+                pred.add_(0.25)
             ade, fde = model.evaluate(obs, pred)
             ade_r, fde_r = model.evaluate_replayed(obs, pred)
             assert torch.equal(ade, ade_r) and torch.equal(fde, fde_r)
@@ -1698,7 +1699,7 @@ def test_scene_calls_replayed_from_a_graph(dev):
         if rnd == 1:
             obs_fit2, pred_fit2 = synthetic_trajectories_torch(3000, dev, seed=2)
             model.calculate_parameters(obs_fit2, pred_fit2)  # new parameter tensors
-    assert len(model._scene_graphs) == 6  # three sizes x two kinds
+    assert len(model._scene_graphs) == 6  # three scenes x two kinds
 
 
 @pytest.mark.parametrize("scene,n_max", [("eth", 60), ("univ", 300)])
