@@ -11,6 +11,11 @@ seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 big = len(sys.argv) > 3
 traceless = os.environ.get("ET_SOAK_TRACELESS") == "1"  # the trace-less fit (no per-iteration inertia) has its own certification
+import ctypes
+from eigentrajectory_amd import _lib as L
+_pf = L.lib().et_internal_kmeans_packed_fits
+_pf.restype = ctypes.c_longlong
+packed0 = _pf()  # fits that iterated on the packed copy (ET_KMEANS_PACKED_MIN=1024 ET_KMEANS_LOOP=chain ET_SOAK_TRACELESS=1: all of them)
 bad = 0
 t0 = time.time()
 for case in range(cases):
@@ -49,4 +54,4 @@ for case in range(cases):
     if not ok:
         bad += 1
         print("MISMATCH case", case, "n", n, "K", K, flush=True)
-print(f"{cases} cases, {bad} mismatches, {time.time() - t0:.0f} s")
+print(f"{cases} cases, {bad} mismatches, {_pf() - packed0} fits on the packed copy, {time.time() - t0:.0f} s")
