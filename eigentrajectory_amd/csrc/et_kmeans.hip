@@ -12,13 +12,19 @@
 //
 // Kernels of a single-GPU fit with d = 6, K <= 32 (the anchor clustering):
 //   farthest-first   kmeans_init_step_kernel        one launch per centroid; steps >= 2 skip the coordinate read of
-//                                                    points that provably keep their running maximum
-//   iteration 0      kmeans_assign_kernel body      exact scan + full accumulation (inside the filter kernel's launch)
+//                                                    points that provably keep their running maximum, steps >= 3 whole
+//                                                    tiles of 256 points on a 16-byte summary
+//   iteration 0      kmeans_assign_kernel body      exact scan + full accumulation (inside the loop kernel's launch); for
+//                                                    shards >= 2^21 points it also writes the packed copy (pack_quad)
 //   iterations >= 1  kmeans_assign_filter_kernel    f16 MFMA upper bounds + exact certification of the old label,
 //                                                    undecided points through an LDS queue; deltas leave as atomics
 //                    kmeans_lloyd_chain_kernel      ... one launch per iteration: every workgroup applies the PREVIOUS
-//                                                    iteration's update itself (fold of 16 copies of the exact totals,
-//                                                    means, error, convergence) and then assigns; no serial section
+//                                                    iteration's update itself (fold of the delta table of exact totals,
+//                                                    means, error, convergence) and then assigns; no serial section.
+//                                                    Trace-less fits of big shards: packed_assign_body, the same test on
+//                                                    an f16 copy of the points (14 B per point instead of 24)
+//                    kmeans_lloyd_persist_kernel    all iterations in one launch (grid barrier without cache fences):
+//                                                    shards <= 32768 points and the side-by-side fits of a batch
 //   after the loop   kmeans_inertia_kernel          inertia of the last assignment when no trace was requested
 // Everything else (other d / K, given labels, the sharded step API) runs the exact scan and a two-kernel fold + update.
 //
