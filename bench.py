@@ -134,7 +134,8 @@ def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None,
 # forces a form).  Which one ran is read off the timing record (iterations per launch).
 CHAIN_KERNEL = "et::kmeans_lloyd_chain_kernel<10, false>"
 PERSIST_KERNEL = "et::kmeans_lloyd_persist_kernel<10, false>"
-# trace-less fits of shards >= 262144 points iterate on a packed copy of the points (16 B per point instead of 24)
+# trace-less fits of shards >= 2^21 points iterate on a packed f16 copy of the points (14 B per point instead of 24,
+# csrc/et_kmeans.hip: kPackedMinPoints)
 PACKED_KERNEL = CHAIN_KERNEL  # (the same kernel: the packed body is a branch of it)
 
 
@@ -528,9 +529,9 @@ def main():
         pr = stages["project"]["ms"] + stages["reconstruct"]["ms"]
         stages["project+reconstruct"] = dict(ms=round(pr, 4), GBs=round(344.0 * n / pr / 1e6, 1),
                                              frac_of_peak=round(344.0 * n / pr / 1e6 / HBM_PEAK_GBS, 4))
-        # dominant kernel by time: the Lloyd assign kernel of iterations >= 1 (kmeans_assign_filter_kernel<10>),
-        # timed with HIP events recorded on the launch stream around every launch inside the timed steps
-        # (et_kmeans_fit)
+        # dominant kernel by time: the Lloyd kernel (kmeans_lloyd_chain_kernel<10,false>: one launch per iteration), timed
+        # with HIP events recorded on the launch stream around a sample of the launches inside the timed steps
+        # (et_kmeans_fit: the first launch and every 8th of the others)
         if timing and sum(c for _, c, _ in timing) > 0:
             launches = sum(c for _, c, _ in timing)
             avg_ms = sum(m for m, _, _ in timing) / launches

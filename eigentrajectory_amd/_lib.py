@@ -17,6 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ET_LIBETAMD") or os.path.join(_HERE, "libetamd.so")
 
 ET_OK = 0
+ET_ERR_BAD_DATA = 5
+ABI_VERSION = 2  # include/eigentraj.h ET_ABI_VERSION: the struct mirrors below are for this version
 MODE_STATIC, MODE_MOVING, MODE_SPLIT, MODE_IDENTITY = 0, 1, 2, 3
 MAX_T, MAX_K, KMEANS_MAX_D, KMEANS_MAX_CLUSTERS = 32, 32, 32, 255
 SCENE_MAX_N = 16384  # ET_SCENE_MAX_N
@@ -31,6 +33,8 @@ SYMBOLS = [
     "et_euc_sim", "et_euc_sim_batch", "et_kmeans_partials_len", "et_kmeans_workspace_bytes", "et_kmeans_scan", "et_kmeans_begin",
     "et_kmeans_init_step", "et_kmeans_init_set", "et_kmeans_init_select", "et_kmeans_gather_point", "et_kmeans_init_farthest",
     "et_kmeans_assign_accumulate", "et_kmeans_update", "et_kmeans_joint_done", "et_kmeans_labels_i64", "et_kmeans_fit", "et_kmeans_batch_workspace_bytes", "et_kmeans_fit_batch", "et_kmeans_predict", "et_kmeans_predict_batch",
+    "et_kmeans_reforder_workspace_bytes", "et_euc_sim_reforder", "et_kmeans_init_farthest_reforder",
+    "et_kmeans_predict_reforder", "et_kmeans_fit_reforder",
     "et_center_columns", "et_kmeanspp_workspace_bytes", "et_kmeanspp_seed", "et_kmeanspp_batch_workspace_bytes", "et_kmeanspp_seed_batch",
     "et_comm_load", "et_comm_unique_id", "et_comm_init_rank", "et_comm_destroy", "et_comm_info",
     "et_fit_gram_sharded", "et_kmeans_sharded_workspace_bytes", "et_kmeans_init_farthest_sharded", "et_kmeans_fit_sharded",
@@ -68,11 +72,14 @@ def lib():
                 f"{LIB_PATH} is missing: build the HIP kernels first (python -c 'import __graft_entry__ as g; "
                 "g.build()' or make -C eigentrajectory_amd/csrc).  eigentrajectory_amd has no CPU fallback.")
         l = C.CDLL(LIB_PATH)
+        if l.et_abi_version() != ABI_VERSION:
+            raise ETLibraryError(f"{LIB_PATH} has ABI version {l.et_abi_version()}, this binding is for {ABI_VERSION}: "
+                                 "rebuild the library (make -C eigentrajectory_amd/csrc)")
         l.et_status_string.restype = C.c_char_p
         l.et_compiled_arch.restype = C.c_char_p
         for name in ("et_fit_gram_workspace_bytes", "et_kmeans_partials_len", "et_kmeans_workspace_bytes",
                      "et_kmeanspp_workspace_bytes", "et_kmeans_sharded_workspace_bytes", "et_kmeans_batch_workspace_bytes",
-                     "et_kmeanspp_batch_workspace_bytes"):
+                     "et_kmeanspp_batch_workspace_bytes", "et_kmeans_reforder_workspace_bytes"):
             getattr(l, name).restype = C.c_size_t
         _lib = l
     return _lib
@@ -81,7 +88,7 @@ def lib():
 def check(rc: int, what: str):
     if rc != ET_OK:
         msg = lib().et_status_string(rc).decode()
-        if rc == 1:
+        if rc in (1, ET_ERR_BAD_DATA):
             raise ValueError(f"{what}: {msg}")
         raise ETLibraryError(f"{what}: {msg} (status {rc})")
 

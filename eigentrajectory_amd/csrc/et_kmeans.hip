@@ -3507,8 +3507,11 @@ extern "C" int et_internal_kmeans_chain_run(const float *X, int64_t N, int d, in
 namespace et {
 __global__ __launch_bounds__(kKmThreads) void kmeans_batch_collect_kernel(const float *cen_staged, const et_kmeans_state *st_staged,
                                                                           et_kmeans_state *st_final, int64_t ws_stride,
-                                                                          float *centroids, int dk) {
+                                                                          float *centroids, int dk, const unsigned *ctl) {
     const int64_t off = (int64_t)blockIdx.x * ws_stride;
+    // a problem whose grid barrier timed out never wrote its staged results: leave the caller's (initial) centroids and
+    // the begun state alone -- the host repeats that fit from them with the chained loop
+    if (byte_shift(ctl, off)[1] != 0u) return;
     const float *src = byte_shift(cen_staged, off);
     for (int e = threadIdx.x; e < dk; e += kKmThreads) centroids[(int64_t)blockIdx.x * dk + e] = src[e];
     constexpr int kStateWords = (int)(sizeof(et_kmeans_state) / sizeof(unsigned));
@@ -3540,14 +3543,18 @@ extern "C" int et_kmeans_fit_batch(const float *X, int64_t x_stride, int64_t N, 
     const KmWorkspace w = km_carve(workspace, N, d, K);  // problem 0's; problem b's is the same layout, b * one bytes on
     const int64_t dk = (int64_t)d * K;
     // every problem alone through et_kmeans_fit: shapes the persistent kernel does not take, or when it is switched off
+    // (NaN / Inf in one problem does not stop the others, but is reported: ET_ERR_BAD_DATA after the loop, like the
+    // side-by-side path)
     auto one_by_one = [&](int64_t from, int64_t to) -> int {
+        bool bad = false;
         for (int64_t b = from; b < to; ++b) {
             const int rc = et_kmeans_fit(X + b * x_stride, N, d, K, max_iter, tol, centroids + b * dk,
                                          labels ? labels + b * N : nullptr, nullptr,
                                          &states_host[b], nullptr, byte_shift((char *)workspace, b * (int64_t)one), one, stream);
             if (rc && rc != ET_ERR_BAD_DATA) return rc;
+            bad = bad || rc == ET_ERR_BAD_DATA;
         }
-        return ET_OK;
+        return bad ? ET_ERR_BAD_DATA : ET_OK;
     };
     bool takes = km_persist_mode() != 'c' && x_stride % 4 == 0;
     for (int64_t b = 0; takes && b < batch; ++b) takes = km_use_filter(X + b * x_stride, N, d, K, w.labels_u8);
@@ -3615,6 +3622,13 @@ extern "C" int et_kmeans_fit_batch(const float *X, int64_t x_stride, int64_t N, 
             hipLaunchKernelGGL((kmeans_lloyd_persist_kernel<16, false>), g, dim3(threads), lds, st, X + b0 * x_stride, N, K, pa,
                                byte_shift(w.labels_u8, off), tol, (float *)nullptr, max_iter);
         ET_LAUNCH_CHECK();
+        // test hook (tests/test_gpu_parity.py): ET_KMEANS_TEST_ABORT = bit mask of problems to treat as timed out
+        if (const char *env = getenv("ET_KMEANS_TEST_ABORT")) {
+            const unsigned long long mask = strtoull(env, nullptr, 0);
+            for (int64_t b = b0; b < b0 + nb; ++b)
+                if (b < 64 && (mask >> b & 1ull))
+                    ET_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(byte_shift(w.persist_ctl, b * (int64_t)one) + 1), 1, 1, st));
+        }
         // did every problem's barrier hold?  (the slots go back when this chunk has run)
         ET_HIP_TRY(hipMemcpy2DAsync(ctl.data() + 2 * b0, 2 * sizeof(unsigned), byte_shift(w.persist_ctl, off), one,
                                     2 * sizeof(unsigned), (size_t)nb, hipMemcpyDeviceToHost, st));
@@ -3623,7 +3637,8 @@ extern "C" int et_kmeans_fit_batch(const float *X, int64_t x_stride, int64_t N, 
     // results: staged centroids / state -> the caller's (B, d, K) array and the problems' state blocks; the inertia of the
     // last assignment; the labels when asked for
     hipLaunchKernelGGL(kmeans_batch_collect_kernel, dim3((unsigned)batch), dim3(kKmThreads), 0, st, (const float *)w.chain_cen[0],
-                       (const et_kmeans_state *)w.chain_state[0], w.state, (int64_t)one, centroids, (int)dk);
+                       (const et_kmeans_state *)w.chain_state[0], w.state, (int64_t)one, centroids, (int)dk,
+                       (const unsigned *)w.persist_ctl);
     {
         const size_t ilds = sizeof(float) * (size_t)K * cpitch_host(d);
         const int igrid = min(km_grid(N / 4 + 1), 1024);
@@ -3643,7 +3658,7 @@ extern "C" int et_kmeans_fit_batch(const float *X, int64_t x_stride, int64_t N, 
     for (int64_t b = 0; b < batch; ++b) {
         if (ctl[2 * b + 1] == 0u) continue;
         const int rc = one_by_one(b, b + 1);
-        if (rc) return rc;
+        if (rc && rc != ET_ERR_BAD_DATA) return rc;  // bad data: states_host[b].bad_input is set, reported below
     }
     for (int64_t b = 0; b < batch; ++b)
         if (states_host[b].bad_input) return ET_ERR_BAD_DATA;

@@ -385,6 +385,71 @@ def kmeans_predict(X, centroids, want_maxsims=True):
     return labels, maxsims
 
 
+# ------------------------------------- BatchKMeans in the reference's own summation orders (opt-in)
+def _reforder_ws(n, d, K, dev):
+    nbytes = L.lib().et_kmeans_reforder_workspace_bytes(L.i64(n), int(d), int(K))
+    if nbytes == 0:
+        raise ValueError(f"k-means dimensions out of range: d={d} (<= {L.KMEANS_MAX_D}), K={K} (<= {L.KMEANS_MAX_CLUSTERS})")
+    return torch.empty((nbytes,), device=dev, dtype=torch.uint8)
+
+
+def euc_sim_reference_order(a, b):
+    """kmeans.py:59-76 with the norms summed in torch's own order: a (d,m), b (d,n) -> (m,n), every bit the reference's."""
+    dev = L.require_device(a, b)
+    a, b = _dev_args(dev, a, b)
+    d, m = a.shape
+    n = b.shape[1]
+    y = torch.empty((m, n), device=dev)
+    L.check(L.lib().et_euc_sim_reforder(L.ptr(a), L.ptr(b), d, L.i64(m), L.i64(n), L.ptr(y), L.stream(dev)),
+            "et_euc_sim_reforder")
+    return y
+
+
+def kmeans_init_farthest_reference_order(X, K, first_index):
+    """kmeans.py:78-112 literally (euc_sim against all current centroids at every step, torch's norm orders)."""
+    dev = L.require_device(X)
+    (X,) = _dev_args(dev, X)
+    d, n = X.shape
+    ws = _reforder_ws(n, d, K, dev)
+    c0 = torch.empty((d, K), device=dev)
+    L.check(L.lib().et_kmeans_init_farthest_reforder(L.ptr(X), L.i64(n), d, int(K), L.i64(first_index), L.ptr(c0), L.ptr(ws),
+                                                     C.c_size_t(ws.numel()), L.stream(dev)), "et_kmeans_init_farthest_reforder")
+    return c0
+
+
+def kmeans_predict_reference_order(X, centroids):
+    """kmeans.py:143-158 with torch's norm orders: labels (N,) int64, maxsims (N,)."""
+    dev = L.require_device(X)
+    X, centroids = _dev_args(dev, X, centroids)
+    d, n = X.shape
+    K = centroids.shape[1]
+    ws = _reforder_ws(n, d, K, dev)
+    labels = torch.empty((n,), device=dev, dtype=torch.int64)
+    maxsims = torch.empty((n,), device=dev)
+    L.check(L.lib().et_kmeans_predict_reforder(L.ptr(X), L.i64(n), d, L.ptr(centroids), K, L.ptr(labels), L.ptr(maxsims),
+                                               L.ptr(ws), C.c_size_t(ws.numel()), L.stream(dev)), "et_kmeans_predict_reforder")
+    return labels, maxsims
+
+
+def kmeans_fit_reference_order(X, centroids, max_iter=100, tol=1e-4, trace=True):
+    """kmeans.py:228-240 with the cluster sums, norms and error in the reference's fp32 orders (single GPU, one problem).
+    Same return dict as :func:`kmeans_fit`."""
+    dev = L.require_device(X)
+    X, centroids = _dev_args(dev, X, centroids)
+    d, n = X.shape
+    K = centroids.shape[1]
+    ws = _reforder_ws(n, d, K, dev)
+    cen = centroids.clone()
+    labels = torch.empty((n,), device=dev, dtype=torch.int64)
+    trace_t = torch.zeros((max_iter, 2), device=dev) if trace else None
+    st = L.KMeansState()
+    L.check(L.lib().et_kmeans_fit_reforder(L.ptr(X), L.i64(n), d, K, int(max_iter), L.f32(tol), L.ptr(cen), L.ptr(labels),
+                                           L.ptr(trace_t), C.byref(st), L.ptr(ws), C.c_size_t(ws.numel()), L.stream(dev)),
+            "et_kmeans_fit_reforder")
+    return dict(centroids=cen, labels=labels, n_iter=int(st.iter), error=float(st.error), inertia=float(st.inertia),
+                trace=trace_t[:int(st.iter)] if trace else None, done=bool(st.done))
+
+
 # ---------------------------------------------------- sklearn-recipe anchors (anchor.py:65-71)
 def center_columns(X, rel_tol=1e-4):
     """KMeans.fit's pre-processing on a COPY of X (d,N): -> (X - mean (d,N), mean (d,), tol (1,) = rel_tol * mean(var))

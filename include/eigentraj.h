@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define ET_ABI_VERSION 1
+#define ET_ABI_VERSION 2  /* 2: et_kmeans_timing grew `iterations` (32 bytes) */
 
 #define ET_OK 0
 #define ET_ERR_INVALID_ARG 1  /* bad shape / null pointer / misaligned buffer */
@@ -222,7 +222,7 @@ int et_euc_sim_batch(const float *a, const float *b, int64_t batch, int d, int64
 /* number of int64 in a partials block: d*K sums (d-major), K counts, sim_sum, nan_count */
 size_t et_kmeans_partials_len(int d, int K);
 /* scratch of every k-means call on a shard of N points: ~5 B per point (labels, running best similarity) + O(d K); for
- * d = 6, 3 <= K <= 32, N >= 262144 and N % 4 == 0 another 46 B per point: the packed copy of the points that the trace-less
+ * d = 6, 3 <= K <= 32, N >= 2097152 (2^21) and N % 4 == 0 another 46 B per point: the packed copy of the points that the trace-less
  * Lloyd iterations of et_kmeans_fit / et_kmeans_fit_sharded read instead of X (csrc/et_kmeans.hip: kmeans_pack_kernel) */
 size_t et_kmeans_workspace_bytes(int64_t N, int d, int K);
 
@@ -316,6 +316,29 @@ size_t et_kmeans_batch_workspace_bytes(int64_t N, int d, int K, int64_t batch);
 int et_kmeans_fit_batch(const float *X, int64_t x_stride, int64_t N, int d, int K, int64_t batch, int max_iter, float tol,
                         float *centroids, int64_t *labels, et_kmeans_state *states_host, void *workspace,
                         size_t workspace_bytes, et_stream_t stream);
+
+/* ---- opt-in: BatchKMeans in the REFERENCE's own fp32 summation orders (csrc/et_kmeans_reforder.hip) ----------
+ * et_kmeans_fit sums the per-cluster coordinates exactly, which makes the result independent of launch geometry and GPU
+ * count but lets a whole run drift away from the reference's (kmeans.py:180-182 sums fp32 in ATen's cascade order; whole-run
+ * label equality with the imported reference: 96/96 runs here against 76/96 with exact sums).  These entry
+ * points restate ATen's CPU orders for kmeans.py:73-74 (norms), :180-182 (cluster sums) and :45-51 (error) literally.
+ * Single GPU, one problem, any d <= 32, K <= 255; serial where the reference's order is serial -- not a fast path.
+ * workspace: et_kmeans_reforder_workspace_bytes. */
+size_t et_kmeans_reforder_workspace_bytes(int64_t N, int d, int K);
+/* kmeans.py:59-76 with both norms in torch's order: every bit of the reference's euc_sim. a (d,m), b (d,n) -> y (m,n) */
+int et_euc_sim_reforder(const float *a, const float *b, int d, int64_t m, int64_t n, float *y, et_stream_t stream);
+/* kmeans.py:78-112, re-evaluating euc_sim against all current centroids at every step like the reference */
+int et_kmeans_init_farthest_reforder(const float *X, int64_t N, int d, int K, int64_t first_index, float *C0,
+                                     void *workspace, size_t workspace_bytes, et_stream_t stream);
+/* kmeans.py:143-158 get_labels: labels int64 (N), maxsims (N) (either may be NULL) */
+int et_kmeans_predict_reforder(const float *X, int64_t N, int d, const float *centroids, int K, int64_t *labels,
+                               float *maxsims, void *workspace, size_t workspace_bytes, et_stream_t stream);
+/* kmeans.py:228-240 from given initial centroids: centroids (d,K) in/out, labels int64 (N) or NULL, trace (max_iter,2) or
+ * NULL, *state_host: iter, done, error, inertia (the inertia is this build's fp64 sum: the reference only prints it).
+ * Synchronises the stream every iteration, like the reference (kmeans.py:239). */
+int et_kmeans_fit_reforder(const float *X, int64_t N, int d, int K, int max_iter, float tol, float *centroids,
+                           int64_t *labels, float *trace, et_kmeans_state *state_host, void *workspace,
+                           size_t workspace_bytes, et_stream_t stream);
 
 /* kmeans.py:261-272 predict: labels int64 (N); maxsims (N) optional */
 int et_kmeans_predict(const float *X, int64_t N, int d, const float *centroids, int K, int64_t *labels,

@@ -428,6 +428,67 @@ static inline float eto_sqnorm(const float *x, int64_t stride, int d)
     return s;
 }
 
+/* torch's own order for `x.pow(2).sum(dim=-2)` (kmeans.py:73-74) -- ATen's CPU sum kernel, outer reduction over the d rows
+ * of a (d, count) tensor (SumKernel.cpp, Vectorized<float> of 8 in the build container's torch 2.10.0): the columns are
+ * handled in blocks of 32 (4 vectors) whose sums run over the rows in cascade order (sequential for d < 16: what
+ * eto_sqnorm does); the count % 32 columns after the last full block go through row_sum instead: rows dealt onto 4
+ * lanes (row mod 4), the d % 4 leftover rows added to lane 0, then lanes 1, 2, 3 added to lane 0.  For d = 6:
+ * ((((s0 + s4) + s5) + s1) + s2) + s3.  |b|^2 of K = 20 centroids takes that order in every column, |a|^2 of the points
+ * only in the last N % 32.  Verified bit for bit against torch (tests/test_oracle_golden.py). */
+static float eto_cascade_f32(const float *v, int64_t stride, int64_t size)
+{
+    int lp = 0;
+    {
+        int64_t w = size - 1;
+        int l = 0;
+        while (size > 2 && w > 0) { w >>= 1; ++l; }
+        if (size <= 2) l = 1;
+        lp = l / 4 > 4 ? l / 4 : 4;
+    }
+    const int64_t step = (int64_t)1 << lp, lmask = step - 1;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int64_t i = 0;
+    while (i + step <= size) {
+        for (int64_t q = 0; q < step; ++q, ++i) acc[0] = acc[0] + v[i * stride];
+        for (int lv = 1; lv < 4; ++lv) {
+            acc[lv] = acc[lv] + acc[lv - 1];
+            acc[lv - 1] = 0.f;
+            if ((i & (lmask << (lv * lp))) != 0) break;
+        }
+    }
+    for (; i < size; ++i) acc[0] = acc[0] + v[i * stride];
+    for (int lv = 1; lv < 4; ++lv) acc[0] = acc[0] + acc[lv];
+    return acc[0];
+}
+
+static float eto_row_sum_f32(const float *v, int64_t size)
+{
+    const int64_t s4 = size / 4;
+    float lane[4];
+    for (int k = 0; k < 4; ++k) lane[k] = eto_cascade_f32(v + k, 4, s4);
+    for (int64_t i = s4 * 4; i < size; ++i) lane[0] = lane[0] + v[i];
+    for (int k = 1; k < 4; ++k) lane[0] = lane[0] + lane[k];
+    return lane[0];
+}
+
+float eto_inner_sum_f32(const float *v, int64_t size);
+
+/* |x|^2 of column `pos` of `count`: ref = 0 this build's sequential order, ref = 1 torch's (above) */
+static inline float eto_sqnorm_at(const float *x, int64_t stride, int d, int64_t pos, int64_t count, int ref)
+{
+    if (!ref) return eto_sqnorm(x, stride, d);
+    /* fewer than 8 columns (one vector): the scalar kernel, blocks of 4 columns instead of 32 */
+    const int64_t seq_cols = count < 8 ? count / 4 * 4 : count / 32 * 32;
+    float sq[64];
+    for (int i = 0; i < d; ++i) {
+        const float v = x[i * stride];
+        sq[i] = v * v;
+    }
+    /* a single column of d >= 8 rows is a CONTIGUOUS reduction for ATen: its inner-sum order */
+    if (count == 1 && d >= 8) return eto_inner_sum_f32(sq, d);
+    return pos < seq_cols ? eto_cascade_f32(sq, 1, d) : eto_row_sum_f32(sq, d);
+}
+
 static inline float eto_sim(const float *a, int64_t sa, float an, const float *b, int64_t sb, float bn, int d)
 {
     float y = 0.0f;
@@ -438,17 +499,21 @@ static inline float eto_sim(const float *a, int64_t sa, float an, const float *b
     return y;
 }
 
-int eto_euc_sim(const float *a, const float *b, int d, int64_t m, int64_t n, float *y)
+static int eto_euc_sim_impl(const float *a, const float *b, int d, int64_t m, int64_t n, float *y, int ref)
 {
+    if (d < 1 || d > 64) return ETO_EINVAL;
     for (int64_t i = 0; i < m; ++i) {
-        const float an = eto_sqnorm(a + i, m, d);
+        const float an = eto_sqnorm_at(a + i, m, d, i, m, ref);
         for (int64_t j = 0; j < n; ++j) {
-            const float bn = eto_sqnorm(b + j, n, d);
+            const float bn = eto_sqnorm_at(b + j, n, d, j, n, ref);
             y[i * n + j] = eto_sim(a + i, m, an, b + j, n, bn, d);
         }
     }
     return ETO_OK;
 }
+int eto_euc_sim(const float *a, const float *b, int d, int64_t m, int64_t n, float *y) { return eto_euc_sim_impl(a, b, d, m, n, y, 0); }
+/* ... with both norms in torch's order: every bit of the reference's euc_sim */
+int eto_euc_sim_ref(const float *a, const float *b, int d, int64_t m, int64_t n, float *y) { return eto_euc_sim_impl(a, b, d, m, n, y, 1); }
 
 /* torch.max semantics (kmeans.py:156): NaN beats everything, first index wins. */
 static inline int eto_gt_nanmax(float cand, float best)
@@ -457,13 +522,14 @@ static inline int eto_gt_nanmax(float cand, float best)
 }
 
 /* kmeans.py:143-158 get_labels: labels (int64) and maxsims for X (d,N) vs C (d,K) */
-int eto_kmeans_assign(const float *X, int64_t N, int d, const float *C, int K, int64_t *labels, float *maxsims)
+static int eto_kmeans_assign_impl(const float *X, int64_t N, int d, const float *C, int K, int64_t *labels, float *maxsims,
+                                  int ref)
 {
-    if (K < 1 || K > 255 || d < 1) return ETO_EINVAL;
+    if (K < 1 || K > 255 || d < 1 || d > 64) return ETO_EINVAL;
     float bn[256];
-    for (int j = 0; j < K; ++j) bn[j] = eto_sqnorm(C + j, K, d);
+    for (int j = 0; j < K; ++j) bn[j] = eto_sqnorm_at(C + j, K, d, j, K, ref);
     for (int64_t n = 0; n < N; ++n) {
-        const float an = eto_sqnorm(X + n, N, d);
+        const float an = eto_sqnorm_at(X + n, N, d, n, N, ref);
         float best = eto_sim(X + n, N, an, C, K, bn[0], d);
         int lb = 0;
         for (int j = 1; j < K; ++j) {
@@ -478,12 +544,20 @@ int eto_kmeans_assign(const float *X, int64_t N, int d, const float *C, int K, i
     }
     return ETO_OK;
 }
+int eto_kmeans_assign(const float *X, int64_t N, int d, const float *C, int K, int64_t *labels, float *maxsims)
+{
+    return eto_kmeans_assign_impl(X, N, d, C, K, labels, maxsims, 0);
+}
+int eto_kmeans_assign_ref(const float *X, int64_t N, int d, const float *C, int K, int64_t *labels, float *maxsims)
+{
+    return eto_kmeans_assign_impl(X, N, d, C, K, labels, maxsims, 1);
+}
 
 /* kmeans.py:78-112 kmeanspp: c_0 = X[:, first_index]; c_i = the point whose
  * max similarity to c_0..c_{i-1} is smallest (argmin: first index on ties,
  * NaN counts as smallest like torch.argmin).  index_out[i] = chosen indices. */
-int eto_kmeans_init_farthest(const float *X, int64_t N, int d, int K, int64_t first_index,
-                             float *C0 /*d,K*/, int64_t *index_out /*K or NULL*/)
+static int eto_kmeans_init_farthest_impl(const float *X, int64_t N, int d, int K, int64_t first_index,
+                                         float *C0 /*d,K*/, int64_t *index_out /*K or NULL*/, int ref)
 {
     if (N < 1 || first_index < 0 || first_index >= N) return ETO_EINVAL;
     float *best = (float *)malloc(sizeof(float) * (size_t)N);
@@ -498,13 +572,28 @@ int eto_kmeans_init_farthest(const float *X, int64_t N, int d, int K, int64_t fi
         if (index_out) index_out[i] = idx;
         if (i == K - 1) break;
         const float bn = eto_sqnorm(cb, 1, d);
+        /* reference order: the reference re-evaluates euc_sim against ALL i + 1 current centroids at every step
+         * (kmeans.py:94-96), and the order of a centroid's |b|^2 depends on its column and on the column count */
+        float bns[256];
+        if (ref)
+            for (int j = 0; j <= i; ++j) bns[j] = eto_sqnorm_at(C0 + j, K, d, j, i + 1, 1);
         int64_t arg = 0;
         float argv = 0.0f;
         for (int64_t n = 0; n < N; ++n) {
-            const float an = eto_sqnorm(X + n, N, d);
-            const float y = eto_sim(X + n, N, an, cb, 1, bn, d);
-            float b = (i == 0) ? y : best[n];
-            if (i > 0 && eto_gt_nanmax(y, b)) b = y;
+            float b;
+            if (ref) {
+                const float an = eto_sqnorm_at(X + n, N, d, n, N, 1);
+                b = eto_sim(X + n, N, an, C0, K, bns[0], d);
+                for (int j = 1; j <= i; ++j) {
+                    const float y = eto_sim(X + n, N, an, C0 + j, K, bns[j], d);
+                    if (eto_gt_nanmax(y, b)) b = y;
+                }
+            } else {
+                const float an = eto_sqnorm(X + n, N, d);
+                const float y = eto_sim(X + n, N, an, cb, 1, bn, d);
+                b = (i == 0) ? y : best[n];
+                if (i > 0 && eto_gt_nanmax(y, b)) b = y;
+            }
             best[n] = b;
             if (n == 0 || (b < argv && !isnan(argv)) || (isnan(b) && !isnan(argv))) {
                 arg = n;
@@ -515,6 +604,14 @@ int eto_kmeans_init_farthest(const float *X, int64_t N, int d, int K, int64_t fi
     }
     free(best);
     return ETO_OK;
+}
+int eto_kmeans_init_farthest(const float *X, int64_t N, int d, int K, int64_t first_index, float *C0, int64_t *index_out)
+{
+    return eto_kmeans_init_farthest_impl(X, N, d, K, first_index, C0, index_out, 0);
+}
+int eto_kmeans_init_farthest_ref(const float *X, int64_t N, int d, int K, int64_t first_index, float *C0, int64_t *index_out)
+{
+    return eto_kmeans_init_farthest_impl(X, N, d, K, first_index, C0, index_out, 1);
 }
 
 /* ---- exactly-associative fixed-point accumulation (design of this build) ----
@@ -557,17 +654,18 @@ int eto_kmeans_sim_frac_bits(double max_abs_x, double max_abs_c, int d, int64_t 
 /* One Lloyd step on a shard: labels (kmeans.py:230), then exact partial sums
  * for compute_centroids (:231) and calculate_inertia (:234).
  * sums (d,K) int64, counts (K) int64, sim_sum int64, nan_count int64. */
-int eto_kmeans_assign_accumulate(const float *X, int64_t N, int d, const float *C, int K, int frac, int sim_frac,
-                                 int64_t *labels, int64_t *sums, int64_t *counts, int64_t *sim_sum, int64_t *nan_count)
+static int eto_kmeans_assign_accumulate_impl(const float *X, int64_t N, int d, const float *C, int K, int frac, int sim_frac,
+                                             int64_t *labels, int64_t *sums, int64_t *counts, int64_t *sim_sum,
+                                             int64_t *nan_count, int ref)
 {
     if (K < 1 || K > 255 || d < 1 || d > 64) return ETO_EINVAL;
     float bn[256];
-    for (int j = 0; j < K; ++j) bn[j] = eto_sqnorm(C + j, K, d);
+    for (int j = 0; j < K; ++j) bn[j] = eto_sqnorm_at(C + j, K, d, j, K, ref);
     memset(sums, 0, sizeof(int64_t) * d * K);
     memset(counts, 0, sizeof(int64_t) * K);
     int64_t ss = 0, nn = 0;
     for (int64_t n = 0; n < N; ++n) {
-        const float an = eto_sqnorm(X + n, N, d);
+        const float an = eto_sqnorm_at(X + n, N, d, n, N, ref);
         float best = eto_sim(X + n, N, an, C, K, bn[0], d);
         int lb = 0;
         for (int j = 1; j < K; ++j) {
@@ -586,6 +684,11 @@ int eto_kmeans_assign_accumulate(const float *X, int64_t N, int d, const float *
     *sim_sum = ss;
     *nan_count = nn;
     return ETO_OK;
+}
+int eto_kmeans_assign_accumulate(const float *X, int64_t N, int d, const float *C, int K, int frac, int sim_frac,
+                                 int64_t *labels, int64_t *sums, int64_t *counts, int64_t *sim_sum, int64_t *nan_count)
+{
+    return eto_kmeans_assign_accumulate_impl(X, N, d, C, K, frac, sim_frac, labels, sums, counts, sim_sum, nan_count, 0);
 }
 
 /* kmeans.py:45-51 sums the d K squared differences with torch's fp32 reduction.  The summation ORDER is this build's own
@@ -667,6 +770,150 @@ int eto_kmeans_fit(const float *X, int64_t N, int d, int K, const float *C_init,
         int64_t ss, nn;
         eto_kmeans_assign_accumulate(X, N, d, cur, K, frac, sfrac, labels, sums, counts, &ss, &nn);
         eto_kmeans_update(sums, counts, ss, nn, N, d, K, frac, sfrac, tol, cur, nxt, &err, &ine, &done);
+        memcpy(cur, nxt, sizeof(float) * d * K);
+        if (trace) {
+            trace[2 * it] = err;
+            trace[2 * it + 1] = ine;
+        }
+        if (done) {
+            ++it;
+            break;
+        }
+    }
+    memcpy(centroids, cur, sizeof(float) * d * K);
+    *n_iter = it;
+    *error = err;
+    *inertia = ine;
+    free(sums);
+    free(cur);
+    return ETO_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* kmeans.py:180-182 in the REFERENCE's summation order ("reference-order" sums) */
+/* ------------------------------------------------------------------------- */
+/* `(data.unsqueeze(-1) * mask.unsqueeze(-3)).sum(dim=-2)` reduces a (d, N, K) fp32 tensor over N with ATen's CPU sum
+ * kernel (aten/src/ATen/native/cpu/SumKernel.cpp; third-party, not under /root/reference; torch 2.10.0 in the build
+ * container): every output column (t, j) is the "cascade sum" of its N terms  x[t,n]·[label_n == j]:
+ *   row_sum:        the terms are dealt round-robin onto 4 lanes (n mod 4; the N mod 4 leftover terms are added to
+ *                   lane 0 afterwards, then lanes 1, 2, 3 are added to lane 0 in that order);
+ *   multi_row_sum:  per lane a 4-level cascade over its size = N/4 terms with level_step = 2^max(4, ceil_log2(size)/4):
+ *                   acc0 sums level_step consecutive terms and is dumped into acc1; acc1 into acc2 every level_step
+ *                   dumps; acc2 into acc3 likewise; leftover terms go to acc0; result ((acc0 + acc1) + acc2) + acc3.
+ * The order per column does not depend on the vector width or the thread count (threads split the output columns, never
+ * the reduced dimension).  Pinned bit for bit against torch on random inputs by tests/test_oracle_golden.py
+ * (test_reforder_sums_equal_torch) and through whole BatchKMeans runs by the G7c fixture.
+ * A term that is not a member contributes x·0 = ±0, which leaves a running fp32 sum that started at +0 unchanged, so
+ * only members are added. */
+static int eto_ceil_log2(int64_t x)
+{
+    if (x <= 2) return 1;
+    int l = 0;
+    int64_t v = x - 1;
+    while (v > 0) { v >>= 1; ++l; }
+    return l;
+}
+
+static float eto_cascade_lane(const float *x, const int64_t *labels, int j, int64_t size, int lane)
+{
+    const int lp_raw = eto_ceil_log2(size) / 4;
+    const int lp = lp_raw > 4 ? lp_raw : 4;
+    const int64_t step = (int64_t)1 << lp, lmask = step - 1;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int64_t i = 0;
+    while (i + step <= size) {
+        for (int64_t q = 0; q < step; ++q, ++i) {
+            const int64_t n = 4 * i + lane;
+            if (labels[n] == j) acc[0] = acc[0] + x[n];
+        }
+        for (int lv = 1; lv < 4; ++lv) {
+            acc[lv] = acc[lv] + acc[lv - 1];
+            acc[lv - 1] = 0.f;
+            if ((i & (lmask << (lv * lp))) != 0) break;
+        }
+    }
+    for (; i < size; ++i) {
+        const int64_t n = 4 * i + lane;
+        if (labels[n] == j) acc[0] = acc[0] + x[n];
+    }
+    for (int lv = 1; lv < 4; ++lv) acc[0] = acc[0] + acc[lv];
+    return acc[0];
+}
+
+/* sums (d,K) fp32 of the members of every cluster, in the reference's order */
+int eto_kmeans_reforder_sums(const float *X, int64_t N, int d, int K, const int64_t *labels, float *sums)
+{
+    if (K < 1 || K > 255 || d < 1 || d > 64 || N < 0) return ETO_EINVAL;
+    const int64_t size = N / 4;
+    for (int t = 0; t < d; ++t)
+        for (int j = 0; j < K; ++j) {
+            const float *x = X + (int64_t)t * N;
+            float lane[4];
+            for (int k = 0; k < 4; ++k) lane[k] = eto_cascade_lane(x, labels, j, size, k);
+            for (int64_t n = size * 4; n < N; ++n)
+                if (labels[n] == j) lane[0] = lane[0] + x[n];
+            for (int k = 1; k < 4; ++k) lane[0] = lane[0] + lane[k];
+            sums[t * K + j] = lane[0];
+        }
+    return ETO_OK;
+}
+
+/* `diff.sum()` of kmeans.py:50 on the contiguous d K squared differences -- ATen's inner (contiguous) reduction: the
+ * first size / 8 * 8 values as 8-float vectors through row_sum (lane-wise), the rest added to a scalar that starts at 0,
+ * then the 8 lanes of the vector sum added to it in lane order.  Verified bit for bit against torch. */
+float eto_inner_sum_f32(const float *v, int64_t size)
+{
+    if (size < 8) return eto_row_sum_f32(v, size); /* less than one vector: the scalar kernel's row_sum */
+    const int64_t nv = size / 8;
+    float lanes[8];
+    for (int l = 0; l < 8; ++l) {
+        /* row_sum over nv vectors for lane l: vectors dealt onto 4 ilp slots */
+        const int64_t s4 = nv / 4;
+        float slot[4];
+        for (int k = 0; k < 4; ++k) slot[k] = eto_cascade_f32(v + 8 * k + l, 32, s4);
+        for (int64_t i = s4 * 4; i < nv; ++i) slot[0] = slot[0] + v[8 * i + l];
+        for (int k = 1; k < 4; ++k) slot[0] = slot[0] + slot[k];
+        lanes[l] = slot[0];
+    }
+    float acc = 0.f;
+    for (int64_t i = nv * 8; i < size; ++i) acc = acc + v[i];
+    for (int l = 0; l < 8; ++l) acc = acc + lanes[l];
+    return acc;
+}
+
+/* kmeans.py:200-259 like eto_kmeans_fit, with the centroids of kmeans.py:180-182 formed as the reference forms them:
+ * fp32 cascade sum / (float)count (0/0 = NaN for an empty cluster), the norms inside euc_sim in torch's order
+ * (eto_sqnorm_at) and the error of kmeans.py:45-51 in torch's order (eto_inner_sum_f32).  The inertia (only printed by
+ * the reference) stays this build's exact sum. */
+int eto_kmeans_fit_reforder(const float *X, int64_t N, int d, int K, const float *C_init, int max_iter, float tol,
+                            float *centroids, int64_t *labels, int *n_iter, float *error, float *inertia, float *trace)
+{
+    if (K < 1 || K > 255 || d < 1 || d > 64 || N < 1) return ETO_EINVAL;
+    int64_t *sums = (int64_t *)malloc(sizeof(int64_t) * (d * K + K));
+    int64_t *counts = sums + d * K;
+    float *cur = (float *)malloc(sizeof(float) * d * K * 4);
+    float *nxt = cur + d * K, *fs = cur + 2 * d * K, *sq = cur + 3 * d * K;
+    memcpy(cur, C_init, sizeof(float) * d * K);
+    int bad = 0;
+    const double mx = eto_max_abs(X, (int64_t)d * N, &bad);
+    if (bad) { free(sums); free(cur); return ETO_EINVAL; }
+    const int frac = eto_kmeans_frac_bits(mx, N);
+    int it = 0, done = 0;
+    float err = 0.0f, ine = 0.0f;
+    for (it = 0; it < max_iter; ++it) {
+        const int sfrac = eto_kmeans_sim_frac_bits(mx, eto_max_abs(cur, d * K, NULL), d, N);
+        int64_t ss, nn;
+        eto_kmeans_assign_accumulate_impl(X, N, d, cur, K, frac, sfrac, labels, sums, counts, &ss, &nn, 1);
+        eto_kmeans_reforder_sums(X, N, d, K, labels, fs);
+        for (int e = 0; e < d * K; ++e) {
+            const float c = fs[e] / (float)counts[e % K];
+            nxt[e] = c;
+            const float diff = cur[e] - c;
+            sq[e] = diff * diff;
+        }
+        err = eto_inner_sum_f32(sq, d * K);
+        ine = nn > 0 ? NAN : (float)(-(ldexp((double)ss, -sfrac) / (double)N));
+        done = (err <= tol) ? 1 : 0;
         memcpy(cur, nxt, sizeof(float) * d * K);
         if (trace) {
             trace[2 * it] = err;

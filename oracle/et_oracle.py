@@ -155,32 +155,45 @@ def eigh_topk(G, k):
 
 
 # --------------------------------------------------------------- BatchKMeans
-def euc_sim(a, b):
+def _ref(name, reference_order):
+    return getattr(lib(), name + ("_ref" if reference_order else ""))
+
+
+def inner_sum(v):
+    """torch's fp32 order for a contiguous full reduction (kmeans.py:50 ``diff.sum()``)."""
+    v = _f32(v).ravel()
+    f = lib().eto_inner_sum_f32
+    f.restype = C.c_float
+    return float(f(_p(v, _f32p), C.c_int64(v.size)))
+
+
+def euc_sim(a, b, reference_order=False):
     a, b = _f32(a), _f32(b)
     d, m = a.shape
     n = b.shape[1]
     y = np.empty((m, n), np.float32)
-    _check(lib().eto_euc_sim(_p(a, _f32p), _p(b, _f32p), d, C.c_int64(m), C.c_int64(n), _p(y, _f32p)), "euc_sim")
+    _check(_ref("eto_euc_sim", reference_order)(_p(a, _f32p), _p(b, _f32p), d, C.c_int64(m), C.c_int64(n), _p(y, _f32p)),
+           "euc_sim")
     return y
 
 
-def kmeans_assign(X, Cn):
+def kmeans_assign(X, Cn, reference_order=False):
     X, Cn = _f32(X), _f32(Cn)
     d, n = X.shape
     labels = np.empty((n,), np.int64)
     maxsims = np.empty((n,), np.float32)
-    _check(lib().eto_kmeans_assign(_p(X, _f32p), C.c_int64(n), d, _p(Cn, _f32p), Cn.shape[1], _p(labels, _i64p),
-                                   _p(maxsims, _f32p)), "kmeans_assign")
+    _check(_ref("eto_kmeans_assign", reference_order)(_p(X, _f32p), C.c_int64(n), d, _p(Cn, _f32p), Cn.shape[1],
+                                                      _p(labels, _i64p), _p(maxsims, _f32p)), "kmeans_assign")
     return labels, maxsims
 
 
-def kmeans_init_farthest(X, K, first_index):
+def kmeans_init_farthest(X, K, first_index, reference_order=False):
     X = _f32(X)
     d, n = X.shape
     c0 = np.empty((d, K), np.float32)
     idx = np.empty((K,), np.int64)
-    _check(lib().eto_kmeans_init_farthest(_p(X, _f32p), C.c_int64(n), d, K, C.c_int64(first_index), _p(c0, _f32p),
-                                          _p(idx, _i64p)), "kmeans_init_farthest")
+    _check(_ref("eto_kmeans_init_farthest", reference_order)(_p(X, _f32p), C.c_int64(n), d, K, C.c_int64(first_index),
+                                                             _p(c0, _f32p), _p(idx, _i64p)), "kmeans_init_farthest")
     return c0, idx
 
 
@@ -225,8 +238,22 @@ def kmeans_update(sums, counts, sim_sum, nan_count, n_total, frac, sim_frac, tol
     return C_new, err.value, ine.value, bool(done.value)
 
 
-def kmeans_fit(X, C_init, max_iter=100, tol=1e-4):
-    """-> dict(centroids (d,K), labels (N,) int64, n_iter, error, inertia, trace (n_iter,2))."""
+def kmeans_reforder_sums(X, labels, K):
+    """Per-cluster member sums (d,K) fp32 in the reference's (ATen cascade) summation order, kmeans.py:180-182."""
+    X = _f32(X)
+    labels = np.ascontiguousarray(labels, np.int64)
+    d, n = X.shape
+    sums = np.empty((d, K), np.float32)
+    _check(lib().eto_kmeans_reforder_sums(_p(X, _f32p), C.c_int64(n), d, int(K), _p(labels, _i64p), _p(sums, _f32p)),
+           "kmeans_reforder_sums")
+    return sums
+
+
+def kmeans_fit(X, C_init, max_iter=100, tol=1e-4, sums="exact"):
+    """-> dict(centroids (d,K), labels (N,) int64, n_iter, error, inertia, trace (n_iter,2)).
+    ``sums="reference-order"``: cluster sums in the reference's fp32 summation order instead of exactly."""
+    if sums not in ("exact", "reference-order"):
+        raise ValueError(sums)
     X, C_init = _f32(X), _f32(C_init)
     d, n = X.shape
     K = C_init.shape[1]
@@ -234,9 +261,9 @@ def kmeans_fit(X, C_init, max_iter=100, tol=1e-4):
     labels = np.empty((n,), np.int64)
     trace = np.zeros((max_iter, 2), np.float32)
     it, err, ine = C.c_int(0), C.c_float(0), C.c_float(0)
-    _check(lib().eto_kmeans_fit(_p(X, _f32p), C.c_int64(n), d, K, _p(C_init, _f32p), int(max_iter), C.c_float(tol),
-                                _p(cen, _f32p), _p(labels, _i64p), C.byref(it), C.byref(err), C.byref(ine),
-                                _p(trace, _f32p)), "kmeans_fit")
+    fn = lib().eto_kmeans_fit if sums == "exact" else lib().eto_kmeans_fit_reforder
+    _check(fn(_p(X, _f32p), C.c_int64(n), d, K, _p(C_init, _f32p), int(max_iter), C.c_float(tol), _p(cen, _f32p),
+              _p(labels, _i64p), C.byref(it), C.byref(err), C.byref(ine), _p(trace, _f32p)), "kmeans_fit")
     return dict(centroids=cen, labels=labels, n_iter=it.value, error=err.value, inertia=ine.value,
                 trace=trace[:it.value].copy())
 

@@ -1758,3 +1758,117 @@ def test_scene_training_form_fused_equals_composite(dev, scene, n_max):
         (out["recon_traj"].square().mean() + out["loss_euclidean_fde"]).backward()
         got.append(model.baseline_model.b.grad.clone())
     close(N_(got[0]), N_(got[1]), tol=2e-5)
+
+
+# ------------------------------------------------ BatchKMeans in the reference's summation orders (opt-in mode)
+@pytest.mark.parametrize("n", [1000, 10000, 100000])
+def test_reference_order_kmeans_g7c(ops, dev, n):
+    """Whole runs of the imported reference's BatchKMeans (tests/golden/g7c: 32 data sets per size, farthest-first seeding +
+    <= 100 Lloyd iterations).  `sums="reference-order"`: the product ends EVERY run with the reference's initial centroids,
+    labels, iteration count and final centroid bits.  Default (exact sums): same initial centroids; the whole-run
+    equality rate is what it is -- 32/32, 31/32, 13/32 -- and is asserted so that it cannot drift unnoticed."""
+    import hashlib
+    from eigentrajectory_amd.synth import gaussian_points_np
+    z = G.load("g7c_batchkmeans_seeds.npz")
+    equal_exact = 0
+    for seed in z["seeds"]:
+        tag = f"n{n}.s{int(seed)}"
+        x = T(gaussian_points_np(6, n, seed=int(seed), n_blobs=int(z[f"{tag}.blobs"])), dev)
+        first = int(z[f"{tag}.first_index"])
+        c0 = ops.kmeans_init_farthest_reference_order(x, 20, first)
+        assert np.array_equal(N_(c0), z[f"{tag}.c0"]), tag
+        assert torch.equal(ops.kmeans_init_farthest(x, 20, first), c0)
+        r = ops.kmeans_fit_reference_order(x, c0, 100, 1e-4)
+        lab = N_(r["labels"]).astype(np.uint8)
+        assert r["n_iter"] == int(z[f"{tag}.n_iter"]), tag
+        assert hashlib.sha256(lab.tobytes()).digest() == bytes(z[f"{tag}.labels_sha256"]), tag
+        assert np.array_equal(N_(r["centroids"]), z[f"{tag}.centroids"]), tag
+        assert N_(r["trace"])[-1, 0] == np.float32(z[f"{tag}.final_error_inertia"][0])
+        np.testing.assert_allclose(r["inertia"], z[f"{tag}.final_error_inertia"][1], rtol=1e-5)
+        e = ops.kmeans_fit(x, c0, 100, 1e-4, trace=False)
+        equal_exact += (e["n_iter"] == int(z[f"{tag}.n_iter"]) and
+                        hashlib.sha256(N_(e["labels"]).astype(np.uint8).tobytes()).digest() == bytes(z[f"{tag}.labels_sha256"]))
+    assert equal_exact == {1000: 32, 10000: 31, 100000: 13}[n]
+
+
+@pytest.mark.parametrize("n,d,K", [(1, 6, 1), (5, 6, 3), (37, 6, 7), (1003, 6, 20), (4099, 6, 33), (20000, 6, 20), (777, 9, 5),
+                                   (3001, 17, 40), (64, 32, 255)])
+def test_reference_order_ops_vs_oracle(ops, oracle, dev, n, d, K):
+    """euc_sim / predict / farthest-first / fit of the reference-order mode against the oracle's restatement (itself pinned
+    against torch, tests/test_oracle_golden.py::test_reforder_arithmetic_equals_torch): every bit, any d, K, N -- the
+    order of a norm depends on the column's position, so odd sizes are the point."""
+    rng = np.random.RandomState(n + d + K)
+    x = (rng.standard_normal((d, n)) * 2 + 0.5).astype(np.float32)
+    x[:, ::13] *= 7.0
+    Kc = min(K, n)
+    first = int(rng.randint(n))
+    c0_ref, _ = oracle.kmeans_init_farthest(x, Kc, first, reference_order=True)
+    X = T(x, dev)
+    c0 = ops.kmeans_init_farthest_reference_order(X, Kc, first)
+    assert np.array_equal(N_(c0), c0_ref)
+    assert np.array_equal(N_(ops.euc_sim_reference_order(X, c0)), oracle.euc_sim(x, c0_ref, reference_order=True))
+    lab_ref, ms_ref = oracle.kmeans_assign(x, c0_ref, reference_order=True)
+    lab, ms = ops.kmeans_predict_reference_order(X, c0)
+    assert np.array_equal(N_(lab), lab_ref) and np.array_equal(N_(ms), ms_ref)
+    ref = oracle.kmeans_fit(x, c0_ref, 30, 1e-4, sums="reference-order")
+    res = ops.kmeans_fit_reference_order(X, c0, 30, 1e-4)
+    assert res["n_iter"] == ref["n_iter"]
+    assert np.array_equal(N_(res["labels"]), ref["labels"])
+    assert np.array_equal(N_(res["centroids"]), ref["centroids"], equal_nan=True)
+    assert np.array_equal(N_(res["trace"])[:, 0], ref["trace"][:, 0], equal_nan=True)
+    np.testing.assert_allclose(N_(res["trace"])[:, 1], ref["trace"][:, 1], rtol=1e-5, equal_nan=True)
+
+
+def test_reference_order_batchkmeans_module_gauss10000(dev):
+    """The G7 case the exact-sum fit does not reproduce (another local optimum): BatchKMeans(sums="reference-order") ends
+    with the reference's labels and centroid bits; the class draws its first centroid where the reference does."""
+    from eigentrajectory_amd import BatchKMeans
+    from eigentrajectory_amd.synth import gaussian_points_np
+    z = G.load("g7_batchkmeans.npz")
+    x = T(gaussian_points_np(6, 10000, seed=11, n_blobs=0), dev)[None].contiguous()
+    km = BatchKMeans(n_clusters=20, max_iter=100, tol=1e-4, sums="reference-order")
+    km.rng = np.random.RandomState(0)
+    labels = km.fit(x)
+    assert np.array_equal(N_(labels[0]), z["gauss10000.labels"].astype(np.int64))
+    assert np.array_equal(N_(km.centroids[0]), z["gauss10000.centroids"])
+    assert km.n_iter_ == [len(z["gauss10000.trace"])]
+    ql = km.predict(T(gaussian_points_np(6, 512, seed=12, n_blobs=0), dev)[None].contiguous())
+    assert np.array_equal(N_(ql[0]), z["gauss10000.query_labels"].astype(np.int64))
+    with pytest.raises(NotImplementedError):
+        km.fit(torch.cat([x, x], dim=0).contiguous())
+    with pytest.raises(ValueError):
+        BatchKMeans(n_clusters=20, sums="fast")
+
+
+# ------------------------------------------------ et_kmeans_fit_batch: a problem whose grid barrier timed out
+def test_kmeans_fit_batch_aborted_problem_is_refitted_from_its_initial_centroids(ops, dev, monkeypatch):
+    """a problem of the side-by-side persistent launch whose barrier timed out never wrote its staged
+    results; the collect step must leave the caller's initial centroids alone so that the chained refit starts from
+    them.  ET_KMEANS_TEST_ABORT marks problems as timed out after the launch: the results must not change."""
+    from eigentrajectory_amd.synth import gaussian_points_np
+    n, K, B = 20000, 20, 5
+    x = gaussian_points_np(6, n, seed=71, n_blobs=6)
+    rng = np.random.RandomState(5)
+    c0 = np.stack([x[:, rng.choice(n, K, replace=False)] for _ in range(B)])
+    X, C0 = T(x, dev), T(c0, dev)
+    want = ops.kmeans_fit_batch(X, C0, 60, 1e-4, want_labels=True)
+    assert len(set(want["n_iter"])) > 1  # the problems do differ
+    monkeypatch.setenv("ET_KMEANS_TEST_ABORT", "0x0a")  # problems 1 and 3
+    got = ops.kmeans_fit_batch(X, C0, 60, 1e-4, want_labels=True)
+    assert got["n_iter"] == want["n_iter"] and got["done"] == want["done"]
+    assert torch.equal(got["centroids"], want["centroids"]) and torch.equal(got["labels"], want["labels"])
+    assert got["error"] == want["error"] and got["inertia"] == want["inertia"]
+
+
+@pytest.mark.parametrize("n", [20000, 600000])
+def test_kmeans_fit_batch_reports_bad_data(ops, dev, n):
+    """NaN in the points: ValueError from the side-by-side path AND from the one-after-the-other fallback (shards that
+    fill the device by themselves) -- ADVICE r3: the fallback used to return ET_OK."""
+    from eigentrajectory_amd.synth import gaussian_points_np
+    x = gaussian_points_np(6, n, seed=3, n_blobs=4)
+    c0 = np.stack([x[:, :20], x[:, 20:40]])
+    x[2, n // 2] = np.nan
+    with pytest.raises(ValueError):
+        ops.kmeans_fit_batch(T(x, dev), T(c0, dev), 10, 1e-4)
+    with pytest.raises(ValueError):
+        ops.kmeans_fit(T(x, dev), T(c0[0], dev), 10, 1e-4)

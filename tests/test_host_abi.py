@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libetamd.so does not export {name}"
     assert sorted(_lib.SYMBOLS) == declared
-    assert lib.et_abi_version() == 1
+    assert lib.et_abi_version() == _lib.ABI_VERSION == 2
     assert lib.et_compiled_arch() == b"gfx950"
     assert lib.et_status_string(0) == b"ok" and b"workspace" in lib.et_status_string(4)
 
