@@ -1002,15 +1002,25 @@ __global__ __launch_bounds__(kTile) void reconstruct_bwd_generic_kernel(
 static bool need_m(int mode) { return mode == ET_MODE_MOVING || mode == ET_MODE_SPLIT; }
 static bool need_s(int mode) { return mode != ET_MODE_MOVING; }
 
-// ET_STREAM=0: keep the workgroup-tile kernels for projection / S = 1 reconstruction (same-process A/B runs)
+// ET_STREAM=1 selects the streaming kernels for one-descriptor calls.  They are NOT the default: built and measured in
+// round 4 (tools/ab_stream.py, profiles/r04a_stream_ab.txt) they lose to the workgroup-tile kernels inside the bench step
+// (project 0.414 against 0.386 ms, reconstruct 0.253 against 0.228 ms at N = 1e7, same box) -- and run at the same
+// speed with ONE workgroup per CU as with three or four: they are not short of bytes in flight, the memory side simply
+// delivers less for 4-KB / 6-KB read pieces and 256-B store pieces from wavefronts that drift apart than for the tile
+// kernel's 16-KB / 24-KB reads and 1-KB stores issued by four wavefronts in step.
 static bool stream_mode() {
     const char *e = getenv("ET_STREAM");
-    return !(e && e[0] == '0');
+    return e && e[0] == '1';
 }
 static int64_t stream_min_rows() {  // ET_STREAM_MIN_ROWS: tests run the streaming form on small inputs
     const char *e = getenv("ET_STREAM_MIN_ROWS");
     const long long v = e ? atoll(e) : 0;
     return v >= 1 ? (int64_t)v : (int64_t)1 << 18;
+}
+static int stream_wgs(int dflt) {  // ET_STREAM_WGS: workgroups per CU of the streaming kernels (measurement aid)
+    const char *e = getenv("ET_STREAM_WGS");
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 && v <= 8 ? v : dflt;
 }
 static int cu_count() {
     int dev = 0, n = 256;
@@ -1043,7 +1053,7 @@ extern "C" int et_norm_project(const float *obs, const float *pred, int64_t N, i
     // one descriptor for all rows and enough rows to fill the device: the streaming form
     if (fast && mode != ET_MODE_SPLIT && C_obs && nrm && stream_mode() && N >= (int64_t)stream_min_rows()) {
         const bool mv = mode == ET_MODE_MOVING;
-        const unsigned g = (unsigned)min((int64_t)cu_count() * kStreamWgPerCu, ceil_div(N, kStreamThreads));
+        const unsigned g = (unsigned)min((int64_t)cu_count() * stream_wgs(kStreamWgPerCu), ceil_div(N, kStreamThreads));
         const float *uo = mv ? U_obs_m : U_obs_s, *up = mv ? U_pred_m : U_pred_s;
 #define ET_PROJECT_STREAM(PRED, MODE)                                                                                         \
     hipLaunchKernelGGL((project_stream_kernel<8, 12, 6, PRED, MODE>), dim3(g), dim3(kStreamThreads), 0, st, obs,              \
@@ -1098,7 +1108,7 @@ extern "C" int et_anchor_reconstruct_fwd(const float *C, int64_t N, int S, int k
     if (fast && S == 1 && mode != ET_MODE_SPLIT && (nrm || mode == ET_MODE_IDENTITY) && stream_mode() &&
         N >= (int64_t)stream_min_rows()) {
         const bool mv = mode == ET_MODE_MOVING;
-        const unsigned g = (unsigned)min((int64_t)cu_count() * kRecStreamWgPerCu, ceil_div(N, kStreamThreads));
+        const unsigned g = (unsigned)min((int64_t)cu_count() * stream_wgs(kRecStreamWgPerCu), ceil_div(N, kStreamThreads));
         const float *a = mv ? A_m : A_s, *u = mv ? U_pred_m : U_pred_s;
         if (mode == ET_MODE_MOVING)
             hipLaunchKernelGGL((reconstruct_stream_kernel<12, 6, ET_MODE_MOVING>), dim3(g), dim3(kStreamThreads), 0, st, C, N, nrm, a, u, out);

@@ -1,25 +1,48 @@
-"""Same-box A/B of the streaming descriptor kernels at N = 1e7 (project obs+pred, reconstruct S = 1)."""
-import os, sys
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import numpy as np, torch
-from eigentrajectory_amd import ops
-from eigentrajectory_amd.synth import synthetic_trajectories_torch
+#!/usr/bin/env python3
+"""Same-process A/B of the projection / S=1 reconstruction kernels at N = 1e7: tile kernels (ET_STREAM=0) against the
+streaming kernels with 1..4 workgroups per CU (ET_STREAM_WGS).  HIP-event medians of 30 launches, alternating."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from eigentrajectory_amd import ops  # noqa: E402
+from eigentrajectory_amd.synth import synthetic_trajectories_torch  # noqa: E402
+
 dev = torch.device("cuda:0")
-n = 10_000_000
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 obs, pred = synthetic_trajectories_torch(n, dev, seed=0, min_disp=1e-3)
-g = torch.Generator(device=dev).manual_seed(1)
-Uo = torch.linalg.qr(torch.randn((16, 6), device=dev, generator=g))[0].contiguous()
-Up = torch.linalg.qr(torch.randn((24, 6), device=dev, generator=g))[0].contiguous()
-def t(fn, reps=9):
-    fn(); ts = []
+g_obs, g_pred, _ = ops.fit_gram(obs, pred, ops.MODE_MOVING, 0.0, 1)
+(Uo, _), (Up, _) = ops.eigh_topk_batch([g_obs, g_pred], 6)
+_, c_pred, nrm, _ = ops.norm_project(obs, pred, Uo, Up, None, None, ops.MODE_MOVING, want_flag=False)
+cp = c_pred.view(6, n, 1)
+
+
+def med(fn, reps=30):
+    for _ in range(3):
+        fn()
+    ev = []
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); fn(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
-    return float(np.median(ts))
-with torch.no_grad():
-    c_obs, c_pred, nrm, _ = ops.norm_project(obs, pred, Uo, Up, None, None, 1, want_flag=False)
-    pj = t(lambda: ops.norm_project(obs, pred, Uo, Up, None, None, 1, want_flag=False))
-    rc = t(lambda: ops.anchor_reconstruct(c_pred.view(6, n, 1), None, None, Up, None, 1, nrm=nrm))
-    gm = t(lambda: ops.fit_gram(obs, pred, 1, 0.0, 1))
-print(os.path.basename(os.environ.get("ET_LIBETAMD", "default")),
-      f"project {pj:.4f} ms {208*n/pj/1e6:.0f} GB/s | reconstruct S=1 {rc:.4f} ms {136*n/rc/1e6:.0f} GB/s | gram {gm:.4f} ms {160*n/gm/1e6:.0f} GB/s")
+        a.record()
+        fn()
+        b.record()
+        ev.append((a, b))
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in ev]))
+
+
+configs = [("tile", "0", "")] + [(f"stream wgs={w}", "1", str(w)) for w in (1, 2, 3, 4)]
+for rnd in range(2):
+    for name, st, wgs in configs:
+        os.environ["ET_STREAM"] = st
+        if wgs:
+            os.environ["ET_STREAM_WGS"] = wgs
+        else:
+            os.environ.pop("ET_STREAM_WGS", None)
+        tp = med(lambda: ops.norm_project(obs, pred, Uo, Up, None, None, ops.MODE_MOVING, want_flag=False))
+        tr = med(lambda: ops.anchor_reconstruct(cp, None, None, Up, None, ops.MODE_MOVING, nrm=nrm))
+        print(f"round {rnd} {name:14s} project {tp:.4f} ms ({208 * n / tp / 1e6 / 8000:.3f})  reconstruct {tr:.4f} ms "
+              f"({136 * n / tr / 1e6 / 8000:.3f})  sum {tp + tr:.4f} ({344 * n / (tp + tr) / 1e6 / 8000:.3f})", flush=True)
