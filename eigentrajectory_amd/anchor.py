@@ -110,6 +110,48 @@ def seeding_uniforms(rng, K, n_init):
 _UNIFORMS_CACHE = {}
 
 
+def _lloyd_relocating(X, c0, max_iter, tol):
+    """sklearn's Lloyd loop INCLUDING its treatment of empty clusters (sklearn/cluster/_k_means_common.pyx
+    _relocate_empty_clusters_dense): in every iteration each empty cluster is re-seeded with the point that is farthest
+    from its own centre, taken out of the cluster it was assigned to.  The fast fits (``et_kmeans_fit*``) keep
+    BatchKMeans' semantics -- 0/0 = NaN, kmeans.py:182 -- so an initialisation that ran into an empty cluster is repeated
+    here: the library's exact-sum steps on the device, the relocation (rare, a handful of points) on the host with the
+    very numpy call sklearn makes (``argpartition`` of the float32 distances).  Does not happen with k-means++ seeds on
+    ETH/UCY; it does when there are more clusters than distinct points.  -> final centres (d,K)."""
+    dev = X.device
+    d, n = X.shape
+    K = c0.shape[1]
+    sh = ops.KMeansShard(X, K)
+    cen = c0.clone().contiguous()
+    sh.scan()
+    sh.begin(n, cen)
+    frac = int(sh.read_state().frac)
+    rows = np.ascontiguousarray(X.T.cpu().numpy())
+    for _ in range(max_iter):
+        part = sh.assign(cen)
+        host = part.cpu().numpy().copy()
+        counts = host[d * K:d * K + K]
+        empty = np.where(counts == 0)[0]
+        if empty.size:
+            labels = sh.labels().cpu().numpy()
+            old = np.ascontiguousarray(cen.T.cpu().numpy())
+            dist = ((rows - old[labels]) ** 2).sum(axis=1)
+            far = np.argpartition(dist, -empty.size)[:-empty.size - 1:-1]
+            sums = host[:d * K].reshape(d, K)
+            for new, f in zip(empty, far):
+                src = labels[f]
+                fx = np.trunc(np.ldexp(rows[f].astype(np.float64), frac)).astype(np.int64)
+                sums[:, src] -= fx
+                sums[:, new] = fx
+                counts[new] = 1
+                counts[src] -= 1
+            part = torch.from_numpy(host).to(dev)
+        sh.update(part, cen, tol)
+        if sh.read_state().done:
+            break
+    return cen
+
+
 def sklearn_style_kmeans(C, K, *, random_state=0, n_init=10, max_iter=300, tol=1e-4, concurrent=True):
     """``KMeans(n_clusters=K, random_state=random_state, init='k-means++', n_init=n_init).fit(C.T)`` as a recipe on
     the device: -> (cluster centres (d,K) fp32 on C's device, inertia = mean squared distance to the final centres,
@@ -135,16 +177,14 @@ def sklearn_style_kmeans(C, K, *, random_state=0, n_init=10, max_iter=300, tol=1
         c0, seeds = ops.kmeanspp_seed_batch(X, K, U)
         res = ops.kmeans_fit_batch(X, c0, max_iter, tol_)
         cens = res["centroids"]                                      # (n_init, d, K)
+        # an initialisation that ran into an empty cluster (NaN centre, kmeans.py:182 semantics): again, with sklearn's
+        # re-seeding of empty clusters
+        for b in torch.nonzero(~torch.isfinite(cens).flatten(1).all(dim=1)).flatten().tolist():
+            cens[b] = _lloyd_relocating(X, c0[b], max_iter, tol_)
         _, maxsims = ops.kmeans_predict(X, cens)                       # every set of centres on the same points
-        # sklearn ranks by the inertia of the FINAL centres; an initialisation with an empty cluster (NaN centre,
-        # kmeans.py:182 semantics -- sklearn would re-seed it) is dropped
-        inertia = (-maxsims.double()).sum(dim=1)
-        inertia = torch.where(torch.isfinite(cens).flatten(1).all(dim=1), inertia, torch.full_like(inertia, float("inf")))
+        inertia = (-maxsims.double()).sum(dim=1)                     # sklearn ranks by the inertia of the FINAL centres
         best = int(torch.argmin(inertia))  # first minimum = the earlier initialisation on ties
-        best_inertia = float(inertia[best])
-        if not np.isfinite(best_inertia):
-            raise RuntimeError("every k-means initialisation produced an empty cluster")
-        return (cens[best] + mean[:, None]).contiguous(), best_inertia / n, seeds
+        return (cens[best] + mean[:, None]).contiguous(), float(inertia[best]) / n, seeds
 
     nbytes = ops.L.lib().et_kmeanspp_workspace_bytes(ops.L.i64(n), d, ops.kmeanspp_trials(K))
     ws_seed = torch.empty((max(nbytes, 8),), device=dev, dtype=torch.uint8)
@@ -154,12 +194,10 @@ def sklearn_style_kmeans(C, K, *, random_state=0, n_init=10, max_iter=300, tol=1
         res = ops.kmeans_fit(X, c0, max_iter, tol_, trace=False)
         seeds.append(idx)
         cen = res["centroids"]
-        if not bool(torch.isfinite(cen).all()):
-            continue  # an empty cluster (kmeans.py:182 semantics): sklearn would re-seed it, here the run is dropped
+        if not bool(torch.isfinite(cen).all()):  # an empty cluster on the way: sklearn's loop re-seeds it
+            cen = _lloyd_relocating(X, c0, max_iter, tol_)
         _, maxsims = ops.kmeans_predict(X, cen)  # sklearn ranks by the inertia of the FINAL centres
         inertia = float((-maxsims.double()).sum())
         if best is None or inertia < best[0]:
             best = (inertia, cen)
-    if best is None:
-        raise RuntimeError("every k-means initialisation produced an empty cluster")
     return (best[1] + mean[:, None]).contiguous(), best[0] / n, torch.stack(seeds)

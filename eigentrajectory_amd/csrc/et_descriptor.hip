@@ -20,6 +20,26 @@ namespace et {
 
 constexpr int kTile = 256;  // trajectories (or pairs) per workgroup = threads per workgroup
 
+// workgroup -> tile.  Workgroup b runs on XCD b % 8; the identity map therefore deals consecutive tiles round-robin over
+// the XCDs.  -DET_TILE_MAP=1 (experiment, tools/build_variant.sh) gives every XCD one contiguous eighth of the tiles.
+#ifndef ET_TILE_MAP
+#define ET_TILE_MAP 0
+#endif
+template <bool PROJECT = false>
+__device__ __forceinline__ int64_t tile_of_block() {
+#if ET_TILE_MAP == 2
+    // projection walks the rows from the END: the fit that precedes it read them front to back, so the last ~250 MB it
+    // touched are still in the Infinity Cache; the reconstruction then walks forward and meets the coefficients the
+    // projection wrote last
+    return PROJECT ? (int64_t)gridDim.x - 1 - blockIdx.x : (int64_t)blockIdx.x;
+#elif ET_TILE_MAP == 1
+    const int64_t per = ((int64_t)gridDim.x + 7) / 8;
+    return (int64_t)(blockIdx.x % 8) * per + blockIdx.x / 8;
+#else
+    return (int64_t)blockIdx.x;
+#endif
+}
+
 // ------------------------------------------------------------------------------------------
 // Projection, specialised: one workgroup = 256 trajectories.
 //   phase 1  coalesced float4 loads of the obs / pred row blocks -> LDS (row pitch padded
@@ -45,7 +65,8 @@ __global__ __launch_bounds__(kTile) void project_tile_kernel(
     __shared__ float sU[2 * UN];  // [descriptor: 0 static, 1 moving][obs rows | pred rows][K]
 
     const int tid = threadIdx.x;
-    const int64_t n0 = (int64_t)blockIdx.x * kTile;
+    const int64_t n0 = tile_of_block<true>() * kTile;
+    if (n0 >= N) return;
     const int rows = (int)min((int64_t)kTile, N - n0);
     const bool has_pred = pred != nullptr && C_pred != nullptr;
 
@@ -522,7 +543,8 @@ __global__ __launch_bounds__(kTile) void reconstruct_tile_kernel(
     const int tid = threadIdx.x;
     const int tiles = S == 1 ? 1 : kReconTiles;
     const int nl = tid / S, s = tid - nl * S;
-    int64_t n0 = (int64_t)blockIdx.x * tiles * TN;
+    int64_t n0 = tile_of_block() * tiles * TN;
+    if (n0 >= N) return;
     int rows = (int)min((int64_t)TN, N - n0);
 
     // issue this lane's coefficient loads first: they are in flight while U / anchors / normaliser

@@ -80,6 +80,19 @@ class TrajectoryData:
         ends = np.cumsum(self.num_peds_in_seq)
         self.seq_start_end = [(int(e - n), int(e)) for e, n in zip(ends, self.num_peds_in_seq)]
 
+    @classmethod
+    def from_arrays(cls, obs, pred, seq_start_end):
+        """The same object from windows that are already assembled: obs (N,obs_len,2), pred (N,pred_len,2) and the scenes'
+        (start, end) row ranges -- preprocessed splits, synthetic data."""
+        self = cls.__new__(cls)
+        self.obs_traj = torch.as_tensor(obs).type(torch.float).contiguous()
+        self.pred_traj = torch.as_tensor(pred).type(torch.float).contiguous()
+        self.obs_len, self.pred_len = int(self.obs_traj.shape[1]), int(self.pred_traj.shape[1])
+        self.seq_start_end = [(int(s), int(e)) for s, e in seq_start_end]
+        self.num_seq = len(self.seq_start_end)
+        self.num_peds_in_seq = np.array([e - s for s, e in self.seq_start_end], dtype=np.int64)
+        return self
+
     def __len__(self):
         return self.num_seq
 

@@ -20,8 +20,10 @@ container (tests/golden/g11_sklearn_anchors.npz, made by tools/make_golden_sklea
 
 Not restated bit-for-bit (and why the pin is on seed indices + centre / ADE / FDE closeness, not on bits):
 the potential is a float32 BLAS dot in sklearn (summation order unspecified; here the float64 sum rounded to
-float32), Lloyd sums are float32 per thread chunk in sklearn (here the oracle's exact sums), empty clusters are
-re-seeded by sklearn (here: that initialisation is discarded).
+float32), Lloyd sums are float32 per thread chunk in sklearn (here the oracle's exact sums).  Empty clusters: sklearn re-seeds each one, in
+every iteration, with the point that is farthest from its own centre (_k_means_common.pyx
+_relocate_empty_clusters_dense) -- restated in lloyd_relocating(), the loop an initialisation takes when the plain fit
+(kmeans.py:182 semantics: 0/0 = NaN) ran into one; pinned by g11 "dup15" (more clusters than distinct points).
 """
 from __future__ import annotations
 
@@ -81,6 +83,46 @@ def kmeanspp_seed(X, K, uniforms):
     return np.ascontiguousarray(X[:, idx]), idx
 
 
+def relocate_empty(Xrows, old_centers, labels, sums, counts, frac):
+    """_relocate_empty_clusters_dense on exact integer sums: Xrows (N,d) float32, old_centers (d,K), labels (N,), sums (d,K)
+    int64 with `frac` fractional bits, counts (K,) int64 -- both modified in place.  The points picked are numpy's own
+    ``argpartition(distances, -n_empty)[:-n_empty-1:-1]`` on the float32 distances, like sklearn."""
+    empty = np.where(counts == 0)[0]
+    if empty.size == 0:
+        return False
+    dist = ((Xrows - np.ascontiguousarray(old_centers.T)[labels]) ** 2).sum(axis=1)
+    far = np.argpartition(dist, -empty.size)[:-empty.size - 1:-1]
+    for new, f in zip(empty, far):
+        old = labels[f]
+        fx = np.trunc(np.ldexp(Xrows[f].astype(np.float64), int(frac))).astype(np.int64)
+        sums[:, old] -= fx
+        sums[:, new] = fx
+        counts[new] = 1
+        counts[old] -= 1
+    return True
+
+
+def lloyd_relocating(X, c0, max_iter, tol):
+    """sklearn's Lloyd loop INCLUDING the relocation of empty clusters, on the oracle's exact-sum steps.
+    -> (centers (d,K) float32, iterations)."""
+    X = np.asarray(X, np.float32)
+    d, n = X.shape
+    K = c0.shape[1]
+    Xrows = np.ascontiguousarray(X.T)
+    cen = np.ascontiguousarray(c0, np.float32)
+    mx = float(np.abs(X).max())
+    frac = eo.kmeans_frac_bits(mx, n)
+    it = 0
+    for it in range(1, max_iter + 1):
+        sf = eo.kmeans_sim_frac_bits(mx, float(np.abs(cen[np.isfinite(cen)]).max()), d, n)
+        labels, sums, counts, ss, nn = eo.kmeans_assign_accumulate(X, cen, frac, sf)
+        relocate_empty(Xrows, cen, labels, sums, counts, frac)
+        cen, err, _, done = eo.kmeans_update(sums, counts, ss, nn, n, frac, sf, float(tol), cen)
+        if done:
+            break
+    return cen, it
+
+
 def kmeans(C, K, random_state=0, n_init=10, max_iter=300, rel_tol=1e-4):
     """The whole call -> dict(centers (d,K) float32 incl. the mean, inertia (sum of squared distances of the
     centred data to the final centres), seeds (n_init,K), inertias (n_init,), best)."""
@@ -92,6 +134,8 @@ def kmeans(C, K, random_state=0, n_init=10, max_iter=300, rel_tol=1e-4):
         seeds.append(idx)
         res = eo.kmeans_fit(X, c0, max_iter, float(tol))
         cen = res["centroids"]
+        if not np.isfinite(cen).all():  # an empty cluster on the way: sklearn's loop re-seeds it
+            cen, _ = lloyd_relocating(X, c0, max_iter, tol)
         inertia = float(-eo.kmeans_assign(X, cen)[1].astype(np.float64).sum()) if np.isfinite(cen).all() else np.nan
         inertias.append(inertia)
         if np.isfinite(inertia) and (best is None or inertia < inertias[best]):

@@ -1224,6 +1224,74 @@ def test_trainer_harness_learns_and_roundtrips_checkpoint(dev, mode):
     assert np.isfinite(best["ADE"]) and best["ADE"] < before["ADE"] + 0.02
 
 
+class TinyAgentFormer(torch.nn.Module):
+    """A trainable stand-in that speaks AgentFormer's calling convention (baseline/agentformer/bridge.py:10-20: a dict goes in
+    through set_data(), the call takes no argument, the answer is read from .data): pre_motion (k+2, N, 1) ->
+    _dec_motion (N, k, S)."""
+
+    def __init__(self, k=6, s=20):
+        super().__init__()
+        self.k, self.s, self.data = k, s, None
+        self.net = torch.nn.Sequential(torch.nn.Linear(k + 2, 64), torch.nn.ReLU(), torch.nn.Linear(64, k * s))
+        for p in self.net[2].parameters():
+            torch.nn.init.normal_(p, std=1e-2)
+
+    def set_data(self, data):
+        assert data["anything_else"] is None  # the bridge hands a defaultdict(lambda: None)
+        self._in = data["pre_motion"]
+
+    def forward(self):
+        x = self._in.squeeze(-1).T  # (N, k+2)
+        self.data = {"_dec_motion": self.net(x).view(-1, self.k, self.s)}
+
+
+def test_trainer_harness_univ_agentformer_bridge_config5(dev):
+    """BASELINE config 5's workload on one GPU: the univ split (train 9 231 / val 2 708 pedestrians; fit set = train + val +
+    y-flip = 23 878 rows), descriptors and anchors fitted HERE by calculate_parameters, the agentformer bridge
+    (pre_motion dict -> set_data() -> call -> data["_dec_motion"]), the reference's collated batch rule (scenes until a
+    batch holds >= 128 pedestrians, utils/trainer.py:211-231 / ETAgentFormerTrainer :380-396), AdamW + StepLR + gradient
+    clipping, best-of-20 ADE / FDE on the 24 334 test pedestrians.  The fitted parameters are the reference's own fit
+    of univ (G2: U sign-aligned 2e-5, anchors paired one to one); one epoch must lower the validation loss and the test
+    error below the zero-refinement predictor's (the reference's own numbers for it: MANIFEST g6 univ.zero)."""
+    from eigentrajectory_amd import EigenTrajectory
+    from eigentrajectory_amd.bridges import get_hook_func
+    from eigentrajectory_amd.data import TrajectoryData
+    from eigentrajectory_amd.trainer import ETTrainer
+    from eigentrajectory_amd.utils import default_hyper_params
+    train, val, test = (TrajectoryData.from_arrays(*G.dataset("univ", ph)) for ph in ("train", "val", "test"))
+    assert (train.obs_traj.shape[0], val.obs_traj.shape[0], test.obs_traj.shape[0]) == (9231, 2708, 24334)
+    hp = default_hyper_params(batch_size=128, lr=1e-3, weight_decay=1e-4, clip_grad=10, lr_schd=True, lr_schd_step=64,
+                              lr_schd_gamma=0.5, static_dist=G.static_dist("univ"))
+    torch.manual_seed(0)
+    model = EigenTrajectory(TinyAgentFormer(), get_hook_func("agentformer"), hp)
+    tr = ETTrainer(model, hp, train_data=train, val_data=val, test_data=test, mode="collated", device=dev)
+    tr.init_descriptor()
+    g2 = G.load("g2_fit_all_scenes.npz")
+    sd = tr.state_dict()
+    for name in ("ET_m_descriptor.U_obs_trunc", "ET_m_descriptor.U_pred_trunc", "ET_s_descriptor.U_obs_trunc",
+                 "ET_s_descriptor.U_pred_trunc"):
+        ref = g2[f"univ.{name}"]
+        np.testing.assert_allclose(G.sign_align(N_(sd[name]), ref), ref, atol=2e-5)
+    for name in ("ET_m_anchor.C_anchor", "ET_s_anchor.C_anchor"):  # anchors: same clusters in some order, U's column signs
+        sign = np.sign((N_(sd[name.replace("anchor.C_anchor", "descriptor.U_pred_trunc")]) *
+                        g2[f"univ.{name.replace('anchor.C_anchor', 'descriptor.U_pred_trunc')}"]).sum(axis=0))
+        mine, ref = N_(sd[name]) * sign[:, None], g2[f"univ.{name}"]
+        dist = np.linalg.norm(mine[:, :, None] - ref[:, None, :], axis=0)
+        assert sorted(dist.argmin(axis=1).tolist()) == list(range(20))
+        assert dist.min(axis=1).max() < 2e-3 * np.abs(ref).max()
+    zero = G.manifest()["g6_ade_fde"]["univ.zero"]
+    before = tr.test()  # the refinement starts near zero: close to the reference's zero-predictor numbers
+    assert abs(before["ADE"] - zero[0]) < 0.02 and abs(before["FDE"] - zero[1]) < 0.03
+    v0 = tr.valid()
+    n_batches = len(tr._batches(train, train=True, seed=0))
+    assert 50 <= n_batches <= 72  # 9 231 pedestrians in batches of >= 128 (scenes of 2..14), the incomplete last one dropped
+    state = tr.fit(epochs=2)
+    assert tr.log["val_loss"][-1] < v0 and np.isfinite(tr.log["train_loss"]).all()
+    after = tr.test()
+    assert after["ADE"] < before["ADE"] and after["FDE"] < before["FDE"]
+    assert {"ET_m_descriptor.U_obs_trunc", "ET_s_anchor.C_anchor", "baseline_model.net.0.weight"} <= set(state)
+
+
 def _trainer_for(dev, mode, batch_size, epochs_seed=0):
     """ETH-test scenes as the training set, the reference's fitted descriptors (G2), a seeded TinyPredictor."""
     import os
@@ -1838,6 +1906,21 @@ def test_reference_order_batchkmeans_module_gauss10000(dev):
         km.fit(torch.cat([x, x], dim=0).contiguous())
     with pytest.raises(ValueError):
         BatchKMeans(n_clusters=20, sums="fast")
+
+
+def test_anchor_clustering_relocates_empty_clusters_like_sklearn(dev):
+    """The device recipe on the input that must produce empty clusters (g11 "dup15": 15 locations x 8 copies, K = 20):
+    the 15 locations + 5 duplicates like sklearn's own fit (its _relocate_empty_clusters_dense) and the numpy restatement,
+    through both drivers (batched and one initialisation after the other)."""
+    import eigentrajectory_amd.anchor as A
+    from .test_oracle_golden import _same_distinct_centres
+    g11 = G.load("g11_sklearn_anchors.npz")
+    C, ref = g11["dup15.x"], g11["dup15.centers"]
+    for concurrent in (True, False):
+        cen, inertia, seeds = A.sklearn_style_kmeans(T(C, dev), 20, concurrent=concurrent)
+        assert torch.isfinite(cen).all() and inertia < 1e-8
+        assert _same_distinct_centres(N_(cen), ref, 1e-5)
+        assert len({tuple(np.round(c, 4)) for c in N_(cen).T}) == 15
 
 
 # ------------------------------------------------ et_kmeans_fit_batch: a problem whose grid barrier timed out

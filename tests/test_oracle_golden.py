@@ -449,6 +449,33 @@ def test_g11_sklearn_recipe_restatement(oracle, tag):
     assert abs(r["inertia"] / float(g11[f"{tag}.inertia"]) - 1) < 1e-5
 
 
+def _same_distinct_centres(mine, ref, tol):
+    """the two centre sets cover each other: every column of one has a column of the other within tol"""
+    mine, ref = np.asarray(mine, np.float64), np.asarray(ref, np.float64)
+    dist = np.linalg.norm(mine[:, :, None] - ref[:, None, :], axis=0)
+    return bool(dist.min(axis=1).max() <= tol and dist.min(axis=0).max() <= tol)
+
+
+def test_g11_empty_clusters_are_relocated_like_sklearn(oracle):
+    """anchor.py:65-71 on an input with more clusters than distinct points (15 locations x 8 copies, K = 20): sklearn
+    re-seeds the 5 clusters that stay empty with points far from their centres and ends with the 15 locations + 5
+    duplicates, inertia 0 -- so does the restated loop.  WHICH locations are duplicated is not comparable: all candidate
+    distances are rounding noise of sklearn's own float32 sums (~1e-14), and its seeding of the last five centres samples
+    from distances that are zero up to the rounding of a BLAS dgemm.)"""
+    from oracle import sklearn_recipe as R
+    g11 = G.load("g11_sklearn_anchors.npz")
+    C, ref = g11["dup15.x"], g11["dup15.centers"]
+    assert len({tuple(c) for c in C.T}) == 15 and len(set(g11["dup15.labels"].tolist())) == 15
+    X, mean, tol = R.center_columns(C)
+    c0, _ = R.kmeanspp_seed(X, 20, R.seeding_uniforms(np.random.RandomState(0), 20, 1)[0])
+    assert not np.isfinite(oracle.kmeans_fit(X, c0, 300, float(tol))["centroids"]).all()  # BatchKMeans semantics: NaN
+    r = R.kmeans(C, 20)
+    assert np.isfinite(r["centers"]).all()
+    assert _same_distinct_centres(r["centers"], ref, 1e-5)
+    assert len({tuple(np.round(c, 4)) for c in r["centers"].T}) == 15 == len({tuple(np.round(c, 4)) for c in ref.T})
+    assert r["inertia"] < 1e-8 and float(g11["dup15.inertia"]) < 1e-8
+
+
 def test_g11_recipe_is_the_reference_anchor_fit_eth(oracle):
     """The recipe on the ETH moving coefficients reproduces the anchors the REFERENCE's calculate_parameters stored
     (G2 `eth.ET_m_anchor.C_anchor`, anchor.py:65-74), cluster for cluster."""

@@ -55,6 +55,20 @@ def main():
         out[f"{tag}.mean"] = X.mean(axis=0)
         out[f"{tag}.tol"] = np.float32(km._tol)  # sklearn's own: mean(var(X)) * 1e-4 of the data as given
         print(f"  {tag}: N={X.shape[0]} inertia={km.inertia_:.4f} n_iter={km.n_iter_}")
+    # an input that MUST produce empty clusters: 15 distinct locations, 8 copies each, K = 20 -- sklearn re-seeds every empty
+    # cluster with the point farthest from its centre (_relocate_empty_clusters_dense) and ends with 5 duplicated centres
+    import warnings
+    rng = np.random.default_rng(5)
+    pts = (rng.standard_normal((6, 15)) * 3).astype(np.float32)
+    C = np.ascontiguousarray(np.repeat(pts, 8, axis=1)[:, rng.permutation(120)])
+    with threadpool_limits(limits=1), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        km = KMeans(n_clusters=20, random_state=0, init="k-means++", n_init=10).fit(np.ascontiguousarray(C.T))
+    out["dup15.x"] = C
+    out["dup15.centers"] = np.ascontiguousarray(km.cluster_centers_.T.astype(np.float32))
+    out["dup15.inertia"] = np.float64(km.inertia_)
+    out["dup15.labels"] = km.labels_.astype(np.int64)
+    print(f"  dup15: inertia={km.inertia_:.3e} n_iter={km.n_iter_} clusters used {len(set(km.labels_.tolist()))}")
     path = os.path.join(args.out, "g11_sklearn_anchors.npz")
     np.savez_compressed(path, **out)
     print(f"  wrote {path} {os.path.getsize(path) / 1024:.1f} KiB")
