@@ -1918,7 +1918,7 @@ def test_anchor_clustering_relocates_empty_clusters_like_sklearn(dev):
     C, ref = g11["dup15.x"], g11["dup15.centers"]
     for concurrent in (True, False):
         cen, inertia, seeds = A.sklearn_style_kmeans(T(C, dev), 20, concurrent=concurrent)
-        assert torch.isfinite(cen).all() and inertia < 1e-8
+        assert torch.isfinite(cen).all() and inertia < 1e-5  # mean over the points of fp32 cancellation noise
         assert _same_distinct_centres(N_(cen), ref, 1e-5)
         assert len({tuple(np.round(c, 4)) for c in N_(cen).T}) == 15
 
