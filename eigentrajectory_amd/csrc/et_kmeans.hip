@@ -2310,17 +2310,17 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_predict_kernel(const float 
 // update cannot fire and best / nearest stay as they are.  Such a point costs 5 B (best + nearest) instead of
 // 32 B; farthest-first picks are far from everything by construction, so most points qualify.  best[] is only
 // written when it changes.  max|x| is collected by step 1, which reads everything anyway.
-template <int D>
-__global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const float *__restrict__ X, int64_t N, int d_rt,
-                                                                      int K, int step, const float *__restrict__ C0,
-                                                                      float *__restrict__ best,
-                                                                      uint8_t *__restrict__ nearest,
-                                                                      unsigned *__restrict__ max_abs_bits,
-                                                                      int64_t index_base,
-                                                                      unsigned long long *__restrict__ block_keys,
-                                                                      const unsigned long long *__restrict__ prev_keys,
-                                                                      int n_prev, float *C0_rw, unsigned char *cand,
-                                                                      uint4 *__restrict__ meta, int meta_valid) {
+// PERSIST: the body runs inside kmeans_init_persist_kernel, steps separated by a fence-free grid barrier: everything that
+// crosses workgroups inside the launch -- the workgroup keys, the centroid columns workgroup 0 stores -- is then written
+// and read with device-scope atomics (served by the memory side: no cache fence); best / nearest / the tile summaries
+// are only re-read by the wavefront that wrote them (the tile -> wavefront map is fixed).
+template <int D, bool PERSIST>
+__device__ __forceinline__ void init_step_body(const float *__restrict__ X, int64_t N, int d_rt, int K, int step,
+                                               const float *C0, float *__restrict__ best, uint8_t *__restrict__ nearest,
+                                               unsigned *__restrict__ max_abs_bits, int64_t index_base,
+                                               unsigned long long *block_keys, const unsigned long long *prev_keys,
+                                               int n_prev, float *C0_rw, unsigned char *cand, uint4 *__restrict__ meta,
+                                               int meta_valid) {
     const int d = D ? D : d_rt;
     __shared__ float sc[ET_KMEANS_MAX_D + 1];
     __shared__ float sDelta[ET_KMEANS_MAX_CLUSTERS + 1];
@@ -2333,7 +2333,8 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
     if constexpr (D != 0) {
         const int jc = (int)threadIdx.x < step - 1 ? (int)threadIdx.x : 0;
 #pragma unroll
-        for (int i = 0; i < D; ++i) cprev[i] = C0[i * K + jc];
+        for (int i = 0; i < D; ++i)
+            cprev[i] = PERSIST ? __hip_atomic_load(&C0[i * K + jc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : C0[i * K + jc];
     }
     if (prev_keys) {
         // Single-GPU path: centroid step-1 has not been stored yet -- every workgroup derives it from the previous
@@ -2345,7 +2346,8 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int b = b0 + u * kKmThreads + (int)threadIdx.x;
-                k4[u] = prev_keys[b < n_prev ? b : 0];
+                k4[u] = PERSIST ? __hip_atomic_load(&prev_keys[b < n_prev ? b : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : prev_keys[b < n_prev ? b : 0];
                 if (b >= n_prev) k4[u] = ~0ull;
             }
 #pragma unroll
@@ -2377,7 +2379,8 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
                 sc[i] = v;
                 bn = bn + v * v;
                 if (blockIdx.x == 0) {
-                    C0_rw[i * K + (step - 1)] = v;
+                    if (PERSIST) __hip_atomic_store(&C0_rw[i * K + (step - 1)], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else C0_rw[i * K + (step - 1)] = v;
                     reinterpret_cast<float *>(cand + 8)[i] = v;
                 }
             }
@@ -2403,7 +2406,9 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
             if (i >= d) break;
             double cj;
             if constexpr (D != 0) cj = j == step - 1 ? (double)sc[i] : (double)cprev[i];  // step <= K < blockDim.x: j == threadIdx.x
-            else cj = j == step - 1 ? (double)sc[i] : (double)C0[i * K + j];
+            else cj = j == step - 1 ? (double)sc[i]
+                                    : (double)(PERSIST ? __hip_atomic_load(&C0[i * K + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                       : C0[i * K + j]);
             const double t = (double)sc[i] - cj;
             s2 += t * t;
             n2 += cj * cj;
@@ -2575,9 +2580,108 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
             key = sKey[w] < key ? sKey[w] : key;
             mb = sMax[w] > mb ? sMax[w] : mb;
         }
-        block_keys[blockIdx.x] = key;
+        if (PERSIST) __hip_atomic_store(&block_keys[blockIdx.x], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else block_keys[blockIdx.x] = key;
         // non-negative floats order like their bits; only a workgroup that would raise the maximum touches it
         if (step == 1 && mb > __hip_atomic_load(max_abs_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_abs_bits, mb);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const float *__restrict__ X, int64_t N, int d_rt,
+                                                                      int K, int step, const float *__restrict__ C0,
+                                                                      float *__restrict__ best,
+                                                                      uint8_t *__restrict__ nearest,
+                                                                      unsigned *__restrict__ max_abs_bits,
+                                                                      int64_t index_base,
+                                                                      unsigned long long *__restrict__ block_keys,
+                                                                      const unsigned long long *__restrict__ prev_keys,
+                                                                      int n_prev, float *C0_rw, unsigned char *cand,
+                                                                      uint4 *__restrict__ meta, int meta_valid) {
+    init_step_body<D, false>(X, N, d_rt, K, step, C0, best, nearest, max_abs_bits, index_base, block_keys, prev_keys, n_prev,
+                             C0_rw, cand, meta, meta_valid);
+}
+
+// Farthest-first steps 2 .. K-1 of a single-GPU initialisation in ONE launch (step 1, the pass that reads every coordinate,
+// keeps its own launch and its own grid).  A step of the launch-per-centroid form is latency: ~12 us at N = 1e7, ~8 us at
+// 1e5, of which the work is a few microseconds -- the rest is the kernel boundary and a prologue that every workgroup
+// starts cold.  Here the grid (<= 2 workgroups per CU, all co-resident) stays and the steps are separated by the same
+// fence-free grid barrier as in kmeans_lloyd_persist_kernel (one relaxed atomic per workgroup after it has drained its
+// own memory operations; one lane polls).  After the last step workgroup 0 reduces the keys into centroid K-1.
+// Every spin carries a time-out (ctl[1] = abort flag): the host then repeats the initialisation with one launch per step.
+template <int D>
+__global__ __launch_bounds__(kKmThreads) void kmeans_init_persist_kernel(const float *__restrict__ X, int64_t N, int d_rt, int K,
+                                                                         float *C0, float *__restrict__ best,
+                                                                         uint8_t *__restrict__ nearest,
+                                                                         unsigned *__restrict__ max_abs_bits,
+                                                                         unsigned long long *keys_odd,
+                                                                         unsigned long long *keys_even, int n_first,
+                                                                         unsigned char *cand,
+                                                                         uint4 *__restrict__ meta, unsigned *ctl) {
+    __shared__ int sAbort;
+    if (threadIdx.x == 0) sAbort = 0;
+    __syncthreads();
+    // a step writes its workgroup keys into the buffer of its parity and reads the other one (step 1, launched before this
+    // kernel, left n_first keys in keys_odd)
+    for (int step = 2; step <= K; ++step) {
+        if (step > 2) {  // ---- grid barrier: every workgroup has stored its key of step - 1 ----
+            if (threadIdx.x == 0) {
+                const unsigned want = (unsigned)(step - 2) * gridDim.x;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                while (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    if (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                        __builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {  // 0.5 s of the 100 MHz clock
+                        __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sAbort = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __syncthreads();
+            if (sAbort) return;
+        }
+        unsigned long long *mine = (step & 1) ? keys_odd : keys_even;
+        const unsigned long long *prev = (step & 1) ? keys_even : keys_odd;
+        const int n_prev = step == 2 ? n_first : (int)gridDim.x;
+        if (step == K) {  // the pick: centroid K-1 from the keys of step K-1
+            if (blockIdx.x != 0) return;
+            __shared__ unsigned long long sKey[kKmThreads / 64];
+            unsigned long long key = ~0ull;
+            for (int b = threadIdx.x; b < n_prev; b += kKmThreads) {
+                const unsigned long long k = __hip_atomic_load(&prev[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                key = k < key ? k : key;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long other = __shfl_xor(key, o);
+                key = other < key ? other : key;
+            }
+            if ((threadIdx.x & 63) == 0) sKey[threadIdx.x >> 6] = key;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (int w = 1; w < kKmThreads / 64; ++w) key = sKey[w] < key ? sKey[w] : key;
+                *reinterpret_cast<unsigned long long *>(cand) = key;
+                const int d = D ? D : d_rt;
+                const int64_t local = (int64_t)(unsigned)(key & 0xffffffffull);
+                for (int i = 0; i < d; ++i) {
+                    const float v = (key != ~0ull && local < N) ? X[(int64_t)i * N + local] : __int_as_float(0x7fc00000);
+                    reinterpret_cast<float *>(cand + 8)[i] = v;
+                    C0[i * K + (K - 1)] = v;
+                }
+            }
+            return;
+        }
+        // (the step's inputs pass through an empty asm: nothing derived from them is hoisted out of the step loop)
+        const float *Xi = X;
+        int64_t Ni = N;
+        int Ki = K;
+        asm volatile("" : "+s"(Xi), "+s"(Ni), "+s"(Ki));
+        init_step_body<D, true>(Xi, Ni, d_rt, Ki, step, C0, best, nearest, max_abs_bits, 0, mine, prev, n_prev, C0, cand, meta,
+                                step > 2 ? 1 : 0);
+        // arrival: this workgroup's stores have been performed (see kmeans_lloyd_persist_kernel)
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -3122,6 +3226,9 @@ extern "C" int et_kmeans_gather_point(const float *X, int64_t N, int d, int64_t 
     return ET_OK;
 }
 
+static int km_init_persist_run(const float *X, int64_t N, int d, int K, float *C0, const KmWorkspace &w, hipStream_t st,
+                               bool *aborted);
+
 extern "C" int et_kmeans_init_farthest(const float *X, int64_t N, int d, int K, int64_t first_index, float *C0,
                                        void *workspace, size_t workspace_bytes, et_stream_t stream) {
     if (!km_dims_ok(d, K) || N < 1 || !X || !C0 || first_index < 0 || first_index >= N || N > 0xffffffffll)
@@ -3132,6 +3239,17 @@ extern "C" int et_kmeans_init_farthest(const float *X, int64_t N, int d, int K, 
     int rc = et_kmeans_gather_point(X, N, d, first_index, pt, stream);
     if (rc) return rc;
     rc = et_kmeans_init_set(C0, d, K, 0, pt, stream);
+    if (rc) return rc;
+    // steps 2 .. K-1 and the final pick in ONE persistent launch (ET_KMEANS_INIT=steps: one launch per step, the form the
+    // sharded path and a timed-out grid barrier take)
+    const char *mode = getenv("ET_KMEANS_INIT");
+    if (K >= 3 && !(mode && mode[0] == 's')) {
+        rc = init_step_impl(X, N, d, K, 1, C0, w.best, 0, w.cand, workspace, workspace_bytes, stream, C0, false);
+        if (rc) return rc;
+        bool aborted = false;
+        rc = km_init_persist_run(X, N, d, K, C0, w, (hipStream_t)stream, &aborted);
+        if (rc || !aborted) return rc;
+    }
     for (int i = 1; i < K && !rc; ++i)  // one launch per new centroid (+ one pick for the last)
         rc = init_step_impl(X, N, d, K, i, C0, w.best, 0, w.cand, workspace, workspace_bytes, stream, C0, i == K - 1);
     return rc;
@@ -3342,6 +3460,45 @@ class PersistSlots {
     std::condition_variable cv_;
     int used_ = 0;
 };
+
+}  // namespace et
+// Steps 2 .. K-1 + the final pick of the farthest-first initialisation as one persistent launch (kmeans_init_persist_kernel).
+// *aborted: the grid barrier timed out (another process on the GPU) -- the caller starts over with one launch per step.
+// Synchronises the stream (the abort flag must be read before the result is used; the launch-per-step form does not).
+static int km_init_persist_run(const float *X, int64_t N, int d, int K, float *C0, const et::KmWorkspace &w, hipStream_t st,
+                               bool *aborted) {
+    using namespace et;
+    int dev = 0;
+    const int n_cu = km_cu_count(&dev);
+    // as many workgroups as a step of the launch-per-step form would get, capped at two per CU (all co-resident; the
+    // barrier's cost grows with the number of arrivals)
+    int grid = init_step_grid(N, 2);
+    if (grid > 2 * n_cu) grid = 2 * n_cu;
+    ET_HIP_TRY(hipMemsetAsync(w.persist_ctl, 0, 2 * sizeof(unsigned), st));
+    uint4 *meta = (K <= 32 && km_init_tiles_mode()) ? w.init_meta : nullptr;
+    const int n_first = init_step_grid(N, 1);
+    PersistSlots &slots = PersistSlots::of_device(dev);
+    const int need = (grid + 1) / 2;  // CUs' worth of residency (two workgroups per CU)
+    slots.acquire(need, n_cu);
+    struct Release {
+        PersistSlots &s;
+        int n;
+        ~Release() { s.release(n); }
+    } release_on_exit{slots, need};
+    if (d == 6)
+        hipLaunchKernelGGL((kmeans_init_persist_kernel<6>), dim3(grid), dim3(kKmThreads), 0, st, X, N, d, K, C0, w.best, w.labels_u8,
+                           w.init_maxabs, w.block_keys2, w.block_keys, n_first, w.cand, meta, w.persist_ctl);
+    else
+        hipLaunchKernelGGL((kmeans_init_persist_kernel<0>), dim3(grid), dim3(kKmThreads), 0, st, X, N, d, K, C0, w.best, w.labels_u8,
+                           w.init_maxabs, w.block_keys2, w.block_keys, n_first, w.cand, meta, w.persist_ctl);
+    ET_LAUNCH_CHECK();
+    unsigned ctl[2] = {0u, 0u};
+    ET_HIP_TRY(hipMemcpyAsync(ctl, w.persist_ctl, sizeof ctl, hipMemcpyDeviceToHost, st));
+    ET_HIP_TRY(hipStreamSynchronize(st));
+    *aborted = ctl[1] != 0u;
+    return ET_OK;
+}
+namespace et {
 
 __global__ __launch_bounds__(kKmThreads) void kmeans_persist_prepare_kernel(int plen, long long *l0, long long *l1, long long *l2,
                                                                             unsigned *ctl, long long *sim_total,
