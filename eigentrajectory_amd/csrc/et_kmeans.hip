@@ -3240,10 +3240,14 @@ extern "C" int et_kmeans_init_farthest(const float *X, int64_t N, int d, int K, 
     if (rc) return rc;
     rc = et_kmeans_init_set(C0, d, K, 0, pt, stream);
     if (rc) return rc;
-    // steps 2 .. K-1 and the final pick in ONE persistent launch (ET_KMEANS_INIT=steps: one launch per step, the form the
-    // sharded path and a timed-out grid barrier take)
+    // ET_KMEANS_INIT=persist: steps 2 .. K-1 and the final pick in ONE persistent launch.  NOT the default -- measured in
+    // round 4 (profiles/r04b_init_persist.txt): 0.51 ms against 0.25 ms for the 19 launches at N = 1e7, 1.54 against 1.52 ms
+    // for the whole step at N = 1e5.  A step is a chain of dependent round trips either way (keys -> the new centroid's
+    // coordinates -> tile summaries -> the failing tiles' rows -> key); inside one launch three of them become device-scope
+    // atomics served by the memory side (~2 us each) where the launch form reads its predecessor's stores from L2, and
+    // the barrier (drain stores, arrive, poll) costs what the kernel boundary does.
     const char *mode = getenv("ET_KMEANS_INIT");
-    if (K >= 3 && !(mode && mode[0] == 's')) {
+    if (K >= 3 && mode && mode[0] == 'p') {
         rc = init_step_impl(X, N, d, K, 1, C0, w.best, 0, w.cand, workspace, workspace_bytes, stream, C0, false);
         if (rc) return rc;
         bool aborted = false;
