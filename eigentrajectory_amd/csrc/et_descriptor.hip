@@ -966,6 +966,135 @@ __global__ __launch_bounds__(kTile) void reconstruct_bwd_tile_kernel(
     for (int j = 0; j < K; ++j) dC[((int64_t)j * N + n) * S + s] = acc[j];
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused evaluation epilogue on the MATRIX cores (T_pred = 12, k = 6).  In reconstruct_metrics_tile_kernel the contraction
+// U (24 x 6) . (C + A) (6 x S) per trajectory -- 144 fused multiply-adds and as many LDS reads of U per (trajectory,
+// sample) pair -- is what the kernel waits for (VALU bound at 0.27 of the HBM roof, S = 20).  U is the same for every
+// pair, i.e. this is ONE skinny GEMM V = U . C' with the pairs as columns:  v_mfma_f32_32x32x2_f32 (rows = the 24
+// features padded to 32, two k per instruction, 32 pairs per tile, fp32 in / fp32 accumulate -- the same fmaf chain
+// over k = 0..5 as the vector code, bit for bit) does it in three instructions per 32 pairs on a pipe that runs BESIDE
+// the vector ALU.  Its fp32 rate equals the vector rate, so the gain is not flops: the 144 instructions and the U reads
+// leave the vector ALU / LDS, which keep only the epilogue (~45 instructions per lane and tile):
+//   lane (col, h) of a tile holds rows 8g + 4h + r of column col = the time steps {4g + 2h, 4g + 2h + 1}, x and y adjacent;
+//   h = 0 and h = 1 each own 6 of the 12 steps, their displacement sums meet through one cross-lane exchange.
+// Per-row descriptor choice (mode SPLIT): both descriptors' U are A operands and a column's coefficients go to the B
+// operand of its own descriptor, zero to the other's -- six instructions, products with zero do not change the chain.
+// ------------------------------------------------------------------------------------------
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+template <int TP, int K>
+__global__ __launch_bounds__(kTile) void reconstruct_metrics_mfma_kernel(
+    const float *__restrict__ C, int64_t N, int S, int TN, int T_obs,
+    const float *__restrict__ obs, const float *__restrict__ nrm,
+    const float *__restrict__ A_m, const float *__restrict__ A_s,
+    const float *__restrict__ U_m, const float *__restrict__ U_s,
+    int mode, float static_dist, const float *__restrict__ gt, float *__restrict__ ade, float *__restrict__ fde) {
+    static_assert(TP == 12 && K == 6, "rows = 24 features in a 32-row tile, k = 6 = three k-pairs");
+    constexpr int DP = 2 * TP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sGn = smem;                                   // TN * DP: normalised ground truth (16-B aligned rows)
+    float *sMet = sGn + TN * DP;                         // 2 * kTile: (ADE, FDE) per pair
+    float *sBack = sMet + 2 * kTile;                     // TN: 1 / sca (1 for the static descriptor)
+    int *sMv = reinterpret_cast<int *>(sBack + TN);      // TN: descriptor of the row
+    float *sA = reinterpret_cast<float *>(sMv + TN);     // 2 * K * S anchors [descriptor][k][s]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col_in_tile = lane & 31, h = lane >> 5;
+    const int64_t n0 = (int64_t)blockIdx.x * TN;
+    const int rows = (int)min((int64_t)TN, N - n0);
+    const int npairs = rows * S;
+
+    // A operands: U[f][2 j + h] of both descriptors (f = the lane's row; rows 24..31 are padding)
+    float aU[2][3];
+#pragma unroll
+    for (int desc = 0; desc < 2; ++desc) {
+        const float *U = desc ? U_m : U_s;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) aU[desc][j] = (U && col_in_tile < DP) ? U[col_in_tile * K + 2 * j + h] : 0.f;
+    }
+    for (int i = tid; i < 2 * K * S; i += kTile) {
+        const float *src = (i >= K * S) ? A_m : A_s;
+        sA[i] = src ? src[i % (K * S)] : 0.f;
+    }
+    // ground truth, normalised once per row (||denorm(w) - gt|| = ||w - normalise(gt)|| / sca): one point per thread
+    for (int q = tid; q < rows * TP; q += kTile) {
+        const int r = q / TP, t = q - r * TP;
+        const RowNorm p = load_row_norm(nrm, obs, N, n0 + r, T_obs, mode, static_dist);
+        const float2 g = *reinterpret_cast<const float2 *>(gt + (n0 + r) * DP + 2 * t);
+        float2 o;
+        normalize_point(p, g.x, g.y, o.x, o.y);
+        *reinterpret_cast<float2 *>(sGn + r * DP + 2 * t) = o;
+        if (t == 0) {
+            sBack[r] = p.mv ? p.inv : 1.0f;
+            sMv[r] = p.mv;
+        }
+    }
+    __syncthreads();
+
+    const int n_tiles = (npairs + 31) >> 5;
+    const int64_t plane = N * S;
+    for (int ct = wave; ct < n_tiles; ct += kTile / 64) {
+        const int col = ct * 32 + col_in_tile;
+        const bool valid = col < npairs;
+        const int r = valid ? col / S : 0, sidx = valid ? col - (col / S) * S : 0;
+        const int mv = sMv[r];
+        const float *cp = C + (n0 * S + col) + (int64_t)h * plane;  // + 2 j planes
+        float b[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) b[j] = valid ? cp[(int64_t)(2 * j) * plane] + sA[(mv * K + 2 * j + h) * S + sidx] : 0.f;  // anchor.py:87
+        f32x16_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (mode == ET_MODE_SPLIT) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[0][j], mv ? 0.f : b[j], acc, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[1][j], mv ? b[j] : 0.f, acc, 0, 0, 0);
+        } else if (mode == ET_MODE_MOVING) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[1][j], b[j], acc, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[0][j], b[j], acc, 0, 0, 0);
+        }
+        // rows 8 g + 4 h + (0..3) of this column: steps 4 g + 2 h and 4 g + 2 h + 1 (g = 3 is padding)
+        const float4 *g4 = reinterpret_cast<const float4 *>(sGn + r * DP + 4 * h);
+        float sum = 0.f, last = 0.f;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const float4 gn = g4[2 * g];
+            const float ex = acc[4 * g] - gn.x, ey = acc[4 * g + 1] - gn.y, fx = acc[4 * g + 2] - gn.z, fy = acc[4 * g + 3] - gn.w;
+            // v_sqrt_f32 (1 ulp): the metric is compared at 1e-5 m
+            const float d0 = __builtin_amdgcn_sqrtf(ex * ex + ey * ey), d1 = __builtin_amdgcn_sqrtf(fx * fx + fy * fy);
+            sum = (sum + d0) + d1;
+            last = d1;  // h = 1, g = 2: step 11
+        }
+        const float other_sum = __shfl_xor(sum, 32), other_last = __shfl_xor(last, 32);
+        if (h == 0 && valid) {
+            const float back = sBack[r];
+            sMet[2 * col] = ((sum + other_sum) / (float)TP) * back;
+            sMet[2 * col + 1] = other_last * back;
+        }
+    }
+    __syncthreads();
+    // best of S per pedestrian: a tree over the S consecutive pairs of a row
+    const int nl = tid / S, s = tid - nl * S;
+    for (int len = S; len > 1;) {
+        const int half = (len + 1) >> 1;
+        if (tid < npairs && s + half < len) {  // the partner slot s + half >= len - half is not written in this step
+            float2 mine = *reinterpret_cast<const float2 *>(sMet + 2 * tid);
+            const float2 other = *reinterpret_cast<const float2 *>(sMet + 2 * (tid + half));
+            mine.x = (other.x < mine.x || isnan(other.x)) ? other.x : mine.x;  // torch.min propagates NaN
+            mine.y = (other.y < mine.y || isnan(other.y)) ? other.y : mine.y;
+            *reinterpret_cast<float2 *>(sMet + 2 * tid) = mine;
+        }
+        __syncthreads();
+        len = half;
+    }
+    if (tid < rows) {
+        ade[n0 + tid] = sMet[2 * (tid * S)];
+        fde[n0 + tid] = sMet[2 * (tid * S) + 1];
+    }
+}
+
 // Any-shape fallbacks: lane = (trajectory, sample) pair, direct global accesses.
 __global__ __launch_bounds__(kTile) void reconstruct_generic_kernel(
     const float *__restrict__ C, int64_t N, int S, int k, int T_obs, int T_pred,
@@ -1166,10 +1295,17 @@ extern "C" int et_anchor_reconstruct_metrics(const float *C, int64_t N, int S, i
     const bool fast = T_pred == 12 && k == 6 && S <= kTile && aligned16(gt);
     if (fast) {
         const int TN = kTile / S;
-        const size_t lds = sizeof(float) * ((size_t)TN * 24 + (size_t)TN * S * 2 + (size_t)TN * kNormStride + 2 * 24 * 6 +
-                                            2 * 6 * (size_t)S);
-        hipLaunchKernelGGL((reconstruct_metrics_tile_kernel<12, 6>), dim3((unsigned)ceil_div(N, TN)), dim3(kTile), lds, st,
-                           C, N, S, TN, T_obs, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, gt, ade, fde);
+        const char *e = getenv("ET_METRICS_MFMA");  // 0: the vector-ALU kernel (A/B runs, tests)
+        if (!(e && e[0] == '0') && aligned16(gt)) {
+            const size_t lds = sizeof(float) * ((size_t)TN * 24 + 2 * (size_t)kTile + 2 * (size_t)TN + 2 * 6 * (size_t)S);
+            hipLaunchKernelGGL((reconstruct_metrics_mfma_kernel<12, 6>), dim3((unsigned)ceil_div(N, TN)), dim3(kTile), lds, st,
+                               C, N, S, TN, T_obs, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, gt, ade, fde);
+        } else {
+            const size_t lds = sizeof(float) * ((size_t)TN * 24 + (size_t)TN * S * 2 + (size_t)TN * kNormStride + 2 * 24 * 6 +
+                                                2 * 6 * (size_t)S);
+            hipLaunchKernelGGL((reconstruct_metrics_tile_kernel<12, 6>), dim3((unsigned)ceil_div(N, TN)), dim3(kTile), lds, st,
+                               C, N, S, TN, T_obs, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, gt, ade, fde);
+        }
     } else {
         hipLaunchKernelGGL(reconstruct_metrics_generic_kernel, dim3((unsigned)ceil_div(N, kTile)), dim3(kTile), 0, st, C, N,
                            S, k, T_obs, T_pred, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, gt, ade, fde);

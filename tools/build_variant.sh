@@ -13,7 +13,7 @@ make -C "$C" -s
 BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
 EXTRA=""
 [ "$SRC" = "et_kmeans.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize"
-[ "$SRC" = "et_descriptor.hip" ] && EXTRA="-fno-slp-vectorize"
+[ "$SRC" = "et_descriptor.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize"
 [ "$SRC" = "et_fit.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize"
 /opt/rocm/bin/hipcc $BASE $EXTRA $FLAGS -c "$C/$SRC" -o "$V/${SRC%.hip}_$NAME.o"
 OBJS=""
