@@ -1004,6 +1004,17 @@ __global__ __launch_bounds__(kTile) void reconstruct_metrics_mfma_kernel(
     const int rows = (int)min((int64_t)TN, N - n0);
     const int npairs = rows * S;
 
+    // this wavefront's coefficient loads go out first (a workgroup has at most 256 / 32 = 8 column tiles: two per
+    // wavefront): they travel while U, the anchors and the ground truth are staged -- one exposed latency per workgroup
+    const int64_t plane = N * S;
+    float craw[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int col = (wave + (kTile / 64) * t) * 32 + col_in_tile;
+        const float *cp = C + (n0 * S + col) + (int64_t)h * plane;  // + 2 j planes
+#pragma unroll
+        for (int j = 0; j < 3; ++j) craw[t][j] = col < npairs ? cp[(int64_t)(2 * j) * plane] : 0.f;
+    }
     // A operands: U[f][2 j + h] of both descriptors (f = the lane's row; rows 24..31 are padding)
     float aU[2][3];
 #pragma unroll
@@ -1031,17 +1042,16 @@ __global__ __launch_bounds__(kTile) void reconstruct_metrics_mfma_kernel(
     }
     __syncthreads();
 
-    const int n_tiles = (npairs + 31) >> 5;
-    const int64_t plane = N * S;
-    for (int ct = wave; ct < n_tiles; ct += kTile / 64) {
-        const int col = ct * 32 + col_in_tile;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int col = (wave + (kTile / 64) * t) * 32 + col_in_tile;
+        if ((wave + (kTile / 64) * t) * 32 >= npairs) break;  // (uniform over the wavefront)
         const bool valid = col < npairs;
         const int r = valid ? col / S : 0, sidx = valid ? col - (col / S) * S : 0;
         const int mv = sMv[r];
-        const float *cp = C + (n0 * S + col) + (int64_t)h * plane;  // + 2 j planes
         float b[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) b[j] = valid ? cp[(int64_t)(2 * j) * plane] + sA[(mv * K + 2 * j + h) * S + sidx] : 0.f;  // anchor.py:87
+        for (int j = 0; j < 3; ++j) b[j] = valid ? craw[t][j] + sA[(mv * K + 2 * j + h) * S + sidx] : 0.f;  // anchor.py:87
         f32x16_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (mode == ET_MODE_SPLIT) {
 #pragma unroll
