@@ -982,39 +982,36 @@ __global__ __launch_bounds__(kTile) void reconstruct_bwd_tile_kernel(
 // ------------------------------------------------------------------------------------------
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
+// The workgroup-tile form of this kernel (and of its vector-ALU predecessor, reconstruct_metrics_tile_kernel) is bound by
+// neither pipe: a workgroup lives through load -> barrier -> compute -> barrier -> min tree (five barriers) -> store for
+// ONE tile of 240 pairs, and 2.7 ms at N = 1e7 is 34 cycles per pair and SIMD where the vector form issues 12 (round 4:
+// the matrix-core contraction alone changed nothing, 2.82 against 2.74 ms).  Hence: a persistent grid of AUTONOMOUS
+// wavefronts.  A wavefront takes TNW = 64 / S trajectories (S = 20: 3 trajectories = 60 pairs = two 32-column tiles)
+// per pass in its own LDS slice, requests the next pass's coefficients / ground truth / normaliser state before it
+// computes this one, and never meets a workgroup barrier after the prologue.
+constexpr int kMetWaves = 4;  // wavefronts per workgroup
+
 template <int TP, int K>
-__global__ __launch_bounds__(kTile) void reconstruct_metrics_mfma_kernel(
-    const float *__restrict__ C, int64_t N, int S, int TN, int T_obs,
+__global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kernel(
+    const float *__restrict__ C, int64_t N, int S, int TNW, int T_obs,
     const float *__restrict__ obs, const float *__restrict__ nrm,
     const float *__restrict__ A_m, const float *__restrict__ A_s,
     const float *__restrict__ U_m, const float *__restrict__ U_s,
     int mode, float static_dist, const float *__restrict__ gt, float *__restrict__ ade, float *__restrict__ fde) {
     static_assert(TP == 12 && K == 6, "rows = 24 features in a 32-row tile, k = 6 = three k-pairs");
     constexpr int DP = 2 * TP;
+    constexpr int kMetRows = 8;  // >= 64 / S for S >= 12 (rounded up to keep the slices 16-byte aligned)
+    constexpr int kSlice = kMetRows * DP + 2 * 64 + kMetRows + kMetRows;  // floats per wavefront: normalised gt | (ADE, FDE) per pair | 1/sca | descriptor
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *sGn = smem;                                   // TN * DP: normalised ground truth (16-B aligned rows)
-    float *sMet = sGn + TN * DP;                         // 2 * kTile: (ADE, FDE) per pair
-    float *sBack = sMet + 2 * kTile;                     // TN: 1 / sca (1 for the static descriptor)
-    int *sMv = reinterpret_cast<int *>(sBack + TN);      // TN: descriptor of the row
-    float *sA = reinterpret_cast<float *>(sMv + TN);     // 2 * K * S anchors [descriptor][k][s]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *sGn = smem + wave * kSlice;                    // TNW * DP (16-B aligned rows)
+    float *sMet = sGn + kMetRows * DP;                    // 2 * 64
+    float *sBack = sMet + 2 * 64;                         // TNW
+    int *sMv = reinterpret_cast<int *>(sBack + kMetRows); // TNW
+    float *sA = smem + kMetWaves * kSlice;                // 2 * K * S anchors [descriptor][k][s], shared by the workgroup
     const int col_in_tile = lane & 31, h = lane >> 5;
-    const int64_t n0 = (int64_t)blockIdx.x * TN;
-    const int rows = (int)min((int64_t)TN, N - n0);
-    const int npairs = rows * S;
 
-    // this wavefront's coefficient loads go out first (a workgroup has at most 256 / 32 = 8 column tiles: two per
-    // wavefront): they travel while U, the anchors and the ground truth are staged -- one exposed latency per workgroup
-    const int64_t plane = N * S;
-    float craw[2][3];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int col = (wave + (kTile / 64) * t) * 32 + col_in_tile;
-        const float *cp = C + (n0 * S + col) + (int64_t)h * plane;  // + 2 j planes
-#pragma unroll
-        for (int j = 0; j < 3; ++j) craw[t][j] = col < npairs ? cp[(int64_t)(2 * j) * plane] : 0.f;
-    }
     // A operands: U[f][2 j + h] of both descriptors (f = the lane's row; rows 24..31 are padding)
     float aU[2][3];
 #pragma unroll
@@ -1023,85 +1020,118 @@ __global__ __launch_bounds__(kTile) void reconstruct_metrics_mfma_kernel(
 #pragma unroll
         for (int j = 0; j < 3; ++j) aU[desc][j] = (U && col_in_tile < DP) ? U[col_in_tile * K + 2 * j + h] : 0.f;
     }
-    for (int i = tid; i < 2 * K * S; i += kTile) {
+    for (int i = tid; i < 2 * K * S; i += kMetWaves * 64) {
         const float *src = (i >= K * S) ? A_m : A_s;
         sA[i] = src ? src[i % (K * S)] : 0.f;
     }
-    // ground truth, normalised once per row (||denorm(w) - gt|| = ||w - normalise(gt)|| / sca): one point per thread
-    for (int q = tid; q < rows * TP; q += kTile) {
-        const int r = q / TP, t = q - r * TP;
-        const RowNorm p = load_row_norm(nrm, obs, N, n0 + r, T_obs, mode, static_dist);
-        const float2 g = *reinterpret_cast<const float2 *>(gt + (n0 + r) * DP + 2 * t);
-        float2 o;
-        normalize_point(p, g.x, g.y, o.x, o.y);
-        *reinterpret_cast<float2 *>(sGn + r * DP + 2 * t) = o;
-        if (t == 0) {
-            sBack[r] = p.mv ? p.inv : 1.0f;
-            sMv[r] = p.mv;
-        }
-    }
-    __syncthreads();
+    __syncthreads();  // the only workgroup barrier
 
+    auto wave_sync = [&]() {  // LDS hand-over between the lanes of this wavefront
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    const int64_t plane = N * S;
+    const int64_t n_pass = (N + TNW - 1) / TNW;
+    const int64_t stride = (int64_t)gridDim.x * kMetWaves;
+    // this lane's part of a pass: column col of tile t (t = 0, 1), and ground-truth point (row gr, step gs) if lane < rows * 12
+    const int gr = lane / TP, gs = lane - gr * TP;
+    float craw[2][3], nr[4];
+    float2 gp;
+    auto request = [&](int64_t pass) {
+        const int64_t n0 = pass * TNW;
+        const int rows = (int)min((int64_t)TNW, N - n0), npairs = rows * S;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int col = (wave + (kTile / 64) * t) * 32 + col_in_tile;
-        if ((wave + (kTile / 64) * t) * 32 >= npairs) break;  // (uniform over the wavefront)
-        const bool valid = col < npairs;
-        const int r = valid ? col / S : 0, sidx = valid ? col - (col / S) * S : 0;
-        const int mv = sMv[r];
-        float b[3];
+        for (int t = 0; t < 2; ++t) {
+            const int col = 32 * t + col_in_tile;
+            const float *cp = C + (n0 * S + col) + (int64_t)h * plane;  // + 2 j planes
 #pragma unroll
-        for (int j = 0; j < 3; ++j) b[j] = valid ? craw[t][j] + sA[(mv * K + 2 * j + h) * S + sidx] : 0.f;  // anchor.py:87
-        f32x16_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (mode == ET_MODE_SPLIT) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[0][j], mv ? 0.f : b[j], acc, 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[1][j], mv ? b[j] : 0.f, acc, 0, 0, 0);
-        } else if (mode == ET_MODE_MOVING) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[1][j], b[j], acc, 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[0][j], b[j], acc, 0, 0, 0);
+            for (int j = 0; j < 3; ++j) craw[t][j] = col < npairs ? cp[(int64_t)(2 * j) * plane] : 0.f;
         }
-        // rows 8 g + 4 h + (0..3) of this column: steps 4 g + 2 h and 4 g + 2 h + 1 (g = 3 is padding)
-        const float4 *g4 = reinterpret_cast<const float4 *>(sGn + r * DP + 4 * h);
-        float sum = 0.f, last = 0.f;
+        const bool live = gr < rows;  // (TNW <= 5 whenever it matters: S >= 12; rows * 12 <= 64 is checked by the host)
+        gp = live ? *reinterpret_cast<const float2 *>(gt + (n0 + gr) * DP + 2 * gs) : make_float2(0.f, 0.f);
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            const float4 gn = g4[2 * g];
-            const float ex = acc[4 * g] - gn.x, ey = acc[4 * g + 1] - gn.y, fx = acc[4 * g + 2] - gn.z, fy = acc[4 * g + 3] - gn.w;
-            // v_sqrt_f32 (1 ulp): the metric is compared at 1e-5 m
-            const float d0 = __builtin_amdgcn_sqrtf(ex * ex + ey * ey), d1 = __builtin_amdgcn_sqrtf(fx * fx + fy * fy);
-            sum = (sum + d0) + d1;
-            last = d1;  // h = 1, g = 2: step 11
+        for (int j = 0; j < 4; ++j) nr[j] = (live && nrm && mode != ET_MODE_IDENTITY) ? nrm[(int64_t)j * N + n0 + gr] : 0.f;
+    };
+    int64_t pass = (int64_t)blockIdx.x * kMetWaves + wave;
+    if (pass < n_pass) request(pass);
+    for (; pass < n_pass; pass += stride) {
+        const int64_t n0 = pass * TNW;
+        const int rows = (int)min((int64_t)TNW, N - n0), npairs = rows * S;
+        wave_sync();  // the previous pass is done with the slice
+        if (gr < rows) {
+            RowNorm p;
+            if (nrm || mode == ET_MODE_IDENTITY) p = row_norm(nr[0], nr[1], nr[2], nr[3], mode, static_dist);
+            else p = load_row_norm(nullptr, obs, N, n0 + gr, T_obs, mode, static_dist);
+            float2 o;
+            normalize_point(p, gp.x, gp.y, o.x, o.y);  // ||denorm(w) - gt|| = ||w - normalise(gt)|| / sca
+            *reinterpret_cast<float2 *>(sGn + gr * DP + 2 * gs) = o;
+            if (gs == 0) {
+                sBack[gr] = p.mv ? p.inv : 1.0f;
+                sMv[gr] = p.mv;
+            }
         }
-        const float other_sum = __shfl_xor(sum, 32), other_last = __shfl_xor(last, 32);
-        if (h == 0 && valid) {
-            const float back = sBack[r];
-            sMet[2 * col] = ((sum + other_sum) / (float)TP) * back;
-            sMet[2 * col + 1] = other_last * back;
+        float cur[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) cur[t][j] = craw[t][j];
+        if (pass + stride < n_pass) request(pass + stride);  // travels while this pass is computed
+        wave_sync();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (32 * t >= npairs) break;  // (uniform over the wavefront)
+            const int col = 32 * t + col_in_tile;
+            const bool valid = col < npairs;
+            const int r = valid ? col / S : 0, sidx = valid ? col - (col / S) * S : 0;
+            const int mv = sMv[r];
+            float b[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) b[j] = valid ? cur[t][j] + sA[(mv * K + 2 * j + h) * S + sidx] : 0.f;  // anchor.py:87
+            f32x16_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (mode == ET_MODE_SPLIT) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[0][j], mv ? 0.f : b[j], acc, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[1][j], mv ? b[j] : 0.f, acc, 0, 0, 0);
+            } else if (mode == ET_MODE_MOVING) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[1][j], b[j], acc, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[0][j], b[j], acc, 0, 0, 0);
+            }
+            // rows 8 g + 4 h + (0..3) of this column: steps 4 g + 2 h and 4 g + 2 h + 1 (g = 3 is padding)
+            const float4 *g4 = reinterpret_cast<const float4 *>(sGn + r * DP + 4 * h);
+            float sum = 0.f, last = 0.f;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const float4 gn = g4[2 * g];
+                const float ex = acc[4 * g] - gn.x, ey = acc[4 * g + 1] - gn.y, fx = acc[4 * g + 2] - gn.z, fy = acc[4 * g + 3] - gn.w;
+                // v_sqrt_f32 (1 ulp): the metric is compared at 1e-5 m
+                const float d0 = __builtin_amdgcn_sqrtf(ex * ex + ey * ey), d1 = __builtin_amdgcn_sqrtf(fx * fx + fy * fy);
+                sum = (sum + d0) + d1;
+                last = d1;  // h = 1, g = 2: step 11
+            }
+            const float other_sum = __shfl_xor(sum, 32), other_last = __shfl_xor(last, 32);
+            if (h == 0 && valid) {
+                const float back = sBack[r];
+                sMet[2 * col] = ((sum + other_sum) / (float)TP) * back;
+                sMet[2 * col + 1] = other_last * back;
+            }
         }
-    }
-    __syncthreads();
-    // best of S per pedestrian: a tree over the S consecutive pairs of a row
-    const int nl = tid / S, s = tid - nl * S;
-    for (int len = S; len > 1;) {
-        const int half = (len + 1) >> 1;
-        if (tid < npairs && s + half < len) {  // the partner slot s + half >= len - half is not written in this step
-            float2 mine = *reinterpret_cast<const float2 *>(sMet + 2 * tid);
-            const float2 other = *reinterpret_cast<const float2 *>(sMet + 2 * (tid + half));
-            mine.x = (other.x < mine.x || isnan(other.x)) ? other.x : mine.x;  // torch.min propagates NaN
-            mine.y = (other.y < mine.y || isnan(other.y)) ? other.y : mine.y;
-            *reinterpret_cast<float2 *>(sMet + 2 * tid) = mine;
+        wave_sync();
+        if (lane < rows) {  // best of S (torch.min propagates NaN)
+            const float2 *m2 = reinterpret_cast<const float2 *>(sMet) + lane * S;
+            float2 best = m2[0];
+            for (int s = 1; s < S; ++s) {
+                const float2 o = m2[s];
+                best.x = (o.x < best.x || isnan(o.x)) ? o.x : best.x;
+                best.y = (o.y < best.y || isnan(o.y)) ? o.y : best.y;
+            }
+            ade[n0 + lane] = best.x;
+            fde[n0 + lane] = best.y;
         }
-        __syncthreads();
-        len = half;
-    }
-    if (tid < rows) {
-        ade[n0 + tid] = sMet[2 * (tid * S)];
-        fde[n0 + tid] = sMet[2 * (tid * S) + 1];
     }
 }
 
@@ -1305,11 +1335,16 @@ extern "C" int et_anchor_reconstruct_metrics(const float *C, int64_t N, int S, i
     const bool fast = T_pred == 12 && k == 6 && S <= kTile && aligned16(gt);
     if (fast) {
         const int TN = kTile / S;
-        const char *e = getenv("ET_METRICS_MFMA");  // 0: the vector-ALU kernel (A/B runs, tests)
-        if (!(e && e[0] == '0') && aligned16(gt)) {
-            const size_t lds = sizeof(float) * ((size_t)TN * 24 + 2 * (size_t)kTile + 2 * (size_t)TN + 2 * 6 * (size_t)S);
-            hipLaunchKernelGGL((reconstruct_metrics_mfma_kernel<12, 6>), dim3((unsigned)ceil_div(N, TN)), dim3(kTile), lds, st,
-                               C, N, S, TN, T_obs, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, gt, ade, fde);
+        const char *e = getenv("ET_METRICS_MFMA");  // 0: the vector-ALU workgroup-tile kernel (A/B runs, tests)
+        // the matrix-core kernel: a wavefront takes 64 / S trajectories per pass and normalises one ground-truth point
+        // per lane, so S <= 64 and (64 / S) * 12 <= 64, i.e. 12 <= S <= 64 (the model form is S = 20)
+        if (!(e && e[0] == '0') && aligned16(gt) && S >= 12 && S <= 64 && (nrm || obs || mode == ET_MODE_IDENTITY)) {
+            const int TNW = 64 / S;
+            const size_t lds = sizeof(float) * ((size_t)kMetWaves * (8 * 24 + 2 * 64 + 8 + 8) + 2 * 6 * (size_t)S);
+            const int64_t passes = ceil_div(N, TNW);
+            const unsigned g = (unsigned)min((int64_t)cu_count() * 6, ceil_div(passes, kMetWaves));  // 78 VGPRs: 6 wavefronts per SIMD
+            hipLaunchKernelGGL((reconstruct_metrics_mfma_kernel<12, 6>), dim3(g), dim3(kMetWaves * 64), lds, st,
+                               C, N, S, TNW, T_obs, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, gt, ade, fde);
         } else {
             const size_t lds = sizeof(float) * ((size_t)TN * 24 + (size_t)TN * S * 2 + (size_t)TN * kNormStride + 2 * 24 * 6 +
                                                 2 * 6 * (size_t)S);
