@@ -1055,6 +1055,10 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
     };
     int64_t pass = (int64_t)blockIdx.x * kMetWaves + wave;
     if (pass < n_pass) request(pass);
+    // a pass's two results are stored at the START of the next pass, in front of that pass's prefetch: the counted wait
+    // for a prefetch then never includes stores issued after it (their round trip would be exposed in every pass)
+    float2 held = make_float2(0.f, 0.f);
+    int64_t held_n = -1;
     for (; pass < n_pass; pass += stride) {
         const int64_t n0 = pass * TNW;
         const int rows = (int)min((int64_t)TNW, N - n0), npairs = rows * S;
@@ -1076,6 +1080,10 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int j = 0; j < 3; ++j) cur[t][j] = craw[t][j];
+        if (held_n >= 0) {
+            ade[held_n] = held.x;
+            fde[held_n] = held.y;
+        }
         if (pass + stride < n_pass) request(pass + stride);  // travels while this pass is computed
         wave_sync();
 #pragma unroll
@@ -1129,9 +1137,15 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
                 best.x = (o.x < best.x || isnan(o.x)) ? o.x : best.x;
                 best.y = (o.y < best.y || isnan(o.y)) ? o.y : best.y;
             }
-            ade[n0 + lane] = best.x;
-            fde[n0 + lane] = best.y;
+            held = best;
+            held_n = n0 + lane;
+        } else {
+            held_n = -1;
         }
+    }
+    if (held_n >= 0) {
+        ade[held_n] = held.x;
+        fde[held_n] = held.y;
     }
 }
 
