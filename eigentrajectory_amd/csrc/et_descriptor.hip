@@ -1034,38 +1034,85 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
     const int64_t plane = N * S;
     const int64_t n_pass = (N + TNW - 1) / TNW;
     const int64_t stride = (int64_t)gridDim.x * kMetWaves;
-    // this lane's part of a pass: column col of tile t (t = 0, 1), and ground-truth point (row gr, step gs) if lane < rows * 12
+    const int full_pairs = TNW * S;
+    // Everything a lane derives from its position alone is computed ONCE (the integer divisions by S, the anchor and
+    // ground-truth offsets): the loop below was bound by instruction issue (~1000 instructions per pass, most of them
+    // index arithmetic) before this -- the six matrix instructions and ~90 of epilogue are what is left.
+    int row_t[2], anc_t[2];  // tile t: this lane's row of the pass, and (2 * 0 + h) * S + sample
+    bool col_ok[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int col = 32 * t + col_in_tile;
+        col_ok[t] = col < full_pairs;
+        row_t[t] = col_ok[t] ? col / S : 0;
+        anc_t[t] = h * S + (col_ok[t] ? col - row_t[t] * S : 0);
+    }
+    // ground-truth point of this lane: (row gr, step gs) if lane < TNW * 12
     const int gr = lane / TP, gs = lane - gr * TP;
+    const bool g_ok = gr < TNW;
+    // best-of-S: four lanes per row, each takes every fourth sample
+    const int mr = lane >> 2, mq = lane & 3;
+    // per-lane pointers of the 11 loads of a pass, advanced by one stride of passes per iteration
+    int64_t pass = (int64_t)blockIdx.x * kMetWaves + wave;
+    const float *pc[2][3], *pg, *pn[4];
+    {
+        const int64_t n0 = pass * TNW;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) pc[t][j] = C + (int64_t)(2 * j + h) * plane + n0 * S + (col_ok[t] ? 32 * t + col_in_tile : 0);
+        pg = gt + (n0 + (g_ok ? gr : 0)) * DP + 2 * gs;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pn[j] = (nrm ? nrm : gt) + (int64_t)j * N + n0 + (g_ok ? gr : 0);
+    }
+    const int64_t adv_c = stride * TNW * S, adv_g = stride * TNW * DP, adv_n = stride * TNW;
+    const bool use_nrm = nrm != nullptr && mode != ET_MODE_IDENTITY;
     float craw[2][3], nr[4];
     float2 gp;
-    auto request = [&](int64_t pass) {
-        const int64_t n0 = pass * TNW;
-        const int rows = (int)min((int64_t)TNW, N - n0), npairs = rows * S;
+    // loads of the pass the pointers stand on; `rows` < TNW only for the very last pass (masked: nothing is read past the
+    // arrays), every other pass is straight-line code
+    auto request = [&](int rows) {
+        if (rows == TNW) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int col = 32 * t + col_in_tile;
-            const float *cp = C + (n0 * S + col) + (int64_t)h * plane;  // + 2 j planes
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) craw[t][j] = col < npairs ? cp[(int64_t)(2 * j) * plane] : 0.f;
+                for (int j = 0; j < 3; ++j) craw[t][j] = *pc[t][j];
+            gp = *reinterpret_cast<const float2 *>(pg);
+            if (use_nrm) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nr[j] = *pn[j];
+            }
+        } else {
+            const int npairs = rows * S;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) craw[t][j] = (32 * t + col_in_tile < npairs) ? *pc[t][j] : 0.f;
+            gp = gr < rows ? *reinterpret_cast<const float2 *>(pg) : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nr[j] = (use_nrm && gr < rows) ? *pn[j] : 0.f;
         }
-        const bool live = gr < rows;  // (TNW <= 5 whenever it matters: S >= 12; rows * 12 <= 64 is checked by the host)
-        gp = live ? *reinterpret_cast<const float2 *>(gt + (n0 + gr) * DP + 2 * gs) : make_float2(0.f, 0.f);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) nr[j] = (live && nrm && mode != ET_MODE_IDENTITY) ? nrm[(int64_t)j * N + n0 + gr] : 0.f;
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) pc[t][j] += adv_c;
+        pg += adv_g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pn[j] += adv_n;
     };
-    int64_t pass = (int64_t)blockIdx.x * kMetWaves + wave;
-    if (pass < n_pass) request(pass);
-    // a pass's two results are stored at the START of the next pass, in front of that pass's prefetch: the counted wait
-    // for a prefetch then never includes stores issued after it (their round trip would be exposed in every pass)
+    auto rows_of = [&](int64_t ps) { return (int)min((int64_t)TNW, N - ps * TNW); };
+    if (pass < n_pass) request(rows_of(pass));
+    // a pass's two results are stored at the START of the next pass, in front of that pass's prefetch: the wait for a
+    // prefetch then never includes stores issued after it
     float2 held = make_float2(0.f, 0.f);
     int64_t held_n = -1;
     for (; pass < n_pass; pass += stride) {
         const int64_t n0 = pass * TNW;
-        const int rows = (int)min((int64_t)TNW, N - n0), npairs = rows * S;
+        const int rows = rows_of(pass), npairs = rows * S;
         wave_sync();  // the previous pass is done with the slice
-        if (gr < rows) {
+        if (g_ok && gr < rows) {
             RowNorm p;
-            if (nrm || mode == ET_MODE_IDENTITY) p = row_norm(nr[0], nr[1], nr[2], nr[3], mode, static_dist);
+            if (use_nrm || mode == ET_MODE_IDENTITY) p = row_norm(nr[0], nr[1], nr[2], nr[3], mode, static_dist);
             else p = load_row_norm(nullptr, obs, N, n0 + gr, T_obs, mode, static_dist);
             float2 o;
             normalize_point(p, gp.x, gp.y, o.x, o.y);  // ||denorm(w) - gt|| = ||w - normalise(gt)|| / sca
@@ -1084,18 +1131,19 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
             ade[held_n] = held.x;
             fde[held_n] = held.y;
         }
-        if (pass + stride < n_pass) request(pass + stride);  // travels while this pass is computed
+        if (pass + stride < n_pass) request(rows_of(pass + stride));  // travels while this pass is computed
         wave_sync();
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (32 * t >= npairs) break;  // (uniform over the wavefront)
             const int col = 32 * t + col_in_tile;
             const bool valid = col < npairs;
-            const int r = valid ? col / S : 0, sidx = valid ? col - (col / S) * S : 0;
+            const int r = row_t[t];
             const int mv = sMv[r];
+            const float *an = sA + mv * (K * S) + anc_t[t];
             float b[3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) b[j] = valid ? cur[t][j] + sA[(mv * K + 2 * j + h) * S + sidx] : 0.f;  // anchor.py:87
+            for (int j = 0; j < 3; ++j) b[j] = valid ? cur[t][j] + an[2 * j * S] : 0.f;  // anchor.py:87
             f32x16_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (mode == ET_MODE_SPLIT) {
 #pragma unroll
@@ -1129,18 +1177,22 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
             }
         }
         wave_sync();
-        if (lane < rows) {  // best of S (torch.min propagates NaN)
-            const float2 *m2 = reinterpret_cast<const float2 *>(sMet) + lane * S;
-            float2 best = m2[0];
-            for (int s = 1; s < S; ++s) {
+        {   // best of S (torch.min propagates NaN): lane (mr, mq) takes samples mq, mq + 4, ...; then two exchanges
+            const float2 *m2 = reinterpret_cast<const float2 *>(sMet) + (mr < rows ? mr : 0) * S;
+            float2 best = m2[mq < S ? mq : 0];
+            for (int s = mq + 4; s < S; s += 4) {
                 const float2 o = m2[s];
                 best.x = (o.x < best.x || isnan(o.x)) ? o.x : best.x;
                 best.y = (o.y < best.y || isnan(o.y)) ? o.y : best.y;
             }
+#pragma unroll
+            for (int o = 1; o < 4; o <<= 1) {
+                const float ox = __shfl_xor(best.x, o), oy = __shfl_xor(best.y, o);
+                best.x = (ox < best.x || isnan(ox)) ? ox : best.x;
+                best.y = (oy < best.y || isnan(oy)) ? oy : best.y;
+            }
             held = best;
-            held_n = n0 + lane;
-        } else {
-            held_n = -1;
+            held_n = (mq == 0 && mr < rows) ? n0 + mr : -1;
         }
     }
     if (held_n >= 0) {
