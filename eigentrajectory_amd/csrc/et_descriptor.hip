@@ -1052,65 +1052,82 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
     const bool g_ok = gr < TNW;
     // best-of-S: four lanes per row, each takes every fourth sample
     const int mr = lane >> 2, mq = lane & 3;
-    // per-lane pointers of the 11 loads of a pass, advanced by one stride of passes per iteration
+    // Every pass is a FULL pass: the last one is moved back to end at row N (it recomputes a few rows of its
+    // predecessor -- same values, same addresses), so the loads below are unconditional straight-line code.  (A masked
+    // variant for a short last pass made the compiler merge two load paths with register copies -- and wait for every
+    // prefetch right where it was issued.)
     int64_t pass = (int64_t)blockIdx.x * kMetWaves + wave;
-    const float *pc[2][3], *pg, *pn[4];
-    {
-        const int64_t n0 = pass * TNW;
+    // The loads and stores of a pass are BUFFER operations: a 128-bit descriptor in scalar registers, a per-lane 32-bit byte
+    // offset that lives in ONE vector register for the whole loop, and the pass's position as a scalar byte offset.  With
+    // 64-bit per-lane pointers the register allocator recycles the address temporaries -- into the registers of the matrix
+    // instruction's accumulator, among others -- and the compiler then drains the memory queue (s_waitcnt vmcnt(0))
+    // before it overwrites them: in front of every tile's first matrix instruction and after every store, i.e. the
+    // prefetch bought nothing (2.9-3.2 ms; with descriptors the waits are counted ones).  Offsets must fit 32 bits: the
+    // host takes this kernel for 2 N S 4 B < 2^32 only.
+    auto rsrc_of = [](const void *base, int64_t bytes) {
+        const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        const int nb = __builtin_amdgcn_readfirstlane((int)(bytes > 0xffffffffll ? 0xffffffffll : bytes));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, nb, 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t rc[3];  // coefficient planes 2 j and 2 j + 1
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+    for (int j = 0; j < 3; ++j) rc[j] = rsrc_of(C + (int64_t)(2 * j) * plane, 2 * plane * 4);
+    const float *nsrc = nrm ? nrm : gt;  // (always a readable address; the values are only used with nrm)
+    const __amdgpu_buffer_rsrc_t rg = rsrc_of(gt, N * DP * 4), rn = rsrc_of(nsrc, nrm ? 4 * N * 4 : N * DP * 4),
+                                 ra = rsrc_of(ade, N * 4), rf = rsrc_of(fde, N * 4);
+    int oc[2];  // tile t's coefficient loads: (h * plane + column) * 4
 #pragma unroll
-            for (int j = 0; j < 3; ++j) pc[t][j] = C + (int64_t)(2 * j + h) * plane + n0 * S + (col_ok[t] ? 32 * t + col_in_tile : 0);
-        pg = gt + (n0 + (g_ok ? gr : 0)) * DP + 2 * gs;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pn[j] = (nrm ? nrm : gt) + (int64_t)j * N + n0 + (g_ok ? gr : 0);
-    }
-    const int64_t adv_c = stride * TNW * S, adv_g = stride * TNW * DP, adv_n = stride * TNW;
+    for (int t = 0; t < 2; ++t) oc[t] = 4 * (int)((int64_t)h * plane + (col_ok[t] ? 32 * t + col_in_tile : 0));
+    const int og = 4 * ((g_ok ? gr : 0) * DP + 2 * gs);
+    const int on = 4 * (g_ok ? gr : 0);
     const bool use_nrm = nrm != nullptr && mode != ET_MODE_IDENTITY;
     float craw[2][3], nr[4];
     float2 gp;
-    // loads of the pass the pointers stand on; `rows` < TNW only for the very last pass (masked: nothing is read past the
-    // arrays), every other pass is straight-line code
-    auto request = [&](int rows) {
-        if (rows == TNW) {
+    auto first_row = [&](int64_t ps) { return min(ps * TNW, N - TNW); };
+    auto request = [&](int64_t n0) {
+        const int so_c = __builtin_amdgcn_readfirstlane((int)(n0 * S * 4)), so_g = __builtin_amdgcn_readfirstlane((int)(n0 * DP * 4));
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) craw[t][j] = *pc[t][j];
-            gp = *reinterpret_cast<const float2 *>(pg);
-            if (use_nrm) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) nr[j] = *pn[j];
-            }
-        } else {
-            const int npairs = rows * S;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) craw[t][j] = (32 * t + col_in_tile < npairs) ? *pc[t][j] : 0.f;
-            gp = gr < rows ? *reinterpret_cast<const float2 *>(pg) : make_float2(0.f, 0.f);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) nr[j] = (use_nrm && gr < rows) ? *pn[j] : 0.f;
+            for (int t = 0; t < 2; ++t) craw[t][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc[j], oc[t], so_c, 0));
+        {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 g = __builtin_amdgcn_raw_buffer_load_b64(rg, og, so_g, 0);
+            gp = make_float2(__uint_as_float(g.x), __uint_as_float(g.y));
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) pc[t][j] += adv_c;
-        pg += adv_g;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pn[j] += adv_n;
+        for (int j = 0; j < 4; ++j) {
+            const int so_n = __builtin_amdgcn_readfirstlane((int)((nrm ? (int64_t)j * N + n0 : n0) * 4));
+            nr[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rn, on, so_n, 0));
+        }
     };
-    auto rows_of = [&](int64_t ps) { return (int)min((int64_t)TNW, N - ps * TNW); };
-    if (pass < n_pass) request(rows_of(pass));
-    // a pass's two results are stored at the START of the next pass, in front of that pass's prefetch: the wait for a
-    // prefetch then never includes stores issued after it
+    if (pass < n_pass) request(first_row(pass));
+    // (the first pass's loads are waited for HERE: entering the loop with loads outstanding, the compiler's merged
+    // bookkeeping at the loop head makes it wait for most of every later prefetch in front of the first matrix instruction)
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+    // A pass's two results are stored at the START of the next pass, in front of that pass's prefetch (the wait for a
+    // prefetch then never includes stores issued after it), by ALL lanes, unconditionally, through a scalar base + a
+    // per-lane offset that lives in one register for the whole loop: lanes beyond the pass's rows repeat its last row
+    // (same value, same address).  A store under a branch, or one whose address temporaries are recycled, makes the
+    // compiler drain the memory queue (s_waitcnt vmcnt(0)) in the middle of the pass.  The first iteration has nothing
+    // to store yet: it writes zeros to its own pass's slots, which the second iteration overwrites.
+    const int mrow = mr < TNW ? mr : TNW - 1;
+    const int om = 4 * mrow;
+    auto store_held = [&](float2 v, int64_t n0) {
+        const int so = __builtin_amdgcn_readfirstlane((int)(n0 * 4));
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), ra, om, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), rf, om, so, 0);
+    };
     float2 held = make_float2(0.f, 0.f);
-    int64_t held_n = -1;
+    int64_t held_n0 = pass < n_pass ? first_row(pass) : 0;
+    const bool did_any = pass < n_pass;
     for (; pass < n_pass; pass += stride) {
-        const int64_t n0 = pass * TNW;
-        const int rows = rows_of(pass), npairs = rows * S;
+        const int64_t n0 = first_row(pass);
+        constexpr bool valid_all = true;
+        const int npairs = full_pairs;
         wave_sync();  // the previous pass is done with the slice
-        if (g_ok && gr < rows) {
+        if (g_ok) {
             RowNorm p;
             if (use_nrm || mode == ET_MODE_IDENTITY) p = row_norm(nr[0], nr[1], nr[2], nr[3], mode, static_dist);
             else p = load_row_norm(nullptr, obs, N, n0 + gr, T_obs, mode, static_dist);
@@ -1127,17 +1144,14 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int j = 0; j < 3; ++j) cur[t][j] = craw[t][j];
-        if (held_n >= 0) {
-            ade[held_n] = held.x;
-            fde[held_n] = held.y;
-        }
-        if (pass + stride < n_pass) request(rows_of(pass + stride));  // travels while this pass is computed
+        store_held(held, held_n0);
+        if (pass + stride < n_pass) request(first_row(pass + stride));  // travels while this pass is computed
         wave_sync();
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (32 * t >= npairs) break;  // (uniform over the wavefront)
             const int col = 32 * t + col_in_tile;
-            const bool valid = col < npairs;
+            const bool valid = valid_all && col_ok[t];
             const int r = row_t[t];
             const int mv = sMv[r];
             const float *an = sA + mv * (K * S) + anc_t[t];
@@ -1178,7 +1192,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
         }
         wave_sync();
         {   // best of S (torch.min propagates NaN): lane (mr, mq) takes samples mq, mq + 4, ...; then two exchanges
-            const float2 *m2 = reinterpret_cast<const float2 *>(sMet) + (mr < rows ? mr : 0) * S;
+            const float2 *m2 = reinterpret_cast<const float2 *>(sMet) + mrow * S;
             float2 best = m2[mq < S ? mq : 0];
             for (int s = mq + 4; s < S; s += 4) {
                 const float2 o = m2[s];
@@ -1192,13 +1206,10 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
                 best.y = (oy < best.y || isnan(oy)) ? oy : best.y;
             }
             held = best;
-            held_n = (mq == 0 && mr < rows) ? n0 + mr : -1;
+            held_n0 = n0;
         }
     }
-    if (held_n >= 0) {
-        ade[held_n] = held.x;
-        fde[held_n] = held.y;
-    }
+    if (did_any) store_held(held, held_n0);
 }
 
 // Any-shape fallbacks: lane = (trajectory, sample) pair, direct global accesses.
@@ -1404,7 +1415,7 @@ extern "C" int et_anchor_reconstruct_metrics(const float *C, int64_t N, int S, i
         const char *e = getenv("ET_METRICS_MFMA");  // 0: the vector-ALU workgroup-tile kernel (A/B runs, tests)
         // the matrix-core kernel: a wavefront takes 64 / S trajectories per pass and normalises one ground-truth point
         // per lane, so S <= 64 and (64 / S) * 12 <= 64, i.e. 12 <= S <= 64 (the model form is S = 20)
-        if (!(e && e[0] == '0') && aligned16(gt) && S >= 12 && S <= 64 && (nrm || obs || mode == ET_MODE_IDENTITY)) {
+        if (!(e && e[0] == '0') && aligned16(gt) && S >= 12 && S <= 64 && N >= 64 / S && N * S < ((int64_t)1 << 29) && N * 24 < ((int64_t)1 << 30)) {
             const int TNW = 64 / S;
             const size_t lds = sizeof(float) * ((size_t)kMetWaves * (8 * 24 + 2 * 64 + 8 + 8) + 2 * 6 * (size_t)S);
             const int64_t passes = ceil_div(N, TNW);
