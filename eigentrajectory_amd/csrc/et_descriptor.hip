@@ -1160,10 +1160,17 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
             for (int j = 0; j < 3; ++j) b[j] = valid ? cur[t][j] + an[2 * j * S] : 0.f;  // anchor.py:87
             f32x16_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (mode == ET_MODE_SPLIT) {
+                // (a tile spans two or three rows: most tiles hold one descriptor only and skip the other's instructions --
+                // the fp32 matrix instructions run on the vector ALU's multipliers, their time ADDS to the epilogue's)
+                const bool any_s = __ballot(valid && !mv) != 0ull, any_m = __ballot(valid && mv) != 0ull;
+                if (any_s) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[0][j], mv ? 0.f : b[j], acc, 0, 0, 0);
+                    for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[0][j], mv ? 0.f : b[j], acc, 0, 0, 0);
+                }
+                if (any_m) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[1][j], mv ? b[j] : 0.f, acc, 0, 0, 0);
+                    for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[1][j], mv ? b[j] : 0.f, acc, 0, 0, 0);
+                }
             } else if (mode == ET_MODE_MOVING) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[1][j], b[j], acc, 0, 0, 0);
@@ -1186,7 +1193,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
             const float other_sum = __shfl_xor(sum, 32), other_last = __shfl_xor(last, 32);
             if (h == 0 && valid) {
                 const float back = sBack[r];
-                sMet[2 * col] = ((sum + other_sum) / (float)TP) * back;
+                sMet[2 * col] = ((sum + other_sum) * (1.0f / (float)TP)) * back;
                 sMet[2 * col + 1] = other_last * back;
             }
         }
