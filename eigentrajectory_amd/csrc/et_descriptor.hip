@@ -1426,7 +1426,13 @@ extern "C" int et_anchor_reconstruct_metrics(const float *C, int64_t N, int S, i
             const int TNW = 64 / S;
             const size_t lds = sizeof(float) * ((size_t)kMetWaves * (8 * 24 + 2 * 64 + 8 + 8) + 2 * 6 * (size_t)S);
             const int64_t passes = ceil_div(N, TNW);
-            const unsigned g = (unsigned)min((int64_t)cu_count() * 6, ceil_div(passes, kMetWaves));  // 78 VGPRs: 6 wavefronts per SIMD
+            // a persistent grid: exactly the workgroups that are resident together (a surplus workgroup would start when
+            // the others are done and double the run time of its CU)
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reconstruct_metrics_mfma_kernel<12, 6>, kMetWaves * 64, lds) !=
+                    hipSuccess || per_cu < 1)
+                per_cu = 4;
+            const unsigned g = (unsigned)min((int64_t)cu_count() * per_cu, ceil_div(passes, kMetWaves));
             hipLaunchKernelGGL((reconstruct_metrics_mfma_kernel<12, 6>), dim3(g), dim3(kMetWaves * 64), lds, st,
                                C, N, S, TNW, T_obs, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, gt, ade, fde);
         } else {
