@@ -972,9 +972,11 @@ __global__ __launch_bounds__(kTile) void reconstruct_bwd_tile_kernel(
 // sample) pair -- is what the kernel waits for (VALU bound at 0.27 of the HBM roof, S = 20).  U is the same for every
 // pair, i.e. this is ONE skinny GEMM V = U . C' with the pairs as columns:  v_mfma_f32_32x32x2_f32 (rows = the 24
 // features padded to 32, two k per instruction, 32 pairs per tile, fp32 in / fp32 accumulate -- the same fmaf chain
-// over k = 0..5 as the vector code, bit for bit) does it in three instructions per 32 pairs on a pipe that runs BESIDE
-// the vector ALU.  Its fp32 rate equals the vector rate, so the gain is not flops: the 144 instructions and the U reads
-// leave the vector ALU / LDS, which keep only the epilogue (~45 instructions per lane and tile):
+// over k = 0..5 as the vector code, bit for bit) does it in three instructions per 32 pairs.  Not a flops gain: the fp32
+// matrix instructions run at the vector rate AND on the vector ALU's multipliers (their busy cycles add to the
+// epilogue's, profiles/r04c_metrics_pmc.txt: SPLIT's three extra instructions per tile cost exactly their 192 cycles) --
+// what it buys is issue slots and LDS traffic: 144 instructions and as many broadcast reads of U per pair become 3 per
+// 32 pairs, and the vector ALU keeps the epilogue (~45 instructions per lane and tile):
 //   lane (col, h) of a tile holds rows 8g + 4h + r of column col = the time steps {4g + 2h, 4g + 2h + 1}, x and y adjacent;
 //   h = 0 and h = 1 each own 6 of the 12 steps, their displacement sums meet through one cross-lane exchange.
 // Per-row descriptor choice (mode SPLIT): both descriptors' U are A operands and a column's coefficients go to the B
@@ -1128,15 +1130,44 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
         const int npairs = full_pairs;
         wave_sync();  // the previous pass is done with the slice
         if (g_ok) {
-            RowNorm p;
-            if (use_nrm || mode == ET_MODE_IDENTITY) p = row_norm(nr[0], nr[1], nr[2], nr[3], mode, static_dist);
-            else p = load_row_norm(nullptr, obs, N, n0 + gr, T_obs, mode, static_dist);
+            float ox = nr[0], oy = nr[1], dx = nr[2], dy = nr[3];
+            if (!use_nrm && mode != ET_MODE_IDENTITY) {  // (no cached state: from the observed row)
+                const float *row = obs + (n0 + gr) * 2 * T_obs;
+                ox = row[2 * (T_obs - 1)];
+                oy = row[2 * (T_obs - 1) + 1];
+                dx = ox - row[2 * (T_obs - 3)];
+                dy = oy - row[2 * (T_obs - 3) + 1];
+            }
+            // normaliser state as row_norm() forms it, with the hardware's 1-ulp square root and reciprocal in place of
+            // the correctly rounded sequences (~40 instructions per pass on every lane): the metric is compared at
+            // 1e-5 m, these differ by 1e-7 relative.  The moving / static decision (model.py:46) keeps row_norm's exact test.
+            int mv = mode == ET_MODE_MOVING;
+            if (mode == ET_MODE_SPLIT) {
+                const float hx = dx * 0.5f, hy = dy * 0.5f;
+                mv = sqrtf(hx * hx + hy * hy) > static_dist ? 1 : 0;
+            }
+            float c = 1.f, sn = 0.f, sca = 1.f, back = 1.f;
+            if (mode != ET_MODE_IDENTITY) {
+                const float r2 = dx * dx + dy * dy;
+                const float r = __builtin_amdgcn_sqrtf(r2), ir = __builtin_amdgcn_rcpf(r);
+                const bool still = !(r > 0.0f);
+                c = still ? (isnan(r) ? r : 1.0f) : dx * ir;
+                sn = still ? (isnan(r) ? r : 0.0f) : dy * ir;
+                sca = mv ? ir * 2.0f : 1.0f;
+                back = mv ? r * 0.5f : 1.0f;
+            } else {
+                ox = 0.f;
+                oy = 0.f;
+            }
+            // normalizer.py:42-51: ((p - ori) @ R) * sca;  ||denorm(w) - gt|| = ||w - normalise(gt)|| / sca
+            const float tx = gp.x - ox, ty = gp.y - oy;
             float2 o;
-            normalize_point(p, gp.x, gp.y, o.x, o.y);  // ||denorm(w) - gt|| = ||w - normalise(gt)|| / sca
+            o.x = (tx * c + ty * sn) * sca;
+            o.y = (tx * (-sn) + ty * c) * sca;
             *reinterpret_cast<float2 *>(sGn + gr * DP + 2 * gs) = o;
             if (gs == 0) {
-                sBack[gr] = p.mv ? p.inv : 1.0f;
-                sMv[gr] = p.mv;
+                sBack[gr] = back;
+                sMv[gr] = mv;
             }
         }
         float cur[2][3];
@@ -1157,7 +1188,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
             const float *an = sA + mv * (K * S) + anc_t[t];
             float b[3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) b[j] = valid ? cur[t][j] + an[2 * j * S] : 0.f;  // anchor.py:87
+            for (int j = 0; j < 3; ++j) b[j] = cur[t][j] + an[2 * j * S];  // anchor.py:87 (padding columns: never stored)
             f32x16_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (mode == ET_MODE_SPLIT) {
                 // (a tile spans two or three rows: most tiles hold one descriptor only and skip the other's instructions --
