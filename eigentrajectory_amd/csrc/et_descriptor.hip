@@ -974,7 +974,7 @@ __global__ __launch_bounds__(kTile) void reconstruct_bwd_tile_kernel(
 // features padded to 32, two k per instruction, 32 pairs per tile, fp32 in / fp32 accumulate -- the same fmaf chain
 // over k = 0..5 as the vector code, bit for bit) does it in three instructions per 32 pairs.  Not a flops gain: the fp32
 // matrix instructions run at the vector rate AND on the vector ALU's multipliers (their busy cycles add to the
-// epilogue's, profiles/r04c_metrics_pmc.txt: SPLIT's three extra instructions per tile cost exactly their 192 cycles) --
+// epilogue's: SPLIT's three extra instructions per tile cost exactly their 192 cycles, profiles/r04c_metrics_pmc.txt) --
 // what it buys is issue slots and LDS traffic: 144 instructions and as many broadcast reads of U per pair become 3 per
 // 32 pairs, and the vector ALU keeps the epilogue (~45 instructions per lane and tile):
 //   lane (col, h) of a tile holds rows 8g + 4h + r of column col = the time steps {4g + 2h, 4g + 2h + 1}, x and y adjacent;
