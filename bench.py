@@ -412,6 +412,86 @@ def extra_stages(ops, obs, pred, n, K, max_iter, first_index, dev):
     return out, sizes
 
 
+def lloyd_beyond_cache(ops, dev, K, max_iter, first_index, n_big=40_000_000):
+    """The dominant kernel on a shard whose working set does NOT fit the 256 MB Infinity Cache: at N = 1e7 an iteration
+    streams 140 MB of packed rows + 10 MB of labels -- cache resident, so the headline `roofline` is an algorithmic rate,
+    not HBM traffic.  N = 4e7: 560 + 40 MB per iteration, every iteration from HBM.  One k-means fit (farthest-first +
+    Lloyd) on the projection of 4 x 1e7 synthetic trajectories; same timing fields as the headline."""
+    from eigentrajectory_amd.synth import synthetic_trajectories_torch
+    chunk = 10_000_000
+    with torch.no_grad():
+        c = torch.empty((6, n_big), device=dev)
+        U = None
+        for i in range(n_big // chunk):
+            o, p = synthetic_trajectories_torch(chunk, dev, seed=100 + i, min_disp=1e-3)
+            if U is None:
+                g_obs, g_pred, _ = ops.fit_gram(o, p, ops.MODE_MOVING, 0.0, 1)
+                (U_obs, _), (U_pred, _) = ops.eigh_topk_batch([g_obs, g_pred], 6)
+                U = (U_obs, U_pred)
+            _, cp, _, _ = ops.norm_project(o, p, U[0], U[1], None, None, ops.MODE_MOVING, want_flag=False, want_nrm=False)
+            c[:, i * chunk:(i + 1) * chunk] = cp
+            del o, p, cp
+        torch.cuda.empty_cache()
+        c0 = ops.kmeans_init_farthest(c, K, first_index)
+        ops.kmeans_fit(c, c0, 3, 1e-4, trace=False)  # warm-up
+        res = ops.kmeans_fit(c, c0, max_iter, 1e-4, timing=True, trace=False)
+        del c
+        torch.cuda.empty_cache()
+    avg_ms = res["assign_ms"] / max(res["assign_launches"], 1)
+    return dict(n=n_big, iterations=res["n_iter"], avg_launch_ms=round(avg_ms, 5),
+                algorithmic_GBs=round(BYTES["kmeans_iter"] * n_big / avg_ms / 1e6, 1),
+                algorithmic_frac=round(BYTES["kmeans_iter"] * n_big / avg_ms / 1e6 / HBM_PEAK_GBS, 4),
+                moved_bytes_per_point=15.0,
+                moved_GBs=round(15.0 * n_big / avg_ms / 1e6, 1), moved_frac=round(15.0 * n_big / avg_ms / 1e6 / HBM_PEAK_GBS, 4),
+                note="packed f16 rows (14 B) + labels (1 B) per point and iteration = 600 MB > the 256 MB Infinity Cache: "
+                     "`moved_*` is HBM traffic here (at N = 1e7 the 150 MB of an iteration stay cache resident)")
+
+
+def scaling_model(ops, obs, pred, K, max_iter, first_index, dev, single_ms, n_it):
+    """What the first multi-rank run should show (none could be measured: the pool has one GPU per box).  Measured here:
+    the sharded path on ONE rank through a real RCCL communicator (the library enqueues ncclAllReduce / ncclAllGather
+    between its launches; nobody to add).  Modelled: per exchange the difference between an assumed P-rank latency of
+    RCCL's small-message collectives over xGMI and the one-rank latency measured in this run.  Weak scaling (every rank
+    its own N rows): the step time of P ranks = the one-rank sharded step + exchanges x that difference."""
+    import torch.distributed as tdist
+    from eigentrajectory_amd.dist import Communicator, ShardedKMeans
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    out = dict(measured_single_gpu_ms=round(single_ms, 3))
+    try:
+        tdist.init_process_group("nccl", device_id=dev)
+        comm = Communicator(dev)
+        km = (lambda x, k: ShardedKMeans(x, k, comm=comm))
+        sw = Stage()
+        for _ in range(2):
+            one_step(ops, obs, pred, K, max_iter, first_index, sw, km, [], comm)
+        torch.cuda.synchronize()
+        sw = Stage()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            one_step(ops, obs, pred, K, max_iter, first_index, sw, km, [], comm)
+        torch.cuda.synchronize()
+        w1 = (time.perf_counter() - t0) / 5 * 1e3
+        lloyd_w1 = float(np.mean(sw.ms("kmeans_lloyd")))
+        comm.close()
+        tdist.destroy_process_group()
+    except Exception as exc:  # noqa: BLE001 -- the model is an extra: never lose the headline over it
+        out["error"] = repr(exc)
+        return out
+    assumed_us = {1: 0.0, 2: 8.0, 4: 12.0, 8: 16.0}  # extra latency of a <= 1.1 KB all-reduce / all-gather over P ranks vs one rank
+    exchanges = n_it + (K - 1) + 2  # one all-reduce per Lloyd iteration, one all-gather per farthest-first step, Gram + scale scan
+    pred_ms = {p_: round(w1 + exchanges * us * 1e-3, 3) for p_, us in assumed_us.items()}
+    out.update(measured_sharded_world1_ms=round(w1, 3), measured_sharded_world1_lloyd_ms=round(lloyd_w1, 3),
+               exchanges_per_step=exchanges, assumed_extra_latency_us_per_exchange=assumed_us,
+               predicted_ms_per_step=pred_ms,
+               predicted_weak_scaling_efficiency={p_: round(single_ms / v, 3) for p_, v in pred_ms.items()},
+               note="efficiency = single-GPU step / P-rank step at the same rows per rank; the assumed latencies are "
+                    "the only unmeasured input")
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): start the N
     ranks ourselves -- one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1 -- and hand their
@@ -502,15 +582,28 @@ def main():
     packed_before = packed_fits()
     barrier()
     t0 = time.perf_counter()
-    iters = []
+    iters, step_ends = [], []
     for _ in range(args.steps):
         iters.append(one_step(ops, obs, pred, K, args.max_iter, first_index, sw, km, timing, comm))
+        step_ends.append(time.perf_counter())  # (a step ends synchronised: the k-means fit hands its iteration count to the host)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank must have run the same Lloyd loop (identical integers in, identical convergence flag out): a
+        # disagreement means the ranks' collectives did not pair up -- say so loudly instead of printing a number
+        mine = torch.tensor(iters, device=dev, dtype=torch.int64)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        if any(not torch.equal(e, every[0]) for e in every):
+            if rank == 0:
+                print("bench.py: the ranks disagree on the Lloyd iteration counts per step: " +
+                      "; ".join(f"rank {r}: {e.tolist()}" for r, e in enumerate(every)), file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            sys.exit(3)
+    step_ms = np.diff(np.asarray([t0] + step_ends)) * 1e3
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -555,7 +648,11 @@ def main():
                                         else "fp32 rows, 24 B per point"))
         out = dict(metric="trajectories/sec fit+project+reconstruct+kmeans", value=total_traj / (elapsed / args.steps),
                    unit="trajectories/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+                   ms_per_step=round(ms_per_step, 3),
+                   ms_per_step_spread=dict(min=round(float(step_ms.min()), 3), median=round(float(np.median(step_ms)), 3),
+                                           max=round(float(step_ms.max()), 3), note="rank 0, per step of the timed region"),
+                   lloyd_iterations_per_step=[int(i) for i in iters],
+                   higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype="f32", data="synthetic",
                    config=dict(workload=f"synthetic N={n:.0e} trajectories per GPU (obs 8 / pred 12 steps), k=6, "
                                         f"fit + project(obs+pred) + reconstruct(S=1) + k-means(K=20, farthest-first, "
@@ -567,6 +664,10 @@ def main():
         if world == 1 and not force_dist and not args.no_extras:
             more, sizes = extra_stages(ops, obs, pred, n, K, args.max_iter, first_index, dev)
             stages.update(more)
+            if n == 10_000_000:
+                roofline["beyond_infinity_cache"] = lloyd_beyond_cache(ops, dev, K, args.max_iter, first_index)
+            out["scaling_model"] = scaling_model(ops, obs, pred, K, args.max_iter, first_index, dev, ms_per_step,
+                                                 float(np.mean(iters)))
             sizes[f"{n:.0e}".replace("+0", "")] = dict(value=round(out["value"], 1), unit="trajectories/s",
                                                        ms_per_step=out["ms_per_step"], lloyd_iterations=float(np.mean(iters)))
             out["sizes"] = sizes

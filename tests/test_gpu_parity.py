@@ -392,28 +392,15 @@ def test_sharded_driver_on_one_gpu_matches_oracle(ops, oracle, dev):
     assert torch.equal(U_obs, ops.eigh_topk(g_obs, 6)[0]) and torch.equal(U_pred, ops.eigh_topk(g_pred, 6)[0])
 
 
-@pytest.mark.parametrize("n,cut,trace", [(30000, 8192, False), (30000, 20004, True), (30000, 1024, False), (30000, 10001, False),
-                                         (30000, 29501, True), (560000, 280000, False)])
-def test_native_chained_loop_two_shards_one_gpu(ops, oracle, dev, n, cut, trace, monkeypatch):
+def _two_shards_native(ops, dev, x, c0, cut, K, max_iter, tol, trace):
     """The library's sharded Lloyd loop (csrc/et_kmeans.hip: km_chain_run with a reduction between two launches -- what
-    et_kmeans_fit_sharded runs with ncclAllReduce) on TWO shards of one GPU: two host threads, one stream each, and a
-    test reduction in place of RCCL (barrier, sum of the two shards' buffers).  Exercises what a one-rank run cannot:
-    the table being summed between the launches, the lockstep convergence polling, the final inertia reduction.
-    Centroids, labels, iteration count, error and inertia must be the oracle's on the whole data, bit for bit."""
+    et_kmeans_fit_sharded runs with ncclAllReduce) on TWO shards of one GPU: two host threads, one stream each, and a test
+    reduction in place of RCCL (barrier, sum of the two shards' buffers).  -> (centroids per shard, state per shard,
+    traces per shard, labels of the whole data)."""
     import ctypes as C
     import threading
     from eigentrajectory_amd import _lib as L
-    from eigentrajectory_amd.synth import gaussian_points_np
-    # (the last case: both shards big enough for the PACKED copy of the points, each with its own origin and scale)
-    monkeypatch.setenv("ET_KMEANS_PACKED_MIN", "262144")
-    K, max_iter, tol = 20, 40 if n <= 30000 else 16, 1e-4
-    packed_fits = L.lib().et_internal_kmeans_packed_fits
-    packed_fits.restype = C.c_longlong
-    packed_before = packed_fits()
-    x = gaussian_points_np(6, n, seed=31, n_blobs=9)
-    x[:, ::53] *= 40.0
-    c0, _ = oracle.kmeans_init_farthest(x, K, 77)
-    ref = oracle.kmeans_fit(x, c0, max_iter, tol)
+    n = x.shape[1]
     lib = L.lib()
     REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
     run = lib.et_internal_kmeans_chain_run
@@ -483,16 +470,63 @@ def test_native_chained_loop_two_shards_one_gpu(ops, oracle, dev, n, cut, trace,
         t.join(timeout=120)
     assert not errors, errors
     torch.cuda.synchronize()
+    states = [L.KMeansState.from_buffer_copy(sh.state.cpu().numpy().tobytes()) for sh in shards]
+    labels = np.concatenate([N_(shards[0].labels_u8)[:cut], N_(shards[1].labels_u8)[:n - cut]]).astype(np.int64)
+    return cens, states, traces, labels
+
+
+@pytest.mark.parametrize("n,cut,trace", [(30000, 8192, False), (30000, 20004, True), (30000, 1024, False), (30000, 10001, False),
+                                         (30000, 29501, True), (560000, 280000, False)])
+def test_native_chained_loop_two_shards_one_gpu(ops, oracle, dev, n, cut, trace, monkeypatch):
+    """_two_shards_native exercises what a one-rank run cannot: the table being summed between the launches, the lockstep
+    convergence polling, the final inertia reduction.  Centroids, labels, iteration count, error and inertia must be the
+    oracle's on the whole data, bit for bit."""
+    import ctypes as C
+    from eigentrajectory_amd import _lib as L
+    from eigentrajectory_amd.synth import gaussian_points_np
+    # (the last case: both shards big enough for the PACKED copy of the points, each with its own origin and scale)
+    monkeypatch.setenv("ET_KMEANS_PACKED_MIN", "262144")
+    K, max_iter, tol = 20, 40 if n <= 30000 else 16, 1e-4
+    packed_fits = L.lib().et_internal_kmeans_packed_fits
+    packed_fits.restype = C.c_longlong
+    packed_before = packed_fits()
+    x = gaussian_points_np(6, n, seed=31, n_blobs=9)
+    x[:, ::53] *= 40.0
+    c0, _ = oracle.kmeans_init_farthest(x, K, 77)
+    ref = oracle.kmeans_fit(x, c0, max_iter, tol)
+    cens, states, traces, labels = _two_shards_native(ops, dev, x, c0, cut, K, max_iter, tol, trace)
     assert packed_fits() == packed_before + (2 if n > 30000 and not trace else 0)
-    for r, sh in enumerate(shards):
+    for r in range(2):
         assert np.array_equal(N_(cens[r]), ref["centroids"]), r
-        st = L.KMeansState.from_buffer_copy(sh.state.cpu().numpy().tobytes())
+        st = states[r]
         assert int(st.iter) == ref["n_iter"]
         assert np.float32(st.error) == np.float32(ref["error"]) and np.float32(st.inertia) == np.float32(ref["inertia"])
         if trace:
             assert np.array_equal(N_(traces[r])[:ref["n_iter"]], ref["trace"])
-    labels = np.concatenate([N_(shards[0].labels_u8)[:cut], N_(shards[1].labels_u8)[:n - cut]]).astype(np.int64)
     assert np.array_equal(labels, ref["labels"])
+
+
+@pytest.mark.parametrize("cut", [12000, 4100])
+def test_native_two_shards_equal_the_rccl_world1_run(ops, dev, tmp_path, cut):
+    """The two halves of what a multi-rank run is, on the SAME data: (i) et_kmeans_fit_sharded through a real RCCL
+    communicator (world 1: one GPU per box here; ncclAllReduce is enqueued between the launches but has nobody to add),
+    (ii) the same loop on two shards of this GPU with a test reduction where RCCL would add the ranks' tables.  Both end
+    with the same centroids, labels and iteration count, bit for bit -- so the first N > 1 RCCL run has one unknown
+    left, RCCL's own sum of 142 int64."""
+    import socket
+    import torch.multiprocessing as mp
+    from eigentrajectory_amd.synth import gaussian_points_np
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_nccl_world1_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")  # (the worker asserts native == torch.distributed step API before it saves)
+    x = gaussian_points_np(6, 24000, seed=6, n_blobs=7)  # the worker's data
+    x[:, ::97] *= 300.0
+    cens, states, _, labels = _two_shards_native(ops, dev, x, r0["c0"], cut, 20, 30, 1e-4, False)
+    for r in range(2):
+        assert np.array_equal(N_(cens[r]), r0["centroids"]) and int(states[r].iter) == int(r0["n_iter"])
+    assert np.array_equal(labels, r0["labels"])
 
 
 def _two_rank_gpu_worker(rank, world, port, cuts, out_dir):
