@@ -20,24 +20,23 @@ namespace et {
 
 constexpr int kTile = 256;  // trajectories (or pairs) per workgroup = threads per workgroup
 
-// workgroup -> tile.  Workgroup b runs on XCD b % 8; the identity map therefore deals consecutive tiles round-robin over
-// the XCDs.  -DET_TILE_MAP=1 (experiment, tools/build_variant.sh) gives every XCD one contiguous eighth of the tiles.
+// workgroup -> tile.  Workgroup b runs on XCD b % 8, so the identity map deals consecutive tiles round-robin over the
+// XCDs.  The projection instead gives every XCD one contiguous eighth of the tiles: -1.1 ... -2.0 % on its 0.40 ms in
+// four same-box A/B runs (profiles/r04d_tile_maps.txt); the S = 1 reconstruction LOSES 3-4 % with the same map and keeps
+// the identity.  (-DET_TILE_MAP=0 / 1 forces one map for both; 2: projection walks the rows from the end -- the rows the
+// preceding fit read last might still be in the Infinity Cache: they are not, +-0.)
 #ifndef ET_TILE_MAP
-#define ET_TILE_MAP 0
+#define ET_TILE_MAP 3
 #endif
 template <bool PROJECT = false>
 __device__ __forceinline__ int64_t tile_of_block() {
-#if ET_TILE_MAP == 2
-    // projection walks the rows from the END: the fit that precedes it read them front to back, so the last ~250 MB it
-    // touched are still in the Infinity Cache; the reconstruction then walks forward and meets the coefficients the
-    // projection wrote last
-    return PROJECT ? (int64_t)gridDim.x - 1 - blockIdx.x : (int64_t)blockIdx.x;
-#elif ET_TILE_MAP == 1
-    const int64_t per = ((int64_t)gridDim.x + 7) / 8;
-    return (int64_t)(blockIdx.x % 8) * per + blockIdx.x / 8;
-#else
+    constexpr bool contiguous = ET_TILE_MAP == 1 || (ET_TILE_MAP == 3 && PROJECT);
+    if (ET_TILE_MAP == 2 && PROJECT) return (int64_t)gridDim.x - 1 - blockIdx.x;
+    if (contiguous) {
+        const int64_t per = ((int64_t)gridDim.x + 7) / 8;
+        return (int64_t)(blockIdx.x % 8) * per + blockIdx.x / 8;
+    }
     return (int64_t)blockIdx.x;
-#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -43,6 +43,9 @@ class _SceneLosses(torch.autograd.Function):
         if rc:
             ops.L.check(rc, "et_wrapper_losses_fwd")
         ctx.save_for_backward(Cc, nrm, C_gt, gt, recon, arg)
+        # outputs nobody differentiates arrive as None in backward (autograd would otherwise hand over zero tensors: an
+        # (S,N,T,2) fill + a second backward launch + an add in every training step)
+        ctx.set_materialize_grads(False)
         ctx.ptrs, ctx.static_dist, ctx.t_obs = ptrs, model.static_dist, t_obs
         ctx.U = (model.ET_m_descriptor.U_pred_trunc.detach(), model.ET_s_descriptor.U_pred_trunc.detach())
         return recon, small[3 * n], small[3 * n + 1], small[3 * n + 2]
@@ -244,21 +247,29 @@ class EigenTrajectory(nn.Module):
     # (torch.cuda.CUDAGraph; the library's launches go to the capturing stream like any other kernel) and then replayed:
     # one graph launch per call, ~21 us.  The graph reads the scene's tensors where they are (no staging copies: with them a
     # replay cost more than the eager call), so it is keyed by their addresses and keeps them alive.
-    _SCENE_GRAPH_LIMIT = 4096
+    # Memory: every captured graph owns a private allocator pool (>= one 2 MB segment) plus its output buffers, so the
+    # cache is bounded and evicts the least recently used scene; a test split is <= ~1000 scenes (~2-4 GB).
+    _SCENE_GRAPH_LIMIT = 1024
 
     def _graph_for(self, kind, obs_traj, pred_traj, run):
         params = (self.ET_m_descriptor.U_obs_trunc, self.ET_m_descriptor.U_pred_trunc, self.ET_s_descriptor.U_obs_trunc,
                   self.ET_s_descriptor.U_pred_trunc, self.ET_m_anchor.C_anchor, self.ET_s_anchor.C_anchor)
         key = (kind, obs_traj.data_ptr(), tuple(obs_traj.shape), 0 if pred_traj is None else pred_traj.data_ptr(),
                None if pred_traj is None else tuple(pred_traj.shape))
-        # (calculate_parameters / load_state_dict may re-register the parameters: a graph holds raw pointers)
-        stamp = tuple(p.data_ptr() for p in params)
+        # (calculate_parameters / load_state_dict may re-register the parameters, the predictor may be moved, re-allocated
+        # or switched between train() and eval(): a graph holds raw pointers and the code path taken at capture time)
+        stamp = (tuple(p.data_ptr() for p in params), self.training, self.baseline_model.training,
+                 tuple(p.data_ptr() for p in self.baseline_model.parameters()),
+                 tuple(b.data_ptr() for b in self.baseline_model.buffers()))
         cache = self.__dict__.setdefault("_scene_graphs", {})
         entry = cache.get(key)
         if entry is not None and entry["stamp"] == stamp:
+            cache[key] = cache.pop(key)  # most recently used last
             return entry
-        if entry is None and len(cache) >= self._SCENE_GRAPH_LIMIT:
-            return None  # scenes that are new every time: nothing to replay
+        if entry is not None:
+            del cache[key]  # stale capture
+        while len(cache) >= self._SCENE_GRAPH_LIMIT:
+            cache.pop(next(iter(cache)))  # least recently used first: its graph, pool and buffers are released
         dev = obs_traj.device
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -280,8 +291,10 @@ class EigenTrajectory(nn.Module):
         Needs contiguous fp32 tensors on the device, a predictor and hooks that are plain tensor code (no host
         synchronisation, no data-dependent Python control flow -- the ten bridges of the reference qualify) and no
         ``addl_info``.  The returned tensors are the graph's own output buffers: valid until the next replayed call on the
-        same scene (``.clone()`` to keep them).  The cache keeps the scene's tensors alive; beyond 4096 scenes, and for
-        inputs the scene path does not take, the call is the eager one."""
+        same scene (``.clone()`` to keep them).  The cache keeps the scene's tensors alive and holds at most 1024 scenes (least
+        recently used evicted: every graph owns an allocator pool of >= 2 MB); a capture is redone when the ET parameters,
+        the predictor's parameters / buffers or the train / eval mode changed.  For inputs the scene path does not take the
+        call is the eager one."""
         if not (self._scene_ok(obs_traj) and self._scene_ok(pred_traj)):
             return self.evaluate(obs_traj, pred_traj)
         entry = self._graph_for("evaluate", obs_traj, pred_traj, lambda o, p: self.evaluate(o, p))
