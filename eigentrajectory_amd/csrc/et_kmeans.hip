@@ -826,6 +826,13 @@ __device__ __forceinline__ void filter_drain(const unsigned *q, int cnt, int K, 
     if (SIM) sim_acc += to_fixed(best, sfrac);
 }
 
+#ifdef ET_EXP_WAITSTAMP  // development aid (tools/waitstamp.py): where a pass of packed_assign_body spends its time, in
+// shader cycles (s_memtime) summed over all wavefronts and launches: [0] passes, [1] cycles from a pass's start to the
+// arrival of its own (prefetched) rows = the exposed load wait, [2] cycles of whole passes, [3] cycles inside queue drains,
+// [4] drains, [5] cycles from kernel start to the first pass, [6] wavefronts
+__device__ unsigned long long g_waitstamp[8];
+#endif
+
 #ifdef ET_PERSIST_STAMPS  // development aid (tools/persist_stamps.py): per workgroup and iteration, 10 ns ticks
 // kinds 0..5 (persistent kernel): top (own arrival done), go, folded, updated, body start, body end;
 // kinds 6..9 (inside the filter body): operands staged, passes done (wavefront 0), queue drained, deltas emitted
@@ -1461,7 +1468,17 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
     unsigned lpn = 0u;
     int64_t g = take();
     if (g >= 0) packed_issue(pk, N, labels, g, half, col, vn, rn, lpn);
+#ifdef ET_EXP_WAITSTAMP
+    unsigned long long ws_wait = 0, ws_pass = 0, ws_drain = 0, ws_n = 0, ws_nd = 0;
+#endif
     while (g >= 0) {
+#ifdef ET_EXP_WAITSTAMP
+        const unsigned long long ws_t0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this pass's rows (requested one pass ago) have arrived
+        const unsigned long long ws_t1 = __builtin_amdgcn_s_memtime();
+        ws_wait += ws_t1 - ws_t0;
+        ++ws_n;
+#endif
         const int64_t n = g * 256 + 128 * half + 4 * col;
         const bool valid = n < N;
         uint4 v[3];
@@ -1534,11 +1551,32 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
 #endif
                 if (qn >= 64) {
                     qn -= 64;
+#ifdef ET_EXP_WAITSTAMP
+                    const unsigned long long ws_d0 = __builtin_amdgcn_s_memtime();
+#endif
                     packed_drain(queue + qn, 64, K, sC, pk.xa, labels, sAcc, frac, lane);
+#ifdef ET_EXP_WAITSTAMP
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    ws_drain += __builtin_amdgcn_s_memtime() - ws_d0;
+                    ++ws_nd;
+#endif
                 }
             }
         }
+#ifdef ET_EXP_WAITSTAMP
+        ws_pass += __builtin_amdgcn_s_memtime() - ws_t0;
+#endif
     }
+#ifdef ET_EXP_WAITSTAMP
+    if (lane == 0) {
+        atomicAdd(&g_waitstamp[0], ws_n);
+        atomicAdd(&g_waitstamp[1], ws_wait);
+        atomicAdd(&g_waitstamp[2], ws_pass);
+        atomicAdd(&g_waitstamp[3], ws_drain);
+        atomicAdd(&g_waitstamp[4], ws_nd);
+        atomicAdd(&g_waitstamp[6], 1ull);
+    }
+#endif
     if (qn) packed_drain(queue, qn, K, sC, pk.xa, labels, sAcc, frac, lane);
     __syncthreads();
     for (int i = tx; i < plen; i += n_thr) {  // the copies -> copy 0
@@ -3629,6 +3667,17 @@ static int km_persist_run(const float *X, int64_t N, int d, int K, int max_iter,
 }
 }  // namespace et
 
+#ifdef ET_EXP_WAITSTAMP
+extern "C" int et_debug_waitstamp(unsigned long long *host, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(et::g_waitstamp), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(et::g_waitstamp), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 #ifdef ET_PERSIST_STAMPS
 extern "C" int et_debug_persist_stamps(void *host, size_t bytes) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(et::g_persist_stamps), bytes) == hipSuccess ? 0 : 1;
