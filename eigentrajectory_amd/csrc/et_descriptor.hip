@@ -33,8 +33,9 @@ __device__ __forceinline__ int64_t tile_of_block() {
     constexpr bool contiguous = ET_TILE_MAP == 1 || (ET_TILE_MAP == 3 && PROJECT);
     if (ET_TILE_MAP == 2 && PROJECT) return (int64_t)gridDim.x - 1 - blockIdx.x;
     if (contiguous) {
-        const int64_t per = ((int64_t)gridDim.x + 7) / 8;
-        return (int64_t)(blockIdx.x % 8) * per + blockIdx.x / 8;
+        // XCD x owns the tiles [x q + min(x, r), ...) with q = grid / 8, r = grid % 8: a bijection for EVERY grid size
+        const unsigned q = gridDim.x / 8, r = gridDim.x % 8, x = blockIdx.x % 8;
+        return (int64_t)(x * q + (x < r ? x : r) + blockIdx.x / 8);
     }
     return (int64_t)blockIdx.x;
 }
@@ -991,6 +992,8 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 // per pass in its own LDS slice, requests the next pass's coefficients / ground truth / normaliser state before it
 // computes this one, and never meets a workgroup barrier after the prologue.
 constexpr int kMetWaves = 4;  // wavefronts per workgroup
+constexpr float kMetScaleU = 1024.f, kMetScaleC = 128.f, kMetUnscale = 1.f / (1024.f * 128.f);
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
 template <int TP, int K>
 __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kernel(
@@ -998,7 +1001,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
     const float *__restrict__ obs, const float *__restrict__ nrm,
     const float *__restrict__ A_m, const float *__restrict__ A_s,
     const float *__restrict__ U_m, const float *__restrict__ U_s,
-    int mode, float static_dist, const float *__restrict__ gt, float *__restrict__ ade, float *__restrict__ fde) {
+    int mode, float static_dist, const float *__restrict__ gt, float *__restrict__ ade, float *__restrict__ fde, int use_f16) {
     static_assert(TP == 12 && K == 6, "rows = 24 features in a 32-row tile, k = 6 = three k-pairs");
     constexpr int DP = 2 * TP;
     constexpr int kMetRows = 8;  // >= 64 / S for S >= 12 (rounded up to keep the slices 16-byte aligned)
@@ -1014,16 +1017,31 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
     const int col_in_tile = lane & 31, h = lane >> 5;
 
     // A operands: U[f][2 j + h] of both descriptors (f = the lane's row; rows 24..31 are padding)
+    // Both operands carry a power-of-two scale (U: 2^10, coefficients + anchors: 2^7; exact, undone by the epilogue's
+    // fused multiply-subtract) -- it keeps the LOW halves of the two-term f16 splits below out of f16's denormal range.
     float aU[2][3];
+    f16x8_t aH1[2], aH2[2];  // the f16 split of U: (Uh0 Uh1 Uh2 Uh0 Uh1 Uh2 Ul0 Ul1), (Ul2 Ul0 Ul1 Ul2 0 0 0 0)
+    bool u_small = true;
 #pragma unroll
     for (int desc = 0; desc < 2; ++desc) {
         const float *U = desc ? U_m : U_s;
+        _Float16 uh[3], ul[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) aU[desc][j] = (U && col_in_tile < DP) ? U[col_in_tile * K + 2 * j + h] : 0.f;
+        for (int j = 0; j < 3; ++j) {
+            const float u = (U && col_in_tile < DP) ? U[col_in_tile * K + 2 * j + h] * kMetScaleU : 0.f;
+            aU[desc][j] = u;
+            u_small = u_small && fabsf(u) < 32768.f;
+            uh[j] = (_Float16)u;
+            ul[j] = (_Float16)(u - (float)uh[j]);
+        }
+        const _Float16 z = (_Float16)0.f;
+        aH1[desc] = f16x8_t{uh[0], uh[1], uh[2], uh[0], uh[1], uh[2], ul[0], ul[1]};
+        aH2[desc] = f16x8_t{ul[2], ul[0], ul[1], ul[2], z, z, z, z};
     }
+    const bool f16_ok = use_f16 && __ballot(!u_small) == 0ull;
     for (int i = tid; i < 2 * K * S; i += kMetWaves * 64) {
         const float *src = (i >= K * S) ? A_m : A_s;
-        sA[i] = src ? src[i % (K * S)] : 0.f;
+        sA[i] = src ? src[i % (K * S)] * kMetScaleC : 0.f;
     }
     __syncthreads();  // the only workgroup barrier
 
@@ -1185,28 +1203,53 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
             const int r = row_t[t];
             const int mv = sMv[r];
             const float *an = sA + mv * (K * S) + anc_t[t];
-            float b[3];
+            float b[3];  // (coefficient + anchor) * 2^7 (anchor.py:87; padding columns: never stored)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) b[j] = cur[t][j] + an[2 * j * S];  // anchor.py:87 (padding columns: never stored)
+            for (int j = 0; j < 3; ++j) b[j] = fmaf(cur[t][j], kMetScaleC, an[2 * j * S]);
             f32x16_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (mode == ET_MODE_SPLIT) {
-                // (a tile spans two or three rows: most tiles hold one descriptor only and skip the other's instructions --
-                // the fp32 matrix instructions run on the vector ALU's multipliers, their time ADDS to the epilogue's)
-                const bool any_s = __ballot(valid && !mv) != 0ull, any_m = __ballot(valid && mv) != 0ull;
+            const bool any_s = mode == ET_MODE_SPLIT ? __ballot(valid && !mv) != 0ull : mode != ET_MODE_MOVING;
+            const bool any_m = mode == ET_MODE_SPLIT ? __ballot(valid && mv) != 0ull : mode == ET_MODE_MOVING;
+            const float big = fmaxf(fmaxf(fabsf(b[0]), fabsf(b[1])), fabsf(b[2]));
+            if (f16_ok && __ballot(!(big < 32768.f)) == 0ull) {
+                // x = hi + lo with hi = f16(x), lo = f16(x - hi): 22 bits of x.  The four cross products of the two
+                // splits are exact in the fp32 accumulator; 12 products per lane (3 k of this half x 4) = 16 + 8 slots
+                // of two 32x32x16 f16 instructions -- on the matrix pipe, beside the vector ALU instead of on it.
+                typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                const f16x2_t p0 = __builtin_convertvector((f32x2_t){b[0], b[1]}, f16x2_t);
+                const float r0 = b[0] - (float)p0.x, r1 = b[1] - (float)p0.y;
+                const f16x2_t p1 = __builtin_convertvector((f32x2_t){b[2], r0}, f16x2_t);
+                const float r2 = b[2] - (float)p1.x;
+                const f16x2_t p2 = __builtin_convertvector((f32x2_t){r1, r2}, f16x2_t);
+                const unsigned q0 = __builtin_bit_cast(unsigned, p0), q1 = __builtin_bit_cast(unsigned, p1),
+                               q2 = __builtin_bit_cast(unsigned, p2);
                 if (any_s) {
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[0][j], mv ? 0.f : b[j], acc, 0, 0, 0);
+                    const bool z = mode == ET_MODE_SPLIT && mv;
+                    const unsigned z0 = z ? 0u : q0, z1 = z ? 0u : q1, z2 = z ? 0u : q2;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH1[0], __builtin_bit_cast(f16x8_t, (u32x4_t){z0, z1, z2, z0}), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH2[0], __builtin_bit_cast(f16x8_t, (u32x4_t){z1, z2, 0u, 0u}), acc, 0, 0, 0);
                 }
                 if (any_m) {
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[1][j], mv ? b[j] : 0.f, acc, 0, 0, 0);
+                    const bool z = mode == ET_MODE_SPLIT && !mv;
+                    const unsigned z0 = z ? 0u : q0, z1 = z ? 0u : q1, z2 = z ? 0u : q2;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH1[1], __builtin_bit_cast(f16x8_t, (u32x4_t){z0, z1, z2, z0}), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH2[1], __builtin_bit_cast(f16x8_t, (u32x4_t){z1, z2, 0u, 0u}), acc, 0, 0, 0);
                 }
-            } else if (mode == ET_MODE_MOVING) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[1][j], b[j], acc, 0, 0, 0);
             } else {
+                // fp32 matrix instructions: the vector code's fmaf chain over k = 0..5, bit for bit (the scales are exact)
+                // (a tile spans two or three rows: most tiles hold one descriptor only and skip the other's instructions --
+                // the fp32 matrix instructions run on the vector ALU's multipliers, their time ADDS to the epilogue's)
+                if (any_s) {
+                    const bool z = mode == ET_MODE_SPLIT && mv;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[0][j], b[j], acc, 0, 0, 0);
+                    for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[0][j], z ? 0.f : b[j], acc, 0, 0, 0);
+                }
+                if (any_m) {
+                    const bool z = mode == ET_MODE_SPLIT && !mv;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[1][j], z ? 0.f : b[j], acc, 0, 0, 0);
+                }
             }
             // rows 8 g + 4 h + (0..3) of this column: steps 4 g + 2 h and 4 g + 2 h + 1 (g = 3 is padding)
             const float4 *g4 = reinterpret_cast<const float4 *>(sGn + r * DP + 4 * h);
@@ -1214,7 +1257,8 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 const float4 gn = g4[2 * g];
-                const float ex = acc[4 * g] - gn.x, ey = acc[4 * g + 1] - gn.y, fx = acc[4 * g + 2] - gn.z, fy = acc[4 * g + 3] - gn.w;
+                const float ex = fmaf(acc[4 * g], kMetUnscale, -gn.x), ey = fmaf(acc[4 * g + 1], kMetUnscale, -gn.y),
+                            fx = fmaf(acc[4 * g + 2], kMetUnscale, -gn.z), fy = fmaf(acc[4 * g + 3], kMetUnscale, -gn.w);
                 // v_sqrt_f32 (1 ulp): the metric is compared at 1e-5 m
                 const float d0 = __builtin_amdgcn_sqrtf(ex * ex + ey * ey), d1 = __builtin_amdgcn_sqrtf(fx * fx + fy * fy);
                 sum = (sum + d0) + d1;
@@ -1449,7 +1493,8 @@ extern "C" int et_anchor_reconstruct_metrics(const float *C, int64_t N, int S, i
     const bool fast = T_pred == 12 && k == 6 && S <= kTile && aligned16(gt);
     if (fast) {
         const int TN = kTile / S;
-        const char *e = getenv("ET_METRICS_MFMA");  // 0: the vector-ALU workgroup-tile kernel (A/B runs, tests)
+        const char *e = getenv("ET_METRICS_MFMA");  // 0: the vector-ALU workgroup-tile kernel; f32: fp32 matrix instructions only (A/B runs, tests)
+        const int use_f16 = !(e && e[0] == 'f');
         // the matrix-core kernel: a wavefront takes 64 / S trajectories per pass and normalises one ground-truth point
         // per lane, so S <= 64 and (64 / S) * 12 <= 64, i.e. 12 <= S <= 64 (the model form is S = 20)
         if (!(e && e[0] == '0') && aligned16(gt) && S >= 12 && S <= 64 && N >= 64 / S && N * S < ((int64_t)1 << 29) && N * 24 < ((int64_t)1 << 30)) {
@@ -1464,7 +1509,7 @@ extern "C" int et_anchor_reconstruct_metrics(const float *C, int64_t N, int S, i
                 per_cu = 4;
             const unsigned g = (unsigned)min((int64_t)cu_count() * per_cu, ceil_div(passes, kMetWaves));
             hipLaunchKernelGGL((reconstruct_metrics_mfma_kernel<12, 6>), dim3(g), dim3(kMetWaves * 64), lds, st,
-                               C, N, S, TNW, T_obs, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, gt, ade, fde);
+                               C, N, S, TNW, T_obs, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, gt, ade, fde, use_f16);
         } else {
             const size_t lds = sizeof(float) * ((size_t)TN * 24 + (size_t)TN * S * 2 + (size_t)TN * kNormStride + 2 * 24 * 6 +
                                                 2 * 6 * (size_t)S);

@@ -77,7 +77,7 @@ def test_trajnorm_vs_oracle_and_golden(ops, oracle, dev, sca):
 
 
 # ------------------------------------------------------------------------------- projection
-@pytest.mark.parametrize("n", [0, 1, 255, 256, 257, 1000, 70001])
+@pytest.mark.parametrize("n", [0, 1, 255, 256, 257, 1000, 2305, 3500, 70001])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_project_fast_path_vs_oracle(ops, oracle, dev, n, mode):
     p = eth_params()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same-process A/B of the fused metrics epilogue (S = 20, N = 1e7): vector-ALU kernel (ET_METRICS_MFMA=0) against the
-matrix-core kernel; modes MOVING (the bench's) and SPLIT (what the wrapper's evaluate() runs)."""
+matrix-core kernel with fp32 (f32) and two-term f16 (1, the default) matrix instructions; modes MOVING (the bench's) and SPLIT (what the wrapper's evaluate() runs)."""
 import os
 import sys
 
@@ -38,7 +38,7 @@ def med(fn, reps=10):
 
 res = {}
 for rnd in range(2):
-    for mf in ("0", "1"):
+    for mf in ("0", "f32", "1"):
         os.environ["ET_METRICS_MFMA"] = mf
         t_mov = med(lambda: ops.anchor_reconstruct_metrics(C20, pred, A, None, Up, None, ops.MODE_MOVING, nrm=nrm))
         t_spl = med(lambda: ops.anchor_reconstruct_metrics(C20, pred, A, A, Up, Up, ops.MODE_SPLIT, 0.3, nrm=nrm))
@@ -46,6 +46,8 @@ for rnd in range(2):
               f"SPLIT {t_spl:.3f} ms ({600 * n / t_spl / 1e6 / 8000:.3f})", flush=True)
 os.environ["ET_METRICS_MFMA"] = "0"
 a0, f0 = ops.anchor_reconstruct_metrics(C20, pred, A, A, Up, Up, ops.MODE_SPLIT, 0.3, nrm=nrm)
-os.environ["ET_METRICS_MFMA"] = "1"
-a1, f1 = ops.anchor_reconstruct_metrics(C20, pred, A, A, Up, Up, ops.MODE_SPLIT, 0.3, nrm=nrm)
-print("max |ADE diff|", float((a0 - a1).abs().max()), "max |FDE diff|", float((f0 - f1).abs().max()))
+for mf in ("f32", "1"):
+    os.environ["ET_METRICS_MFMA"] = mf
+    a1, f1 = ops.anchor_reconstruct_metrics(C20, pred, A, A, Up, Up, ops.MODE_SPLIT, 0.3, nrm=nrm)
+    print(mf, "max |ADE diff|", float((a0 - a1).abs().max()), "max |FDE diff|", float((f0 - f1).abs().max()),
+          "of max ADE", float(a0.max()), flush=True)
