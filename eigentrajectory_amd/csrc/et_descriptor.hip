@@ -992,10 +992,19 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 // per pass in its own LDS slice, requests the next pass's coefficients / ground truth / normaliser state before it
 // computes this one, and never meets a workgroup barrier after the prologue.
 constexpr int kMetWaves = 4;  // wavefronts per workgroup
+#ifndef ET_MET_EXP
+#define ET_MET_EXP 0  // timing experiments only (tools/build_variant.sh): 1 no matrix instructions, 2 no distance epilogue, 4 no best-of-S, 8 no ground-truth normalisation, 16 no f16 split
+#endif
 constexpr float kMetScaleU = 1024.f, kMetScaleC = 128.f, kMetUnscale = 1.f / (1024.f * 128.f);
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
-template <int TP, int K>
+// memory -> LDS without a destination register: LDS address = M0 + 4 * lane
+__device__ __forceinline__ void lds_dma_b32(unsigned __attribute__((ext_vector_type(4))) desc, unsigned lds_addr, unsigned voffset, unsigned soffset) {
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voffset), "s"(desc), "s"(soffset) : "memory");
+}
+constexpr int kMetStage = 9 * 64;  // floats per ring stage: 6 coefficient slots | 2 x 64 ground truth | normaliser state
+
+template <int TP, int K, int D>
 __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kernel(
     const float *__restrict__ C, int64_t N, int S, int TNW, int T_obs,
     const float *__restrict__ obs, const float *__restrict__ nrm,
@@ -1076,61 +1085,69 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
     // variant for a short last pass made the compiler merge two load paths with register copies -- and wait for every
     // prefetch right where it was issued.)
     int64_t pass = (int64_t)blockIdx.x * kMetWaves + wave;
-    // The loads and stores of a pass are BUFFER operations: a 128-bit descriptor in scalar registers, a per-lane 32-bit byte
-    // offset that lives in ONE vector register for the whole loop, and the pass's position as a scalar byte offset.  With
-    // 64-bit per-lane pointers the register allocator recycles the address temporaries -- into the registers of the matrix
-    // instruction's accumulator, among others -- and the compiler then drains the memory queue (s_waitcnt vmcnt(0))
-    // before it overwrites them: in front of every tile's first matrix instruction and after every store, i.e. the
-    // prefetch bought nothing (2.9-3.2 ms; with descriptors the waits are counted ones).  Offsets must fit 32 bits: the
-    // host takes this kernel for 2 N S 4 B < 2^32 only.
+    // A pass's inputs travel from memory STRAIGHT INTO LDS (buffer_load ... lds: no destination registers), D - 1 passes
+    // ahead, into a ring of D stages per wavefront.  With the loads landing in registers a wavefront could have ONE pass
+    // (1.8 kB) in flight -- 36 kB per CU at 5 wavefronts per SIMD, and by Little's law 3.7 TB/s at the ~2.4 us a loaded
+    // memory system takes: the loop WITHOUT any arithmetic ran 1.6 of the kernel's 2.0 ms (round 4, profiles/r04g).
+    // The loads are inline assembly on purpose: for the compiler's own LDS-DMA intrinsic the wait-count pass puts
+    // s_waitcnt vmcnt(0) in front of EVERY later LDS read of the kernel (it cannot tell the stages apart).  Here the waits
+    // are ours: every iteration issues exactly 2 stores + 9 loads (the tail re-requests the last pass), so "stage i has
+    // landed" is vmcnt <= 11 (D - 1) -- a constant.
+    // Descriptors live in scalar registers, the per-lane byte offsets in one vector register each for the whole loop, the
+    // pass's position is a scalar offset (offsets must fit 32 bits: the host takes this kernel for 2 N S 4 B < 2^32 only).
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    auto desc_of = [](const void *base, int64_t bytes) {
+        const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        const unsigned nb = __builtin_amdgcn_readfirstlane((unsigned)(bytes > 0xffffffffll ? 0xffffffffll : bytes));
+        return u32x4_t{lo, hi & 0xffffu, nb, 0x00020000u};
+    };
     auto rsrc_of = [](const void *base, int64_t bytes) {
         const unsigned long long b = reinterpret_cast<unsigned long long>(base);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
         const int nb = __builtin_amdgcn_readfirstlane((int)(bytes > 0xffffffffll ? 0xffffffffll : bytes));
         return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, nb, 0x00020000);
     };
-    __amdgpu_buffer_rsrc_t rc[3];  // coefficient planes 2 j and 2 j + 1
+    const u32x4_t dc0 = desc_of(C, 2 * plane * 4), dc1 = desc_of(C + 2 * plane, 2 * plane * 4), dc2 = desc_of(C + 4 * plane, 2 * plane * 4);
+    const u32x4_t dg = desc_of(gt, N * DP * 4), dn = nrm ? desc_of(nrm, 4 * N * 4) : dg;  // (without nrm: a readable dummy)
+    const __amdgpu_buffer_rsrc_t ra = rsrc_of(ade, N * 4), rf = rsrc_of(fde, N * 4);
+    unsigned oc[2];  // tile t's coefficient loads: (h * plane + column) * 4
 #pragma unroll
-    for (int j = 0; j < 3; ++j) rc[j] = rsrc_of(C + (int64_t)(2 * j) * plane, 2 * plane * 4);
-    const float *nsrc = nrm ? nrm : gt;  // (always a readable address; the values are only used with nrm)
-    const __amdgpu_buffer_rsrc_t rg = rsrc_of(gt, N * DP * 4), rn = rsrc_of(nsrc, nrm ? 4 * N * 4 : N * DP * 4),
-                                 ra = rsrc_of(ade, N * 4), rf = rsrc_of(fde, N * 4);
-    int oc[2];  // tile t's coefficient loads: (h * plane + column) * 4
-#pragma unroll
-    for (int t = 0; t < 2; ++t) oc[t] = 4 * (int)((int64_t)h * plane + (col_ok[t] ? 32 * t + col_in_tile : 0));
-    const int og = 4 * ((g_ok ? gr : 0) * DP + 2 * gs);
-    const int on = 4 * (g_ok ? gr : 0);
+    for (int t = 0; t < 2; ++t) oc[t] = 4u * (unsigned)((int64_t)h * plane + (col_ok[t] ? 32 * t + col_in_tile : 0));
+    // ground truth: the pass's TNW rows are TNW * 24 contiguous floats -> two loads, lane = float index
+    const unsigned og0 = 4u * (unsigned)(lane < TNW * DP ? lane : 0), og1 = 4u * (unsigned)(64 + lane < TNW * DP ? 64 + lane : 0);
+    // normaliser state [4][N]: lane j * TNW + r loads plane j, row r
+    const unsigned onr = (nrm && lane < 4 * TNW) ? 4u * (unsigned)((int64_t)(lane / TNW) * N + lane % TNW) : 0u;
     const bool use_nrm = nrm != nullptr && mode != ET_MODE_IDENTITY;
-    float craw[2][3], nr[4];
-    float2 gp;
+    float *sRing = sA + ((2 * K * S + 3) & ~3) + wave * (D * kMetStage);
+    const unsigned ring_addr = __builtin_amdgcn_readfirstlane(
+        (unsigned)reinterpret_cast<unsigned long long>((__attribute__((address_space(3))) float *)sRing));
     auto first_row = [&](int64_t ps) { return min(ps * TNW, N - TNW); };
-    auto request = [&](int64_t n0) {
-        const int so_c = __builtin_amdgcn_readfirstlane((int)(n0 * S * 4)), so_g = __builtin_amdgcn_readfirstlane((int)(n0 * DP * 4));
+    auto issue = [&](int64_t ps, int stage) {  // (passes beyond the last re-request the last one: same count every time)
+        const int64_t n0 = first_row(min(ps, n_pass - 1));
+        const unsigned base = ring_addr + (unsigned)stage * (unsigned)(kMetStage * 4);
+        const unsigned so_c = __builtin_amdgcn_readfirstlane((unsigned)(n0 * S * 4)), so_g = __builtin_amdgcn_readfirstlane((unsigned)(n0 * DP * 4)),
+                       so_n = __builtin_amdgcn_readfirstlane((unsigned)(n0 * 4));
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) craw[t][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc[j], oc[t], so_c, 0));
-        {
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            const u32x2 g = __builtin_amdgcn_raw_buffer_load_b64(rg, og, so_g, 0);
-            gp = make_float2(__uint_as_float(g.x), __uint_as_float(g.y));
+        for (int t = 0; t < 2; ++t) {
+            lds_dma_b32(dc0, base + (3 * t + 0) * 256, oc[t], so_c);
+            lds_dma_b32(dc1, base + (3 * t + 1) * 256, oc[t], so_c);
+            lds_dma_b32(dc2, base + (3 * t + 2) * 256, oc[t], so_c);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int so_n = __builtin_amdgcn_readfirstlane((int)((nrm ? (int64_t)j * N + n0 : n0) * 4));
-            nr[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rn, on, so_n, 0));
-        }
+        lds_dma_b32(dg, base + 6 * 256, og0, so_g);
+        lds_dma_b32(dg, base + 7 * 256, og1, so_g);
+        lds_dma_b32(dn, base + 8 * 256, onr, so_n);
     };
-    if (pass < n_pass) request(first_row(pass));
-    // (the first pass's loads are waited for HERE: entering the loop with loads outstanding, the compiler's merged
-    // bookkeeping at the loop head makes it wait for most of every later prefetch in front of the first matrix instruction)
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-    // A pass's two results are stored at the START of the next pass, in front of that pass's prefetch (the wait for a
-    // prefetch then never includes stores issued after it), by ALL lanes, unconditionally, through a scalar base + a
-    // per-lane offset that lives in one register for the whole loop: lanes beyond the pass's rows repeat its last row
-    // (same value, same address).  A store under a branch, or one whose address temporaries are recycled, makes the
-    // compiler drain the memory queue (s_waitcnt vmcnt(0)) in the middle of the pass.  The first iteration has nothing
-    // to store yet: it writes zeros to its own pass's slots, which the second iteration overwrites.
+    const bool did_any = pass < n_pass;
+    if (did_any) {
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d) issue(pass + d * stride, d);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // A pass's two results are stored at the START of the next pass, in front of that pass's loads, by ALL lanes,
+    // unconditionally, through a scalar base + a per-lane offset that lives in one register for the whole loop: lanes
+    // beyond the pass's rows repeat its last row (same value, same address).  The first iteration has nothing to store
+    // yet: it writes zeros to its own pass's slots, which the second iteration overwrites.
     const int mrow = mr < TNW ? mr : TNW - 1;
     const int om = 4 * mrow;
     auto store_held = [&](float2 v, int64_t n0) {
@@ -1139,15 +1156,30 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), rf, om, so, 0);
     };
     float2 held = make_float2(0.f, 0.f);
-    int64_t held_n0 = pass < n_pass ? first_row(pass) : 0;
-    const bool did_any = pass < n_pass;
+    int64_t held_n0 = did_any ? first_row(pass) : 0;
+    int stage = 0;  // ring slot of the current pass
     for (; pass < n_pass; pass += stride) {
         const int64_t n0 = first_row(pass);
         constexpr bool valid_all = true;
         const int npairs = full_pairs;
         wave_sync();  // the previous pass is done with the slice
+        store_held(held, held_n0);
+        {
+            int ahead = stage + D - 1;
+            if (ahead >= D) ahead -= D;
+            issue(pass + (D - 1) * stride, ahead);  // travels while D - 1 passes are computed
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(11 * (D - 1)) : "memory");
+        const float *sIn = sRing + stage * kMetStage;
+        stage = stage + 1 == D ? 0 : stage + 1;
+        float cur[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) cur[t][j] = sIn[(3 * t + j) * 64 + lane];
         if (g_ok) {
-            float ox = nr[0], oy = nr[1], dx = nr[2], dy = nr[3];
+            const float2 gp = *reinterpret_cast<const float2 *>(sIn + 6 * 64 + gr * DP + 2 * gs);
+            float ox = sIn[8 * 64 + gr], oy = sIn[8 * 64 + TNW + gr], dx = sIn[8 * 64 + 2 * TNW + gr], dy = sIn[8 * 64 + 3 * TNW + gr];
             if (!use_nrm && mode != ET_MODE_IDENTITY) {  // (no cached state: from the observed row)
                 const float *row = obs + (n0 + gr) * 2 * T_obs;
                 ox = row[2 * (T_obs - 1)];
@@ -1164,7 +1196,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
                 mv = sqrtf(hx * hx + hy * hy) > static_dist ? 1 : 0;
             }
             float c = 1.f, sn = 0.f, sca = 1.f, back = 1.f;
-            if (mode != ET_MODE_IDENTITY) {
+            if (mode != ET_MODE_IDENTITY && !(ET_MET_EXP & 8)) {
                 const float r2 = dx * dx + dy * dy;
                 const float r = __builtin_amdgcn_sqrtf(r2), ir = __builtin_amdgcn_rcpf(r);
                 const bool still = !(r > 0.0f);
@@ -1187,13 +1219,6 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
                 sMv[gr] = mv;
             }
         }
-        float cur[2][3];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) cur[t][j] = craw[t][j];
-        store_held(held, held_n0);
-        if (pass + stride < n_pass) request(first_row(pass + stride));  // travels while this pass is computed
         wave_sync();
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -1210,13 +1235,21 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
             const bool any_s = mode == ET_MODE_SPLIT ? __ballot(valid && !mv) != 0ull : mode != ET_MODE_MOVING;
             const bool any_m = mode == ET_MODE_SPLIT ? __ballot(valid && mv) != 0ull : mode == ET_MODE_MOVING;
             const float big = fmaxf(fmaxf(fabsf(b[0]), fabsf(b[1])), fabsf(b[2]));
+#if ET_MET_EXP & 1
+            acc[0] = b[0]; acc[1] = b[1]; acc[2] = b[2]; acc[3] = big;
+            if (false) {
+#else
             if (f16_ok && __ballot(!(big < 32768.f)) == 0ull) {
+#endif
                 // x = hi + lo with hi = f16(x), lo = f16(x - hi): 22 bits of x.  The four cross products of the two
                 // splits are exact in the fp32 accumulator; 12 products per lane (3 k of this half x 4) = 16 + 8 slots
                 // of two 32x32x16 f16 instructions -- on the matrix pipe, beside the vector ALU instead of on it.
                 typedef float f32x2_t __attribute__((ext_vector_type(2)));
                 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
                 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+#if ET_MET_EXP & 16
+                const unsigned q0 = __float_as_uint(b[0]), q1 = __float_as_uint(b[1]), q2 = __float_as_uint(b[2]);
+#else
                 const f16x2_t p0 = __builtin_convertvector((f32x2_t){b[0], b[1]}, f16x2_t);
                 const float r0 = b[0] - (float)p0.x, r1 = b[1] - (float)p0.y;
                 const f16x2_t p1 = __builtin_convertvector((f32x2_t){b[2], r0}, f16x2_t);
@@ -1224,6 +1257,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
                 const f16x2_t p2 = __builtin_convertvector((f32x2_t){r1, r2}, f16x2_t);
                 const unsigned q0 = __builtin_bit_cast(unsigned, p0), q1 = __builtin_bit_cast(unsigned, p1),
                                q2 = __builtin_bit_cast(unsigned, p2);
+#endif
                 if (any_s) {
                     const bool z = mode == ET_MODE_SPLIT && mv;
                     const unsigned z0 = z ? 0u : q0, z1 = z ? 0u : q1, z2 = z ? 0u : q2;
@@ -1254,6 +1288,9 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
             // rows 8 g + 4 h + (0..3) of this column: steps 4 g + 2 h and 4 g + 2 h + 1 (g = 3 is padding)
             const float4 *g4 = reinterpret_cast<const float4 *>(sGn + r * DP + 4 * h);
             float sum = 0.f, last = 0.f;
+#if ET_MET_EXP & 2
+            for (int g = 0; g < 3; ++g) { sum += acc[4 * g] + acc[4 * g + 1]; last += acc[4 * g + 2] + acc[4 * g + 3] + g4[2 * g].x; }
+#else
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 const float4 gn = g4[2 * g];
@@ -1264,6 +1301,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
                 sum = (sum + d0) + d1;
                 last = d1;  // h = 1, g = 2: step 11
             }
+#endif
             const float other_sum = __shfl_xor(sum, 32), other_last = __shfl_xor(last, 32);
             if (h == 0 && valid) {
                 const float back = sBack[r];
@@ -1275,6 +1313,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
         {   // best of S (torch.min propagates NaN): lane (mr, mq) takes samples mq, mq + 4, ...; then two exchanges
             const float2 *m2 = reinterpret_cast<const float2 *>(sMet) + mrow * S;
             float2 best = m2[mq < S ? mq : 0];
+#if !(ET_MET_EXP & 4)
             for (int s = mq + 4; s < S; s += 4) {
                 const float2 o = m2[s];
                 best.x = (o.x < best.x || isnan(o.x)) ? o.x : best.x;
@@ -1286,11 +1325,13 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
                 best.x = (ox < best.x || isnan(ox)) ? ox : best.x;
                 best.y = (oy < best.y || isnan(oy)) ? oy : best.y;
             }
+#endif
             held = best;
             held_n0 = n0;
         }
     }
     if (did_any) store_held(held, held_n0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the tail's surplus requests still write into this wavefront's LDS)
 }
 
 // Any-shape fallbacks: lane = (trajectory, sample) pair, direct global accesses.
@@ -1499,17 +1540,31 @@ extern "C" int et_anchor_reconstruct_metrics(const float *C, int64_t N, int S, i
         // per lane, so S <= 64 and (64 / S) * 12 <= 64, i.e. 12 <= S <= 64 (the model form is S = 20)
         if (!(e && e[0] == '0') && aligned16(gt) && S >= 12 && S <= 64 && N >= 64 / S && N * S < ((int64_t)1 << 29) && N * 24 < ((int64_t)1 << 30)) {
             const int TNW = 64 / S;
-            const size_t lds = sizeof(float) * ((size_t)kMetWaves * (8 * 24 + 2 * 64 + 8 + 8) + 2 * 6 * (size_t)S);
             const int64_t passes = ceil_div(N, TNW);
+            static const int stages = [] {  // ring depth = passes in flight per wavefront + 1.  Deeper rings cost residency
+                const char *d = getenv("ET_METRICS_STAGES");  // (LDS) and lose: 1.97 / 2.13 / 2.34 / 3.04 ms for 2 / 3 / 4 / 6
+                const int v = d ? atoi(d) : 2;
+                return v == 3 || v == 4 || v == 6 ? v : 2;
+            }();
+            const size_t lds = sizeof(float) * ((size_t)kMetWaves * (8 * 24 + 2 * 64 + 8 + 8) + ((2 * 6 * (size_t)S + 3) & ~(size_t)3) +
+                                                (size_t)kMetWaves * stages * kMetStage);
             // a persistent grid: exactly the workgroups that are resident together (a surplus workgroup would start when
             // the others are done and double the run time of its CU)
-            int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reconstruct_metrics_mfma_kernel<12, 6>, kMetWaves * 64, lds) !=
-                    hipSuccess || per_cu < 1)
-                per_cu = 4;
-            const unsigned g = (unsigned)min((int64_t)cu_count() * per_cu, ceil_div(passes, kMetWaves));
-            hipLaunchKernelGGL((reconstruct_metrics_mfma_kernel<12, 6>), dim3(g), dim3(kMetWaves * 64), lds, st,
-                               C, N, S, TNW, T_obs, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, gt, ade, fde, use_f16);
+#define ET_METRICS_LAUNCH(D)                                                                                              \
+    do {                                                                                                                  \
+        int per_cu = 0;                                                                                                   \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reconstruct_metrics_mfma_kernel<12, 6, D>,              \
+                                                         kMetWaves * 64, lds) != hipSuccess || per_cu < 1)               \
+            per_cu = 2;                                                                                                   \
+        const unsigned g = (unsigned)min((int64_t)cu_count() * per_cu, ceil_div(passes, kMetWaves));                      \
+        hipLaunchKernelGGL((reconstruct_metrics_mfma_kernel<12, 6, D>), dim3(g), dim3(kMetWaves * 64), lds, st, C, N, S,  \
+                           TNW, T_obs, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, gt, ade, fde, use_f16); \
+    } while (0)
+            if (stages == 3) ET_METRICS_LAUNCH(3);
+            else if (stages == 4) ET_METRICS_LAUNCH(4);
+            else if (stages == 6) ET_METRICS_LAUNCH(6);
+            else ET_METRICS_LAUNCH(2);
+#undef ET_METRICS_LAUNCH
         } else {
             const size_t lds = sizeof(float) * ((size_t)TN * 24 + (size_t)TN * S * 2 + (size_t)TN * kNormStride + 2 * 24 * 6 +
                                                 2 * 6 * (size_t)S);
