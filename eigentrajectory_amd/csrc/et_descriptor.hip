@@ -992,9 +992,6 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 // per pass in its own LDS slice, requests the next pass's coefficients / ground truth / normaliser state before it
 // computes this one, and never meets a workgroup barrier after the prologue.
 constexpr int kMetWaves = 4;  // wavefronts per workgroup
-#ifndef ET_MET_EXP
-#define ET_MET_EXP 0  // timing experiments only (tools/build_variant.sh): 1 no matrix instructions, 2 no distance epilogue, 4 no best-of-S, 8 no ground-truth normalisation, 16 no f16 split
-#endif
 constexpr float kMetScaleU = 1024.f, kMetScaleC = 128.f, kMetUnscale = 1.f / (1024.f * 128.f);
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
@@ -1021,7 +1018,6 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
     float *sGn = smem + wave * kSlice;                    // TNW * DP (16-B aligned rows)
     float *sMet = sGn + kMetRows * DP;                    // 2 * 64
     float *sBack = sMet + 2 * 64;                         // TNW
-    int *sMv = reinterpret_cast<int *>(sBack + kMetRows); // TNW
     float *sA = smem + kMetWaves * kSlice;                // 2 * K * S anchors [descriptor][k][s], shared by the workgroup
     const int col_in_tile = lane & 31, h = lane >> 5;
 
@@ -1048,6 +1044,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
         aH2[desc] = f16x8_t{ul[2], ul[0], ul[1], ul[2], z, z, z, z};
     }
     const bool f16_ok = use_f16 && __ballot(!u_small) == 0ull;
+    const f16x8_t aX1 = mode == ET_MODE_MOVING ? aH1[1] : aH1[0], aX2 = mode == ET_MODE_MOVING ? aH2[1] : aH2[0];
     for (int i = tid; i < 2 * K * S; i += kMetWaves * 64) {
         const float *src = (i >= K * S) ? A_m : A_s;
         sA[i] = src ? src[i % (K * S)] * kMetScaleC : 0.f;
@@ -1160,8 +1157,6 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
     int stage = 0;  // ring slot of the current pass
     for (; pass < n_pass; pass += stride) {
         const int64_t n0 = first_row(pass);
-        constexpr bool valid_all = true;
-        const int npairs = full_pairs;
         wave_sync();  // the previous pass is done with the slice
         store_held(held, held_n0);
         {
@@ -1177,6 +1172,8 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int j = 0; j < 3; ++j) cur[t][j] = sIn[(3 * t + j) * 64 + lane];
+        // bit 12 r (+ step) of mvbits below: row r of the pass takes the moving descriptor
+        int mv_lane = 0;
         if (g_ok) {
             const float2 gp = *reinterpret_cast<const float2 *>(sIn + 6 * 64 + gr * DP + 2 * gs);
             float ox = sIn[8 * 64 + gr], oy = sIn[8 * 64 + TNW + gr], dx = sIn[8 * 64 + 2 * TNW + gr], dy = sIn[8 * 64 + 3 * TNW + gr];
@@ -1195,8 +1192,9 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
                 const float hx = dx * 0.5f, hy = dy * 0.5f;
                 mv = sqrtf(hx * hx + hy * hy) > static_dist ? 1 : 0;
             }
+            mv_lane = mv;
             float c = 1.f, sn = 0.f, sca = 1.f, back = 1.f;
-            if (mode != ET_MODE_IDENTITY && !(ET_MET_EXP & 8)) {
+            if (mode != ET_MODE_IDENTITY) {
                 const float r2 = dx * dx + dy * dy;
                 const float r = __builtin_amdgcn_sqrtf(r2), ir = __builtin_amdgcn_rcpf(r);
                 const bool still = !(r > 0.0f);
@@ -1214,119 +1212,131 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
             o.x = (tx * c + ty * sn) * sca;
             o.y = (tx * (-sn) + ty * c) * sca;
             *reinterpret_cast<float2 *>(sGn + gr * DP + 2 * gs) = o;
-            if (gs == 0) {
-                sBack[gr] = back;
-                sMv[gr] = mv;
-            }
+            if (gs == 0) sBack[gr] = back;
         }
-        wave_sync();
+        // (every lane asks: a ballot inside the branch above would be seen by the lanes that took it only)
+        const unsigned long long mvbits = mode == ET_MODE_SPLIT ? __ballot(mv_lane != 0) : (mode == ET_MODE_MOVING ? ~0ull : 0ull);
+        // Both tiles of the pass in ONE straight line (their LDS round trips, matrix instructions and square roots overlap:
+        // a wavefront's pass is a chain of dependent latencies, ~4500 cycles before this, and the CU holds too few
+        // wavefronts to hide more than a part of it).
+        float b[2][3];  // (coefficient + anchor) * 2^7 (anchor.py:87; padding columns: never stored)
+        int mvt[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            if (32 * t >= npairs) break;  // (uniform over the wavefront)
-            const int col = 32 * t + col_in_tile;
-            const bool valid = valid_all && col_ok[t];
-            const int r = row_t[t];
-            const int mv = sMv[r];
-            const float *an = sA + mv * (K * S) + anc_t[t];
-            float b[3];  // (coefficient + anchor) * 2^7 (anchor.py:87; padding columns: never stored)
+            mvt[t] = (int)((mvbits >> (row_t[t] * TP)) & 1ull);
+            const float *an = sA + mvt[t] * (K * S) + anc_t[t];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) b[j] = fmaf(cur[t][j], kMetScaleC, an[2 * j * S]);
-            f32x16_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const bool any_s = mode == ET_MODE_SPLIT ? __ballot(valid && !mv) != 0ull : mode != ET_MODE_MOVING;
-            const bool any_m = mode == ET_MODE_SPLIT ? __ballot(valid && mv) != 0ull : mode == ET_MODE_MOVING;
-            const float big = fmaxf(fmaxf(fabsf(b[0]), fabsf(b[1])), fabsf(b[2]));
-#if ET_MET_EXP & 1
-            acc[0] = b[0]; acc[1] = b[1]; acc[2] = b[2]; acc[3] = big;
-            if (false) {
-#else
-            if (f16_ok && __ballot(!(big < 32768.f)) == 0ull) {
-#endif
-                // x = hi + lo with hi = f16(x), lo = f16(x - hi): 22 bits of x.  The four cross products of the two
-                // splits are exact in the fp32 accumulator; 12 products per lane (3 k of this half x 4) = 16 + 8 slots
-                // of two 32x32x16 f16 instructions -- on the matrix pipe, beside the vector ALU instead of on it.
-                typedef float f32x2_t __attribute__((ext_vector_type(2)));
-                typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-#if ET_MET_EXP & 16
-                const unsigned q0 = __float_as_uint(b[0]), q1 = __float_as_uint(b[1]), q2 = __float_as_uint(b[2]);
-#else
-                const f16x2_t p0 = __builtin_convertvector((f32x2_t){b[0], b[1]}, f16x2_t);
-                const float r0 = b[0] - (float)p0.x, r1 = b[1] - (float)p0.y;
-                const f16x2_t p1 = __builtin_convertvector((f32x2_t){b[2], r0}, f16x2_t);
-                const float r2 = b[2] - (float)p1.x;
+            for (int j = 0; j < 3; ++j) b[t][j] = fmaf(cur[t][j], kMetScaleC, an[2 * j * S]);
+        }
+        const float big = fmaxf(fmaxf(fmaxf(fabsf(b[0][0]), fabsf(b[0][1])), fabsf(b[0][2])),
+                                fmaxf(fmaxf(fabsf(b[1][0]), fabsf(b[1][1])), fabsf(b[1][2])));
+        f32x16_t acc[2];
+        if (f16_ok && __ballot(!(big < 32768.f)) == 0ull) {
+            // x = hi + lo with hi = f16(x), lo = f16(x - hi): 22 bits of x.  The four cross products of the two splits are
+            // exact in the fp32 accumulator; 12 products per lane (3 k of this half x 4) = 8 + 4 slots of two 32x32x16 f16
+            // instructions -- on the matrix pipe, beside the vector ALU (the fp32 ones run ON its multipliers).
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            unsigned q[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f16x2_t p0 = __builtin_convertvector((f32x2_t){b[t][0], b[t][1]}, f16x2_t);
+                const float r0 = b[t][0] - (float)p0.x, r1 = b[t][1] - (float)p0.y;
+                const f16x2_t p1 = __builtin_convertvector((f32x2_t){b[t][2], r0}, f16x2_t);
+                const float r2 = b[t][2] - (float)p1.x;
                 const f16x2_t p2 = __builtin_convertvector((f32x2_t){r1, r2}, f16x2_t);
-                const unsigned q0 = __builtin_bit_cast(unsigned, p0), q1 = __builtin_bit_cast(unsigned, p1),
-                               q2 = __builtin_bit_cast(unsigned, p2);
-#endif
-                if (any_s) {
-                    const bool z = mode == ET_MODE_SPLIT && mv;
-                    const unsigned z0 = z ? 0u : q0, z1 = z ? 0u : q1, z2 = z ? 0u : q2;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH1[0], __builtin_bit_cast(f16x8_t, (u32x4_t){z0, z1, z2, z0}), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH2[0], __builtin_bit_cast(f16x8_t, (u32x4_t){z1, z2, 0u, 0u}), acc, 0, 0, 0);
-                }
-                if (any_m) {
-                    const bool z = mode == ET_MODE_SPLIT && !mv;
-                    const unsigned z0 = z ? 0u : q0, z1 = z ? 0u : q1, z2 = z ? 0u : q2;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH1[1], __builtin_bit_cast(f16x8_t, (u32x4_t){z0, z1, z2, z0}), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH2[1], __builtin_bit_cast(f16x8_t, (u32x4_t){z1, z2, 0u, 0u}), acc, 0, 0, 0);
-                }
-            } else {
-                // fp32 matrix instructions: the vector code's fmaf chain over k = 0..5, bit for bit (the scales are exact)
-                // (a tile spans two or three rows: most tiles hold one descriptor only and skip the other's instructions --
-                // the fp32 matrix instructions run on the vector ALU's multipliers, their time ADDS to the epilogue's)
-                if (any_s) {
-                    const bool z = mode == ET_MODE_SPLIT && mv;
+                q[t][0] = __builtin_bit_cast(unsigned, p0);
+                q[t][1] = __builtin_bit_cast(unsigned, p1);
+                q[t][2] = __builtin_bit_cast(unsigned, p2);
+            }
+            if (mode != ET_MODE_SPLIT) {  // one descriptor for every row: its U was picked before the loop
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[0][j], z ? 0.f : b[j], acc, 0, 0, 0);
+                for (int t = 0; t < 2; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aX1, __builtin_bit_cast(f16x8_t, (u32x4_t){q[t][0], q[t][1], q[t][2], q[t][0]}), zero, 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aX2, __builtin_bit_cast(f16x8_t, (u32x4_t){q[t][1], q[t][2], 0u, 0u}), acc[t], 0, 0, 0);
                 }
-                if (any_m) {
-                    const bool z = mode == ET_MODE_SPLIT && !mv;
+            } else {  // per-row choice: a column's coefficients go to its own descriptor's instructions, zero to the other's
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[1][j], z ? 0.f : b[j], acc, 0, 0, 0);
+                for (int t = 0; t < 2; ++t) {
+                    const unsigned s0 = mvt[t] ? 0u : q[t][0], s1 = mvt[t] ? 0u : q[t][1], s2 = mvt[t] ? 0u : q[t][2];
+                    const unsigned m0 = mvt[t] ? q[t][0] : 0u, m1 = mvt[t] ? q[t][1] : 0u, m2 = mvt[t] ? q[t][2] : 0u;
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH1[0], __builtin_bit_cast(f16x8_t, (u32x4_t){s0, s1, s2, s0}), zero, 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH2[0], __builtin_bit_cast(f16x8_t, (u32x4_t){s1, s2, 0u, 0u}), acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH1[1], __builtin_bit_cast(f16x8_t, (u32x4_t){m0, m1, m2, m0}), acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH2[1], __builtin_bit_cast(f16x8_t, (u32x4_t){m1, m2, 0u, 0u}), acc[t], 0, 0, 0);
                 }
             }
+        } else {
+            // fp32 matrix instructions: the vector code's fmaf chain over k = 0..5, bit for bit (the scales are exact); taken
+            // when a value leaves f16's range (|U| >= 32 or |coefficient + anchor| >= 256) and with ET_METRICS_MFMA=f32
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x16_t a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (mode != ET_MODE_MOVING) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) a = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[0][j], mvt[t] ? 0.f : b[t][j], a, 0, 0, 0);
+                }
+                if (mode == ET_MODE_MOVING || mode == ET_MODE_SPLIT) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) a = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[1][j], mvt[t] ? b[t][j] : 0.f, a, 0, 0, 0);
+                }
+                acc[t] = a;
+            }
+        }
+        wave_sync();  // the normalised ground truth is in the slice
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
             // rows 8 g + 4 h + (0..3) of this column: steps 4 g + 2 h and 4 g + 2 h + 1 (g = 3 is padding)
-            const float4 *g4 = reinterpret_cast<const float4 *>(sGn + r * DP + 4 * h);
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            const float4 *g4 = reinterpret_cast<const float4 *>(sGn + row_t[t] * DP + 4 * h);
+            const float back = sBack[row_t[t]];
+            const f32x2_t un = {kMetUnscale, kMetUnscale};
             float sum = 0.f, last = 0.f;
-#if ET_MET_EXP & 2
-            for (int g = 0; g < 3; ++g) { sum += acc[4 * g] + acc[4 * g + 1]; last += acc[4 * g + 2] + acc[4 * g + 3] + g4[2 * g].x; }
-#else
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 const float4 gn = g4[2 * g];
-                const float ex = fmaf(acc[4 * g], kMetUnscale, -gn.x), ey = fmaf(acc[4 * g + 1], kMetUnscale, -gn.y),
-                            fx = fmaf(acc[4 * g + 2], kMetUnscale, -gn.z), fy = fmaf(acc[4 * g + 3], kMetUnscale, -gn.w);
+                // (two fp32 per instruction: v_pk_fma_f32 / v_pk_mul_f32 on adjacent accumulator registers)
+                f32x2_t e = __builtin_elementwise_fma((f32x2_t){acc[t][4 * g], acc[t][4 * g + 1]}, un, (f32x2_t){-gn.x, -gn.y});
+                f32x2_t f = __builtin_elementwise_fma((f32x2_t){acc[t][4 * g + 2], acc[t][4 * g + 3]}, un, (f32x2_t){-gn.z, -gn.w});
+                e = e * e;
+                f = f * f;
                 // v_sqrt_f32 (1 ulp): the metric is compared at 1e-5 m
-                const float d0 = __builtin_amdgcn_sqrtf(ex * ex + ey * ey), d1 = __builtin_amdgcn_sqrtf(fx * fx + fy * fy);
+                const float d0 = __builtin_amdgcn_sqrtf(e.x + e.y), d1 = __builtin_amdgcn_sqrtf(f.x + f.y);
                 sum = (sum + d0) + d1;
                 last = d1;  // h = 1, g = 2: step 11
             }
-#endif
-            const float other_sum = __shfl_xor(sum, 32), other_last = __shfl_xor(last, 32);
-            if (h == 0 && valid) {
-                const float back = sBack[r];
-                sMet[2 * col] = ((sum + other_sum) * (1.0f / (float)TP)) * back;
-                sMet[2 * col + 1] = other_last * back;
-            }
+            // the other half's six steps: v_permlane32_swap (x, x) leaves x[lane + 32] in the second result's low half
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+            const u32x2_t ws = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+            const u32x2_t wl = __builtin_amdgcn_permlane32_swap(__float_as_uint(last), __float_as_uint(last), false, false);
+            const float other_sum = __uint_as_float(ws.y), other_last = __uint_as_float(wl.y);
+            if (h == 0 && col_ok[t])
+                *reinterpret_cast<float2 *>(sMet + 2 * (32 * t + col_in_tile)) =
+                    make_float2(((sum + other_sum) * (1.0f / (float)TP)) * back, other_last * back);
         }
         wave_sync();
-        {   // best of S (torch.min propagates NaN): lane (mr, mq) takes samples mq, mq + 4, ...; then two exchanges
-            const float2 *m2 = reinterpret_cast<const float2 *>(sMet) + mrow * S;
-            float2 best = m2[mq < S ? mq : 0];
-#if !(ET_MET_EXP & 4)
-            for (int s = mq + 4; s < S; s += 4) {
-                const float2 o = m2[s];
-                best.x = (o.x < best.x || isnan(o.x)) ? o.x : best.x;
-                best.y = (o.y < best.y || isnan(o.y)) ? o.y : best.y;
+        {   // best of S (torch.min propagates NaN): lane (mr, mq) takes samples mq, mq + 4, ...; then the quad's four meet.
+            // The metrics are >= +0 or NaN: as unsigned integers their order is the floats' and every NaN is above +inf,
+            // so min AND max of the bit patterns decide -- max > 0x7f800000 means a NaN was among them.
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+            const u32x2_t *m2 = reinterpret_cast<const u32x2_t *>(sMet) + mrow * S;
+            u32x2_t mn = m2[mq < S ? mq : 0], mx = mn;
+            for (int s = mq + 4; s < S; s += 8) {
+                const u32x2_t v0 = m2[s], v1 = m2[s + 4 < S ? s + 4 : s];
+                mn.x = min(min(mn.x, v0.x), v1.x);
+                mn.y = min(min(mn.y, v0.y), v1.y);
+                mx.x = max(max(mx.x, v0.x), v1.x);
+                mx.y = max(max(mx.y, v0.y), v1.y);
             }
-#pragma unroll
-            for (int o = 1; o < 4; o <<= 1) {
-                const float ox = __shfl_xor(best.x, o), oy = __shfl_xor(best.y, o);
-                best.x = (ox < best.x || isnan(ox)) ? ox : best.x;
-                best.y = (oy < best.y || isnan(oy)) ? oy : best.y;
-            }
-#endif
-            held = best;
+#define ET_QUAD(v, ctrl) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, 0xf, 0xf, true)
+            mn.x = min(mn.x, ET_QUAD(mn.x, 0xB1)); mn.y = min(mn.y, ET_QUAD(mn.y, 0xB1));  // lane ^ 1
+            mx.x = max(mx.x, ET_QUAD(mx.x, 0xB1)); mx.y = max(mx.y, ET_QUAD(mx.y, 0xB1));
+            mn.x = min(mn.x, ET_QUAD(mn.x, 0x4E)); mn.y = min(mn.y, ET_QUAD(mn.y, 0x4E));  // lane ^ 2
+            mx.x = max(mx.x, ET_QUAD(mx.x, 0x4E)); mx.y = max(mx.y, ET_QUAD(mx.y, 0x4E));
+#undef ET_QUAD
+            held = make_float2(__uint_as_float(mx.x > 0x7f800000u ? mx.x : mn.x), __uint_as_float(mx.y > 0x7f800000u ? mx.y : mn.y));
             held_n0 = n0;
         }
     }

@@ -978,6 +978,61 @@ def test_fused_metrics_epilogue_vs_oracle(ops, oracle, dev, s, n, k, t_pred):
     close(N_(fde), W.batch_fde(rec, gt), tol=2e-6)
 
 
+@pytest.mark.parametrize("variant", ["0", "f32", "1"])
+@pytest.mark.parametrize("s,mode", [(20, 2), (20, 1), (12, 2), (33, 0), (64, 2)])
+def test_fused_metrics_kernel_variants_vs_oracle(ops, oracle, dev, monkeypatch, variant, s, mode):
+    """The three forms of the S >= 12 epilogue -- vector-ALU tile kernel (ET_METRICS_MFMA=0), fp32 matrix instructions
+    (f32), two-term f16 matrix instructions (default) -- against the oracle's reconstruction + compute_batch_ade / fde
+    (utils/metrics.py), per-row descriptor choice included; n is not a multiple of the 64 / S rows of a pass."""
+    from oracle import wrapper_ref as W
+    from eigentrajectory_amd.synth import synthetic_trajectories_np
+    monkeypatch.setenv("ET_METRICS_MFMA", variant)
+    n = 1003
+    rng = np.random.default_rng(s + mode)
+    obs, gt = synthetic_trajectories_np(n, seed=9)
+    um, us_ = (rng.standard_normal((24, 6)).astype(np.float32) * 0.3 for _ in range(2))
+    a_m, a_s = (rng.standard_normal((6, s)).astype(np.float32) for _ in range(2))
+    c = rng.standard_normal((6, n, s)).astype(np.float32)
+    ade, fde = ops.anchor_reconstruct_metrics(T(c, dev), T(gt, dev), T(a_m, dev), T(a_s, dev), T(um, dev), T(us_, dev), mode,
+                                              0.3, obs=T(obs, dev))
+    rec = oracle.anchor_reconstruct(c, obs, a_m, a_s, um, us_, mode, 0.3)
+    close(N_(ade), W.batch_ade(rec, gt), tol=2e-6)
+    close(N_(fde), W.batch_fde(rec, gt), tol=2e-6)
+
+
+@pytest.mark.parametrize("what", ["coefficients", "U", "nan"])
+def test_fused_metrics_values_beyond_f16_take_the_fp32_instructions(ops, oracle, dev, what):
+    """|coefficient + anchor| >= 256 or |U| >= 32 would overflow the scaled f16 operands: those tiles (or the whole launch)
+    run the fp32 matrix instructions; a NaN coefficient makes its trajectory's metrics NaN (torch.min propagates it) and
+    leaves its neighbours alone."""
+    from oracle import wrapper_ref as W
+    from eigentrajectory_amd.synth import synthetic_trajectories_np
+    n, s = 400, 20
+    rng = np.random.default_rng(3)
+    obs, gt = synthetic_trajectories_np(n, seed=10)
+    um, us_ = (rng.standard_normal((24, 6)).astype(np.float32) * 0.3 for _ in range(2))
+    a_m, a_s = (rng.standard_normal((6, s)).astype(np.float32) for _ in range(2))
+    c = rng.standard_normal((6, n, s)).astype(np.float32)
+    if what == "coefficients":
+        c[:, 100:140] *= 3000.0  # a stretch of passes beyond the f16 range, the rest inside
+    elif what == "U":
+        um *= 200.0
+    else:
+        c[2, 57, 11] = np.nan
+    ade, fde = ops.anchor_reconstruct_metrics(T(c, dev), T(gt, dev), T(a_m, dev), T(a_s, dev), T(um, dev), T(us_, dev), 2,
+                                              0.3, obs=T(obs, dev))
+    rec = oracle.anchor_reconstruct(c, obs, a_m, a_s, um, us_, 2, 0.3)
+    want_a, want_f = W.batch_ade(rec, gt), W.batch_fde(rec, gt)
+    if what == "nan":
+        assert np.isnan(N_(ade)[57]) and np.isnan(N_(fde)[57]) and np.isnan(want_a[57])
+        keep = np.arange(n) != 57
+        close(N_(ade)[keep], want_a[keep], tol=2e-6)
+        close(N_(fde)[keep], want_f[keep], tol=2e-6)
+    else:
+        np.testing.assert_allclose(N_(ade), want_a, rtol=3e-6, atol=2e-5)
+        np.testing.assert_allclose(N_(fde), want_f, rtol=3e-6, atol=2e-5)
+
+
 def test_wrapper_evaluate_matches_forward_and_reference_g6(dev):
     from eigentrajectory_amd import EigenTrajectory
     from eigentrajectory_amd.utils import default_hyper_params
