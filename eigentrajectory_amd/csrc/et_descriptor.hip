@@ -967,86 +967,100 @@ __global__ __launch_bounds__(kTile) void reconstruct_bwd_tile_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Fused evaluation epilogue on the MATRIX cores (T_pred = 12, k = 6).  In reconstruct_metrics_tile_kernel the contraction
-// U (24 x 6) . (C + A) (6 x S) per trajectory -- 144 fused multiply-adds and as many LDS reads of U per (trajectory,
-// sample) pair -- is what the kernel waits for (VALU bound at 0.27 of the HBM roof, S = 20).  U is the same for every
-// pair, i.e. this is ONE skinny GEMM V = U . C' with the pairs as columns:  v_mfma_f32_32x32x2_f32 (rows = the 24
-// features padded to 32, two k per instruction, 32 pairs per tile, fp32 in / fp32 accumulate -- the same fmaf chain
-// over k = 0..5 as the vector code, bit for bit) does it in three instructions per 32 pairs.  Not a flops gain: the fp32
-// matrix instructions run at the vector rate AND on the vector ALU's multipliers (their busy cycles add to the
-// epilogue's: SPLIT's three extra instructions per tile cost exactly their 192 cycles, profiles/r04c_metrics_pmc.txt) --
-// what it buys is issue slots and LDS traffic: 144 instructions and as many broadcast reads of U per pair become 3 per
-// 32 pairs, and the vector ALU keeps the epilogue (~45 instructions per lane and tile):
+// Fused evaluation epilogue on the MATRIX cores (T_pred = 12, k = 6, 12 <= S <= 64).  In reconstruct_metrics_tile_kernel
+// the contraction U (24 x 6) . (C + A) (6 x S) per trajectory -- 144 fused multiply-adds and as many LDS reads of U per
+// (trajectory, sample) pair -- is what the kernel waits for (VALU bound at 0.27 of the HBM roof, S = 20).  U is the same
+// for every pair, i.e. this is ONE skinny GEMM V = U . C' with the pairs as columns (rows = the 24 features padded to
+// 32, 32 pairs per tile):
 //   lane (col, h) of a tile holds rows 8g + 4h + r of column col = the time steps {4g + 2h, 4g + 2h + 1}, x and y adjacent;
-//   h = 0 and h = 1 each own 6 of the 12 steps, their displacement sums meet through one cross-lane exchange.
-// Per-row descriptor choice (mode SPLIT): both descriptors' U are A operands and a column's coefficients go to the B
-// operand of its own descriptor, zero to the other's -- six instructions, products with zero do not change the chain.
+//   h = 0 and h = 1 each own 6 of the 12 steps, their displacement sums meet through one v_permlane32_swap.
+// Which matrix instruction: v_mfma_f32_32x32x2_f32 reproduces the vector code's fmaf chain over k = 0..5 bit for bit, but
+// the fp32 matrix instructions run at the vector rate AND on the vector ALU's multipliers (their busy cycles add to the
+// epilogue's, profiles/r04c_metrics_pmc.txt) -- and the vector ALU is what bounds this kernel.  So the default is a
+// TWO-TERM f16 SPLIT on the f16 matrix pipe: x = hi + lo, hi = f16(x), lo = f16(x - hi) carries 22 bits of x; the four
+// cross products (Uh + Ul)(ch + cl) are exact in the fp32 accumulator; 12 products per lane (its 3 k x 4) fill 6 of the 8
+// slots of two v_mfma_f32_32x32x16_f16 that share ONE B operand (bh0 bh1 bh2 bl0 bl1 bl2 . .) against A = (Uh Uh 0 0) and
+// (Ul Ul 0 0).  Both operands carry a power-of-two scale (U: 2^10, coefficients + anchors: 2^7; exact, undone by the
+// epilogue's fused multiply-subtract) that keeps the low halves out of f16's denormal range.  Against the fp32 chain the
+// metrics move by <= 1e-6 relative (tests compare at 2e-6 of the largest value).  A pass whose values leave f16's range
+// (|U| >= 32, |coefficient + anchor| >= 256, NaN) takes the fp32 instructions; ET_METRICS_MFMA=f32 forces them.
+// Per-row descriptor choice (MODE SPLIT): a tile whose rows all take one descriptor uses that descriptor's A operands;
+// a mixed tile sends a column's coefficients to its own descriptor's instructions and zero to the other's.
+//
+// The workgroup-tile form (and its vector-ALU predecessor) is bound by neither pipe: a workgroup lives through load ->
+// barrier -> compute -> barrier -> min tree (five barriers) -> store for ONE tile of 240 pairs.  Hence: a persistent grid
+// of AUTONOMOUS wavefronts.  A wavefront takes TNW = 64 / S trajectories (S = 20: 3 trajectories = 60 pairs = two
+// 32-column tiles) per pass in its own LDS slice and never meets a workgroup barrier after the prologue.  MODE is a
+// template parameter: the pass body is one straight line per mode (the uniform branches on a run-time mode cost ~60
+// scalar and ~40 vector instructions per pass).
 // ------------------------------------------------------------------------------------------
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
-
-// The workgroup-tile form of this kernel (and of its vector-ALU predecessor, reconstruct_metrics_tile_kernel) is bound by
-// neither pipe: a workgroup lives through load -> barrier -> compute -> barrier -> min tree (five barriers) -> store for
-// ONE tile of 240 pairs, and 2.7 ms at N = 1e7 is 34 cycles per pair and SIMD where the vector form issues 12 (round 4:
-// the matrix-core contraction alone changed nothing, 2.82 against 2.74 ms).  Hence: a persistent grid of AUTONOMOUS
-// wavefronts.  A wavefront takes TNW = 64 / S trajectories (S = 20: 3 trajectories = 60 pairs = two 32-column tiles)
-// per pass in its own LDS slice, requests the next pass's coefficients / ground truth / normaliser state before it
-// computes this one, and never meets a workgroup barrier after the prologue.
-constexpr int kMetWaves = 4;  // wavefronts per workgroup
-constexpr float kMetScaleU = 1024.f, kMetScaleC = 128.f, kMetUnscale = 1.f / (1024.f * 128.f);
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+constexpr int kMetWaves = 4;  // wavefronts per workgroup
+constexpr int kMetStages = 2; // ring depth = passes in flight per wavefront + 1 (deeper rings cost residency and lose:
+                              // 1.97 / 2.13 / 2.34 / 3.04 ms for 2 / 3 / 4 / 6 stages, profiles/r04g_metrics.txt)
+constexpr float kMetScaleU = 1024.f, kMetScaleC = 128.f, kMetUnscale = 1.f / (1024.f * 128.f);
+constexpr int kMetStage = 9 * 64;  // floats per ring stage: 6 coefficient slots | 2 x 64 ground truth | normaliser state
+constexpr int kMetRows = 8;        // >= 64 / S for S >= 12 (rounded up to keep the slices 16-byte aligned)
+constexpr int kMetSlice = kMetRows * 24 + 2 * 64 + kMetRows;  // floats per wavefront: normalised gt | (ADE, FDE) per pair | 1 / sca
 
 // memory -> LDS without a destination register: LDS address = M0 + 4 * lane
 __device__ __forceinline__ void lds_dma_b32(unsigned __attribute__((ext_vector_type(4))) desc, unsigned lds_addr, unsigned voffset, unsigned soffset) {
     asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voffset), "s"(desc), "s"(soffset) : "memory");
 }
-constexpr int kMetStage = 9 * 64;  // floats per ring stage: 6 coefficient slots | 2 x 64 ground truth | normaliser state
 
-template <int TP, int K, int D>
+__host__ __device__ constexpr size_t metrics_mfma_lds_floats(int S, int n_desc) {
+    return (size_t)kMetWaves * kMetSlice + (((size_t)n_desc * 6 * S + 3) & ~(size_t)3) + (size_t)kMetWaves * kMetStages * kMetStage;
+}
+
+template <int TP, int K, int MODE>
 __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kernel(
-    const float *__restrict__ C, int64_t N, int S, int TNW, int T_obs,
+    const float *__restrict__ C, int N, int S, int TNW, int T_obs,
     const float *__restrict__ obs, const float *__restrict__ nrm,
     const float *__restrict__ A_m, const float *__restrict__ A_s,
     const float *__restrict__ U_m, const float *__restrict__ U_s,
-    int mode, float static_dist, const float *__restrict__ gt, float *__restrict__ ade, float *__restrict__ fde, int use_f16) {
-    static_assert(TP == 12 && K == 6, "rows = 24 features in a 32-row tile, k = 6 = three k-pairs");
-    constexpr int DP = 2 * TP;
-    constexpr int kMetRows = 8;  // >= 64 / S for S >= 12 (rounded up to keep the slices 16-byte aligned)
-    constexpr int kSlice = kMetRows * DP + 2 * 64 + kMetRows + kMetRows;  // floats per wavefront: normalised gt | (ADE, FDE) per pair | 1/sca | descriptor
+    float static_dist, const float *__restrict__ gt, float *__restrict__ ade, float *__restrict__ fde, int use_f16) {
+    static_assert(TP == 12 && K == 6, "rows = 24 features in a 32-row tile, k = 6 = three k per half");
+    constexpr int DP = 2 * TP, D = kMetStages;
+    constexpr bool SPLIT = MODE == ET_MODE_SPLIT;
+    constexpr int ND = SPLIT ? 2 : 1;  // descriptors in play: SPLIT 0 static / 1 moving, else the mode's own
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float *sGn = smem + wave * kSlice;                    // TNW * DP (16-B aligned rows)
-    float *sMet = sGn + kMetRows * DP;                    // 2 * 64
-    float *sBack = sMet + 2 * 64;                         // TNW
-    float *sA = smem + kMetWaves * kSlice;                // 2 * K * S anchors [descriptor][k][s], shared by the workgroup
+    float *sGn = smem + wave * kMetSlice;  // TNW * DP (16-B aligned rows)
+    float *sMet = sGn + kMetRows * DP;     // 2 * 64
+    float *sBack = sMet + 2 * 64;          // TNW
+    float *sA = smem + kMetWaves * kMetSlice;  // ND * K * S anchors [descriptor][k][s] * 2^7, shared by the workgroup
+    float *sRing = sA + ((ND * K * S + 3) & ~3) + wave * (D * kMetStage);
     const int col_in_tile = lane & 31, h = lane >> 5;
 
-    // A operands: U[f][2 j + h] of both descriptors (f = the lane's row; rows 24..31 are padding)
-    // Both operands carry a power-of-two scale (U: 2^10, coefficients + anchors: 2^7; exact, undone by the epilogue's
-    // fused multiply-subtract) -- it keeps the LOW halves of the two-term f16 splits below out of f16's denormal range.
-    float aU[2][3];
-    f16x8_t aH1[2], aH2[2];  // the f16 split of U: (Uh0 Uh1 Uh2 Uh0 Uh1 Uh2 Ul0 Ul1), (Ul2 Ul0 Ul1 Ul2 0 0 0 0)
+    // A operands of lane (f, h): U[f][2 j + h] * 2^10, j = 0..2 (f = the lane's feature row; rows 24..31 are padding)
+    float aU[ND][3];
+    f16x8_t aHi[ND], aLo[ND];  // (Uh0 Uh1 Uh2 Uh0 Uh1 Uh2 0 0), (Ul0 Ul1 Ul2 Ul0 Ul1 Ul2 0 0)
     bool u_small = true;
 #pragma unroll
-    for (int desc = 0; desc < 2; ++desc) {
-        const float *U = desc ? U_m : U_s;
+    for (int d = 0; d < ND; ++d) {
+        const float *U = (SPLIT ? d == 1 : MODE == ET_MODE_MOVING) ? U_m : U_s;
         _Float16 uh[3], ul[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const float u = (U && col_in_tile < DP) ? U[col_in_tile * K + 2 * j + h] * kMetScaleU : 0.f;
-            aU[desc][j] = u;
+            aU[d][j] = u;
             u_small = u_small && fabsf(u) < 32768.f;
             uh[j] = (_Float16)u;
             ul[j] = (_Float16)(u - (float)uh[j]);
         }
         const _Float16 z = (_Float16)0.f;
-        aH1[desc] = f16x8_t{uh[0], uh[1], uh[2], uh[0], uh[1], uh[2], ul[0], ul[1]};
-        aH2[desc] = f16x8_t{ul[2], ul[0], ul[1], ul[2], z, z, z, z};
+        aHi[d] = f16x8_t{uh[0], uh[1], uh[2], uh[0], uh[1], uh[2], z, z};
+        aLo[d] = f16x8_t{ul[0], ul[1], ul[2], ul[0], ul[1], ul[2], z, z};
     }
     const bool f16_ok = use_f16 && __ballot(!u_small) == 0ull;
-    const f16x8_t aX1 = mode == ET_MODE_MOVING ? aH1[1] : aH1[0], aX2 = mode == ET_MODE_MOVING ? aH2[1] : aH2[0];
-    for (int i = tid; i < 2 * K * S; i += kMetWaves * 64) {
-        const float *src = (i >= K * S) ? A_m : A_s;
+    for (int i = tid; i < ND * K * S; i += kMetWaves * 64) {
+        const float *src = (SPLIT ? i >= K * S : MODE == ET_MODE_MOVING) ? A_m : A_s;
         sA[i] = src ? src[i % (K * S)] * kMetScaleC : 0.f;
     }
     __syncthreads();  // the only workgroup barrier
@@ -1056,43 +1070,44 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    const int64_t plane = N * S;
-    const int64_t n_pass = (N + TNW - 1) / TNW;
-    const int64_t stride = (int64_t)gridDim.x * kMetWaves;
-    const int full_pairs = TNW * S;
+    const int64_t plane = (int64_t)N * S;
+    const int n_pass = (N + TNW - 1) / TNW;
+    const int stride = (int)gridDim.x * kMetWaves;
+    const int full_pairs = TNW * S;  // > 32 for every 12 <= S <= 64: both tiles are always in use
     // Everything a lane derives from its position alone is computed ONCE (the integer divisions by S, the anchor and
-    // ground-truth offsets): the loop below was bound by instruction issue (~1000 instructions per pass, most of them
-    // index arithmetic) before this -- the six matrix instructions and ~90 of epilogue are what is left.
-    int row_t[2], anc_t[2];  // tile t: this lane's row of the pass, and (2 * 0 + h) * S + sample
+    // ground-truth offsets): the loop was bound by instruction issue (~1000 instructions per pass, most of them index
+    // arithmetic) before this.
+    int row_t[2];
+    const float *an_t[2];  // tile t: this lane's row of the pass, and its anchor column &sA[(0 * 2 + h) * S + sample]
     bool col_ok[2];
+    unsigned long long tile_rows[2];  // (SPLIT) bit 12 r: row r has columns in tile t
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int col = 32 * t + col_in_tile;
         col_ok[t] = col < full_pairs;
         row_t[t] = col_ok[t] ? col / S : 0;
-        anc_t[t] = h * S + (col_ok[t] ? col - row_t[t] * S : 0);
+        an_t[t] = sA + h * S + (col_ok[t] ? col - row_t[t] * S : 0);
+        const int r_lo = (32 * t) / S, r_hi = min(TNW - 1, (32 * t + 31) / S);
+        unsigned long long m = 0;
+        for (int r = r_lo; r <= r_hi; ++r) m |= 1ull << (r * TP);
+        tile_rows[t] = m;
     }
     // ground-truth point of this lane: (row gr, step gs) if lane < TNW * 12
     const int gr = lane / TP, gs = lane - gr * TP;
     const bool g_ok = gr < TNW;
     // best-of-S: four lanes per row, each takes every fourth sample
     const int mr = lane >> 2, mq = lane & 3;
-    // Every pass is a FULL pass: the last one is moved back to end at row N (it recomputes a few rows of its
-    // predecessor -- same values, same addresses), so the loads below are unconditional straight-line code.  (A masked
-    // variant for a short last pass made the compiler merge two load paths with register copies -- and wait for every
-    // prefetch right where it was issued.)
-    int64_t pass = (int64_t)blockIdx.x * kMetWaves + wave;
+    const int mrow = mr < TNW ? mr : TNW - 1;
+
     // A pass's inputs travel from memory STRAIGHT INTO LDS (buffer_load ... lds: no destination registers), D - 1 passes
-    // ahead, into a ring of D stages per wavefront.  With the loads landing in registers a wavefront could have ONE pass
-    // (1.8 kB) in flight -- 36 kB per CU at 5 wavefronts per SIMD, and by Little's law 3.7 TB/s at the ~2.4 us a loaded
-    // memory system takes: the loop WITHOUT any arithmetic ran 1.6 of the kernel's 2.0 ms (round 4, profiles/r04g).
-    // The loads are inline assembly on purpose: for the compiler's own LDS-DMA intrinsic the wait-count pass puts
-    // s_waitcnt vmcnt(0) in front of EVERY later LDS read of the kernel (it cannot tell the stages apart).  Here the waits
-    // are ours: every iteration issues exactly 2 stores + 9 loads (the tail re-requests the last pass), so "stage i has
-    // landed" is vmcnt <= 11 (D - 1) -- a constant.
+    // ahead, into a ring of D stages per wavefront.  The loads are inline assembly on purpose: for the compiler's own
+    // LDS-DMA intrinsic the wait-count pass puts s_waitcnt vmcnt(0) in front of EVERY later LDS read of the kernel (it
+    // cannot tell the stages apart).  Here the waits are ours: every iteration issues exactly 2 stores + 9 loads (the tail
+    // re-requests the last pass), so "stage i has landed" is vmcnt <= 11 (D - 1) -- a constant.  Every pass is a FULL pass:
+    // the last one is moved back to end at row N (it recomputes a few rows of its predecessor -- same values, same
+    // addresses), so the loop has no load or store under a branch (the compiler answers those with full drains).
     // Descriptors live in scalar registers, the per-lane byte offsets in one vector register each for the whole loop, the
     // pass's position is a scalar offset (offsets must fit 32 bits: the host takes this kernel for 2 N S 4 B < 2^32 only).
-    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     auto desc_of = [](const void *base, int64_t bytes) {
         const unsigned long long b = reinterpret_cast<unsigned long long>(base);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
@@ -1106,8 +1121,8 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
         return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, nb, 0x00020000);
     };
     const u32x4_t dc0 = desc_of(C, 2 * plane * 4), dc1 = desc_of(C + 2 * plane, 2 * plane * 4), dc2 = desc_of(C + 4 * plane, 2 * plane * 4);
-    const u32x4_t dg = desc_of(gt, N * DP * 4), dn = nrm ? desc_of(nrm, 4 * N * 4) : dg;  // (without nrm: a readable dummy)
-    const __amdgpu_buffer_rsrc_t ra = rsrc_of(ade, N * 4), rf = rsrc_of(fde, N * 4);
+    const u32x4_t dg = desc_of(gt, (int64_t)N * DP * 4), dn = nrm ? desc_of(nrm, (int64_t)4 * N * 4) : dg;  // (without nrm: a readable dummy)
+    const __amdgpu_buffer_rsrc_t ra = rsrc_of(ade, (int64_t)N * 4), rf = rsrc_of(fde, (int64_t)N * 4);
     unsigned oc[2];  // tile t's coefficient loads: (h * plane + column) * 4
 #pragma unroll
     for (int t = 0; t < 2; ++t) oc[t] = 4u * (unsigned)((int64_t)h * plane + (col_ok[t] ? 32 * t + col_in_tile : 0));
@@ -1115,16 +1130,14 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
     const unsigned og0 = 4u * (unsigned)(lane < TNW * DP ? lane : 0), og1 = 4u * (unsigned)(64 + lane < TNW * DP ? 64 + lane : 0);
     // normaliser state [4][N]: lane j * TNW + r loads plane j, row r
     const unsigned onr = (nrm && lane < 4 * TNW) ? 4u * (unsigned)((int64_t)(lane / TNW) * N + lane % TNW) : 0u;
-    const bool use_nrm = nrm != nullptr && mode != ET_MODE_IDENTITY;
-    float *sRing = sA + ((2 * K * S + 3) & ~3) + wave * (D * kMetStage);
+    const bool use_nrm = nrm != nullptr && MODE != ET_MODE_IDENTITY;
     const unsigned ring_addr = __builtin_amdgcn_readfirstlane(
         (unsigned)reinterpret_cast<unsigned long long>((__attribute__((address_space(3))) float *)sRing));
-    auto first_row = [&](int64_t ps) { return min(ps * TNW, N - TNW); };
-    auto issue = [&](int64_t ps, int stage) {  // (passes beyond the last re-request the last one: same count every time)
-        const int64_t n0 = first_row(min(ps, n_pass - 1));
+    auto first_row = [&](int ps) { return min(ps * TNW, N - TNW); };
+    auto issue = [&](int ps, int stage) {  // (passes beyond the last re-request the last one: same count every time)
+        const int n0 = __builtin_amdgcn_readfirstlane(first_row(min(ps, n_pass - 1)));
         const unsigned base = ring_addr + (unsigned)stage * (unsigned)(kMetStage * 4);
-        const unsigned so_c = __builtin_amdgcn_readfirstlane((unsigned)(n0 * S * 4)), so_g = __builtin_amdgcn_readfirstlane((unsigned)(n0 * DP * 4)),
-                       so_n = __builtin_amdgcn_readfirstlane((unsigned)(n0 * 4));
+        const unsigned so_c = (unsigned)n0 * (unsigned)(S * 4), so_g = (unsigned)n0 * (unsigned)(DP * 4), so_n = (unsigned)n0 * 4u;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             lds_dma_b32(dc0, base + (3 * t + 0) * 256, oc[t], so_c);
@@ -1135,6 +1148,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
         lds_dma_b32(dg, base + 7 * 256, og1, so_g);
         lds_dma_b32(dn, base + 8 * 256, onr, so_n);
     };
+    int pass = (int)blockIdx.x * kMetWaves + wave;
     const bool did_any = pass < n_pass;
     if (did_any) {
 #pragma unroll
@@ -1145,25 +1159,25 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
     // unconditionally, through a scalar base + a per-lane offset that lives in one register for the whole loop: lanes
     // beyond the pass's rows repeat its last row (same value, same address).  The first iteration has nothing to store
     // yet: it writes zeros to its own pass's slots, which the second iteration overwrites.
-    const int mrow = mr < TNW ? mr : TNW - 1;
     const int om = 4 * mrow;
-    auto store_held = [&](float2 v, int64_t n0) {
-        const int so = __builtin_amdgcn_readfirstlane((int)(n0 * 4));
+    auto store_held = [&](float2 v, int n0) {
+        const int so = __builtin_amdgcn_readfirstlane(n0 * 4);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), ra, om, so, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), rf, om, so, 0);
     };
+    auto mfma16 = [](f16x8_t hi, f16x8_t lo, u32x4_t bq) {
+        const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const f16x8_t bv = __builtin_bit_cast(f16x8_t, bq);
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(lo, bv, __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, bv, zero, 0, 0, 0), 0, 0, 0);
+    };
     float2 held = make_float2(0.f, 0.f);
-    int64_t held_n0 = did_any ? first_row(pass) : 0;
+    int held_n0 = did_any ? first_row(pass) : 0;
     int stage = 0;  // ring slot of the current pass
     for (; pass < n_pass; pass += stride) {
-        const int64_t n0 = first_row(pass);
+        const int n0 = first_row(pass);
         wave_sync();  // the previous pass is done with the slice
         store_held(held, held_n0);
-        {
-            int ahead = stage + D - 1;
-            if (ahead >= D) ahead -= D;
-            issue(pass + (D - 1) * stride, ahead);  // travels while D - 1 passes are computed
-        }
+        issue(pass + (D - 1) * stride, stage == 0 ? D - 1 : stage - 1);  // travels while D - 1 passes are computed
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(11 * (D - 1)) : "memory");
         const float *sIn = sRing + stage * kMetStage;
         stage = stage + 1 == D ? 0 : stage + 1;
@@ -1172,13 +1186,12 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int j = 0; j < 3; ++j) cur[t][j] = sIn[(3 * t + j) * 64 + lane];
-        // bit 12 r (+ step) of mvbits below: row r of the pass takes the moving descriptor
         int mv_lane = 0;
         if (g_ok) {
             const float2 gp = *reinterpret_cast<const float2 *>(sIn + 6 * 64 + gr * DP + 2 * gs);
             float ox = sIn[8 * 64 + gr], oy = sIn[8 * 64 + TNW + gr], dx = sIn[8 * 64 + 2 * TNW + gr], dy = sIn[8 * 64 + 3 * TNW + gr];
-            if (!use_nrm && mode != ET_MODE_IDENTITY) {  // (no cached state: from the observed row)
-                const float *row = obs + (n0 + gr) * 2 * T_obs;
+            if (!use_nrm && MODE != ET_MODE_IDENTITY) {  // (no cached state: from the observed row)
+                const float *row = obs + (int64_t)(n0 + gr) * 2 * T_obs;
                 ox = row[2 * (T_obs - 1)];
                 oy = row[2 * (T_obs - 1) + 1];
                 dx = ox - row[2 * (T_obs - 3)];
@@ -1187,14 +1200,14 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
             // normaliser state as row_norm() forms it, with the hardware's 1-ulp square root and reciprocal in place of
             // the correctly rounded sequences (~40 instructions per pass on every lane): the metric is compared at
             // 1e-5 m, these differ by 1e-7 relative.  The moving / static decision (model.py:46) keeps row_norm's exact test.
-            int mv = mode == ET_MODE_MOVING;
-            if (mode == ET_MODE_SPLIT) {
+            int mv = MODE == ET_MODE_MOVING;
+            if (SPLIT) {
                 const float hx = dx * 0.5f, hy = dy * 0.5f;
                 mv = sqrtf(hx * hx + hy * hy) > static_dist ? 1 : 0;
             }
             mv_lane = mv;
             float c = 1.f, sn = 0.f, sca = 1.f, back = 1.f;
-            if (mode != ET_MODE_IDENTITY) {
+            if (MODE != ET_MODE_IDENTITY) {
                 const float r2 = dx * dx + dy * dy;
                 const float r = __builtin_amdgcn_sqrtf(r2), ir = __builtin_amdgcn_rcpf(r);
                 const bool still = !(r > 0.0f);
@@ -1208,23 +1221,25 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
             }
             // normalizer.py:42-51: ((p - ori) @ R) * sca;  ||denorm(w) - gt|| = ||w - normalise(gt)|| / sca
             const float tx = gp.x - ox, ty = gp.y - oy;
-            float2 o;
-            o.x = (tx * c + ty * sn) * sca;
-            o.y = (tx * (-sn) + ty * c) * sca;
+            float2 o;  // (stored NEGATED: the epilogue's fused multiply-add then takes it as it is)
+            o.x = (tx * c + ty * sn) * -sca;
+            o.y = (tx * (-sn) + ty * c) * -sca;
             *reinterpret_cast<float2 *>(sGn + gr * DP + 2 * gs) = o;
             if (gs == 0) sBack[gr] = back;
         }
-        // (every lane asks: a ballot inside the branch above would be seen by the lanes that took it only)
-        const unsigned long long mvbits = mode == ET_MODE_SPLIT ? __ballot(mv_lane != 0) : (mode == ET_MODE_MOVING ? ~0ull : 0ull);
-        // Both tiles of the pass in ONE straight line (their LDS round trips, matrix instructions and square roots overlap:
-        // a wavefront's pass is a chain of dependent latencies, ~4500 cycles before this, and the CU holds too few
-        // wavefronts to hide more than a part of it).
+        // bit 12 r (+ step): row r of the pass takes the moving descriptor.  (Every lane asks: a ballot inside the branch
+        // above would be seen by the lanes that took it only.)
+        const unsigned long long mvbits = SPLIT ? __ballot(mv_lane != 0) : 0ull;
+        // Both tiles of the pass in ONE straight line: their LDS round trips, matrix instructions and square roots overlap
         float b[2][3];  // (coefficient + anchor) * 2^7 (anchor.py:87; padding columns: never stored)
-        int mvt[2];
+        int mvt[2] = {0, 0};
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            mvt[t] = (int)((mvbits >> (row_t[t] * TP)) & 1ull);
-            const float *an = sA + mvt[t] * (K * S) + anc_t[t];
+            const float *an = an_t[t];
+            if (SPLIT) {
+                mvt[t] = (int)((mvbits >> (row_t[t] * TP)) & 1ull);
+                an += mvt[t] * (K * S);
+            }
 #pragma unroll
             for (int j = 0; j < 3; ++j) b[t][j] = fmaf(cur[t][j], kMetScaleC, an[2 * j * S]);
         }
@@ -1232,14 +1247,6 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
                                 fmaxf(fmaxf(fabsf(b[1][0]), fabsf(b[1][1])), fabsf(b[1][2])));
         f32x16_t acc[2];
         if (f16_ok && __ballot(!(big < 32768.f)) == 0ull) {
-            // x = hi + lo with hi = f16(x), lo = f16(x - hi): 22 bits of x.  The four cross products of the two splits are
-            // exact in the fp32 accumulator; 12 products per lane (3 k of this half x 4) = 8 + 4 slots of two 32x32x16 f16
-            // instructions -- on the matrix pipe, beside the vector ALU (the fp32 ones run ON its multipliers).
-            typedef float f32x2_t __attribute__((ext_vector_type(2)));
-            typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-            const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            unsigned q[2][3];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const f16x2_t p0 = __builtin_convertvector((f32x2_t){b[t][0], b[t][1]}, f16x2_t);
@@ -1247,40 +1254,36 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
                 const f16x2_t p1 = __builtin_convertvector((f32x2_t){b[t][2], r0}, f16x2_t);
                 const float r2 = b[t][2] - (float)p1.x;
                 const f16x2_t p2 = __builtin_convertvector((f32x2_t){r1, r2}, f16x2_t);
-                q[t][0] = __builtin_bit_cast(unsigned, p0);
-                q[t][1] = __builtin_bit_cast(unsigned, p1);
-                q[t][2] = __builtin_bit_cast(unsigned, p2);
-            }
-            if (mode != ET_MODE_SPLIT) {  // one descriptor for every row: its U was picked before the loop
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aX1, __builtin_bit_cast(f16x8_t, (u32x4_t){q[t][0], q[t][1], q[t][2], q[t][0]}), zero, 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aX2, __builtin_bit_cast(f16x8_t, (u32x4_t){q[t][1], q[t][2], 0u, 0u}), acc[t], 0, 0, 0);
-                }
-            } else {  // per-row choice: a column's coefficients go to its own descriptor's instructions, zero to the other's
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const unsigned s0 = mvt[t] ? 0u : q[t][0], s1 = mvt[t] ? 0u : q[t][1], s2 = mvt[t] ? 0u : q[t][2];
-                    const unsigned m0 = mvt[t] ? q[t][0] : 0u, m1 = mvt[t] ? q[t][1] : 0u, m2 = mvt[t] ? q[t][2] : 0u;
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH1[0], __builtin_bit_cast(f16x8_t, (u32x4_t){s0, s1, s2, s0}), zero, 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH2[0], __builtin_bit_cast(f16x8_t, (u32x4_t){s1, s2, 0u, 0u}), acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH1[1], __builtin_bit_cast(f16x8_t, (u32x4_t){m0, m1, m2, m0}), acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH2[1], __builtin_bit_cast(f16x8_t, (u32x4_t){m1, m2, 0u, 0u}), acc[t], 0, 0, 0);
+                const unsigned q0 = __builtin_bit_cast(unsigned, p0), q1 = __builtin_bit_cast(unsigned, p1), q2 = __builtin_bit_cast(unsigned, p2);
+                // (the fourth register meets the zero slots of A: any finite pattern does)
+                if (!SPLIT) {
+                    acc[t] = mfma16(aHi[0], aLo[0], (u32x4_t){q0, q1, q2, q0});
+                } else {
+                    const bool any_m = (mvbits & tile_rows[t]) != 0ull, any_s = (~mvbits & tile_rows[t]) != 0ull;  // (scalar)
+                    if (!any_m) {
+                        acc[t] = mfma16(aHi[0], aLo[0], (u32x4_t){q0, q1, q2, q0});
+                    } else if (!any_s) {
+                        acc[t] = mfma16(aHi[ND - 1], aLo[ND - 1], (u32x4_t){q0, q1, q2, q0});
+                    } else {
+                        const unsigned s0 = mvt[t] ? 0u : q0, s1 = mvt[t] ? 0u : q1, s2 = mvt[t] ? 0u : q2;
+                        const unsigned m0 = mvt[t] ? q0 : 0u, m1 = mvt[t] ? q1 : 0u, m2 = mvt[t] ? q2 : 0u;
+                        const f16x8_t bm = __builtin_bit_cast(f16x8_t, (u32x4_t){m0, m1, m2, m0});
+                        f32x16_t a = mfma16(aHi[0], aLo[0], (u32x4_t){s0, s1, s2, s0});
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(aHi[ND - 1], bm, a, 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aLo[ND - 1], bm, a, 0, 0, 0);
+                    }
                 }
             }
         } else {
-            // fp32 matrix instructions: the vector code's fmaf chain over k = 0..5, bit for bit (the scales are exact); taken
-            // when a value leaves f16's range (|U| >= 32 or |coefficient + anchor| >= 256) and with ET_METRICS_MFMA=f32
+            // fp32 matrix instructions: the vector code's fmaf chain over k = 0..5, bit for bit (the scales are exact)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f32x16_t a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (mode != ET_MODE_MOVING) {
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) a = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[0][j], mvt[t] ? 0.f : b[t][j], a, 0, 0, 0);
-                }
-                if (mode == ET_MODE_MOVING || mode == ET_MODE_SPLIT) {
+                for (int j = 0; j < 3; ++j) a = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[0][j], (SPLIT && mvt[t]) ? 0.f : b[t][j], a, 0, 0, 0);
+                if (SPLIT) {
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) a = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[1][j], mvt[t] ? b[t][j] : 0.f, a, 0, 0, 0);
+                    for (int j = 0; j < 3; ++j) a = __builtin_amdgcn_mfma_f32_32x32x2f32(aU[ND - 1][j], mvt[t] ? b[t][j] : 0.f, a, 0, 0, 0);
                 }
                 acc[t] = a;
             }
@@ -1289,26 +1292,26 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             // rows 8 g + 4 h + (0..3) of this column: steps 4 g + 2 h and 4 g + 2 h + 1 (g = 3 is padding)
-            typedef float f32x2_t __attribute__((ext_vector_type(2)));
             const float4 *g4 = reinterpret_cast<const float4 *>(sGn + row_t[t] * DP + 4 * h);
             const float back = sBack[row_t[t]];
             const f32x2_t un = {kMetUnscale, kMetUnscale};
-            float sum = 0.f, last = 0.f;
+            f32x2_t sum2 = {0.f, 0.f};
+            float last = 0.f;
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                const float4 gn = g4[2 * g];
-                // (two fp32 per instruction: v_pk_fma_f32 / v_pk_mul_f32 on adjacent accumulator registers)
-                f32x2_t e = __builtin_elementwise_fma((f32x2_t){acc[t][4 * g], acc[t][4 * g + 1]}, un, (f32x2_t){-gn.x, -gn.y});
-                f32x2_t f = __builtin_elementwise_fma((f32x2_t){acc[t][4 * g + 2], acc[t][4 * g + 3]}, un, (f32x2_t){-gn.z, -gn.w});
+                const float4 gn = g4[2 * g];  // = -(normalised ground truth)
+                // (two fp32 per instruction: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on adjacent registers)
+                f32x2_t e = __builtin_elementwise_fma((f32x2_t){acc[t][4 * g], acc[t][4 * g + 1]}, un, (f32x2_t){gn.x, gn.y});
+                f32x2_t f = __builtin_elementwise_fma((f32x2_t){acc[t][4 * g + 2], acc[t][4 * g + 3]}, un, (f32x2_t){gn.z, gn.w});
                 e = e * e;
                 f = f * f;
                 // v_sqrt_f32 (1 ulp): the metric is compared at 1e-5 m
-                const float d0 = __builtin_amdgcn_sqrtf(e.x + e.y), d1 = __builtin_amdgcn_sqrtf(f.x + f.y);
-                sum = (sum + d0) + d1;
-                last = d1;  // h = 1, g = 2: step 11
+                const f32x2_t d = {__builtin_amdgcn_sqrtf(e.x + e.y), __builtin_amdgcn_sqrtf(f.x + f.y)};
+                sum2 = sum2 + d;
+                last = d.y;  // h = 1, g = 2: step 11
             }
+            const float sum = sum2.x + sum2.y;
             // the other half's six steps: v_permlane32_swap (x, x) leaves x[lane + 32] in the second result's low half
-            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
             const u32x2_t ws = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
             const u32x2_t wl = __builtin_amdgcn_permlane32_swap(__float_as_uint(last), __float_as_uint(last), false, false);
             const float other_sum = __uint_as_float(ws.y), other_last = __uint_as_float(wl.y);
@@ -1320,7 +1323,6 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
         {   // best of S (torch.min propagates NaN): lane (mr, mq) takes samples mq, mq + 4, ...; then the quad's four meet.
             // The metrics are >= +0 or NaN: as unsigned integers their order is the floats' and every NaN is above +inf,
             // so min AND max of the bit patterns decide -- max > 0x7f800000 means a NaN was among them.
-            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
             const u32x2_t *m2 = reinterpret_cast<const u32x2_t *>(sMet) + mrow * S;
             u32x2_t mn = m2[mq < S ? mq : 0], mx = mn;
             for (int s = mq + 4; s < S; s += 8) {
@@ -1551,29 +1553,24 @@ extern "C" int et_anchor_reconstruct_metrics(const float *C, int64_t N, int S, i
         if (!(e && e[0] == '0') && aligned16(gt) && S >= 12 && S <= 64 && N >= 64 / S && N * S < ((int64_t)1 << 29) && N * 24 < ((int64_t)1 << 30)) {
             const int TNW = 64 / S;
             const int64_t passes = ceil_div(N, TNW);
-            static const int stages = [] {  // ring depth = passes in flight per wavefront + 1.  Deeper rings cost residency
-                const char *d = getenv("ET_METRICS_STAGES");  // (LDS) and lose: 1.97 / 2.13 / 2.34 / 3.04 ms for 2 / 3 / 4 / 6
-                const int v = d ? atoi(d) : 2;
-                return v == 3 || v == 4 || v == 6 ? v : 2;
-            }();
-            const size_t lds = sizeof(float) * ((size_t)kMetWaves * (8 * 24 + 2 * 64 + 8 + 8) + ((2 * 6 * (size_t)S + 3) & ~(size_t)3) +
-                                                (size_t)kMetWaves * stages * kMetStage);
+            const size_t lds = sizeof(float) * metrics_mfma_lds_floats(S, mode == ET_MODE_SPLIT ? 2 : 1);
             // a persistent grid: exactly the workgroups that are resident together (a surplus workgroup would start when
             // the others are done and double the run time of its CU)
-#define ET_METRICS_LAUNCH(D)                                                                                              \
+#define ET_METRICS_LAUNCH(MODE)                                                                                           \
     do {                                                                                                                  \
         int per_cu = 0;                                                                                                   \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reconstruct_metrics_mfma_kernel<12, 6, D>,              \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reconstruct_metrics_mfma_kernel<12, 6, MODE>,           \
                                                          kMetWaves * 64, lds) != hipSuccess || per_cu < 1)               \
             per_cu = 2;                                                                                                   \
         const unsigned g = (unsigned)min((int64_t)cu_count() * per_cu, ceil_div(passes, kMetWaves));                      \
-        hipLaunchKernelGGL((reconstruct_metrics_mfma_kernel<12, 6, D>), dim3(g), dim3(kMetWaves * 64), lds, st, C, N, S,  \
-                           TNW, T_obs, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, gt, ade, fde, use_f16); \
+        hipLaunchKernelGGL((reconstruct_metrics_mfma_kernel<12, 6, MODE>), dim3(g), dim3(kMetWaves * 64), lds, st, C,     \
+                           (int)N, S, TNW, T_obs, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, static_dist, gt, ade, fde,      \
+                           use_f16);                                                                                      \
     } while (0)
-            if (stages == 3) ET_METRICS_LAUNCH(3);
-            else if (stages == 4) ET_METRICS_LAUNCH(4);
-            else if (stages == 6) ET_METRICS_LAUNCH(6);
-            else ET_METRICS_LAUNCH(2);
+            if (mode == ET_MODE_SPLIT) ET_METRICS_LAUNCH(ET_MODE_SPLIT);
+            else if (mode == ET_MODE_MOVING) ET_METRICS_LAUNCH(ET_MODE_MOVING);
+            else if (mode == ET_MODE_STATIC) ET_METRICS_LAUNCH(ET_MODE_STATIC);
+            else ET_METRICS_LAUNCH(ET_MODE_IDENTITY);
 #undef ET_METRICS_LAUNCH
         } else {
             const size_t lds = sizeof(float) * ((size_t)TN * 24 + (size_t)TN * S * 2 + (size_t)TN * kNormStride + 2 * 24 * 6 +
