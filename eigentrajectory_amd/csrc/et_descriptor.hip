@@ -13,6 +13,7 @@
 // the contraction depth is k=6 / 2T=16..24 and the kernels sit far below the
 // VALU roof.
 #include <cstdlib>
+#include <type_traits>
 
 #include "et_common.h"
 
@@ -1013,6 +1014,22 @@ __host__ __device__ constexpr size_t metrics_mfma_lds_floats(int S, int n_desc) 
     return (size_t)kMetWaves * kMetSlice + (((size_t)n_desc * 6 * S + 3) & ~(size_t)3) + (size_t)kMetWaves * kMetStages * kMetStage;
 }
 
+#ifdef ET_EXP_METSTAMP  // development aid (tools/metstamp.py): shader cycles (s_memtime) a wavefront spends in the phases of
+// a pass, summed over all wavefronts: [0] passes, [1] slice hand-over + stores + requests, [2] wait for this pass's
+// inputs, [3] LDS reads + ground-truth normalisation + operands, [4] matrix instructions + hand-over, [5] distances,
+// [6] best-of-S, [7] wavefronts
+__device__ unsigned long long g_metstamp[8];
+#define ET_METSTAMP(i)                                                  \
+    do {                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();     \
+        ms_acc[i] += t_ - ms_t;                                         \
+        ms_t = t_;                                                      \
+    } while (0)
+#else
+#define ET_METSTAMP(i)
+#endif
+
 template <int TP, int K, int MODE>
 __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kernel(
     const float *__restrict__ C, int N, int S, int TNW, int T_obs,
@@ -1172,13 +1189,27 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
     };
     float2 held = make_float2(0.f, 0.f);
     int held_n0 = did_any ? first_row(pass) : 0;
+    // best-of-S: this lane's first (ADE, FDE) pair in the slice
+    const u32x2_t *m2 = reinterpret_cast<const u32x2_t *>(sMet) + mrow * S + mq;
+    const int nq = S / 4;  // samples mq, mq + 4, ..., mq + 4 (nq - 1) exist for every lane; one more for mq < S % 4
+    // (Instantiating the pass body once per ring stage -- every LDS address a loop-invariant register + an immediate
+    // offset -- saves ~10 vector instructions per pass and costs 4 registers, i.e. the sixth wavefront per SIMD: +-0.)
     int stage = 0;  // ring slot of the current pass
+#ifdef ET_EXP_METSTAMP
+    unsigned long long ms_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ms_t = __builtin_amdgcn_s_memtime();
+#endif
     for (; pass < n_pass; pass += stride) {
         const int n0 = first_row(pass);
+#ifdef ET_EXP_METSTAMP
+        ms_t = __builtin_amdgcn_s_memtime();
+        ms_acc[0] += 1;
+#endif
         wave_sync();  // the previous pass is done with the slice
         store_held(held, held_n0);
         issue(pass + (D - 1) * stride, stage == 0 ? D - 1 : stage - 1);  // travels while D - 1 passes are computed
+        ET_METSTAMP(1);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(11 * (D - 1)) : "memory");
+        ET_METSTAMP(2);
         const float *sIn = sRing + stage * kMetStage;
         stage = stage + 1 == D ? 0 : stage + 1;
         float cur[2][3];
@@ -1246,6 +1277,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
         const float big = fmaxf(fmaxf(fmaxf(fabsf(b[0][0]), fabsf(b[0][1])), fabsf(b[0][2])),
                                 fmaxf(fmaxf(fabsf(b[1][0]), fabsf(b[1][1])), fabsf(b[1][2])));
         f32x16_t acc[2];
+        ET_METSTAMP(3);
         if (f16_ok && __ballot(!(big < 32768.f)) == 0ull) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -1289,6 +1321,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
             }
         }
         wave_sync();  // the normalised ground truth is in the slice
+        ET_METSTAMP(4);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             // rows 8 g + 4 h + (0..3) of this column: steps 4 g + 2 h and 4 g + 2 h + 1 (g = 3 is padding)
@@ -1320,13 +1353,21 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
                     make_float2(((sum + other_sum) * (1.0f / (float)TP)) * back, other_last * back);
         }
         wave_sync();
+        ET_METSTAMP(5);
         {   // best of S (torch.min propagates NaN): lane (mr, mq) takes samples mq, mq + 4, ...; then the quad's four meet.
             // The metrics are >= +0 or NaN: as unsigned integers their order is the floats' and every NaN is above +inf,
             // so min AND max of the bit patterns decide -- max > 0x7f800000 means a NaN was among them.
-            const u32x2_t *m2 = reinterpret_cast<const u32x2_t *>(sMet) + mrow * S;
-            u32x2_t mn = m2[mq < S ? mq : 0], mx = mn;
-            for (int s = mq + 4; s < S; s += 8) {
-                const u32x2_t v0 = m2[s], v1 = m2[s + 4 < S ? s + 4 : s];
+            u32x2_t mn = m2[0], mx = mn;
+            int k = 1;
+            for (; k + 1 < nq; k += 2) {  // (a scalar trip count: two samples per step)
+                const u32x2_t v0 = m2[4 * k], v1 = m2[4 * k + 4];
+                mn.x = min(min(mn.x, v0.x), v1.x);
+                mn.y = min(min(mn.y, v0.y), v1.y);
+                mx.x = max(max(mx.x, v0.x), v1.x);
+                mx.y = max(max(mx.y, v0.y), v1.y);
+            }
+            if (k < nq || (S & 3)) {
+                const u32x2_t v0 = m2[k < nq ? 4 * k : 0], v1 = m2[mq + 4 * nq < S ? 4 * nq : 0];  // (absent: the first again)
                 mn.x = min(min(mn.x, v0.x), v1.x);
                 mn.y = min(min(mn.y, v0.y), v1.y);
                 mx.x = max(max(mx.x, v0.x), v1.x);
@@ -1341,7 +1382,17 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
             held = make_float2(__uint_as_float(mx.x > 0x7f800000u ? mx.x : mn.x), __uint_as_float(mx.y > 0x7f800000u ? mx.y : mn.y));
             held_n0 = n0;
         }
+#ifdef ET_EXP_METSTAMP
+        asm volatile("s_nop 0" ::"v"(held.x), "v"(held.y));
+#endif
+        ET_METSTAMP(6);
     }
+#ifdef ET_EXP_METSTAMP
+    if (lane == 0) {
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_metstamp[i], ms_acc[i]);
+        atomicAdd(&g_metstamp[7], 1ull);
+    }
+#endif
     if (did_any) store_held(held, held_n0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the tail's surplus requests still write into this wavefront's LDS)
 }
@@ -1609,3 +1660,15 @@ extern "C" int et_anchor_reconstruct_bwd(const float *dtraj, int64_t N, int S, i
     ET_LAUNCH_CHECK();
     return ET_OK;
 }
+
+#ifdef ET_EXP_METSTAMP
+extern "C" int et_debug_metstamp(unsigned long long *host, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(et::g_metstamp), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(et::g_metstamp), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
