@@ -1000,6 +1000,24 @@ def test_fused_metrics_kernel_variants_vs_oracle(ops, oracle, dev, monkeypatch, 
     close(N_(fde), W.batch_fde(rec, gt), tol=2e-6)
 
 
+@pytest.mark.parametrize("n,s", [(3, 20), (4, 20), (5, 20), (7, 20), (1, 64), (2, 33), (5, 12), (6, 12), (6145 * 3 + 1, 20)])
+def test_fused_metrics_matrix_kernel_few_rows_and_tail_passes(ops, oracle, dev, n, s):
+    """The persistent matrix-core kernel at its edges: one pass only, a last pass moved back over its predecessor's rows,
+    fewer passes than wavefronts, and one pass more than a whole round of the resident wavefronts."""
+    from oracle import wrapper_ref as W
+    from eigentrajectory_amd.synth import synthetic_trajectories_np
+    rng = np.random.default_rng(n + s)
+    obs, gt = synthetic_trajectories_np(n, seed=11)
+    um, us_ = (rng.standard_normal((24, 6)).astype(np.float32) * 0.3 for _ in range(2))
+    a_m, a_s = (rng.standard_normal((6, s)).astype(np.float32) for _ in range(2))
+    c = rng.standard_normal((6, n, s)).astype(np.float32)
+    ade, fde = ops.anchor_reconstruct_metrics(T(c, dev), T(gt, dev), T(a_m, dev), T(a_s, dev), T(um, dev), T(us_, dev), 2,
+                                              0.3, obs=T(obs, dev))
+    rec = oracle.anchor_reconstruct(c, obs, a_m, a_s, um, us_, 2, 0.3)
+    close(N_(ade), W.batch_ade(rec, gt), tol=2e-6)
+    close(N_(fde), W.batch_fde(rec, gt), tol=2e-6)
+
+
 @pytest.mark.parametrize("what", ["coefficients", "U", "nan"])
 def test_fused_metrics_values_beyond_f16_take_the_fp32_instructions(ops, oracle, dev, what):
     """|coefficient + anchor| >= 256 or |U| >= 32 would overflow the scaled f16 operands: those tiles (or the whole launch)
