@@ -393,6 +393,10 @@ def extra_stages(ops, obs, pred, n, K, max_iter, first_index, dev):
         stage("reconstruct_metrics_S20",
               _median_ms(lambda: ops.anchor_reconstruct_metrics(C20, pred, A, None, U_pred, None, mode, nrm=nrm)),
               480.0 + 16.0 + 96.0 + 8.0)
+        # the wrapper's evaluate() form: descriptor chosen per row (model.py:46,73)
+        stage("reconstruct_metrics_S20_per_row_descriptor",
+              _median_ms(lambda: ops.anchor_reconstruct_metrics(C20, pred, A, A, U_pred, U_pred, ops.MODE_SPLIT, 0.3, nrm=nrm)),
+              480.0 + 16.0 + 96.0 + 8.0)
         del rec, C20
         torch.cuda.empty_cache()
         out["scene_latency"] = scene_latency(dev, U_obs, U_pred)
