@@ -153,7 +153,10 @@ int et_anchor_reconstruct_fwd(const float *C, int64_t N, int S, int k, int T_obs
 
 /* Fused evaluation form (no counterpart in the reference, which materialises recon_traj and calls
  * utils/metrics.py:73-102): best-of-S displacement errors against gt (N,T_pred,2) without writing the
- * trajectories:  ade[n] = min_s mean_t ||out[s][n][t] - gt[n][t]||,  fde[n] = min_s ||out[s][n][T-1] - gt[n][T-1]||. */
+ * trajectories:  ade[n] = min_s mean_t ||out[s][n][t] - gt[n][t]||,  fde[n] = min_s ||out[s][n][T-1] - gt[n][T-1]||.
+ * A NaN anywhere in a trajectory's samples makes its two results NaN (torch.min's propagation).  For T_pred = 12, k = 6,
+ * 12 <= S <= 64 the contraction runs on the matrix cores from two-term f16 splits of both operands: results within 1e-6
+ * (relative to the largest) of et_anchor_reconstruct_fwd + the metrics; operands beyond f16's range take fp32 instructions. */
 int et_anchor_reconstruct_metrics(const float *C, int64_t N, int S, int k, int T_obs, int T_pred,
                                   const float *obs, const float *nrm,
                                   const float *A_m, const float *A_s, const float *U_pred_m, const float *U_pred_s,
