@@ -325,6 +325,21 @@ __global__ __launch_bounds__(kFitThreads) void gram_generic_finish_kernel(const 
 // every wavefront instead of one, and that costs more than the barrier and the LDS hand-off it removes.)
 // ------------------------------------------------------------------------------------------
 constexpr int kJacobiMaxSweeps = 30;
+#ifdef ET_EXP_EIGHSTAMP  // development aid: s_memtime ticks of workgroup 0's first wavefront by phase of a round:
+// [0] rounds, [1] rotation parameters, [2] barrier after them, [3] updates, [4] barrier after them, [5] sweep checks, [6] sweeps
+__device__ unsigned long long g_eighstamp[8];
+#define ET_EIGHSTAMP(i)                                              \
+    do {                                                             \
+        if (stamping) {                                              \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+            es_acc[i] += t_ - es_t;                                  \
+            es_t = t_;                                               \
+        }                                                            \
+    } while (0)
+#else
+#define ET_EIGHSTAMP(i)
+#endif
 #ifndef ET_EIGH_THREADS
 #define ET_EIGH_THREADS 1024
 #endif
@@ -402,7 +417,14 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
         blk_2[t] = b < half * half ? b % half : 0;
     }
     double *sMax = sS + 32;  // 2 * (kEighThreads / 64) partial maxima
+#ifdef ET_EXP_EIGHSTAMP
+    const bool stamping = n == 24 && threadIdx.x < 64;
+    unsigned long long es_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, es_t = __builtin_amdgcn_s_memtime();
+#endif
     for (int sweep = 0; sweep < kJacobiMaxSweeps; ++sweep) {
+#ifdef ET_EXP_EIGHSTAMP
+        if (stamping) { es_t = __builtin_amdgcn_s_memtime(); es_acc[6] += 1; }
+#endif
         // converged when max |off-diagonal| <= 1e-15 max |diagonal| (maxima: order independent)
         double off = 0.0, diag = 0.0;
         for (int e = lane; e < n * n; e += kEighThreads) {
@@ -429,8 +451,12 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
             sFlag = (off <= 1e-15 * diag) ? 1 : 0;
         }
         __syncthreads();
+        ET_EIGHSTAMP(5);
         if (sFlag) break;
         for (int r = 0; r < m - 1; ++r) {
+#ifdef ET_EXP_EIGHSTAMP
+            if (stamping) es_acc[0] += 1;
+#endif
             if (lane < half) {
                 int p, q;
                 jacobi_schedule(m, r, lane, p, q);
@@ -467,7 +493,9 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
                 }
                 sAct[lane] = act;
             }
+            ET_EIGHSTAMP(1);
             __syncthreads();
+            ET_EIGHSTAMP(2);
             // A' = J^T A J for the round's disjoint rotations, one 2 x 2 block per work item: the row rotation of pair
             // i1 followed by the column rotation of pair i2 touches exactly these four entries, so "all row updates,
             // then all column updates" (the oracle's order, with its intermediate roundings) needs no barrier in
@@ -529,9 +557,15 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
                     V[j * n + q] = sn * vjp + c * vjq;
                 }
             }
+            ET_EIGHSTAMP(3);
             __syncthreads();
+            ET_EIGHSTAMP(4);
         }
     }
+#ifdef ET_EXP_EIGHSTAMP
+    if (stamping && threadIdx.x == 0)
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_eighstamp[i], es_acc[i]);
+#endif
     __syncthreads();
     // Top-k extraction, all columns at once (a single lane walking through n diagonal entries and n vector entries per
     // column cost ~4 us per column: 22 us of a 243 us solve).  Rank of eigenvalue i = number of eigenvalues that come before
@@ -678,3 +712,15 @@ extern "C" int et_eigh_topk(const double *G, int n, int k, float *U, float *sigm
     ET_LAUNCH_CHECK();
     return ET_OK;
 }
+
+#ifdef ET_EXP_EIGHSTAMP
+extern "C" int et_debug_eighstamp(unsigned long long *host, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(et::g_eighstamp), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(et::g_eighstamp), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
