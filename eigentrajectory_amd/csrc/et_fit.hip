@@ -377,38 +377,71 @@ __device__ __forceinline__ void jacobi_schedule(int m, int r, int i, int &p, int
     q = a < b ? b : a;
 }
 
+// The same schedule carried from round to round: every position but the fixed player's moves on by one modulo m - 1 each
+// round (and is back where it started after the m - 1 rounds of a sweep), so a work item keeps the positions of its pairs
+// in registers and advances them with add / subtract / unsigned-min -- no compare -> select chains through VCC.  (Deriving
+// the pairs from the round number cost 340 of the 980 cycles of an update, profiles/r04i_eigh_stamps.txt.)
+struct JacobiPair {
+    int a, b;
+    bool fixed;  // pair 0: its first player is m - 1 in every round
+    __device__ __forceinline__ void init(int m, int i) {
+        fixed = i == 0;
+        a = i;
+        b = i == 0 ? 0 : m - 1 - i;
+    }
+    __device__ __forceinline__ void get(int m, int &p, int &q) const {
+        const int ae = fixed ? m - 1 : a;
+        p = ae < b ? ae : b;
+        q = ae < b ? b : ae;
+    }
+    __device__ __forceinline__ void step(int m) {
+        const unsigned a1 = (unsigned)a + 1u, b1 = (unsigned)b + 1u, w = (unsigned)(m - 1);
+        a = (int)min(a1, a1 - w);
+        b = (int)min(b1, b1 - w);
+    }
+};
+
 __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int n, int k, float *__restrict__ U,
                                                float *__restrict__ sigma) {
+    // Round 4: the matrix lives in LDS padded with zeros to m x m (m = n rounded up to even).  The padding index pairs
+    // with a zero entry, i.e. is an inactive pair, and an INACTIVE pair is applied as the identity rotation (c, s) = (1, 0)
+    // -- 1 * x - 0 * y is x again, bit for bit up to the sign of a zero -- so the update phase has no `q < n` / `active`
+    // branches: every work item reads its four entries in one go, rotates twice, writes four.  A round was 2 208 cycles
+    // (profiles/r04i_eigh_stamps.txt: half of it ONE work item's latency through ~10 exec-mask branches); the maxima
+    // of the stop test go through two LDS integer maxima (|x| of non-negative doubles orders like its bit pattern).
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *A = sm;                  // n*n
-    double *V = sm + n * n;          // n*n
-    double *sC = V + n * n;          // 32 cosines
-    double *sS = sC + 32;            // 32 sines
-    int *sP = reinterpret_cast<int *>(sS + 32 + 2 * (kEighThreads / 64));  // 32 p, 32 q, 32 active, 64 used, 1 flag
-    int *sQ = sP + 32, *sAct = sQ + 32, *sUsed = sAct + 32;
-    int &sFlag = sUsed[64];
     const int lane = threadIdx.x;
     const int m = (n + 1) & ~1, half = m / 2;
-    for (int i = lane; i < n * n; i += kEighThreads) {
-        A[i] = G[i];
-        V[i] = (i / n == i % n) ? 1.0 : 0.0;
+    double *A = sm;                  // m*m
+    double *V = sm + m * m;          // m*m
+    double *sC = V + m * m;          // 32 cosines
+    double *sS = sC + 32;            // 32 sines
+    unsigned long long *sMax = reinterpret_cast<unsigned long long *>(sS + 32);  // [sweep parity][off, diag]
+    int *sAct = reinterpret_cast<int *>(sMax + 4);  // 32 active, 64 used
+    int *sUsed = sAct + 32;
+    for (int i = lane; i < m * m; i += kEighThreads) {
+        const int r = i / m, c = i - r * m;
+        A[i] = (r < n && c < n) ? G[r * n + c] : 0.0;
+        V[i] = (r == c && r < n) ? 1.0 : 0.0;
     }
+    if (lane < 4) sMax[lane] = 0ull;
     __syncthreads();
     // work items of this thread in the update phase:
-    //   V: e = lane + t*256 -> (pair i, row j): columns p_i, q_i of row j
-    //   A: b = lane + t*256 -> (pair i1, pair i2): the 2 x 2 block rows {p1, q1} x columns {p2, q2}
+    //   V: e = lane + t*T - T/2 -> (pair i, row j): columns p_i, q_i of row j
+    //   A: b = lane + t*T       -> (pair i1, pair i2): the 2 x 2 block rows {p1, q1} x columns {p2, q2}
     // (the V items start half a workgroup away from the A blocks: for the usual small n the two kinds of work land on
     // different wavefronts and a round's critical path is the longer of the two, not their sum)
     constexpr int kVShift = kEighThreads / 2;
     constexpr int kSlots = (32 * 64 + kVShift + kEighThreads - 1) / kEighThreads;
     constexpr int kBlkSlots = (32 * 32 + kEighThreads - 1) / kEighThreads;
-    int slot_i[kSlots], slot_j[kSlots], blk_1[kBlkSlots], blk_2[kBlkSlots];
+    constexpr int kChkSlots = (64 * 64 + kEighThreads - 1) / kEighThreads;
+    int slot_i[kSlots], slot_row[kSlots], blk_1[kBlkSlots], blk_2[kBlkSlots], chk[kChkSlots];
 #pragma unroll
     for (int t = 0; t < kSlots; ++t) {
         const int e = lane + t * kEighThreads - kVShift;
         const bool ok = e >= 0 && e < half * n;
         slot_i[t] = ok ? e / n : -1;
-        slot_j[t] = ok ? e % n : 0;
+        slot_row[t] = ok ? (e % n) * m : 0;  // (row j) * m
     }
 #pragma unroll
     for (int t = 0; t < kBlkSlots; ++t) {
@@ -416,7 +449,21 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
         blk_1[t] = b < half * half ? b / half : -1;
         blk_2[t] = b < half * half ? b % half : 0;
     }
-    double *sMax = sS + 32;  // 2 * (kEighThreads / 64) partial maxima
+    // (carried positions for the parameter lanes and the A blocks -- the critical path; the V items, on other wavefronts
+    // and shorter, derive theirs from the round number: stepping three more slots on every wavefront costs what it saves)
+    JacobiPair par, b1[kBlkSlots], b2[kBlkSlots];
+    par.init(m, lane < half ? lane : 0);
+#pragma unroll
+    for (int t = 0; t < kBlkSlots; ++t) {
+        b1[t].init(m, blk_1[t] < 0 ? 0 : blk_1[t]);
+        b2[t].init(m, blk_2[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < kChkSlots; ++t) {  // element of the upper triangle or the diagonal: its LDS index, +(1 << 20) for the diagonal
+        const int e = lane + t * kEighThreads;
+        const int i = e / n, j = e - i * n;
+        chk[t] = (e < n * n && j >= i) ? (i * m + j) | (i == j ? 1 << 20 : 0) : -1;
+    }
 #ifdef ET_EXP_EIGHSTAMP
     const bool stamping = n == 24 && threadIdx.x < 64;
     unsigned long long es_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, es_t = __builtin_amdgcn_s_memtime();
@@ -426,80 +473,60 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
         if (stamping) { es_t = __builtin_amdgcn_s_memtime(); es_acc[6] += 1; }
 #endif
         // converged when max |off-diagonal| <= 1e-15 max |diagonal| (maxima: order independent)
-        double off = 0.0, diag = 0.0;
-        for (int e = lane; e < n * n; e += kEighThreads) {
-            const int i = e / n, j = e - i * n;
-            const double a = fabs(A[e]);
-            if (i == j) diag = a > diag ? a : diag;
-            else if (j > i) off = a > off ? a : off;
+        unsigned long long *mx = sMax + 2 * (sweep & 1);
+#pragma unroll
+        for (int t = 0; t < kChkSlots; ++t) {
+            if (chk[t] < 0) continue;
+            const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(fabs(A[chk[t] & 0xfffff])));
+            atomicMax(mx + (chk[t] >> 20), bits);
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            const double po = __shfl_xor(off, o), pd = __shfl_xor(diag, o);
-            off = po > off ? po : off;
-            diag = pd > diag ? pd : diag;
-        }
-        if ((lane & 63) == 0) {
-            sMax[2 * (lane >> 6)] = off;
-            sMax[2 * (lane >> 6) + 1] = diag;
-        }
+        if (lane < 2) sMax[2 * ((sweep + 1) & 1) + lane] = 0ull;  // (the other parity: last read a sweep of barriers ago)
         __syncthreads();
-        if (lane == 0) {
-            for (int w = 1; w < kEighThreads / 64; ++w) {
-                off = sMax[2 * w] > off ? sMax[2 * w] : off;
-                diag = sMax[2 * w + 1] > diag ? sMax[2 * w + 1] : diag;
-            }
-            sFlag = (off <= 1e-15 * diag) ? 1 : 0;
-        }
-        __syncthreads();
+        const double off = __longlong_as_double(static_cast<long long>(mx[0])), diag = __longlong_as_double(static_cast<long long>(mx[1]));
         ET_EIGHSTAMP(5);
-        if (sFlag) break;
+        if (off <= 1e-15 * diag) break;
         for (int r = 0; r < m - 1; ++r) {
 #ifdef ET_EXP_EIGHSTAMP
             if (stamping) es_acc[0] += 1;
 #endif
             if (lane < half) {
                 int p, q;
-                jacobi_schedule(m, r, lane, p, q);
-                int act = 0;
-                if (q < n) {
-                    const double apq = A[p * n + q], app = A[p * n + p], aqq = A[q * n + q];
-                    if (apq != 0.0) {
-                        // c = D / g, s = sgn |beta| / g with D = |alpha| + sqrt(alpha^2 + beta^2), g = sqrt(D^2 + beta^2)
-                        // (the oracle's formulas).  This chain -- sqrt -> sqrt -> divide, each a ~100-150 ns correctly
-                        // rounded software sequence in fp64 -- is on the critical path of every one of the ~200 rounds
-                        // while 15 of the 16 wavefronts wait at the barrier; here both roots come from v_rsq_f64 + two
-                        // Goldschmidt steps (sqrt_rsqrt: full double precision, not correctly rounded) and the divisions
-                        // become multiplications by 1 / g.  c^2 + s^2 = 1 to a few 1e-16 as before; the result is no
-                        // longer bit-identical to the oracle's correctly rounded chain (U agrees to ~1e-14, i.e. to the
-                        // last bit of its fp32 value except on a rounding boundary) but is the same on every GPU / rank.
-                        const double alpha = aqq - app, beta = 2.0 * apq;
+                par.get(m, p, q);
+                const double apq = A[__mul24(p, m) + q], app = A[__mul24(p, m) + p], aqq = A[__mul24(q, m) + q];
+                // c = D / g, s = sgn |beta| / g with D = |alpha| + sqrt(alpha^2 + beta^2), g = sqrt(D^2 + beta^2)
+                // (the oracle's formulas).  This chain -- sqrt -> sqrt -> divide, each a ~100-150 ns correctly
+                // rounded software sequence in fp64 -- is on the critical path of every one of the ~200 rounds
+                // while 15 of the 16 wavefronts wait at the barrier; here both roots come from v_rsq_f64 + two
+                // Goldschmidt steps (sqrt_rsqrt: full double precision, not correctly rounded) and the divisions
+                // become multiplications by 1 / g.  c^2 + s^2 = 1 to a few 1e-16 as before; the result is no
+                // longer bit-identical to the oracle's correctly rounded chain (U agrees to ~1e-14, i.e. to the
+                // last bit of its fp32 value except on a rounding boundary) but is the same on every GPU / rank.
+                // An inactive pair (a_pq == 0: also the padding pair of an odd n) runs the chain on zeros and drops it.
+                const double alpha = aqq - app, beta = 2.0 * apq;
 #ifdef ET_EIGH_IEEE_PARAMS
-                        const double h = sqrt(alpha * alpha + beta * beta);
-                        const double D = fabs(alpha) + h;
-                        const double g = sqrt(D * D + beta * beta);
-                        const double rg = 1.0 / g;
+                const double h = sqrt(alpha * alpha + beta * beta);
+                const double D = fabs(alpha) + h;
+                const double g = sqrt(D * D + beta * beta);
+                const double rg = 1.0 / g;
 #else
-                        double h, rh;
-                        sqrt_rsqrt(alpha * alpha + beta * beta, h, rh);
-                        const double D = fabs(alpha) + h;
-                        double g, rg;
-                        sqrt_rsqrt(D * D + beta * beta, g, rg);
+                double h, rh;
+                sqrt_rsqrt(alpha * alpha + beta * beta, h, rh);
+                const double D = fabs(alpha) + h;
+                double g, rg;
+                sqrt_rsqrt(D * D + beta * beta, g, rg);
 #endif
-                        const double sgn = (alpha == 0.0 || ((alpha > 0.0) == (beta > 0.0))) ? 1.0 : -1.0;
-                        sC[lane] = D * rg;
-                        sS[lane] = sgn * fabs(beta) * rg;
-                        act = 1;
-                    }
-                }
-                sAct[lane] = act;
+                const double sgn = (alpha == 0.0 || ((alpha > 0.0) == (beta > 0.0))) ? 1.0 : -1.0;
+                const bool act = apq != 0.0;
+                sC[lane] = act ? D * rg : 1.0;
+                sS[lane] = act ? sgn * fabs(beta) * rg : 0.0;
+                sAct[lane] = act ? 1 : 0;
             }
             ET_EIGHSTAMP(1);
             __syncthreads();
             ET_EIGHSTAMP(2);
             // A' = J^T A J for the round's disjoint rotations, one 2 x 2 block per work item: the row rotation of pair
             // i1 followed by the column rotation of pair i2 touches exactly these four entries, so "all row updates,
-            // then all column updates" (the oracle's order, with its intermediate roundings) needs no barrier in
-            // between.  Inactive pairs (a_pq == 0, or the padding index of an odd n) leave their side untouched.
+            // then all column updates" (the oracle's order, with its intermediate roundings) needs no barrier in between.
 #pragma unroll
             for (int t = 0; t < kBlkSlots; ++t) {
                 const int i1 = blk_1[t], i2 = blk_2[t];
@@ -507,55 +534,44 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
                 // (the pairs follow from the round number, so the rotations AND the four matrix entries are requested from
                 // LDS together: one round trip after the barrier, not two)
                 int p1, q1, p2, q2;
-                jacobi_schedule(m, r, i1, p1, q1);
-                jacobi_schedule(m, r, i2, p2, q2);
-                const bool hq1 = q1 < n, hq2 = q2 < n;  // an active pair always has q < n
-                const int a1 = sAct[i1], a2 = sAct[i2];
+                b1[t].get(m, p1, q1);
+                b2[t].get(m, p2, q2);
+                const int rp = __mul24(p1, m), rq = __mul24(q1, m);
+                const int diag_act = sAct[i1] & (i1 == i2 ? 1 : 0);  // (read by every lane: a read under a branch is a round trip of its own)
                 const double c1 = sC[i1], s1 = sS[i1], c2 = sC[i2], s2 = sS[i2];
-                double x_pp = A[p1 * n + p2], x_pq = hq2 ? A[p1 * n + q2] : 0.0;
-                double x_qp = hq1 ? A[q1 * n + p2] : 0.0, x_qq = (hq1 && hq2) ? A[q1 * n + q2] : 0.0;
-                if (!a1 && !a2) continue;
-                if (a1) {  // rows p1, q1 (columns p2 and q2)
-                    const double c = c1, sn = s1;
-                    const double t_pp = c * x_pp - sn * x_qp, t_qp = sn * x_pp + c * x_qp;
-                    const double t_pq = c * x_pq - sn * x_qq, t_qq = sn * x_pq + c * x_qq;
-                    x_pp = t_pp;
-                    x_qp = t_qp;
-                    x_pq = t_pq;
-                    x_qq = t_qq;
+                const double x_pp = A[rp + p2], x_pq = A[rp + q2], x_qp = A[rq + p2], x_qq = A[rq + q2];
+                // rows p1, q1 (columns p2 and q2), then columns p2, q2 (rows p1 and q1)
+                const double t_pp = c1 * x_pp - s1 * x_qp, t_qp = s1 * x_pp + c1 * x_qp;
+                const double t_pq = c1 * x_pq - s1 * x_qq, t_qq = s1 * x_pq + c1 * x_qq;
+                const double r_pp = c2 * t_pp - s2 * t_pq, r_qp = c2 * t_qp - s2 * t_qq;
+                double r_pq = s2 * t_pp + c2 * t_pq, r_qp2 = r_qp;
+                const double r_qq = s2 * t_qp + c2 * t_qq;
+                if (diag_act) {  // the rotated pair entries are exactly zero, like in the oracle
+                    r_pq = 0.0;
+                    r_qp2 = 0.0;
                 }
-                if (a2) {  // columns p2, q2 (rows p1 and q1)
-                    const double c = c2, sn = s2;
-                    const double r_pp = c * x_pp - sn * x_pq, r_pq = sn * x_pp + c * x_pq;
-                    const double r_qp = c * x_qp - sn * x_qq, r_qq = sn * x_qp + c * x_qq;
-                    x_pp = r_pp;
-                    x_pq = r_pq;
-                    x_qp = r_qp;
-                    x_qq = r_qq;
-                }
-                if (i1 == i2) {  // (active) the rotated pair entries are exactly zero, like in the oracle
-                    x_pq = 0.0;
-                    x_qp = 0.0;
-                }
-                A[p1 * n + p2] = x_pp;
-                if (hq2) A[p1 * n + q2] = x_pq;
-                if (hq1) A[q1 * n + p2] = x_qp;
-                if (hq1 && hq2) A[q1 * n + q2] = x_qq;
+                A[rp + p2] = r_pp;
+                A[rp + q2] = r_pq;
+                A[rq + p2] = r_qp2;
+                A[rq + q2] = r_qq;
             }
 #pragma unroll
             for (int t = 0; t < kSlots; ++t) {  // V' = V J: columns p, q of every row
-                const int i = slot_i[t], j = slot_j[t];
+                const int i = slot_i[t];
                 if (i < 0) continue;
                 int p, q;
                 jacobi_schedule(m, r, i, p, q);
-                const int act = sAct[i];
                 const double c = sC[i], sn = sS[i];
-                const int qs = q < n ? q : p;  // (an inactive padding pair: any valid address)
-                const double vjp = V[j * n + p], vjq = V[j * n + qs];
-                if (act) {
-                    V[j * n + p] = c * vjp - sn * vjq;
-                    V[j * n + q] = sn * vjp + c * vjq;
-                }
+                double *row = V + slot_row[t];
+                const double vjp = row[p], vjq = row[q];
+                row[p] = c * vjp - sn * vjq;
+                row[q] = sn * vjp + c * vjq;
+            }
+            par.step(m);
+#pragma unroll
+            for (int t = 0; t < kBlkSlots; ++t) {
+                b1[t].step(m);
+                b2[t].step(m);
             }
             ET_EIGHSTAMP(3);
             __syncthreads();
@@ -572,10 +588,10 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
     // it in "largest first, lower index first on ties" order -- the order the serial selection (strict `>`) produces; the
     // sign makes the first entry of largest magnitude positive.
     if (lane < n) {
-        const double di = A[lane * n + lane];
+        const double di = A[lane * m + lane];
         int rank = 0;
         for (int i = 0; i < n; ++i) {
-            const double dj = A[i * n + i];
+            const double dj = A[i * m + i];
             rank += (dj > di || (dj == di && i < lane)) ? 1 : 0;
         }
         sUsed[lane] = rank;
@@ -586,11 +602,11 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
         if (sUsed[col] != j) continue;
         int im = 0;
         for (int i = 1; i < n; ++i)
-            if (fabs(V[i * n + col]) > fabs(V[im * n + col])) im = i;
-        const double sgn = V[im * n + col] < 0.0 ? -1.0 : 1.0;
-        const double lam = A[col * n + col];
+            if (fabs(V[i * m + col]) > fabs(V[im * m + col])) im = i;
+        const double sgn = V[im * m + col] < 0.0 ? -1.0 : 1.0;
+        const double lam = A[col * m + col];
         sigma[j] = (float)sqrt(lam > 0.0 ? lam : 0.0);
-        for (int i = 0; i < n; ++i) U[i * k + j] = (float)(sgn * V[i * n + col]);
+        for (int i = 0; i < n; ++i) U[i * k + j] = (float)(sgn * V[i * m + col]);
     }
 }
 
@@ -675,7 +691,8 @@ extern "C" int et_fit_gram(const float *obs, const float *pred, int64_t N, int T
 }
 
 static size_t eigh_lds_bytes(int n) {
-    return sizeof(double) * (2 * (size_t)n * n + 64 + 2 * (kEighThreads / 64)) + sizeof(int) * (32 * 3 + 64 + 2);
+    const size_t m = ((size_t)n + 1) & ~(size_t)1;  // zero-padded to even
+    return sizeof(double) * (2 * m * m + 64 + 4) + sizeof(int) * (32 + 64 + 2);
 }
 
 extern "C" int et_eigh_topk_batch(int batch, const double *const *G, const int *n, const int *k, float *const *U,
