@@ -831,6 +831,29 @@ __device__ __forceinline__ void filter_drain(const unsigned *q, int cnt, int K, 
 // arrival of its own (prefetched) rows = the exposed load wait, [2] cycles of whole passes, [3] cycles inside queue drains,
 // [4] drains, [5] cycles from kernel start to the first pass, [6] wavefronts
 __device__ unsigned long long g_waitstamp[8];
+// ... and where a LAUNCH of the chained kernel goes (thread 0 of every workgroup, cycles between consecutive stamps, summed
+// over workgroups and launches): [0] workgroup-launches, [1] entry -> prologue loads arrived, [2] fold + barrier, [3] update,
+// [4] barrier + publish, [5] tables, matrix operand, barrier, [6] the pass loop, [7] final drain + barrier,
+// [8] copies -> one + barrier + emit
+__device__ unsigned long long g_prostamp[16];
+__shared__ unsigned long long s_ps_last, s_ps_acc[16];
+#define KM_PSTAMP(i)                                                        \
+    do {                                                                    \
+        if (threadIdx.x == 0) {                                             \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();     \
+            s_ps_acc[i] = (i) ? t_ - s_ps_last : 1ull;                      \
+            s_ps_last = t_;                                                 \
+        }                                                                   \
+    } while (0)
+#define KM_PSTAMP_FLUSH()                                                           \
+    do {                                                                            \
+        if (threadIdx.x == 0)                                                       \
+            for (int i_ = 0; i_ < 9; ++i_) atomicAdd(&g_prostamp[i_], s_ps_acc[i_]); \
+    } while (0)
+#else
+#define KM_PSTAMP(i)
+#define KM_PSTAMP_FLUSH()
 #endif
 
 #ifdef ET_PERSIST_STAMPS  // development aid (tools/persist_stamps.py): per workgroup and iteration, 10 ns ticks
@@ -1349,7 +1372,7 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
                                                    const float *__restrict__ X, int64_t N, int K,
                                                    const et_kmeans_state *state, const float *cen,
                                                    uint8_t *__restrict__ labels, long long *__restrict__ lanes,
-                                                   int copy_mask) {
+                                                   int copy_mask, int range_bad = -1) {
     const unsigned tx = thread_x();  // (opaque per call: see thread_x)
     constexpr int d = 6;
     const int n_thr = (int)blockDim.x, n_wav = n_thr >> 6;
@@ -1370,9 +1393,13 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
     const float s = hdr[6];
     bool fallback = state->iter <= 0 || !state->fast_ok || __float_as_uint(hdr[8]) == 0u;
     if (!fallback) {  // every |s (c - mu)| inside the packed range?  (cen: d x K floats in LDS, the same in every workgroup)
-        int bad = 0;
-        for (int e = tx; e < d * K; e += n_thr) bad |= !(fabsf((cen[e] - hdr[e / K]) * s) < 31.0f);
-        fallback = __syncthreads_or(bad) != 0;
+        if (range_bad >= 0) {  // (the caller's update has looked already: uniform over the workgroup)
+            fallback = range_bad != 0;
+        } else {
+            int bad = 0;
+            for (int e = tx; e < d * K; e += n_thr) bad |= !(fabsf((cen[e] - hdr[e / K]) * s) < 31.0f);
+            fallback = __syncthreads_or(bad) != 0;
+        }
     }
     if (fallback) {
         filter_assign_body<NREGS, false>(X, N, K, state, cen, labels, nullptr, lanes, copy_mask);
@@ -1402,7 +1429,8 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
             qq = fmaf(ct, ct, qq);
             sL[j * kPkRow + i] = 2.0f * s * ct;
         }
-        const float Q = sqrtf(qq) * s * 1.001f + 1e-30f, M = m_up + sqrtf(sC[j * 8 + 6]) * s * 1.001f;
+        // (v_sqrt_f32, 1 ulp: both are upper bounds with a 1e-3 margin)
+        const float Q = __builtin_amdgcn_sqrtf(qq) * s * 1.001f + 1e-30f, M = m_up + __builtin_amdgcn_sqrtf(sC[j * 8 + 6]) * s * 1.001f;
         sL[j * kPkRow + 6] = qq * s2;
         // th(R) = R^2 k1 + R thr_r + thr_1:  epsR + Ew_l + E1_l  (header comment), coefficients rounded up
         sL[j * kPkRow + 7] = fmaf(9.86e-4f, Q, 9.7e-7f * M) * kUp + 1e-30f;
@@ -1442,6 +1470,7 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
     }
     const f16x8 A1 = __builtin_bit_cast(f16x8, a1);
     __syncthreads();  // sL complete
+    KM_PSTAMP(5);
     const float4 *l4 = reinterpret_cast<const float4 *>(sL);
 
     int qn = 0;  // wave-uniform number of queued points
@@ -1577,8 +1606,10 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
         atomicAdd(&g_waitstamp[6], 1ull);
     }
 #endif
+    KM_PSTAMP(6);
     if (qn) packed_drain(queue, qn, K, sC, pk.xa, labels, sAcc, frac, lane);
     __syncthreads();
+    KM_PSTAMP(7);
     for (int i = tx; i < plen; i += n_thr) {  // the copies -> copy 0
         long long v = sAcc[i];
 #pragma unroll
@@ -1587,6 +1618,11 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
     }
     __syncthreads();
     emit_partials(sAcc, plen, n_thr, nullptr, lanes, copy_mask);
+#ifdef ET_EXP_WAITSTAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    KM_PSTAMP(8);
+    KM_PSTAMP_FLUSH();
 }
 
 template <int NREGS>
@@ -1629,9 +1665,35 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_reduce_partials_kernel(cons
 // already loaded it.
 // `last` (may be null): {d*K floats, then one int64 at the next 8-byte boundary} receives the centroids and sim_frac
 // the assignment just consumed was made with -- what kmeans_inertia_kernel needs to evaluate its inertia afterwards.
+// x[lane + O] for the lanes that are multiples of 2 O (what a level of a "x[i] += x[i + O]" tree needs), without the LDS
+// crossbar: inside a row of 16 lanes a DPP row shift, across rows v_permlane16_swap / v_permlane32_swap.  (__shfl_down is a
+// ds_bpermute per 32-bit half and ~130 cycles per level; the update's two reduction trees were ~800 cycles of every
+// launch's prologue, profiles/r04k_lloyd_launch_stamps.txt.)
+template <int O>
+__device__ __forceinline__ unsigned lane_down_u32(unsigned v) {
+    static_assert(O == 1 || O == 2 || O == 4 || O == 8 || O == 16 || O == 32, "a power of two below the wavefront size");
+    if constexpr (O < 16) {
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + O, 0xf, 0xf, true);  // row_shl:O
+    } else if constexpr (O == 16) {
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // second result: rows (1, 1, 3, 3)
+        return r.y;
+    } else {
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // second result: (upper half, upper half)
+        return r.y;
+    }
+}
+template <int O>
+__device__ __forceinline__ double lane_down_f64(double v) {
+    const unsigned lo = lane_down_u32<O>((unsigned)__double2loint(v)), hi = lane_down_u32<O>((unsigned)__double2hiint(v));
+    return __hiloint2double((int)hi, (int)lo);
+}
+
 __device__ __forceinline__ void update_body(et_kmeans_state *state, const long long *partials, int d, int K, float tol,
                                             float *cen, float *trace, const et_kmeans_state *pre = nullptr,
-                                            float *last = nullptr) {
+                                            float *last = nullptr, bool need_inertia = true,
+                                            const float *pk_hdr = nullptr, int *pk_bad = nullptr) {
     const unsigned tx = thread_x();  // (opaque per call: see thread_x)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *sSq = reinterpret_cast<float *>(smem_raw);  // d*K squared differences
@@ -1672,8 +1734,13 @@ __device__ __forceinline__ void update_body(et_kmeans_state *state, const long l
 #pragma unroll
             for (int q = 0; q < 4; ++q) f[q] = b0 + 4 * l + q < dk ? sSq[b0 + 4 * l + q] : 0.f;
             double t = ((double)f[0] + (double)f[1]) + ((double)f[2] + (double)f[3]);
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) t = t + __shfl_down(t, o);  // valid in the lanes that are multiples of 2 o
+            // t += t[lane + o], o = 1 ... 32: valid in the lanes that are multiples of 2 o
+            t = t + lane_down_f64<1>(t);
+            t = t + lane_down_f64<2>(t);
+            t = t + lane_down_f64<4>(t);
+            t = t + lane_down_f64<8>(t);
+            t = t + lane_down_f64<16>(t);
+            t = t + lane_down_f64<32>(t);
             total = total + t;
         }
         if (l == 0) sErr = total;
@@ -1682,32 +1749,68 @@ __device__ __forceinline__ void update_body(et_kmeans_state *state, const long l
         float mx = 0.f;
         unsigned mn = 0x7f800000u;
         int bad = 0;
-        for (int e = tx; e < d * K; e += 64) {
-            const float a = fabsf(sNew[e]);
-            if (!(a <= 3.402823466e+38f)) bad = 1;
-            if (a > mx) mx = a;  // false for NaN: ignored, like the oracle
-            const unsigned b = (unsigned)__float_as_int(a);
-            if (a <= 3.402823466e+38f && b != 0u && b < mn) mn = b;
+        // (d K <= 192 for the shapes the chained kernel takes: up to three values per lane, requested from LDS together with
+        // the packed copy's header -- a loop with a dependent header read per value was 1 000 of this phase's 1 600 cycles)
+        float h[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (pk_hdr) {
+#pragma unroll
+            for (int q = 0; q < 7; ++q) h[q] = pk_hdr[q];
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            mx = fmaxf(mx, __shfl_xor(mx, o));
-            const unsigned other = (unsigned)__shfl_xor((int)mn, o);
-            mn = other < mn ? other : mn;
-            bad |= __shfl_xor(bad, o);
+        for (int e0 = tx; e0 < d * K; e0 += 3 * 64) {
+            float v[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) v[u] = sNew[e0 + 64 * u < d * K ? e0 + 64 * u : e0];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int e = e0 + 64 * u;
+                if (e >= d * K) break;
+                const float a = fabsf(v[u]);
+                if (!(a <= 3.402823466e+38f)) bad = 1;
+                if (a > mx) mx = a;  // false for NaN: ignored, like the oracle
+                const unsigned b = (unsigned)__float_as_int(a);
+                if (a <= 3.402823466e+38f && b != 0u && b < mn) mn = b;
+                if (pk_hdr) {  // packed_assign_body's range test of the new centroids (bit 1 of `bad`), while they are at hand
+                    float mu = h[0];
+#pragma unroll
+                    for (int q = 1; q < 6; ++q) mu = (q < d && e >= q * K) ? h[q] : mu;  // mu[e / K]
+                    if (!(fabsf((v[u] - mu) * h[6]) < 31.0f)) bad |= 2;
+                }
+            }
         }
+        // (order independent: any tree; lane 0 ends up with the result)
+#define ET_DOWN(O)                                                                        \
+    do {                                                                                  \
+        mx = fmaxf(mx, __uint_as_float(lane_down_u32<O>(__float_as_uint(mx))));           \
+        const unsigned other = lane_down_u32<O>(mn);                                      \
+        mn = other < mn ? other : mn;                                                     \
+        bad |= (int)lane_down_u32<O>((unsigned)bad);                                      \
+    } while (0)
+        ET_DOWN(32);
+        ET_DOWN(16);
+        ET_DOWN(8);
+        ET_DOWN(4);
+        ET_DOWN(2);
+        ET_DOWN(1);
+#undef ET_DOWN
         if (tx == 0) {
             sRed[0] = mx;
             sRed[1] = __int_as_float((int)mn);
-            sRed[2] = bad ? 1.f : 0.f;
+            sRed[2] = (bad & 1) ? 1.f : 0.f;
+            if (pk_bad) *pk_bad = bad >> 1;
         }
     }
     __syncthreads();
     if (tx == 0) {
         const float error = (float)sErr;
         const int64_t n_total = st.n_total;
-        float inertia;
-        if (nan_count > 0) inertia = __int_as_float(0x7fc00000);
-        else inertia = (float)(-(((double)sim_sum * ldexp(1.0, -(int)st.sim_frac)) / (double)n_total));  // :57
+        // (need_inertia == false: a trace-less fit's launches, which do not accumulate the similarity sum -- the inertia of
+        // the last assignment is evaluated after the loop -- and the workgroups that publish nothing: an fp64 division
+        // less on the serial tail of every launch's prologue)
+        float inertia = (float)st.inertia;
+        if (need_inertia) {
+            if (nan_count > 0) inertia = __int_as_float(0x7fc00000);
+            else inertia = (float)(-(((double)sim_sum * ldexp(1.0, -(int)st.sim_frac)) / (double)n_total));  // :57
+        }
         const double mc = (double)sRed[0];
         const double mx = st.max_abs_x;
         state->max_abs_c = mc;
@@ -1875,8 +1978,11 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     // and a kernel with a private segment pays for it at every wavefront launch)
     // Everything the prologue needs from memory is requested at once -- the convergence flag, the centroids (d K <= 192
     // <= blockDim.x values), the delta table and the previous totals: one round trip, not three dependent ones.
+    KM_PSTAMP(0);
     const int64_t done0 = ch.st_rd->done, iter0 = ch.st_rd->iter;
     __shared__ float sPkHdr[12];
+    __shared__ int sPkBad;  // the packed copy's range test of the new centroids, made by update_body (-1: not made)
+    if (threadIdx.x == 0) sPkBad = -1;
     float pk_word = 0.f;
     if constexpr (!SIM) {  // the packed copy's header (9 words), with the other prologue loads
         if (ch.pk.xh && threadIdx.x < 9) pk_word = reinterpret_cast<const float *>(ch.pk.hdr)[threadIdx.x];
@@ -1899,13 +2005,20 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
         }
         return;
     }
+#ifdef ET_EXP_WAITSTAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    KM_PSTAMP(1);
     if ((int)threadIdx.x < d * K) sCen[threadIdx.x] = cen0;
     if (!SIM && threadIdx.x < 9) sPkHdr[threadIdx.x] = pk_word;
     if ((int)threadIdx.x < kStateWords) reinterpret_cast<unsigned *>(&sSt)[threadIdx.x] = st_word;  // the state block, word by word
     if (has_pending) {
         fold_combine(fr, iter0 > 0, plen, sTot, ch.compact != 0);
         __syncthreads();
-        update_body(&sSt, sTot, d, K, tol, sCen, wg0 ? trace : nullptr, nullptr, wg0 ? ch.last : nullptr);  // reads its copy in LDS
+        KM_PSTAMP(2);
+        update_body(&sSt, sTot, d, K, tol, sCen, wg0 ? trace : nullptr, nullptr, wg0 ? ch.last : nullptr, SIM && wg0,
+                    (!SIM && ch.pk.xh) ? sPkHdr : nullptr, &sPkBad);  // reads its copy in LDS
+        KM_PSTAMP(3);
     }
     __syncthreads();
     if (wg0) {  // publish (read by the next launch, the host's convergence polling and the finalize kernel)
@@ -1921,6 +2034,7 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
         const int total = plen * kAccLanes;
         for (int i = threadIdx.x; i < total; i += (int)blockDim.x) ch.lanes_zero[i] = 0;
     }
+    KM_PSTAMP(4);
     if (sSt.done) return;  // the update just applied met the tolerance: no further assignment (kmeans.py:239)
     const int copy_mask = ch.compact ? -1 : kAccLanes - 1;
     // a shard whose rows do not allow 16-byte loads (sharded runs cut the points anywhere), or a tiny one: the plain exact
@@ -1929,7 +2043,7 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     if (ch.vec_ok) {
         if constexpr (!SIM) {
             if (ch.pk.xh) {
-                packed_assign_body<NREGS>(ch.pk, sPkHdr, X, N, K, &sSt, sCen, labels, ch.lanes_wr, copy_mask);
+                packed_assign_body<NREGS>(ch.pk, sPkHdr, X, N, K, &sSt, sCen, labels, ch.lanes_wr, copy_mask, sPkBad);
                 return;
             }
         }
@@ -3674,6 +3788,15 @@ extern "C" int et_debug_waitstamp(unsigned long long *host, int reset) {
     if (reset) {
         unsigned long long z[8] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(et::g_waitstamp), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+extern "C" int et_debug_prostamp(unsigned long long *host, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(et::g_prostamp), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(et::g_prostamp), z, sizeof z) != hipSuccess) return 1;
     }
     return 0;
 }
