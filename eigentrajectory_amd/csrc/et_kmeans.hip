@@ -836,20 +836,25 @@ __device__ unsigned long long g_waitstamp[8];
 // [4] barrier + publish, [5] tables, matrix operand, barrier, [6] the pass loop, [7] final drain + barrier,
 // [8] copies -> one + barrier + emit
 __device__ unsigned long long g_prostamp[16];
-__shared__ unsigned long long s_ps_last, s_ps_acc[16];
+__shared__ unsigned long long s_ps_last, s_ps_acc[16], s_ws_acc[8];
 #define KM_PSTAMP(i)                                                        \
     do {                                                                    \
         if (threadIdx.x == 0) {                                             \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
             const unsigned long long t_ = __builtin_amdgcn_s_memtime();     \
             s_ps_acc[i] = (i) ? t_ - s_ps_last : 1ull;                      \
+            if ((i) == 0)                                                   \
+                for (int z_ = 0; z_ < 8; ++z_) s_ws_acc[z_] = 0ull;         \
             s_ps_last = t_;                                                 \
         }                                                                   \
     } while (0)
-#define KM_PSTAMP_FLUSH()                                                           \
-    do {                                                                            \
-        if (threadIdx.x == 0)                                                       \
-            for (int i_ = 0; i_ < 9; ++i_) atomicAdd(&g_prostamp[i_], s_ps_acc[i_]); \
+#define KM_PSTAMP_FLUSH()                                                               \
+    do {                                                                                \
+        __syncthreads();                                                                \
+        if (threadIdx.x == 0) {                                                         \
+            for (int i_ = 0; i_ < 9; ++i_) atomicAdd(&g_prostamp[i_], s_ps_acc[i_]);     \
+            for (int i_ = 0; i_ < 7; ++i_) atomicAdd(&g_waitstamp[i_], s_ws_acc[i_]);    \
+        }                                                                               \
     } while (0)
 #else
 #define KM_PSTAMP(i)
@@ -1378,7 +1383,13 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
     const int n_thr = (int)blockDim.x, n_wav = n_thr >> 6;
     // (hdr: the caller's copy of *pk.hdr in LDS -- mu[6], s, mu_norm, ok --, requested together with the kernel's other
     // prologue loads: read here, it would be one more dependent round trip to memory in every launch)
-    if (state->iter <= 0 && pk.fused) {
+    // (everything the decisions below read from LDS is requested at once: read where it is used -- behind one branch after
+    // the other -- it was five dependent round trips, ~500 cycles of every launch's prologue)
+    const int64_t st_iter = state->iter, st_fast_ok = state->fast_ok;
+    const int frac = (int)state->frac;
+    const float s = hdr[6], m_up = hdr[7];
+    const unsigned pk_ok = __float_as_uint(hdr[8]);
+    if (st_iter <= 0 && pk.fused) {
         // the fit's first launch: the exact scan of every point -- which also writes the packed copy, from the rows it reads
         // anyway (the scan is bound by its arithmetic, ~130 us at 1e7 points, and has the memory side to spare: a pass of
         // its own over X, kmeans_pack_kernel, costs 175-190 us)
@@ -1390,8 +1401,7 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
         assign_body_valu<6, 4>(X, N, d, K, state, cen, nullptr, labels, nullptr, lanes, copy_mask, po);
         return;
     }
-    const float s = hdr[6];
-    bool fallback = state->iter <= 0 || !state->fast_ok || __float_as_uint(hdr[8]) == 0u;
+    bool fallback = st_iter <= 0 || !st_fast_ok || pk_ok == 0u;
     if (!fallback) {  // every |s (c - mu)| inside the packed range?  (cen: d x K floats in LDS, the same in every workgroup)
         if (range_bad >= 0) {  // (the caller's update has looked already: uniform over the workgroup)
             fallback = range_bad != 0;
@@ -1412,9 +1422,8 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
     float *sL = sC + K * 8;                                                                    // K * kPkRow: label table
     const int lane = tx & 63, wave = tx >> 6, half = lane >> 5, col = lane & 31;
     unsigned *queue = reinterpret_cast<unsigned *>(sL + K * kPkRow) + wave * kPkQueue;
-    const int frac = (int)state->frac;
     constexpr float kUp = 1.001953125f, kTiny = 1.1920928955078125e-7f;  // (1 + 2^-9) v + 2^-23 survives the rtz to f16
-    const float s2 = s * s, m_up = hdr[7];
+    const float s2 = s * s;
     stage_centroids(cen, d, K, sC);
     __shared__ int sNext;
     if (tx == 0) sNext = n_wav;
@@ -1597,13 +1606,13 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
 #endif
     }
 #ifdef ET_EXP_WAITSTAMP
-    if (lane == 0) {
-        atomicAdd(&g_waitstamp[0], ws_n);
-        atomicAdd(&g_waitstamp[1], ws_wait);
-        atomicAdd(&g_waitstamp[2], ws_pass);
-        atomicAdd(&g_waitstamp[3], ws_drain);
-        atomicAdd(&g_waitstamp[4], ws_nd);
-        atomicAdd(&g_waitstamp[6], 1ull);
+    if (lane == 0) {  // (into LDS: six device atomics per wavefront here made the build's launches 4-5x slower)
+        atomicAdd(&s_ws_acc[0], ws_n);
+        atomicAdd(&s_ws_acc[1], ws_wait);
+        atomicAdd(&s_ws_acc[2], ws_pass);
+        atomicAdd(&s_ws_acc[3], ws_drain);
+        atomicAdd(&s_ws_acc[4], ws_nd);
+        atomicAdd(&s_ws_acc[6], 1ull);
     }
 #endif
     KM_PSTAMP(6);
@@ -2021,6 +2030,8 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
         KM_PSTAMP(3);
     }
     __syncthreads();
+    const int64_t done1 = sSt.done;  // (requested together: the flag of the update just applied and its range test)
+    const int range_bad = sPkBad;
     if (wg0) {  // publish (read by the next launch, the host's convergence polling and the finalize kernel)
         if (threadIdx.x == 0) {
             *ch.st_wr = sSt;
@@ -2035,7 +2046,7 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
         for (int i = threadIdx.x; i < total; i += (int)blockDim.x) ch.lanes_zero[i] = 0;
     }
     KM_PSTAMP(4);
-    if (sSt.done) return;  // the update just applied met the tolerance: no further assignment (kmeans.py:239)
+    if (done1) return;  // the update just applied met the tolerance: no further assignment (kmeans.py:239)
     const int copy_mask = ch.compact ? -1 : kAccLanes - 1;
     // a shard whose rows do not allow 16-byte loads (sharded runs cut the points anywhere), or a tiny one: the plain exact
     // scan, one point per lane, inside the same launch -- which loop form a sharded fit takes then depends on (d, K)
@@ -2043,7 +2054,7 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     if (ch.vec_ok) {
         if constexpr (!SIM) {
             if (ch.pk.xh) {
-                packed_assign_body<NREGS>(ch.pk, sPkHdr, X, N, K, &sSt, sCen, labels, ch.lanes_wr, copy_mask, sPkBad);
+                packed_assign_body<NREGS>(ch.pk, sPkHdr, X, N, K, &sSt, sCen, labels, ch.lanes_wr, copy_mask, range_bad);
                 return;
             }
         }
