@@ -1372,12 +1372,107 @@ __device__ __forceinline__ void packed_issue(const LloydPacked &pk, int64_t N, c
     lpn = *reinterpret_cast<const unsigned *>(labels + nl);
 }
 
+// ---- the per-launch tables of packed_assign_body, as functions of a cluster's centroid (c[0..5], |c|^2 as stage_centroids
+// sums it): the label-table row and the matrix operand of lane (col, half).  Made either inside packed_assign_body or --
+// chained kernel -- by otherwise idle wavefronts beside the update's reductions (packed_tables_side).
+__device__ __forceinline__ void pk_table_row(const float (&c)[6], float bn, const float *hdr, float s, float m_up, float *row) {
+    constexpr float kUp = 1.001953125f;
+    const float s2 = s * s;
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const float ct = c[i] - hdr[i];
+        qq = fmaf(ct, ct, qq);
+        row[i] = 2.0f * s * ct;
+    }
+    // (v_sqrt_f32, 1 ulp: both are upper bounds with a 1e-3 margin)
+    const float Q = __builtin_amdgcn_sqrtf(qq) * s * 1.001f + 1e-30f, M = m_up + __builtin_amdgcn_sqrtf(bn) * s * 1.001f;
+    row[6] = qq * s2;
+    // th(R) = R^2 k1 + R thr_r + thr_1:  epsR + Ew_l + E1_l  (header comment), coefficients rounded up
+    row[7] = fmaf(9.86e-4f, Q, 9.7e-7f * M) * kUp + 1e-30f;
+    row[8] = (fmaf(9.6e-7f * Q, Q, 2.4e-7f * Q) + fmaf(4.85e-7f * M, M, 1e-12f)) * kUp;
+}
+
+// A operand of a lane's cluster (layout as in filter_assign_body): lower half-wave lanes carry k-slots 0..7 =
+// {hi(2 q)_0..5, -|q|^2 + const as hi, lo * 2^10}, upper half-wave lanes k-slots 8..15 = {lo(2 q)_0..5, slope, 0}
+__device__ __forceinline__ u32x4 pk_a_operand(const float (&c)[6], float bn, bool valid, const float *hdr, float s, float m_up,
+                                              int half) {
+    constexpr float kUp = 1.001953125f, kTiny = 1.1920928955078125e-7f;  // (1 + 2^-9) v + 2^-23 survives the rtz to f16
+    const float s2 = s * s;
+    unsigned ch[3] = {0u, 0u, 0u}, cl[3] = {0u, 0u, 0u};
+    float nb = -60000.0f;
+    unsigned ebd = 0u;
+    if (valid) {
+        float ct[6], qq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            ct[i] = c[i] - hdr[i];
+            qq = fmaf(ct[i], ct[i], qq);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) split_f16(ct[2 * p], ct[2 * p + 1], 2.0f * s, ch[p], cl[p]);
+        const float Q = sqrtf(qq) * s * 1.001f + 1e-30f, M = m_up + sqrtf(bn) * s * 1.001f;
+        // u_j - epsR(R) = t'_j + R ebd_r + ebd_1
+        const float ebd_r = fmaf(9.95e-4f, Q, fmaf(9.7e-7f, M, 4.8e-7f));
+        // (+ 2e-10: the 2^-34 of E2 and, for a cluster so close to mu that -|q|^2 + const is positive, what the
+        // round-toward-zero hi / lo pair below can fall short of it: < 2^-24 / 1024 = 5.8e-11)
+        const float ebd_1 = fmaf(5.4e-6f * Q, Q, 4.8e-7f * Q) + fmaf(4.85e-7f * M, M, 2e-10f);
+        nb = fmaf(-qq, s2, ebd_1 * kUp);
+        nb = fmaf(fabsf(nb), 3.814697265625e-6f, nb) + 1e-12f;  // + 2^-18 |nb|: the hi / lo pair below never rounds it down
+        ebd = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(fmaf(ebd_r, kUp, kTiny), 0.f));
+    }
+    const auto nh = __builtin_amdgcn_cvt_pkrtz(nb, 0.f);
+    const unsigned bnd = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(nb, (nb - (float)nh[0]) * 1024.0f));
+    return half == 0 ? u32x4{ch[0], ch[1], ch[2], bnd} : u32x4{cl[0], cl[1], cl[2], ebd};
+}
+
+// The tables above from the NEW centroids `cen` (d x K, LDS) while the update that made them is still reducing its error and
+// flags: role 0 = label table (lanes < K), role 1 = matrix operand of the 64 (col, half) lanes -> tables[lane], role 2 =
+// the exact rows for the drains (stage_centroids).  One wavefront per role; nothing written here overlaps the prologue's
+// scratch (sC / sL lie behind the accumulator copies).  Speculative: if the update ends the fit or the launch falls back
+// to the fp32 filter, the tables are simply not used.
+__device__ __forceinline__ void packed_tables_side(int role, int lane, const float *cen, const float *hdr, int K, u32x4 *tables) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *sC = reinterpret_cast<float *>(smem_raw + sizeof(long long) * kPkAccCopies * kPkAccPitch);
+    float *sL = sC + K * 8;
+    const float s = hdr[6], m_up = hdr[7];
+    if (role == 2) {
+        if (lane < K) {
+            float bn = 0.f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const float v = cen[i * K + lane];
+                sC[lane * 8 + i] = v;
+                bn = bn + v * v;  // kmeans.py:74 |b|^2: sequential sum of rounded squares (stage_centroids)
+            }
+            sC[lane * 8 + 6] = bn;
+        }
+        return;
+    }
+    const int col = lane & 31, half = lane >> 5;
+    const int j = role == 0 ? lane : 2 * (4 * (col >> 3) + (col & 3)) + ((col >> 2) & 1);
+    float c[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float bn = 0.f;
+    if (j < K) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            c[i] = cen[i * K + j];
+            bn = bn + c[i] * c[i];
+        }
+    }
+    if (role == 0) {
+        if (j < K) pk_table_row(c, bn, hdr, s, m_up, sL + j * kPkRow);
+    } else {
+        tables[lane] = pk_a_operand(c, bn, j < K, hdr, s, m_up, half);
+    }
+}
+
 template <int NREGS>
 __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const float *hdr,
                                                    const float *__restrict__ X, int64_t N, int K,
                                                    const et_kmeans_state *state, const float *cen,
                                                    uint8_t *__restrict__ labels, long long *__restrict__ lanes,
-                                                   int copy_mask, int range_bad = -1) {
+                                                   int copy_mask, int range_bad = -1, const u32x4 *tables = nullptr) {
     const unsigned tx = thread_x();  // (opaque per call: see thread_x)
     constexpr int d = 6;
     const int n_thr = (int)blockDim.x, n_wav = n_thr >> 6;
@@ -1422,60 +1517,37 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
     float *sL = sC + K * 8;                                                                    // K * kPkRow: label table
     const int lane = tx & 63, wave = tx >> 6, half = lane >> 5, col = lane & 31;
     unsigned *queue = reinterpret_cast<unsigned *>(sL + K * kPkRow) + wave * kPkQueue;
-    constexpr float kUp = 1.001953125f, kTiny = 1.1920928955078125e-7f;  // (1 + 2^-9) v + 2^-23 survives the rtz to f16
-    const float s2 = s * s;
-    stage_centroids(cen, d, K, sC);
+    constexpr float kUp = 1.001953125f;  // (1 + 2^-9): rounding the thresholds up
+    u32x4 a1;
     __shared__ int sNext;
-    if (tx == 0) sNext = n_wav;
-    __syncthreads();  // (`cen` -- the chained kernel's prologue scratch -- lies inside the accumulator copies: cleared only now)
-    for (int i = tx; i < kPkAccCopies * kPkAccPitch; i += n_thr) sAcc[i] = 0;
-    // per cluster: the centred, scaled row for the old-label chain and the two threshold coefficients
-    for (int j = tx; j < K; j += n_thr) {
-        float qq = 0.f;
+    if (tables) {
+        // the caller's update made the tables beside its reductions (packed_tables_side): sC, sL and the operand are there
+        if (tx == 0) sNext = n_wav;
+        for (int i = tx; i < kPkAccCopies * kPkAccPitch; i += n_thr) sAcc[i] = 0;  // (the prologue scratch inside it is dead)
+        a1 = tables[lane];
+    } else {
+        stage_centroids(cen, d, K, sC);
+        if (tx == 0) sNext = n_wav;
+        __syncthreads();  // (`cen` -- the chained kernel's prologue scratch -- lies inside the accumulator copies: cleared only now)
+        for (int i = tx; i < kPkAccCopies * kPkAccPitch; i += n_thr) sAcc[i] = 0;
+        // per cluster: the centred, scaled row for the old-label chain and the two threshold coefficients
+        for (int j = tx; j < K; j += n_thr) {
+            float c[d];
 #pragma unroll
-        for (int i = 0; i < d; ++i) {
-            const float ct = sC[j * 8 + i] - hdr[i];
-            qq = fmaf(ct, ct, qq);
-            sL[j * kPkRow + i] = 2.0f * s * ct;
+            for (int i = 0; i < d; ++i) c[i] = sC[j * 8 + i];
+            pk_table_row(c, sC[j * 8 + 6], hdr, s, m_up, sL + j * kPkRow);
         }
-        // (v_sqrt_f32, 1 ulp: both are upper bounds with a 1e-3 margin)
-        const float Q = __builtin_amdgcn_sqrtf(qq) * s * 1.001f + 1e-30f, M = m_up + __builtin_amdgcn_sqrtf(sC[j * 8 + 6]) * s * 1.001f;
-        sL[j * kPkRow + 6] = qq * s2;
-        // th(R) = R^2 k1 + R thr_r + thr_1:  epsR + Ew_l + E1_l  (header comment), coefficients rounded up
-        sL[j * kPkRow + 7] = fmaf(9.86e-4f, Q, 9.7e-7f * M) * kUp + 1e-30f;
-        sL[j * kPkRow + 8] = (fmaf(9.6e-7f * Q, Q, 2.4e-7f * Q) + fmaf(4.85e-7f * M, M, 1e-12f)) * kUp;
-    }
-
-    // A operand of this lane's cluster (layout as in filter_assign_body): lower half-wave lanes carry k-slots 0..7 =
-    // {hi(2 q)_0..5, -|q|^2 + const as hi, lo * 2^10}, upper half-wave lanes k-slots 8..15 = {lo(2 q)_0..5, slope, 0}
-    u32x4 a1 = {0u, 0u, 0u, 0u};
-    {
-        const int j = 2 * (4 * (col >> 3) + (col & 3)) + ((col >> 2) & 1);
-        unsigned ch[3] = {0u, 0u, 0u}, cl[3] = {0u, 0u, 0u};
-        float nb = -60000.0f;
-        unsigned ebd = 0u;
-        if (j < K) {
-            float ct[d], qq = 0.f;
+        {
+            const int j = 2 * (4 * (col >> 3) + (col & 3)) + ((col >> 2) & 1);
+            float c[d] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float bn = 0.f;
+            if (j < K) {
 #pragma unroll
-            for (int i = 0; i < d; ++i) {
-                ct[i] = sC[j * 8 + i] - hdr[i];
-                qq = fmaf(ct[i], ct[i], qq);
+                for (int i = 0; i < d; ++i) c[i] = sC[j * 8 + i];
+                bn = sC[j * 8 + 6];
             }
-#pragma unroll
-            for (int p = 0; p < 3; ++p) split_f16(ct[2 * p], ct[2 * p + 1], 2.0f * s, ch[p], cl[p]);
-            const float Q = sqrtf(qq) * s * 1.001f + 1e-30f, M = m_up + sqrtf(sC[j * 8 + 6]) * s * 1.001f;
-            // u_j - epsR(R) = t'_j + R ebd_r + ebd_1
-            const float ebd_r = fmaf(9.95e-4f, Q, fmaf(9.7e-7f, M, 4.8e-7f));
-            // (+ 2e-10: the 2^-34 of E2 and, for a cluster so close to mu that -|q|^2 + const is positive, what the
-            // round-toward-zero hi / lo pair below can fall short of it: < 2^-24 / 1024 = 5.8e-11)
-            const float ebd_1 = fmaf(5.4e-6f * Q, Q, 4.8e-7f * Q) + fmaf(4.85e-7f * M, M, 2e-10f);
-            nb = fmaf(-qq, s2, ebd_1 * kUp);
-            nb = fmaf(fabsf(nb), 3.814697265625e-6f, nb) + 1e-12f;  // + 2^-18 |nb|: the hi / lo pair below never rounds it down
-            ebd = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(fmaf(ebd_r, kUp, kTiny), 0.f));
+            a1 = pk_a_operand(c, bn, j < K, hdr, s, m_up, half);
         }
-        const auto nh = __builtin_amdgcn_cvt_pkrtz(nb, 0.f);
-        const unsigned bnd = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(nb, (nb - (float)nh[0]) * 1024.0f));
-        a1 = half == 0 ? u32x4{ch[0], ch[1], ch[2], bnd} : u32x4{cl[0], cl[1], cl[2], ebd};
     }
     const f16x8 A1 = __builtin_bit_cast(f16x8, a1);
     __syncthreads();  // sL complete
@@ -1699,10 +1771,16 @@ __device__ __forceinline__ double lane_down_f64(double v) {
     return __hiloint2double((int)hi, (int)lo);
 }
 
+struct NoSideWork {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+// `side(w)`: work for wavefront 2 + w of the workgroup, run beside the reductions (between the update's two barriers) --
+// it may read the new centroids in `cen`
+template <class Side = NoSideWork>
 __device__ __forceinline__ void update_body(et_kmeans_state *state, const long long *partials, int d, int K, float tol,
                                             float *cen, float *trace, const et_kmeans_state *pre = nullptr,
                                             float *last = nullptr, bool need_inertia = true,
-                                            const float *pk_hdr = nullptr, int *pk_bad = nullptr) {
+                                            const float *pk_hdr = nullptr, int *pk_bad = nullptr, Side side = Side()) {
     const unsigned tx = thread_x();  // (opaque per call: see thread_x)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *sSq = reinterpret_cast<float *>(smem_raw);  // d*K squared differences
@@ -1754,6 +1832,7 @@ __device__ __forceinline__ void update_body(et_kmeans_state *state, const long l
         }
         if (l == 0) sErr = total;
     }
+    if (tx >= 128) side((int)(tx >> 6) - 2);
     if (tx < 64) {
         float mx = 0.f;
         unsigned mn = 0x7f800000u;
@@ -1990,6 +2069,8 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     KM_PSTAMP(0);
     const int64_t done0 = ch.st_rd->done, iter0 = ch.st_rd->iter;
     __shared__ float sPkHdr[12];
+    __shared__ u32x4 sPkTab[64];  // packed_assign_body's matrix operand per lane, when made beside the update
+    bool tables_ready = false;
     __shared__ int sPkBad;  // the packed copy's range test of the new centroids, made by update_body (-1: not made)
     if (threadIdx.x == 0) sPkBad = -1;
     float pk_word = 0.f;
@@ -2025,8 +2106,15 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
         fold_combine(fr, iter0 > 0, plen, sTot, ch.compact != 0);
         __syncthreads();
         KM_PSTAMP(2);
+        // (trace-less fit on the packed copy: the next assignment's tables are made by wavefronts 2, 3 and 4 beside the
+        // update's reductions -- 1.3 us of every launch's prologue when they followed it)
+        const bool side_tables = !SIM && ch.pk.xh && ch.vec_ok && blockDim.x >= 320;
+        auto side = [&](int w) {
+            if (side_tables && w < 3) packed_tables_side(w, (int)(threadIdx.x & 63), sCen, sPkHdr, K, sPkTab);
+        };
         update_body(&sSt, sTot, d, K, tol, sCen, wg0 ? trace : nullptr, nullptr, wg0 ? ch.last : nullptr, SIM && wg0,
-                    (!SIM && ch.pk.xh) ? sPkHdr : nullptr, &sPkBad);  // reads its copy in LDS
+                    (!SIM && ch.pk.xh) ? sPkHdr : nullptr, &sPkBad, side);  // reads its copy in LDS
+        tables_ready = side_tables;
         KM_PSTAMP(3);
     }
     __syncthreads();
@@ -2054,7 +2142,8 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     if (ch.vec_ok) {
         if constexpr (!SIM) {
             if (ch.pk.xh) {
-                packed_assign_body<NREGS>(ch.pk, sPkHdr, X, N, K, &sSt, sCen, labels, ch.lanes_wr, copy_mask, range_bad);
+                packed_assign_body<NREGS>(ch.pk, sPkHdr, X, N, K, &sSt, sCen, labels, ch.lanes_wr, copy_mask, range_bad,
+                                          tables_ready ? sPkTab : nullptr);
                 return;
             }
         }
