@@ -1770,6 +1770,22 @@ __device__ __forceinline__ double lane_down_f64(double v) {
     const unsigned lo = lane_down_u32<O>((unsigned)__double2loint(v)), hi = lane_down_u32<O>((unsigned)__double2hiint(v));
     return __hiloint2double((int)hi, (int)lo);
 }
+template <int O>
+__device__ __forceinline__ unsigned long long lane_down_u64(unsigned long long v) {
+    const unsigned lo = lane_down_u32<O>((unsigned)v), hi = lane_down_u32<O>((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+// the minimum of a 64-bit key over the wavefront, in lane 0 (register exchanges only)
+__device__ __forceinline__ unsigned long long wave_min_u64_lane0(unsigned long long key) {
+    unsigned long long o;
+    o = lane_down_u64<32>(key); key = o < key ? o : key;
+    o = lane_down_u64<16>(key); key = o < key ? o : key;
+    o = lane_down_u64<8>(key); key = o < key ? o : key;
+    o = lane_down_u64<4>(key); key = o < key ? o : key;
+    o = lane_down_u64<2>(key); key = o < key ? o : key;
+    o = lane_down_u64<1>(key); key = o < key ? o : key;
+    return key;
+}
 
 struct NoSideWork {
     __device__ __forceinline__ void operator()(int) const {}
@@ -2588,6 +2604,17 @@ __device__ __forceinline__ void init_step_body(const float *__restrict__ X, int6
         for (int i = 0; i < D; ++i)
             cprev[i] = PERSIST ? __hip_atomic_load(&C0[i * K + jc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : C0[i * K + jc];
     }
+    // the tile summaries of this wavefront's first 64 tiles do not depend on the new centroid either: requested now, their
+    // round trip (the fourth dependent one of a step) runs under the prologue's
+    const int lane = (int)(threadIdx.x & 63);
+    const bool vec = step > 1 && ((reinterpret_cast<uintptr_t>(best) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(nearest) & 3u) == 0);
+    const int64_t n4 = vec ? N / 4 : 0;
+    const int64_t n_tiles = (n4 + 63) >> 6, n_waves = (int64_t)gridDim.x * (kKmThreads / 64);
+    const int64_t per = (n_tiles + n_waves - 1) / n_waves;
+    const int64_t t_begin = ((int64_t)blockIdx.x * (kKmThreads / 64) + (threadIdx.x >> 6)) * per;
+    const int64_t t_end = t_begin + per < n_tiles ? t_begin + per : n_tiles;
+    uint4 meta0 = make_uint4(0u, 0u, 0u, 0u);
+    if (meta && vec && meta_valid && t_begin + lane < t_end) meta0 = meta[t_begin + lane];
     if (prev_keys) {
         // Single-GPU path: centroid step-1 has not been stored yet -- every workgroup derives it from the previous
         // step's workgroup keys (the same minimum everywhere), workgroup 0 also stores it.  Two short round trips
@@ -2605,10 +2632,7 @@ __device__ __forceinline__ void init_step_body(const float *__restrict__ X, int6
 #pragma unroll
             for (int u = 0; u < 4; ++u) key = k4[u] < key ? k4[u] : key;
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_xor(key, o);
-            key = other < key ? other : key;
-        }
+        key = wave_min_u64_lane0(key);  // (register exchanges: six ds_bpermute levels on a 64-bit key were ~800 cycles)
         if ((threadIdx.x & 63) == 0) sKey[threadIdx.x >> 6] = key;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -2715,8 +2739,6 @@ __device__ __forceinline__ void init_step_body(const float *__restrict__ X, int6
     const int64_t stride = (int64_t)gridDim.x * kKmThreads;
     const int64_t tid = (int64_t)blockIdx.x * kKmThreads + threadIdx.x;
     // steps >= 2 look at four points per lane through one 16-B load of best[] and one 4-B load of nearest[]
-    const bool vec = step > 1 && ((reinterpret_cast<uintptr_t>(best) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(nearest) & 3u) == 0);
-    const int64_t n4 = vec ? N / 4 : 0;
     // Steps >= 3 first look at a 16-byte summary of each tile of 256 points (the smallest key, the largest running
     // similarity, the set of nearest centroids -- written by the step before): if the skip test holds for the tile's
     // WORST values it holds for every point in it (E - b and the product are monotone in b, the distance bound is the
@@ -2725,7 +2747,6 @@ __device__ __forceinline__ void init_step_body(const float *__restrict__ X, int6
     // (one summary each: one round trip for the whole run, not one per tile), then the whole wavefront goes through the
     // tiles that failed, point by point as before.  After a farthest-first pick almost every tile passes: the sweep of a
     // step was 9 of its 18 us, all of it reading best[] and nearest[].
-    const int lane = (int)(threadIdx.x & 63);
     auto sweep_tile = [&](int64_t tile) {  // the whole wavefront: four points per lane, and the tile's new summary
         const int64_t g = tile * 64 + lane;
         const bool act = g < n4;
@@ -2754,26 +2775,29 @@ __device__ __forceinline__ void init_step_body(const float *__restrict__ X, int6
             key = tkey < before ? tkey : before;
         }
         if (meta) {
-            for (int o = 32; o > 0; o >>= 1) {
-                const unsigned long long ok = __shfl_xor(tkey, o);
-                tkey = ok < tkey ? ok : tkey;
-                tmax = fmaxf(tmax, __shfl_xor(tmax, o));
-                tmask |= (unsigned)__shfl_xor((int)tmask, o);
-            }
+            tkey = wave_min_u64_lane0(tkey);
+#define ET_DOWN(O)                                                                          \
+    do {                                                                                    \
+        tmax = fmaxf(tmax, __uint_as_float(lane_down_u32<O>(__float_as_uint(tmax))));       \
+        tmask |= lane_down_u32<O>(tmask);                                                   \
+    } while (0)
+            ET_DOWN(32);
+            ET_DOWN(16);
+            ET_DOWN(8);
+            ET_DOWN(4);
+            ET_DOWN(2);
+            ET_DOWN(1);
+#undef ET_DOWN
             if (lane == 0)
                 meta[tile] = make_uint4((unsigned)(tkey & 0xffffffffull), (unsigned)(tkey >> 32), __float_as_uint(tmax), tmask);
         }
     };
     if (meta && vec) {
-        const int64_t n_tiles = (n4 + 63) >> 6, n_waves = (int64_t)gridDim.x * (kKmThreads / 64);
-        const int64_t per = (n_tiles + n_waves - 1) / n_waves;
-        const int64_t t_begin = ((int64_t)blockIdx.x * (kKmThreads / 64) + (threadIdx.x >> 6)) * per;
-        const int64_t t_end = t_begin + per < n_tiles ? t_begin + per : n_tiles;
         for (int64_t tb = t_begin; tb < t_end; tb += 64) {  // (wave-uniform)
             const int64_t mine = tb + lane;
             bool todo_mine = mine < t_end;
             if (meta_valid && todo_mine) {
-                const uint4 m = meta[mine];
+                const uint4 m = tb == t_begin ? meta0 : meta[mine];
                 const unsigned ob = m.y;  // orderable(b_min) -> b_min
                 const float b_min = __uint_as_float((ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob), b_max = __uint_as_float(m.z);
                 float dmin = __int_as_float(0x7f800000);
@@ -2816,10 +2840,14 @@ __device__ __forceinline__ void init_step_body(const float *__restrict__ X, int6
         int lab_after;
         visit(n, b, skip, b_after, lab_after);
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(key, o);
-        key = other < key ? other : key;
-        mabs = fmaxf(mabs, __shfl_xor(mabs, o));
+    key = wave_min_u64_lane0(key);
+    if (step == 1) {  // (the largest |x|: made in the first step only)
+        mabs = fmaxf(mabs, __uint_as_float(lane_down_u32<32>(__float_as_uint(mabs))));
+        mabs = fmaxf(mabs, __uint_as_float(lane_down_u32<16>(__float_as_uint(mabs))));
+        mabs = fmaxf(mabs, __uint_as_float(lane_down_u32<8>(__float_as_uint(mabs))));
+        mabs = fmaxf(mabs, __uint_as_float(lane_down_u32<4>(__float_as_uint(mabs))));
+        mabs = fmaxf(mabs, __uint_as_float(lane_down_u32<2>(__float_as_uint(mabs))));
+        mabs = fmaxf(mabs, __uint_as_float(lane_down_u32<1>(__float_as_uint(mabs))));
     }
     if ((threadIdx.x & 63) == 0) {
         sKey[threadIdx.x >> 6] = key;
