@@ -9,9 +9,12 @@
 // trajectory against ~500 flop), so the design goal is full-width coalesced
 // traffic: 16-byte-per-lane global accesses on the AoS trajectory rows, staged
 // through LDS so that each lane can then own one trajectory (or one
-// (trajectory, sample) pair) for the tiny k<=6 contraction.  MFMA is not used:
+// (trajectory, sample) pair) for the tiny k<=6 contraction.  MFMA is not used there:
 // the contraction depth is k=6 / 2T=16..24 and the kernels sit far below the
-// VALU roof.
+// VALU roof.  The one exception is the fused best-of-S evaluation epilogue
+// (reconstruct_metrics_mfma_kernel, 12 <= S <= 64): 600 B per trajectory against
+// 5 760 flop -- its contraction runs on the f16 matrix pipe from two-term f16 splits,
+// its inputs travel memory -> LDS without destination registers (round 4).
 #include <cstdlib>
 #include <type_traits>
 

@@ -22,7 +22,10 @@
 //                                                    iteration's update itself (fold of the delta table of exact totals,
 //                                                    means, error, convergence) and then assigns; no serial section.
 //                                                    Trace-less fits of big shards: packed_assign_body, the same test on
-//                                                    an f16 copy of the points (14 B per point instead of 24)
+//                                                    an f16 copy of the points (14 B per point instead of 24); its
+//                                                    per-launch tables are made by idle wavefronts beside the update's
+//                                                    reductions (packed_tables_side; round 4, with the other prologue
+//                                                    trims: profiles/r04k_lloyd_launch_stamps.txt)
 //                    kmeans_lloyd_persist_kernel    all iterations in one launch (grid barrier without cache fences):
 //                                                    shards <= 32768 points and the side-by-side fits of a batch
 //   after the loop   kmeans_inertia_kernel          inertia of the last assignment when no trace was requested
