@@ -15,6 +15,7 @@
 // (reconstruct_metrics_mfma_kernel, 12 <= S <= 64): 600 B per trajectory against
 // 5 760 flop -- its contraction runs on the f16 matrix pipe from two-term f16 splits,
 // its inputs travel memory -> LDS without destination registers (round 4).
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1612,10 +1613,18 @@ extern "C" int et_anchor_reconstruct_metrics(const float *C, int64_t N, int S, i
             // the others are done and double the run time of its CU)
 #define ET_METRICS_LAUNCH(MODE)                                                                                           \
     do {                                                                                                                  \
+        /* (asked once per mode and LDS size: the query is a few microseconds of host time, as much as a scene call's   \
+           whole kernel) */                                                                                               \
+        static std::atomic<unsigned long long> cached{0};                                                                 \
         int per_cu = 0;                                                                                                   \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reconstruct_metrics_mfma_kernel<12, 6, MODE>,           \
-                                                         kMetWaves * 64, lds) != hipSuccess || per_cu < 1)               \
-            per_cu = 2;                                                                                                   \
+        const unsigned long long c = cached.load(std::memory_order_relaxed);                                             \
+        if ((c >> 32) == (unsigned long long)lds + 1) per_cu = (int)(c & 0xffffffffull);                                  \
+        else {                                                                                                            \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reconstruct_metrics_mfma_kernel<12, 6, MODE>,       \
+                                                             kMetWaves * 64, lds) != hipSuccess || per_cu < 1)           \
+                per_cu = 2;                                                                                               \
+            cached.store((((unsigned long long)lds + 1) << 32) | (unsigned)per_cu, std::memory_order_relaxed);            \
+        }                                                                                                                 \
         const unsigned g = (unsigned)min((int64_t)cu_count() * per_cu, ceil_div(passes, kMetWaves));                      \
         hipLaunchKernelGGL((reconstruct_metrics_mfma_kernel<12, 6, MODE>), dim3(g), dim3(kMetWaves * 64), lds, st, C,     \
                            (int)N, S, TNW, T_obs, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, static_dist, gt, ade, fde,      \
