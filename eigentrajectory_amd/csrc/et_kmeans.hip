@@ -3031,6 +3031,28 @@ __global__ void kmeans_gather_point_kernel(const float *__restrict__ X, int64_t 
     if (i < d) point[i] = X[(int64_t)i * N + idx];
 }
 
+// farthest-first, before its first step, in ONE launch: the first centroid = point `idx` (-> column 0 of C0 and the
+// candidate record's point slot) and the running max |x| cleared (a gather kernel, a set kernel and a memset were three
+// ~5 us packets with a kernel boundary each)
+__global__ void kmeans_init_first_kernel(const float *__restrict__ X, int64_t N, int d, int K, int64_t idx,
+                                         float *__restrict__ C0, float *__restrict__ point, unsigned *__restrict__ maxabs) {
+    const int i = threadIdx.x;
+    if (i < d) {
+        const float v = X[(int64_t)i * N + idx];
+        point[i] = v;
+        C0[i * K] = v;
+    }
+    if (i == 0) *maxabs = 0u;
+}
+
+// the state block before a scan: all zero, "no non-zero value yet" = +inf (two memsets were two packets)
+__global__ void kmeans_state_reset_kernel(et_kmeans_state *state) {
+    constexpr int kWords = (int)(sizeof(et_kmeans_state) / sizeof(unsigned));
+    for (int i = threadIdx.x; i < kWords; i += blockDim.x) reinterpret_cast<unsigned *>(state)[i] = 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) *reinterpret_cast<unsigned *>(&state->min_nz_x_bits) = 0x7f800000u;
+}
+
 static int km_grid(int64_t work_items) {
     const int64_t b = ceil_div(work_items, (int64_t)kKmThreads);
     return (int)(b < 1 ? 1 : (b > kKmMaxBlocks ? kKmMaxBlocks : b));
@@ -3209,8 +3231,8 @@ extern "C" size_t et_kmeans_workspace_bytes(int64_t N, int d, int K) {
 extern "C" int et_kmeans_scan(const float *X, int64_t N, int d, et_kmeans_state *state, et_stream_t stream) {
     if (!state || N < 0 || d < 1 || d > ET_KMEANS_MAX_D || (N > 0 && !X)) return ET_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    ET_HIP_TRY(hipMemsetAsync(state, 0, sizeof(et_kmeans_state), st));
-    ET_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)&state->min_nz_x_bits, 0x7f800000, 1, st));  // "+inf": no non-zero yet
+    hipLaunchKernelGGL(kmeans_state_reset_kernel, dim3(1), dim3(64), 0, st, state);  // zero; min_nz_x_bits = "+inf"
+    ET_LAUNCH_CHECK();
     if (N == 0) return ET_OK;
     const int64_t scan_blocks = ceil_div(N * d / 4 + 1, (int64_t)kKmThreads);
     hipLaunchKernelGGL(kmeans_scan_kernel, dim3((unsigned)(scan_blocks < 1024 ? scan_blocks : 1024)), dim3(kKmThreads), 0, st,
@@ -3452,7 +3474,7 @@ static int init_step_impl(const float *X, int64_t N, int d, int K, int i, const 
     hipStream_t st = (hipStream_t)stream;
     const KmWorkspace w = km_carve(workspace, N, d, K);
     const int grid = init_step_grid(N, i);
-    if (i == 1) ET_HIP_TRY(hipMemsetAsync(w.init_maxabs, 0, sizeof(unsigned), st));
+    if (i == 1 && !fused) ET_HIP_TRY(hipMemsetAsync(w.init_maxabs, 0, sizeof(unsigned), st));  // (fused: kmeans_init_first_kernel did)
     // key buffers alternate in the fused path (a step reads its predecessor's keys while it writes its own)
     unsigned long long *keys = (fused && (i & 1)) ? w.block_keys2 : w.block_keys;
     const unsigned long long *prev = (fused && i > 1) ? ((i & 1) ? w.block_keys : w.block_keys2) : nullptr;
@@ -3519,10 +3541,10 @@ extern "C" int et_kmeans_init_farthest(const float *X, int64_t N, int d, int K, 
     if (!workspace || workspace_bytes < et_kmeans_workspace_bytes(N, d, K)) return ET_ERR_WORKSPACE;
     const KmWorkspace w = km_carve(workspace, N, d, K);
     float *pt = reinterpret_cast<float *>(w.cand + 8);
-    int rc = et_kmeans_gather_point(X, N, d, first_index, pt, stream);
-    if (rc) return rc;
-    rc = et_kmeans_init_set(C0, d, K, 0, pt, stream);
-    if (rc) return rc;
+    hipLaunchKernelGGL(kmeans_init_first_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, X, N, d, K, first_index, C0, pt,
+                       w.init_maxabs);
+    ET_LAUNCH_CHECK();
+    int rc = ET_OK;
     // ET_KMEANS_INIT=persist: steps 2 .. K-1 and the final pick in ONE persistent launch.  NOT the default -- measured in
     // round 4 (profiles/r04b_init_persist.txt): 0.51 ms against 0.25 ms for the 19 launches at N = 1e7, 1.54 against 1.52 ms
     // for the whole step at N = 1e5.  A step is a chain of dependent round trips either way (keys -> the new centroid's
