@@ -204,7 +204,7 @@ def fit_gram(obs, pred, mode, static_dist=0.0, which=1):
     t_pred = pred.shape[1]
     g_obs = torch.empty((2 * t_obs, 2 * t_obs), device=dev, dtype=torch.float64)
     g_pred = torch.empty((2 * t_pred, 2 * t_pred), device=dev, dtype=torch.float64)
-    count = torch.zeros((1,), device=dev, dtype=torch.int64)
+    count = torch.empty((1,), device=dev, dtype=torch.int64)  # (written by the finish kernel, or zeroed for n == 0: no fill)
     ws_bytes = L.lib().et_fit_gram_workspace_bytes(L.i64(n), t_obs, t_pred)
     ws = torch.empty((max(ws_bytes, 8),), device=dev, dtype=torch.uint8)
     L.check(L.lib().et_fit_gram(L.ptr(obs), L.ptr(pred), L.i64(n), t_obs, t_pred, int(mode), L.f32(static_dist),
