@@ -2176,8 +2176,11 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
 __global__ __launch_bounds__(kKmThreads) void kmeans_chain_finalize_kernel(const LloydChain ch, et_kmeans_state *state,
                                                                            long long *partials, float *cen, int d, int K,
                                                                            float tol, float *trace, int has_pending,
-                                                                           long long *sim_total) {
+                                                                           long long *sim_total, int last_was_sim = 0) {
     if (sim_total && threadIdx.x < 2) sim_total[threadIdx.x] = 0;  // for the inertia pass that follows a trace-less fit
+    // sim_total[2]: the pending assignment was made by a launch that accumulated the similarity sum (the trace-less loop's
+    // LAST launch when it runs to max_iter) -- the update below turns it into the inertia and the inertia pass is skipped
+    if (sim_total && threadIdx.x == 2) sim_total[2] = (last_was_sim && has_pending && !ch.st_rd->done) ? 1 : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int plen = d * K + K + 2;
     long long *sTot = reinterpret_cast<long long *>(smem_raw) + 512;
@@ -2378,7 +2381,9 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_inertia_kernel(const float 
                                                                      const float *__restrict__ last,
                                                                      const uint8_t *__restrict__ labels,
                                                                      long long *__restrict__ sim_total,
-                                                                     int64_t ws_stride = 0, int64_t x_stride = 0) {
+                                                                     int64_t ws_stride = 0, int64_t x_stride = 0,
+                                                                     const long long *__restrict__ skip = nullptr) {
+    if (skip && *skip) return;  // (chained loop: the last launch accumulated the similarity sum itself)
     const int d = D ? D : d_rt;
     if (blockIdx.y) {  // problem of a batch: last / labels / sim_total live in workspaces ws_stride bytes apart
         X += (int64_t)blockIdx.y * x_stride;
@@ -2459,8 +2464,10 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_inertia_kernel(const float 
 }
 
 __global__ void kmeans_inertia_finish_kernel(et_kmeans_state *state, const float *__restrict__ last, int d, int K,
-                                             const long long *__restrict__ sim_total, int64_t ws_stride = 0) {
+                                             const long long *__restrict__ sim_total, int64_t ws_stride = 0,
+                                             const long long *__restrict__ skip = nullptr) {
     if (threadIdx.x != 0) return;
+    if (skip && *skip) return;  // (the inertia the finalize kernel's update made from the last launch's sum stands)
     if (blockIdx.x) {  // problem of a batch
         state = byte_shift(state, (int64_t)blockIdx.x * ws_stride);
         last = byte_shift(last, (int64_t)blockIdx.x * ws_stride);
@@ -3166,7 +3173,7 @@ static KmWorkspace km_carve(void *base, int64_t N, int d, int K) {
     w.last = (float *)(p + off);
     off = align_up(off + sizeof(float) * (((size_t)d * K + 1) & ~(size_t)1) + sizeof(long long), 256);
     w.sim_total = (long long *)(p + off);
-    off = align_up(off + 2 * sizeof(long long), 256);
+    off = align_up(off + 3 * sizeof(long long), 256);  // (sum, non-finite count, "the last launch made the sum")
     for (int i = 0; i < 2; ++i) {
         w.chain_state[i] = (et_kmeans_state *)(p + off);
         off = align_up(off + sizeof(et_kmeans_state), 256);
@@ -3660,8 +3667,17 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
     };
     int grid = 0, launched = 0;
     bool done = false;
+    // A trace-less fit evaluates the inertia of its last assignment in a pass of its own over the points (48 us at 1e7
+    // points + two packets).  When the loop runs to max_iter its last launch is known beforehand: that one launch takes the
+    // form that accumulates the exact similarity sum (the traced fits' kernel on the fp32 rows, +9 us at 1e7 points), the
+    // finalize kernel's update turns the sum into the inertia -- the same integers, the same bits -- and the pass is skipped
+    // ON THE DEVICE (sim_total[2]): a fit that converges earlier never reaches that launch's assignment and keeps the pass.
+    const bool sim_tail = !want_sim && vec_ok && max_iter >= 2;
+    bool last_was_sim = false;
     for (int it = 0; it < max_iter && !done; ++it) {
         const LloydChain ch = chain_for(it);
+        const bool sim_now = want_sim || (sim_tail && it == max_iter - 1);
+        last_was_sim = sim_now && !want_sim;
         if (timed(it)) ET_HIP_TRY(hipEventRecord((*events)[2 * it], st));
 #define ET_LAUNCH_CHAIN(NR, SIM)                                                                                          \
     do {                                                                                                                  \
@@ -3670,10 +3686,10 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
                            labels_u8, tol, trace, it > 0 ? 1 : 0);                                                        \
     } while (0)
         if (K <= 20) {
-            if (want_sim) ET_LAUNCH_CHAIN(10, true);
+            if (sim_now) ET_LAUNCH_CHAIN(10, true);
             else ET_LAUNCH_CHAIN(10, false);
         } else {
-            if (want_sim) ET_LAUNCH_CHAIN(16, true);
+            if (sim_now) ET_LAUNCH_CHAIN(16, true);
             else ET_LAUNCH_CHAIN(16, false);
         }
 #undef ET_LAUNCH_CHAIN
@@ -3712,7 +3728,8 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
     const LloydChain ch = chain_for(launched);
     const size_t flds = 4096 + sizeof(long long) * plen;
     hipLaunchKernelGGL(kmeans_chain_finalize_kernel, dim3(1), dim3(kKmThreads), flds, st, ch, state, partials, centroids, d,
-                       K, tol, trace, launched > 0 ? 1 : 0, want_sim ? (long long *)nullptr : w.sim_total);
+                       K, tol, trace, launched > 0 ? 1 : 0, want_sim ? (long long *)nullptr : w.sim_total,
+                       (last_was_sim && launched == max_iter) ? 1 : 0);
     ET_LAUNCH_CHECK();
     if (!want_sim) {  // inertia of the last assignment (over all ranks' points); the finalize kernel zeroed sim_total
         const size_t ilds = sizeof(float) * (size_t)K * cpitch_host(d);
@@ -3720,14 +3737,15 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
         // pass atomic-bound at 64 us; four points per lane and 1024 workgroups stream instead)
         const int igrid = min(km_grid(N / 4 + 1), 1024);
         hipLaunchKernelGGL((kmeans_inertia_kernel<6>), dim3(igrid), dim3(kKmThreads), ilds, st, X, N, d, K,
-                           (const float *)w.last, (const uint8_t *)labels_u8, w.sim_total);
+                           (const float *)w.last, (const uint8_t *)labels_u8, w.sim_total, (int64_t)0, (int64_t)0,
+                           (const long long *)(w.sim_total + 2));
         ET_LAUNCH_CHECK();
         if (hook.reduce) {
             rc = hook.reduce(hook.ctx, w.sim_total, 2, st);
             if (rc) return rc;
         }
         hipLaunchKernelGGL(kmeans_inertia_finish_kernel, dim3(1), dim3(64), 0, st, state, (const float *)w.last, d, K,
-                           (const long long *)w.sim_total);
+                           (const long long *)w.sim_total, (int64_t)0, (const long long *)(w.sim_total + 2));
         ET_LAUNCH_CHECK();
     }
     if (launched_out) *launched_out = launched;
