@@ -34,7 +34,8 @@ SYMBOLS = [
     "et_kmeans_init_step", "et_kmeans_init_set", "et_kmeans_init_select", "et_kmeans_gather_point", "et_kmeans_init_farthest",
     "et_kmeans_assign_accumulate", "et_kmeans_update", "et_kmeans_joint_done", "et_kmeans_labels_i64", "et_kmeans_fit", "et_kmeans_batch_workspace_bytes", "et_kmeans_fit_batch", "et_kmeans_predict", "et_kmeans_predict_batch",
     "et_kmeans_reforder_workspace_bytes", "et_euc_sim_reforder", "et_kmeans_init_farthest_reforder",
-    "et_kmeans_predict_reforder", "et_kmeans_fit_reforder",
+    "et_kmeans_predict_reforder", "et_kmeans_fit_reforder", "et_kmeans_reforder_batch_workspace_bytes",
+    "et_kmeans_fit_reforder_batch",
     "et_center_columns", "et_kmeanspp_workspace_bytes", "et_kmeanspp_seed", "et_kmeanspp_batch_workspace_bytes", "et_kmeanspp_seed_batch",
     "et_comm_load", "et_comm_unique_id", "et_comm_init_rank", "et_comm_destroy", "et_comm_info",
     "et_fit_gram_sharded", "et_kmeans_sharded_workspace_bytes", "et_kmeans_init_farthest_sharded", "et_kmeans_fit_sharded",
@@ -79,7 +80,8 @@ def lib():
         l.et_compiled_arch.restype = C.c_char_p
         for name in ("et_fit_gram_workspace_bytes", "et_kmeans_partials_len", "et_kmeans_workspace_bytes",
                      "et_kmeanspp_workspace_bytes", "et_kmeans_sharded_workspace_bytes", "et_kmeans_batch_workspace_bytes",
-                     "et_kmeanspp_batch_workspace_bytes", "et_kmeans_reforder_workspace_bytes"):
+                     "et_kmeanspp_batch_workspace_bytes", "et_kmeans_reforder_workspace_bytes",
+                     "et_kmeans_reforder_batch_workspace_bytes"):
             getattr(l, name).restype = C.c_size_t
         _lib = l
     return _lib

@@ -2151,6 +2151,9 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
             for (int e = threadIdx.x; e < plen; e += (int)blockDim.x) ch.tot_wr[e] = sTot[e];
         const int total = plen * kAccLanes;
         for (int i = threadIdx.x; i < total; i += (int)blockDim.x) ch.lanes_zero[i] = 0;
+        // sCen / sTot lie inside the area the assignment bodies clear for their accumulators: this workgroup's other
+        // wavefronts must not start clearing while the ones above still read (uniform per workgroup: only workgroup 0 waits)
+        __syncthreads();
     }
     KM_PSTAMP(4);
     if (done1) return;  // the update just applied met the tolerance: no further assignment (kmeans.py:239)
@@ -3672,7 +3675,9 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
     // form that accumulates the exact similarity sum (the traced fits' kernel on the fp32 rows, +9 us at 1e7 points), the
     // finalize kernel's update turns the sum into the inertia -- the same integers, the same bits -- and the pass is skipped
     // ON THE DEVICE (sim_total[2]): a fit that converges earlier never reaches that launch's assignment and keeps the pass.
-    const bool sim_tail = !want_sim && vec_ok && max_iter >= 2;
+    // (the decision must not depend on this rank's shard: a shard without 16-byte rows runs the exact scan, which adds the
+    // similarity sum in every launch -- so every rank of a sharded fit feeds the last launch's sum and skips the pass)
+    const bool sim_tail = !want_sim && max_iter >= 2;
     bool last_was_sim = false;
     for (int it = 0; it < max_iter && !done; ++it) {
         const LloydChain ch = chain_for(it);

@@ -28,7 +28,11 @@
 // (oracle == torch on random inputs) and tests/golden/g7c_* (whole runs of the imported reference).
 #include <cstdlib>
 
+#include <vector>
+#include <sched.h>
+
 #include "et_common.h"
+#include "et_hostring.h"
 
 namespace et {
 namespace reforder {
@@ -429,14 +433,1025 @@ static int grid_for(int64_t items) {
     return (int)(b < 1 ? 1 : (b > kMaxBlocks ? kMaxBlocks : b));
 }
 
+
+// =====================================================================================================================
+// The FAST form of the reference-order Lloyd iteration (d = 6, K <= 32, 1024 <= N < 2^29): one launch per iteration.
+//
+// ATen's cascade (kmeans.py:180-182) is a fixed tree over INDEX RANGES, so it parallelises without changing a single
+// addition: with L = level step, lane k in 0..3 and lane-term r <-> point n = 4 r + k,
+//   level 0   a "chain" = the L consecutive lane terms of one (chunk, lane): sequential adds into the chunk's per-cluster
+//             accumulators -- one work item per (chain, coordinate), the K accumulators in LDS ([cluster][chain]: the
+//             lanes of a wavefront never share a bank), L read-add-write steps;
+//   level 1   a "group" = L consecutive chunks (4 L^2 points): per (lane, coordinate, cluster) the chunk results are
+//             added in chunk order -- one workgroup owns a group, so this never leaves LDS;
+//   level 2   a "block" = L consecutive groups: folded, in group order, by whichever workgroup of the block arrives last;
+//   level 3 + the leftovers (partial block / group / chunk, the N mod 4 terms), the lane combination, the division by the
+//             count, the error in ATen's inner-sum order and the stop flag: by the workgroup that arrives last of all.
+// Everything that crosses workgroups inside a launch travels through device-scope stores / loads / atomics (served by the
+// memory side: no cache fence), arrivals are one relaxed atomic after s_waitcnt + barrier (the idiom of
+// kmeans_lloyd_persist_kernel).  The same workgroup first ASSIGNS its group's points (exact arg-max, kmeans.py:143-158,
+// norms in ATen's orders), so an iteration reads the coordinates once from memory.
+//
+// Layout: the points of the full groups are kept in a permuted copy XT made once per fit (reforder_permute_kernel): per
+// group and coordinate the 4 L^2 values as [tile][r / 4][chain][r % 4] (tile = 16 chunks = 64 chains), so that a lane's
+// 16-byte load is four consecutive steps of its own chain and a wavefront's load is 1 KB contiguous; labels live in the
+// same order (LT) and are un-permuted once, when the fit hands them out.  The points after the last full group (< 4 L^2 +
+// 4 L + 4: the "tail") stay where they are and belong to one extra workgroup.
+//
+// Several problems (blockIdx.y) iterate in ONE loop and stop TOGETHER on the error summed over the whole batch in ATen's
+// inner-sum order over the contiguous (l, d, K) tensor -- kmeans.py:228-240.
+// =====================================================================================================================
+namespace fast {
+
+constexpr int kD = 6;
+constexpr int kFThreads = 384;  // six wavefronts: one per coordinate in the level-0 phase
+constexpr int kFMaxK = 32;
+constexpr int kFMaxBatch = 64;
+constexpr int kFMaxLp = 6;  // L <= 64 (N < 2^29)
+constexpr int kUThreads = 256;  // reforder_update_kernel2
+constexpr size_t kUMaxLds = 128 * 1024;
+
+struct Geo {
+    int64_t N;
+    int lp;               // L = 1 << lp
+    int64_t G;            // full level-1 groups
+    int64_t tail0;        // first point of the tail = G * 4 L^2
+    int64_t full_chunks;  // (N / 4) / L
+    int n_blk, full_blk;  // level-2 blocks (a partial last one included) / complete ones
+};
+static Geo make_geo(int64_t N) {
+    Geo g;
+    g.N = N;
+    g.lp = level_power(N / 4);
+    const int64_t L = (int64_t)1 << g.lp;
+    g.full_chunks = N / 4 / L;
+    g.G = g.full_chunks / L;
+    g.tail0 = g.G * 4 * L * L;
+    g.full_blk = (int)(g.G / L);
+    g.n_blk = (int)((g.G + L - 1) / L);
+    return g;
+}
+
+// byte offsets inside one problem's block of the workspace.  S1 / S2 / T hold one float4 = the four lanes k of a (group |
+// block | tail part, coordinate, cluster) entry.
+struct Layout {
+    size_t state, cen, arrive, cnt, S1, S2, T, Sin, XT, LT, tail, bytes;
+};
+static Layout make_layout(const Geo &g, int K) {
+    Layout l;
+    const size_t dk = (size_t)kD * K;
+    size_t off = 0;
+    l.state = off;
+    off = up(off + sizeof(et_kmeans_state));
+    l.cen = off;
+    off = up(off + sizeof(float) * dk);
+    l.arrive = off;
+    off = up(off + sizeof(unsigned) * 4);
+    l.cnt = off;  // per workgroup of the groups kernel: its points per cluster
+    off = up(off + sizeof(unsigned) * (size_t)(g.G + 1) * kFMaxK);
+    l.S1 = off;
+    off = up(off + sizeof(float4) * (size_t)g.G * dk);
+    l.S2 = off;
+    off = up(off + sizeof(float4) * (size_t)(g.n_blk + 1) * (dk + kFMaxK / 4));  // a row: d K sums, then the block's counts
+    l.T = off;
+    off = up(off + sizeof(float4) * (2 * dk + 1));
+    l.Sin = off;
+    off = up(off + sizeof(double) * (size_t)(g.G + 1));
+    l.XT = off;
+    off = up(off + sizeof(float) * (size_t)g.tail0 * kD);
+    l.LT = off;
+    off = up(off + (size_t)g.tail0 + 4);
+    l.tail = off;
+    off = up(off + (size_t)(g.N - g.tail0) + 4);
+    l.bytes = off;
+    return l;
+}
+// in front of the problems' blocks: the batch-wide arrival counter and the batch's squared centroid differences
+static size_t shared_bytes(int K, int64_t batch) { return up(256 + sizeof(float) * (size_t)batch * kD * K); }
+
+struct Args {
+    const float *X;     // problem 0's points (d, N); problem b: X + b * x_stride
+    int64_t x_stride;
+    unsigned char *ws;  // problem 0's block; problem b: ws + b * ws_stride
+    int64_t ws_stride;
+    unsigned *batch_arrive;
+    float *sq_all;      // (batch, d K) squared centroid differences of this iteration
+    Layout lay;
+    Geo geo;
+    int K, batch;
+    float tol;
+    float *trace;       // (batch, max_iter, 2) or nullptr
+    int max_iter;
+    int tiles_per_round;  // level-0 tiles in LDS at a time (1 or 2)
+    unsigned long long *mail;  // host-visible progress word or nullptr
+};
+
+template <typename T>
+__device__ __forceinline__ T *at(unsigned char *ws, size_t off) { return reinterpret_cast<T *>(ws + off); }
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16-byte device-scope (sc1: served by the memory side, write-through) accesses through buffer instructions
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void *base, int64_t bytes) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const int nb = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffffll ? 0x7fffffffll : bytes));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, nb, 0x00020000);
+}
+constexpr int kAuxSc1 = 1 << 4;  // gfx940+ cache-policy immediate: bit 0 sc0, bit 1 nt, bit 4 sc1
+__device__ __forceinline__ float4 ld16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, kAuxSc1);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 f) {
+    const u32x4_t v = {__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, kAuxSc1);
+}
+
+// X (d, N) -> XT: one work item per (group, tile, r / 4, chain): four strided reads per coordinate, one 16-byte store
+__global__ __launch_bounds__(kThreads) void reforder_permute_kernel(const float *__restrict__ X, int64_t x_stride,
+                                                                    unsigned char *ws, int64_t ws_stride, size_t off_XT,
+                                                                    Geo geo) {
+    X += (int64_t)blockIdx.y * x_stride;
+    float4 *XT4 = reinterpret_cast<float4 *>(ws + (int64_t)blockIdx.y * ws_stride + off_XT);
+    const int lp = geo.lp;
+    const int64_t L = (int64_t)1 << lp, L2 = L * L;
+    const int64_t total = geo.G * L2;  // quads
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = w >> (2 * lp), qi = w & (L2 - 1);
+        const int t = (int)(qi & 63);
+        const int64_t qrb = qi >> 6;                 // tile * (L / 4) + rb
+        const int64_t q = qrb / (L / 4), rb = qrb % (L / 4);
+        const int64_t c = q * 16 + (t >> 2);         // chunk inside the group
+        const int64_t n0 = g * 4 * L2 + 4 * (c * L + 4 * rb) + (t & 3);
+#pragma unroll
+        for (int i = 0; i < kD; ++i) {
+            const float *x = X + (int64_t)i * geo.N + n0;
+            XT4[(g * kD + i) * L2 + qi] = make_float4(x[0], x[4], x[8], x[12]);
+        }
+    }
+}
+
+// arg-max over the K centroid rows in LDS (row j = c[0..5], |c_j|^2, -) for NP points; NANS: torch.max's rule (a NaN beats
+// everything, the first one stays), else plain `>` (no similarity can be NaN).  The next row is requested while this one
+// is evaluated.
+template <bool NANS, int NP>
+__device__ __forceinline__ void points_best(const float (&x)[NP][kD], const float (&an)[NP], const float *sC, int K, int (&lb)[NP],
+                                            float (&bv)[NP]) {
+    const float4 *s4 = reinterpret_cast<const float4 *>(sC);
+    float4 n0 = s4[0], n1 = s4[1];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        lb[p] = 0;
+        bv[p] = 0.f;
+    }
+    for (int j = 0; j < K; ++j) {
+        const float4 c0 = n0, c1 = n1;
+        if (j + 1 < K) {
+            n0 = s4[2 * j + 2];
+            n1 = s4[2 * j + 3];
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float y = fmaf(x[p][0], c0.x, 0.f);  // kmeans.py:71
+            y = fmaf(x[p][1], c0.y, y);
+            y = fmaf(x[p][2], c0.z, y);
+            y = fmaf(x[p][3], c0.w, y);
+            y = fmaf(x[p][4], c1.x, y);
+            y = fmaf(x[p][5], c1.y, y);
+            y = y * 2.0f;   // :72
+            y = y - an[p];  // :73
+            y = y - c1.z;   // :74
+            const bool take = NANS ? (j == 0 || gt_nanmax(y, bv[p])) : (j == 0 || y > bv[p]);
+            bv[p] = take ? y : bv[p];
+            lb[p] = take ? j : lb[p];
+        }
+    }
+}
+
+// points_best<false> for the four points of a quad as two packed pairs (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: the
+// same IEEE operations, two points per instruction).  No similarity can be NaN or infinite here (the caller checked the
+// magnitudes), so "the first row always wins" is `y > -inf`.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void quad_best(const float4 (&xv)[kD], const float *sC, int K, int (&lb)[4], float (&bv)[4]) {
+    f32x2 xa[kD], xb[kD];
+#pragma unroll
+    for (int i = 0; i < kD; ++i) {
+        xa[i] = f32x2{xv[i].x, xv[i].y};
+        xb[i] = f32x2{xv[i].z, xv[i].w};
+    }
+    f32x2 ana = xa[0] * xa[0], anb = xb[0] * xb[0];  // kmeans.py:73, a full block's column: rows in sequence (0 + s0 = s0)
+#pragma unroll
+    for (int i = 1; i < kD; ++i) {
+        ana = ana + xa[i] * xa[i];
+        anb = anb + xb[i] * xb[i];
+    }
+    int opaque = 0;  // (keeps the first rows' loads and their splats inside the caller's loop: hoisted, they cost 20 registers)
+    asm volatile("" : "+v"(opaque));
+    const float4 *s4 = reinterpret_cast<const float4 *>(sC) + opaque;
+    float4 n0 = s4[0], n1 = s4[1];
+    lb[0] = lb[1] = lb[2] = lb[3] = 0;
+    bv[0] = bv[1] = bv[2] = bv[3] = -__builtin_inff();
+    const f32x2 zero = {0.f, 0.f};
+#pragma clang loop unroll(disable)
+    for (int j = 0; j < K; ++j) {
+        const float4 c0 = n0, c1 = n1;
+        n0 = s4[2 * j + 2];  // (row K: the table has kFMaxK + 1 rows)
+        n1 = s4[2 * j + 3];
+        const float cc[kD] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
+        f32x2 ya = zero, yb = zero;
+#pragma unroll
+        for (int i = 0; i < kD; ++i) {
+            const f32x2 c = {cc[i], cc[i]};
+            ya = __builtin_elementwise_fma(xa[i], c, ya);  // kmeans.py:71
+            yb = __builtin_elementwise_fma(xb[i], c, yb);
+        }
+        ya = ya * 2.0f;  // :72
+        yb = yb * 2.0f;
+        ya = ya - ana;   // :73
+        yb = yb - anb;
+        const f32x2 bn = {c1.z, c1.z};
+        ya = ya - bn;    // :74
+        yb = yb - bn;
+        const float y[4] = {ya.x, ya.y, yb.x, yb.y};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const bool take = y[p] > bv[p];
+            bv[p] = take ? y[p] : bv[p];
+            lb[p] = take ? j : lb[p];
+        }
+    }
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {  // fixed tree: the same bits for the same inputs
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = v + __shfl_xor(v, o);
+    return v;
+}
+
+#ifdef ET_EXP_RFSTAMP  // measurement build (tools/rfstamp.py): s_memrealtime at the phase boundaries of four workgroups
+__device__ unsigned long long g_rf_stamps[4 * 16];
+#define RF_STAMP(who, i)                                                                                           \
+    do {                                                                                                           \
+        if ((who) < 4 && threadIdx.x == 0 && blockIdx.y == 0) g_rf_stamps[(who) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+// slot `i` of row `who`: the latest time any workgroup passed here
+#define RF_STAMP_MAX(who, i)                                                                               \
+    do {                                                                                                   \
+        if (threadIdx.x == 0 && blockIdx.y == 0) atomicMax(&g_rf_stamps[(who) * 16 + (i)], __builtin_amdgcn_s_memrealtime()); \
+    } while (0)
+#else
+#define RF_STAMP_MAX(who, i) \
+    do {                     \
+    } while (0)
+#define RF_STAMP(who, i) \
+    do {                 \
+    } while (0)
+#endif
+
+// Levels 0 and 1 of the cascade for the chunks 0 .. n_all-1 of one group (n_all <= L), TR tiles (of 16 chunks) at a time:
+//   level 0  wavefront = coordinate, lane = chain (chunk, lane k); the chain's K (+ one dummy) accumulators are the LDS
+//            words [row][chain]; a step = read, add, write of the row its label names;
+//   level 1  work item (coordinate, cluster): adds the results of the chunks < n_l1 in chunk order (four lanes k side by
+//            side in one 16-byte read; the items walk skewed by (cluster mod 8) steps so that a wavefront's reads spread
+//            over all banks); the result of chunk n_l1 (if n_all > n_l1: the lane terms after the last full chunk) is
+//            handed back untouched in acc0.
+// load(tile, rb, lane, coordinate) -> the four values of steps 4 rb .. 4 rb + 3 of chain `lane` of `tile`; sLab: the same
+// steps' labels, one word per (tile, rb, chain); a label = K routes a term that does not exist to the dummy row.
+template <class Load>
+__device__ __forceinline__ void cascade_levels(Load load, const unsigned *sLab, float *sAcc, int K, int L, int TR, int n_all,
+                                               int n_l1, float4 &acc1, float4 &acc0) {
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int RB = L / 4, rows = K + 1, dk = kD * K;
+    const int tiles = (n_all + 15) >> 4;
+    const int ci = tid / K, cj = tid % K;
+    for (int q0 = 0; q0 < tiles; q0 += TR) {
+        const int tr = tiles - q0 < TR ? tiles - q0 : TR;
+        for (int ql = 0; ql < tr; ++ql) {
+            float *acc = sAcc + ((size_t)(ql * kD + wave) * rows) * 64 + lane;
+            for (int j = 0; j < rows; ++j) acc[j * 64] = 0.f;
+            const unsigned *lr = sLab + (q0 + ql) * RB * 64 + lane;
+            // the chain's values, four 16-byte loads (= 16 steps) in flight at a time: with one load per four steps the loop ran
+            // at the latency of its loads, not of its LDS updates (eight in flight cost the registers of a seventh wavefront)
+            for (int rb0 = 0; rb0 < RB; rb0 += 4) {
+                float4 xc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xc[u] = load(q0 + ql, rb0 + u, lane, wave);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 xv = xc[u];
+                    const unsigned l4 = lr[(rb0 + u) * 64];
+                    float *p0 = acc + (l4 & 255u) * 64;
+                    *p0 = *p0 + xv.x;
+                    float *p1 = acc + ((l4 >> 8) & 255u) * 64;
+                    *p1 = *p1 + xv.y;
+                    float *p2 = acc + ((l4 >> 16) & 255u) * 64;
+                    *p2 = *p2 + xv.z;
+                    float *p3 = acc + (l4 >> 24) * 64;
+                    *p3 = *p3 + xv.w;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < dk) {
+            const int nch = tr * 16, sk = cj & 7;
+            for (int s = 0; s < nch + 7; ++s) {
+                const int c = s - sk;
+                if (c >= 0 && c < nch) {
+                    const float4 v = *reinterpret_cast<const float4 *>(sAcc + ((size_t)((c >> 4) * kD + ci) * rows + cj) * 64 + (c & 15) * 4);
+                    const int cg = q0 * 16 + c;
+                    if (cg < n_l1) {
+                        acc1.x = acc1.x + v.x;
+                        acc1.y = acc1.y + v.y;
+                        acc1.z = acc1.z + v.z;
+                        acc1.w = acc1.w + v.w;
+                    } else if (cg == n_l1) {
+                        acc0 = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- one Lloyd iteration, first half: assignment + levels 0 and 1.  Workgroup g < G: group g; workgroup G: the tail ----
+__global__ __launch_bounds__(kFThreads, 7) void reforder_groups_kernel(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K, dk = kD * K;
+    unsigned char *ws = a.ws + (int64_t)blockIdx.y * a.ws_stride;
+    const et_kmeans_state *state = at<et_kmeans_state>(ws, a.lay.state);
+    // (the centroids are requested together with the flag: one round trip to memory, not two)
+    float cpre[kD];
+    {
+        const float *cen0 = at<float>(ws, a.lay.cen);
+#pragma unroll
+        for (int i = 0; i < kD; ++i) cpre[i] = cen0[i * K + (tid < K ? tid : 0)];
+    }
+    const int64_t done0 = state->done;
+    const double max_abs_x = state->max_abs_x;
+    if (done0) return;  // the whole batch stopped in an earlier launch (kmeans.py:239), or bad input was flagged
+    const float *X = a.X + (int64_t)blockIdx.y * a.x_stride;
+    const Geo &geo = a.geo;
+    const int lp = geo.lp;
+    const int L = 1 << lp, L2 = L * L, RB = L / 4;
+    const int64_t N = geo.N;
+    unsigned *cnt = at<unsigned>(ws, a.lay.cnt);
+    float4 *S1 = at<float4>(ws, a.lay.S1);
+    float4 *T = at<float4>(ws, a.lay.T);
+    double *Sin = at<double>(ws, a.lay.Sin);
+    const float4 *XT4 = at<const float4>(ws, a.lay.XT);
+    unsigned *LT32 = at<unsigned>(ws, a.lay.LT);
+    uint8_t *tail_lab = at<uint8_t>(ws, a.lay.tail);
+
+    __shared__ __attribute__((aligned(16))) float sC[(kFMaxK + 1) * 8];  // (+ a row the arg-max loop's last prefetch may read)
+    __shared__ unsigned sCnt[kFMaxK];
+    __shared__ double sWsum[8];
+    const int TR = a.tiles_per_round;
+    float *sAcc = reinterpret_cast<float *>(smem);                                          // [tile in round][coordinate][row][64 chains]
+    unsigned *sLab = reinterpret_cast<unsigned *>(sAcc + (size_t)TR * kD * (K + 1) * 64);   // a group's labels, one word per quad
+    const int64_t gidx = blockIdx.x;
+    const bool is_tail = gidx == geo.G;
+    [[maybe_unused]] const int who = is_tail ? 1 : (gidx == 0 ? 0 : 9);
+    RF_STAMP(who, 0);
+
+    // ---- prologue: centroid rows with |c_j|^2 in ATen's order for column j of K (kmeans.py:74), NaN / overflow test ----
+    int bad = 0;
+    if (tid < K) {
+        float sq[kMaxD];
+#pragma unroll
+        for (int i = 0; i < kD; ++i) {
+            const float v = cpre[i];
+            sC[tid * 8 + i] = v;
+            sq[i] = v * v;
+            bad |= !(fabsf(v) < 1e18f);
+        }
+        sC[tid * 8 + 6] = sqnorm_at(sq, kD, tid, K);
+        sC[tid * 8 + 7] = 0.f;
+    }
+    if (tid < kFMaxK) sCnt[tid] = 0u;
+    const bool nans = __syncthreads_or(bad) != 0 || !(max_abs_x < 1e18);
+    double sim = 0.0;
+    float4 acc1 = make_float4(0.f, 0.f, 0.f, 0.f), acc0 = acc1;
+    RF_STAMP(who, 1);
+
+    if (!is_tail) {
+        // ---- assignment of the group's 4 L^2 points (kmeans.py:143-158): a quad = four consecutive steps of one chain ----
+        const float4 *x4 = XT4 + gidx * kD * L2;
+        for (int qi = tid; qi < L2; qi += kFThreads) {
+            float4 xv[kD];
+#pragma unroll
+            for (int i = 0; i < kD; ++i) xv[i] = x4[i * L2 + qi];
+            int lb[4];
+            float bv[4];
+            if (!nans) {
+                quad_best(xv, sC, K, lb, bv);
+            } else {  // (an empty cluster's NaN centroid, or magnitudes near the fp32 range: torch.max's NaN rule, point by point)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float x[1][kD], an[1], b1[1];
+                    int l1[1];
+#pragma unroll
+                    for (int i = 0; i < kD; ++i) x[0][i] = p == 0 ? xv[i].x : (p == 1 ? xv[i].y : (p == 2 ? xv[i].z : xv[i].w));
+                    float sacc = x[0][0] * x[0][0];
+#pragma unroll
+                    for (int i = 1; i < kD; ++i) sacc = sacc + x[0][i] * x[0][i];
+                    an[0] = sacc;
+                    points_best<true, 1>(x, an, sC, K, l1, b1);
+                    lb[p] = l1[0];
+                    bv[p] = b1[0];
+                }
+            }
+            const unsigned packed = (unsigned)lb[0] | ((unsigned)lb[1] << 8) | ((unsigned)lb[2] << 16) | ((unsigned)lb[3] << 24);
+            sLab[qi] = packed;
+            LT32[gidx * L2 + qi] = packed;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                atomicAdd(&sCnt[lb[p]], 1u);
+                sim = sim + (double)bv[p];
+            }
+        }
+        __syncthreads();
+        RF_STAMP(who, 2);
+        RF_STAMP_MAX(0, 8);
+        cascade_levels([&](int q, int rb, int ln, int i) { return x4[i * L2 + (q * RB + rb) * 64 + ln]; }, sLab, sAcc, K, L, TR, L, L,
+                       acc1, acc0);
+        if (tid < dk) S1[gidx * dk + tid] = acc1;
+        RF_STAMP(who, 3);
+        RF_STAMP_MAX(0, 9);
+    } else {
+        // ---- the tail: the points tail0 .. N-1 where they lie in X -- the chunks of the partial group (level 1 of their
+        //      level-0 sums -> T[0 .. d K)), the lane terms after the last full chunk (level 0 -> T[d K ..)), and the
+        //      N mod 4 points after the lanes' ranges (their labels -> T[2 d K]) ----
+        const int64_t tail0 = geo.tail0, size = N / 4;
+        const int nt = (int)(N - tail0);
+        const int pc = (int)(geo.full_chunks - geo.G * L);    // full chunks of the partial group (< L)
+        const int rem = (int)(size - geo.full_chunks * L);    // lane terms after them (< L)
+        const int n_all = pc + (rem > 0 ? 1 : 0);
+        uint8_t *sTail = reinterpret_cast<uint8_t *>(sLab + L2);
+        for (int m0 = 2 * tid; m0 < nt; m0 += 2 * kFThreads) {  // two points per thread side by side
+            float x[2][kD], an[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int64_t n = tail0 + (m0 + p < nt ? m0 + p : m0);
+                float sq[kMaxD];
+#pragma unroll
+                for (int i = 0; i < kD; ++i) {
+                    x[p][i] = X[(int64_t)i * N + n];
+                    sq[i] = x[p][i] * x[p][i];
+                }
+                an[p] = sqnorm_at(sq, kD, n, N);  // the last N mod 32 columns take the 4-lane order
+            }
+            int lb[2];
+            float bv[2];
+            if (nans) points_best<true, 2>(x, an, sC, K, lb, bv);
+            else points_best<false, 2>(x, an, sC, K, lb, bv);
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                if (m0 + p < nt) {
+                    sTail[m0 + p] = (uint8_t)lb[p];
+                    tail_lab[m0 + p] = (uint8_t)lb[p];
+                    atomicAdd(&sCnt[lb[p]], 1u);
+                    sim = sim + (double)bv[p];
+                }
+        }
+        __syncthreads();
+        RF_STAMP(who, 2);
+        // the label words of the chains' steps; a step past the lane's range gets the dummy row
+        const int tiles = (n_all + 15) >> 4;
+        for (int w = tid; w < tiles * RB * 64; w += kFThreads) {
+            const int t = w & 63, rb = (w >> 6) % RB, q = (w >> 6) / RB;
+            const int c = q * 16 + (t >> 2), k = t & 3;
+            unsigned word = 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = 4 * rb + u;
+                const bool real = c < pc || (c == pc && r < rem);
+                const unsigned lb = real ? (unsigned)sTail[4 * (c * L + r) + k] : (unsigned)K;
+                word |= lb << (8 * u);
+            }
+            sLab[w] = word;
+        }
+        __syncthreads();
+        const int64_t lim = N - tail0;
+        cascade_levels(
+            [&](int q, int rb, int ln, int i) {
+                const float *x = X + (int64_t)i * N + tail0;
+                const int64_t m0 = 4 * ((int64_t)(q * 16 + (ln >> 2)) * L + 4 * rb) + (ln & 3);
+                float4 v;
+                v.x = m0 < lim ? x[m0] : 0.f;
+                v.y = m0 + 4 < lim ? x[m0 + 4] : 0.f;
+                v.z = m0 + 8 < lim ? x[m0 + 8] : 0.f;
+                v.w = m0 + 12 < lim ? x[m0 + 12] : 0.f;
+                return v;
+            },
+            sLab, sAcc, K, L, TR, n_all, pc, acc1, acc0);
+        if (tid < dk) {
+            T[tid] = acc1;
+            T[dk + tid] = acc0;
+        }
+        if (tid == 0) {  // labels of the N mod 4 leftover points, for the workgroup that combines the lanes
+            unsigned lw = 0u;
+            for (int64_t n = size * 4; n < N; ++n) lw |= (unsigned)sTail[n - tail0] << (8 * (int)(n & 3));
+            T[2 * dk] = make_float4(__uint_as_float(lw), 0.f, 0.f, 0.f);
+        }
+        RF_STAMP(who, 3);
+    }
+    // ---- this workgroup's counts and similarity sum (read by the next kernel) ----
+    sim = wave_sum_f64(sim);
+    if (lane == 0) sWsum[wave] = sim;
+    __syncthreads();
+    if (tid < kFMaxK) cnt[gidx * kFMaxK + tid] = sCnt[tid];
+    if (tid == 0) {
+        double s = sWsum[0];
+        for (int w = 1; w < kFThreads / 64; ++w) s = s + sWsum[w];
+        Sin[gidx] = s;
+    }
+    RF_STAMP(who, 4);
+    RF_STAMP_MAX(0, 10);
+}
+
+// ATen's inner (contiguous) sum (inner_sum_f32) of v[0..size) in LDS, its 32 (vector lane, slot) cascades side by side;
+// scratch: 40 floats of LDS.  Called by a whole workgroup (>= 64 threads); the result is returned to every thread.
+__device__ __forceinline__ float inner_sum_parallel(const float *v, int size, float *scratch) {
+    const int tid = (int)threadIdx.x;
+    if (size < 8) {
+        if (tid == 0) scratch[0] = row_sum_f32(v, size);
+        __syncthreads();
+        const float r = scratch[0];
+        __syncthreads();
+        return r;
+    }
+    const int nv = size / 8, s4 = nv / 4;
+    if (tid < 32) scratch[tid] = cascade_f32(v + 8 * (tid >> 3) + (tid & 7), 32, s4);  // slot k = tid / 8 of lane l = tid % 8
+    __syncthreads();
+    if (tid < 8) {
+        float s = scratch[tid];
+        for (int i = s4 * 4; i < nv; ++i) s = s + v[8 * i + tid];
+        for (int k = 1; k < 4; ++k) s = s + scratch[8 * k + tid];
+        scratch[32 + tid] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float acc = 0.f;
+        for (int i = nv * 8; i < size; ++i) acc = acc + v[i];
+        for (int l = 0; l < 8; ++l) acc = acc + scratch[32 + l];
+        scratch[0] = acc;
+    }
+    __syncthreads();
+    const float r = scratch[0];
+    __syncthreads();
+    return r;
+}
+
+// ---- second half: level 2 (workgroup b: block b, its groups' results in group order); the workgroup that arrives last:
+//      level 3, the leftovers, the lane combination, the new centroids (kmeans.py:180-182); the last one of the batch: the
+//      error over the whole (l, d, K) tensor in ATen's order (kmeans.py:45-51, 232), the stop flag, the next launch's
+//      counters.  Rows travel memory -> LDS with every load of a pass in flight at once. ----
+__global__ __launch_bounds__(kUThreads) void reforder_update_kernel2(const Args a, int rows_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K, dk = kD * K;
+    unsigned char *ws = a.ws + (int64_t)blockIdx.y * a.ws_stride;
+    et_kmeans_state *state = at<et_kmeans_state>(ws, a.lay.state);
+    if (state->done) {
+        if (a.mail && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)  // (the host stops launching when it reads this)
+            __hip_atomic_store(a.mail, (1ull << 63) | (unsigned long long)state->iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    const float *X = a.X + (int64_t)blockIdx.y * a.x_stride;
+    const Geo &geo = a.geo;
+    const int lp = geo.lp, L = 1 << lp;
+    const int64_t N = geo.N;
+    float *cen = at<float>(ws, a.lay.cen);
+    unsigned *arrive = at<unsigned>(ws, a.lay.arrive);
+    const float4 *S1 = at<const float4>(ws, a.lay.S1);
+    float4 *S2 = at<float4>(ws, a.lay.S2);
+    const float4 *T = at<const float4>(ws, a.lay.T);
+    const double *Sin = at<const double>(ws, a.lay.Sin);
+    __shared__ double sWsum[8];
+    __shared__ int sFlag[2];
+    __shared__ float sScr[40];
+    float4 *sRows = reinterpret_cast<float4 *>(smem);
+    [[maybe_unused]] const int who = blockIdx.x == 0 ? 2 : 9;
+    RF_STAMP(who, 0);
+
+    // ---- level 2 ----
+    const int blk = (int)blockIdx.x;
+    const int64_t g0 = (int64_t)blk << lp;
+    const int ng = (int)((geo.G - g0) < L ? (geo.G - g0) : L);
+    float4 a2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int rowlen = dk + kFMaxK / 4;  // float4 per row of S2: the sums, then the block's points per cluster (bit patterns)
+    uint4 c2 = make_uint4(0u, 0u, 0u, 0u);
+    const uint4 *cnt4 = at<const uint4>(ws, a.lay.cnt);  // rows of kFMaxK counts = kFMaxK / 4 words of 16 bytes
+    for (int r0 = 0; r0 < ng; r0 += rows_cap) {
+        const int nr = ng - r0 < rows_cap ? ng - r0 : rows_cap;
+        const float4 *src = S1 + (g0 + r0) * dk;
+        const uint4 *csrc = cnt4 + (g0 + r0) * (kFMaxK / 4);
+        for (int r8 = 0; r8 < nr; r8 += 16) {  // sixteen rows' loads in flight per thread: thread = column, rows in sequence
+            if (tid < rowlen) {
+                float4 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int r = r8 + u < nr ? r8 + u : r8;
+                    v[u] = tid < dk ? src[r * dk + tid] : __builtin_bit_cast(float4, csrc[r * (kFMaxK / 4) + (tid - dk)]);
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (r8 + u < nr) sRows[(r8 + u) * rowlen + tid] = v[u];
+            }
+        }
+        __syncthreads();
+        if (tid < dk) {
+            for (int g = 0; g < nr; ++g) {
+                const float4 v = sRows[g * rowlen + tid];
+                a2.x = a2.x + v.x;
+                a2.y = a2.y + v.y;
+                a2.z = a2.z + v.z;
+                a2.w = a2.w + v.w;
+            }
+        } else if (tid < rowlen) {  // (integers: any order)
+            for (int g = 0; g < nr; ++g) {
+                const uint4 v = __builtin_bit_cast(uint4, sRows[g * rowlen + tid]);
+                c2.x += v.x;
+                c2.y += v.y;
+                c2.z += v.z;
+                c2.w += v.w;
+            }
+        }
+        __syncthreads();
+    }
+    const __amdgpu_buffer_rsrc_t rS2 = rsrc_of(S2, (int64_t)sizeof(float4) * (geo.n_blk + 1) * rowlen);
+    if (tid < dk) st16_sc1(rS2, (unsigned)(((int64_t)blk * rowlen + tid) * sizeof(float4)), a2);
+    if (tid >= dk && tid < rowlen) {
+        if (blk == 0) {  // block 0 takes the tail's counts along
+            const uint4 v = cnt4[geo.G * (kFMaxK / 4) + (tid - dk)];
+            c2.x += v.x;
+            c2.y += v.y;
+            c2.z += v.z;
+            c2.w += v.w;
+        }
+        st16_sc1(rS2, (unsigned)(((int64_t)blk * rowlen + tid) * sizeof(float4)), __builtin_bit_cast(float4, c2));
+    }
+    RF_STAMP(who, 1);
+    // ---- arrival: the stores have been performed at the memory side ----
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) sFlag[0] = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)geo.n_blk - 1u;
+    __syncthreads();
+    RF_STAMP(who, 2);
+    if (!sFlag[0]) return;
+
+    // ---- last workgroup of this problem: level 3 over the complete blocks, in block order ----
+    RF_STAMP(3, 0);
+    float4 a3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned ctot[4] = {0u, 0u, 0u, 0u};
+    __shared__ unsigned sCntTot[kFMaxK];
+    for (int r0 = 0; r0 < geo.full_blk; r0 += rows_cap) {
+        const int nr = geo.full_blk - r0 < rows_cap ? geo.full_blk - r0 : rows_cap;
+        const unsigned base = (unsigned)((int64_t)r0 * rowlen * sizeof(float4));
+        for (int e0 = 0; e0 < nr * rowlen; e0 += 16 * kUThreads) {  // sixteen 16-byte loads per lane in flight
+            float4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = e0 + u * kUThreads + tid;
+                v[u] = ld16_sc1(rS2, base + (unsigned)((e < nr * rowlen ? e : 0) * sizeof(float4)));
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = e0 + u * kUThreads + tid;
+                if (e < nr * rowlen) sRows[e] = v[u];
+            }
+        }
+        __syncthreads();
+        if (tid < dk) {
+            for (int b = 0; b < nr; ++b) {
+                const float4 v = sRows[b * rowlen + tid];
+                a3.x = a3.x + v.x;
+                a3.y = a3.y + v.y;
+                a3.z = a3.z + v.z;
+                a3.w = a3.w + v.w;
+            }
+        } else if (tid < rowlen) {
+            for (int b = 0; b < nr; ++b) {
+                const float4 v = sRows[b * rowlen + tid];
+                ctot[0] += __float_as_uint(v.x);
+                ctot[1] += __float_as_uint(v.y);
+                ctot[2] += __float_as_uint(v.z);
+                ctot[3] += __float_as_uint(v.w);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid >= dk && tid < rowlen) {
+        if (geo.n_blk > geo.full_blk) {
+            const float4 v = ld16_sc1(rS2, (unsigned)(((int64_t)geo.full_blk * rowlen + tid) * sizeof(float4)));
+            ctot[0] += __float_as_uint(v.x);
+            ctot[1] += __float_as_uint(v.y);
+            ctot[2] += __float_as_uint(v.z);
+            ctot[3] += __float_as_uint(v.w);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sCntTot[4 * (tid - dk) + u] = ctot[u];
+    }
+    // the inertia of this assignment (kmeans.py:234; only printed by the reference): fp64, a fixed order
+    double part = 0.0;
+    for (int64_t gb = 0; gb <= geo.G; gb += 8 * kUThreads) {  // eight loads in flight; a fixed order per thread
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t g = gb + (int64_t)u * kUThreads + tid;
+            v[u] = Sin[g <= geo.G ? g : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (gb + (int64_t)u * kUThreads + tid <= geo.G) part = part + v[u];
+    }
+    part = wave_sum_f64(part);
+    if (lane == 0) sWsum[wave] = part;
+    float *sq_mine = a.sq_all + (int64_t)blockIdx.y * dk;
+    float *sSq = reinterpret_cast<float *>(smem);
+    __syncthreads();  // sCntTot, sWsum
+    if (tid < dk) {
+        const int j = tid % K;
+        const float *x = X + (int64_t)(tid / K) * N;
+        const float4 p2 = geo.n_blk > geo.full_blk ? ld16_sc1(rS2, (unsigned)(((int64_t)geo.full_blk * rowlen + tid) * sizeof(float4)))
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 p1 = T[tid], p0 = T[dk + tid];
+        const unsigned lw = __float_as_uint(T[2 * dk].x);
+        float p = ((p0.x + p1.x) + p2.x) + a3.x;
+        // the N mod 4 terms after the lanes' ranges go onto lane 0 (their labels: one word from the tail's workgroup)
+        for (int64_t n = N / 4 * 4; n < N; ++n)
+            if (((lw >> (8 * (int)(n & 3))) & 255u) == (unsigned)j) p = p + x[n];
+        p = p + (((p0.y + p1.y) + p2.y) + a3.y);
+        p = p + (((p0.z + p1.z) + p2.z) + a3.z);
+        p = p + (((p0.w + p1.w) + p2.w) + a3.w);
+        const float c = p / (float)sCntTot[j];  // 0/0 = NaN for an empty cluster (kmeans.py:182)
+        const float diff = cen[tid] - c;
+        cen[tid] = c;
+        if (a.batch > 1) __hip_atomic_store(&sq_mine[tid], diff * diff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else sSq[tid] = diff * diff;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double s = sWsum[0];
+        for (int w = 1; w < kUThreads / 64; ++w) s = s + sWsum[w];
+        __hip_atomic_store(&state->inertia, (double)(float)(-(s / (double)N)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    RF_STAMP(3, 1);
+    if (a.batch > 1) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0)
+            sFlag[1] = __hip_atomic_fetch_add(a.batch_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)a.batch - 1u;
+        __syncthreads();
+        if (!sFlag[1]) return;
+        const int tot = a.batch * dk;
+        for (int e = tid; e < tot; e += kUThreads) sSq[e] = __hip_atomic_load(&a.sq_all[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+    }
+    RF_STAMP(3, 2);
+    const float error = inner_sum_parallel(sSq, a.batch * dk, sScr);
+    const int done = (error <= a.tol) ? 1 : 0;
+    RF_STAMP(3, 3);
+    for (int b = tid; b < a.batch; b += kUThreads) {
+        et_kmeans_state *st = at<et_kmeans_state>(a.ws + (int64_t)b * a.ws_stride, a.lay.state);
+        const int64_t it = st->iter;
+        const double ine = __hip_atomic_load(&st->inertia, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.trace) {
+            float *tr = a.trace + ((int64_t)b * a.max_iter + it) * 2;
+            tr[0] = error;
+            tr[1] = (float)ine;
+        }
+        st->error = (double)error;
+        st->iter = it + 1;
+        st->done = done;
+        if (b == 0 && a.mail)
+            __hip_atomic_store(a.mail, ((unsigned long long)(done != 0) << 63) | (unsigned long long)(it + 1), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    for (int b = 0; b < a.batch; ++b) {
+        unsigned char *wb = a.ws + (int64_t)b * a.ws_stride;
+        if (tid == 0) at<unsigned>(wb, a.lay.arrive)[0] = 0u;
+    }
+    if (tid == 0) *a.batch_arrive = 0u;
+    RF_STAMP(3, 4);
+}
+
+// before the loop: state, working centroids, counters
+__global__ __launch_bounds__(kThreads) void reforder_fast_prepare_kernel(const Args a, const float *__restrict__ cen_in) {
+    unsigned char *ws = a.ws + (int64_t)blockIdx.x * a.ws_stride;
+    const int dk = kD * a.K;
+    et_kmeans_state *st = at<et_kmeans_state>(ws, a.lay.state);
+    if (threadIdx.x == 0) {  // (max_abs_x / bad_input stay as the scan left them)
+        st->n_total = a.geo.N;
+        st->iter = 0;
+        st->done = st->bad_input ? 1 : 0;
+        st->error = 0.0;
+        st->inertia = 0.0;
+    }
+    for (int e = threadIdx.x; e < dk; e += blockDim.x) at<float>(ws, a.lay.cen)[e] = cen_in[(int64_t)blockIdx.x * dk + e];
+    if (threadIdx.x == 0) at<unsigned>(ws, a.lay.arrive)[0] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.batch_arrive = 0u;
+}
+
+// after the loop: labels in the caller's order (int64), centroids
+__global__ __launch_bounds__(kThreads) void reforder_fast_finish_kernel(const Args a, float *__restrict__ cen_out,
+                                                                        int64_t *__restrict__ labels) {
+    unsigned char *ws = a.ws + (int64_t)blockIdx.y * a.ws_stride;
+    const int dk = kD * a.K;
+    const Geo &geo = a.geo;
+    const int lp = geo.lp;
+    const int64_t L = (int64_t)1 << lp, L2 = L * L, N = geo.N;
+    if (blockIdx.x == 0)
+        for (int e = threadIdx.x; e < dk; e += blockDim.x) cen_out[(int64_t)blockIdx.y * dk + e] = at<float>(ws, a.lay.cen)[e];
+    if (!labels) return;
+    const uint8_t *LT = at<const uint8_t>(ws, a.lay.LT), *tl = at<const uint8_t>(ws, a.lay.tail);
+    int64_t *out = labels + (int64_t)blockIdx.y * N;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        uint8_t v;
+        if (n >= geo.tail0) {
+            v = tl[n - geo.tail0];
+        } else {
+            const int64_t g = n / (4 * L2), m = n % (4 * L2);
+            const int64_t k = m & 3, lt = m >> 2, c = lt >> lp, r = lt & (L - 1);
+            const int64_t q = c >> 4, t = (c & 15) * 4 + k, rb = r >> 2, u = r & 3;
+            v = LT[(g * L2 + (q * (L / 4) + rb) * 64 + t) * 4 + u];
+        }
+        out[n] = (int64_t)v;
+    }
+}
+
+static bool fast_shape(int64_t N, int d, int K) {
+    if (d != kD || K < 1 || K > kFMaxK || N < 1024 || N >= ((int64_t)1 << 29)) return false;
+    const Geo g = make_geo(N);
+    return g.lp <= kFMaxLp && g.G >= 1;
+}
+// level-0 tiles (16 chunks) whose accumulators are in LDS at a time: ONE -- at L = 32 two tiles (73 KB, two workgroups per
+// CU) took 123 us per iteration at 1e7 points against 111 us with one (38 KB, four per CU), same box
+static int fast_tiles_per_round(const Geo &) { return 1; }
+static size_t fast_lds_bytes(const Geo &g, int K, int TR) {
+    const int L = 1 << g.lp;
+    // level-0 accumulators (K rows + a dummy one), a group's label words, the tail's label bytes
+    const size_t body = sizeof(float) * (size_t)TR * kD * (K + 1) * 64 + sizeof(unsigned) * (size_t)L * L + (size_t)(4 * L * L + 4 * L + 16);
+    return (body + 15) / 16 * 16;
+}
+// rows of d K float4 the update kernel stages at a time, and its dynamic LDS
+static int update_rows_cap(const Geo &g, int K, int batch, size_t *lds) {
+    const size_t row = sizeof(float4) * ((size_t)kD * K + kFMaxK / 4);
+    const int L = 1 << g.lp;
+    int want = g.full_blk > L ? g.full_blk : L;
+    if ((size_t)want * row > kUMaxLds) want = (int)(kUMaxLds / row);
+    size_t bytes = (size_t)want * row;
+    const size_t sq = sizeof(float) * (size_t)batch * kD * K;
+    if (sq > bytes) bytes = sq;
+    *lds = (bytes + 15) / 16 * 16;
+    return want;
+}
+
+#ifdef ET_EXP_RFSTAMP
+extern "C" int et_debug_rfstamps(unsigned long long *host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rf_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : 3;
+}
+#endif
+
+}  // namespace fast
+
 }  // namespace reforder
 }  // namespace et
 
 using namespace et::reforder;
 
+static size_t fast_workspace_bytes(int64_t N, int K, int64_t batch) {
+    const fast::Geo g = fast::make_geo(N);
+    return fast::shared_bytes(K, batch) + (size_t)batch * fast::make_layout(g, K).bytes;
+}
+
 extern "C" size_t et_kmeans_reforder_workspace_bytes(int64_t N, int d, int K) {
     if (!dims_ok(d, K) || N < 0) return 0;
-    return carve(nullptr, N, d, K).bytes;
+    const size_t generic = carve(nullptr, N, d, K).bytes;
+    const size_t quick = fast::fast_shape(N, d, K) ? fast_workspace_bytes(N, K, 1) : 0;
+    return generic > quick ? generic : quick;
+}
+
+extern "C" size_t et_kmeans_reforder_batch_workspace_bytes(int64_t N, int d, int K, int64_t batch) {
+    if (!dims_ok(d, K) || N < 0 || batch < 1) return 0;
+    if (batch == 1) return et_kmeans_reforder_workspace_bytes(N, d, K);
+    if (!fast::fast_shape(N, d, K) || batch > fast::kFMaxBatch) return 0;
+    return fast_workspace_bytes(N, K, batch);
+}
+
+// the fast form (see namespace fast): all `batch` problems in one loop of one launch per iteration, joint stop
+static int fast_fit(const float *X, int64_t x_stride, int64_t N, int K, int64_t batch, int max_iter, float tol, float *centroids,
+                    int64_t *labels, float *trace, et_kmeans_state *states_host, et_kmeans_timing *timing_host, void *workspace,
+                    hipStream_t st) {
+    using namespace fast;
+    Args a;
+    a.geo = make_geo(N);
+    a.lay = make_layout(a.geo, K);
+    unsigned char *base = (unsigned char *)workspace;
+    a.batch_arrive = (unsigned *)base;
+    a.sq_all = (float *)(base + 256);
+    a.ws = base + shared_bytes(K, batch);
+    a.ws_stride = (int64_t)a.lay.bytes;
+    a.X = X;
+    a.x_stride = x_stride;
+    a.K = K;
+    a.batch = (int)batch;
+    a.tol = tol;
+    a.trace = trace;
+    a.max_iter = max_iter;
+    a.mail = nullptr;
+    int rc = ET_OK;
+    et::StateRing *ring = et::StateRing::get(&rc);
+    if (!ring) return rc;
+    a.mail = ring->mailbox_device();
+    if (a.mail) ring->mailbox_reset();
+    a.tiles_per_round = fast_tiles_per_round(a.geo);
+    const size_t lds = fast_lds_bytes(a.geo, K, a.tiles_per_round);
+    size_t ulds = 0;
+    const int rows_cap = update_rows_cap(a.geo, K, (int)batch, &ulds);
+    {
+        static bool lds_set[64] = {};
+        int dev_id = 0;
+        ET_HIP_TRY(hipGetDevice(&dev_id));
+        if (!lds_set[dev_id & 63]) {
+            ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(reforder_groups_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(reforder_update_kernel2),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUMaxLds));
+            lds_set[dev_id & 63] = true;
+        }
+    }
+    for (int64_t b = 0; b < batch; ++b) {
+        rc = et_kmeans_scan(X + b * x_stride, N, kD, (et_kmeans_state *)(a.ws + b * a.ws_stride + a.lay.state), (et_stream_t)st);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(reforder_fast_prepare_kernel, dim3((unsigned)batch), dim3(kThreads), 0, st, a, (const float *)centroids);
+    {
+        const int64_t quads = a.geo.G << (2 * a.geo.lp);
+        const int pg = (int)std::min<int64_t>((quads + kThreads - 1) / kThreads, 2048);
+        hipLaunchKernelGGL(reforder_permute_kernel, dim3(pg, (unsigned)batch), dim3(kThreads), 0, st, X, x_stride, a.ws,
+                           a.ws_stride, a.lay.XT, a.geo);
+    }
+    ET_LAUNCH_CHECK();
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    if (timing_host) {
+        ET_HIP_TRY(hipEventCreate(&ev[0]));
+        ET_HIP_TRY(hipEventCreate(&ev[1]));
+        ET_HIP_TRY(hipEventRecord(ev[0], st));
+    }
+    constexpr int kAhead = 16, kEvery = 4;
+    et_kmeans_state *state0 = (et_kmeans_state *)(a.ws + a.lay.state);
+    int launched = 0;
+    bool done = false;
+    const dim3 grid((unsigned)(a.geo.G + 1), (unsigned)batch), ugrid((unsigned)a.geo.n_blk, (unsigned)batch);
+    for (int it = 0; it < max_iter && !done; ++it) {
+        hipLaunchKernelGGL(reforder_groups_kernel, grid, dim3(kFThreads), lds, st, a);
+        hipLaunchKernelGGL(reforder_update_kernel2, ugrid, dim3(kUThreads), ulds, st, a, rows_cap);
+        ET_LAUNCH_CHECK();
+        launched = it + 1;
+        if (a.mail) {  // stay at most kAhead launches ahead of the device's report; stop when it carries the flag
+            for (unsigned spins = 0;; ++spins) {
+                if (ring->mailbox_done()) {
+                    done = true;
+                    break;
+                }
+                if ((long long)launched - ring->mailbox_iter() <= kAhead) break;
+                if ((spins & 0xfffu) == 0xfffu && hipStreamQuery(st) == hipSuccess) break;
+                sched_yield();
+            }
+        } else {
+            if (launched % kEvery == 0) {
+                rc = ring->post(state0, st, &done);
+                if (rc) return rc;
+            }
+            ring->poll(&done);
+        }
+    }
+    if (timing_host) ET_HIP_TRY(hipEventRecord(ev[1], st));
+    const int64_t fgrid = std::min<int64_t>((N + kThreads - 1) / kThreads, 2048);
+    hipLaunchKernelGGL(reforder_fast_finish_kernel, dim3((unsigned)fgrid, (unsigned)batch), dim3(kThreads), 0, st, a, centroids,
+                       labels);
+    ET_LAUNCH_CHECK();
+    for (int64_t b = 0; b < batch; ++b)
+        ET_HIP_TRY(hipMemcpyAsync(&states_host[b], a.ws + b * a.ws_stride + a.lay.state, sizeof(et_kmeans_state),
+                                  hipMemcpyDeviceToHost, st));
+    ET_HIP_TRY(hipStreamSynchronize(st));
+    if (timing_host) {
+        float ms = 0.f;
+        ET_HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
+        timing_host->assign_ms = ms;
+        timing_host->assign_launches = launched;
+        timing_host->first_assign_ms = 0.0;
+        timing_host->iterations = states_host[0].iter;
+        (void)hipEventDestroy(ev[0]);
+        (void)hipEventDestroy(ev[1]);
+    }
+    for (int64_t b = 0; b < batch; ++b)
+        if (states_host[b].bad_input) return ET_ERR_BAD_DATA;
+    return ET_OK;
 }
 
 extern "C" int et_euc_sim_reforder(const float *a, const float *b, int d, int64_t m, int64_t n, float *y,
@@ -487,6 +1502,8 @@ extern "C" int et_kmeans_fit_reforder(const float *X, int64_t N, int d, int K, i
                                       size_t workspace_bytes, et_stream_t stream) {
     if (!dims_ok(d, K) || N < 1 || !X || !centroids || !state_host || max_iter < 1) return ET_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < et_kmeans_reforder_workspace_bytes(N, d, K)) return ET_ERR_WORKSPACE;
+    if (fast::fast_shape(N, d, K))
+        return fast_fit(X, 0, N, K, 1, max_iter, tol, centroids, labels, trace, state_host, nullptr, workspace, (hipStream_t)stream);
     const Workspace w = carve(workspace, N, d, K);
     hipStream_t st = (hipStream_t)stream;
     // non-finite input: reported like et_kmeans_fit does (the reference would propagate NaN)
@@ -526,4 +1543,21 @@ extern "C" int et_kmeans_fit_reforder(const float *X, int64_t N, int d, int K, i
         ET_HIP_TRY(hipStreamSynchronize(st));
     }
     return ET_OK;
+}
+
+/* kmeans.py:228-240 for `batch` problems in ONE loop, stopped TOGETHER on the error summed over the whole (l, d, K) tensor in
+ * ATen's order; d = 6, K <= 32, 1024 <= N < 2^29, batch <= 64 (batch = 1: any shape, like et_kmeans_fit_reforder). */
+extern "C" int et_kmeans_fit_reforder_batch(const float *X, int64_t x_stride, int64_t N, int d, int K, int64_t batch,
+                                            int max_iter, float tol, float *centroids, int64_t *labels, float *trace,
+                                            et_kmeans_state *states_host, et_kmeans_timing *timing_host, void *workspace,
+                                            size_t workspace_bytes, et_stream_t stream) {
+    if (!dims_ok(d, K) || N < 1 || batch < 1 || !X || !centroids || !states_host || max_iter < 1) return ET_ERR_INVALID_ARG;
+    const size_t need = et_kmeans_reforder_batch_workspace_bytes(N, d, K, batch);
+    if (need == 0) return ET_ERR_INVALID_ARG;  // a batch of a shape the fast form does not take
+    if (!workspace || workspace_bytes < need) return ET_ERR_WORKSPACE;
+    if (fast::fast_shape(N, d, K))
+        return fast_fit(X, x_stride, N, K, batch, max_iter, tol, centroids, labels, trace, states_host, timing_host, workspace,
+                        (hipStream_t)stream);
+    return et_kmeans_fit_reforder(X, N, d, K, max_iter, tol, centroids, labels, trace, states_host, workspace, workspace_bytes,
+                                  stream);
 }

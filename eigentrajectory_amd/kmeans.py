@@ -202,11 +202,8 @@ class BatchKMeans(nn.Module):
         the device and sets every problem's convergence flag; the host looks at the flag a few iterations late (the
         steps enqueued meanwhile are no-ops)."""
         n_b = data.shape[0]
-        if self.sums == "reference-order":
-            if n_b != 1:
-                raise NotImplementedError("sums='reference-order' takes one problem (l = 1): the joint error of a batch is "
-                                          "one fp32 sum over all problems' centroids in the reference")
-            return [ops.kmeans_fit_reference_order(data[0], centroids[0], self.max_iter, self.tol, trace=self.verbose)]
+        if self.sums == "reference-order":  # one loop for the whole batch, joint stop in ATen's order (csrc/et_kmeans_reforder.hip)
+            return ops.kmeans_fit_reference_order_batch(data, centroids, self.max_iter, self.tol, trace=self.verbose)
         if n_b == 1:
             return [ops.kmeans_fit(data[0], centroids[0], self.max_iter, self.tol, trace=self.verbose)]
         dev = ops.L.require_device(data)

@@ -431,23 +431,45 @@ def kmeans_predict_reference_order(X, centroids):
     return labels, maxsims
 
 
-def kmeans_fit_reference_order(X, centroids, max_iter=100, tol=1e-4, trace=True):
-    """kmeans.py:228-240 with the cluster sums, norms and error in the reference's fp32 orders (single GPU, one problem).
-    Same return dict as :func:`kmeans_fit`."""
+def kmeans_fit_reference_order(X, centroids, max_iter=100, tol=1e-4, trace=True, timing=False):
+    """kmeans.py:228-240 with the cluster sums, norms and error in the reference's fp32 orders (single GPU).
+    Same return dict as :func:`kmeans_fit`.  d = 6, K <= 32, N >= 1024: one launch per iteration (the parallel form of
+    ATen's cascade, csrc/et_kmeans_reforder.hip, namespace fast); any other shape: the plain kernels."""
+    return kmeans_fit_reference_order_batch(X[None], centroids[None], max_iter, tol, trace=trace, timing=timing)[0]
+
+
+def kmeans_fit_reference_order_batch(X, centroids, max_iter=100, tol=1e-4, trace=True, timing=False):
+    """BatchKMeans.fit's loop (kmeans.py:228-240) for X (l, d, N), centroids (l, d, K) in the reference's summation
+    orders: ALL problems iterate in one loop and stop together on the error summed over the whole (l, d, K) tensor.
+    Returns one dict per problem (all with the same n_iter / error)."""
     dev = L.require_device(X)
     X, centroids = _dev_args(dev, X, centroids)
-    d, n = X.shape
-    K = centroids.shape[1]
-    ws = _reforder_ws(n, d, K, dev)
+    nb, d, n = X.shape
+    K = centroids.shape[2]
+    nbytes = L.lib().et_kmeans_reforder_batch_workspace_bytes(L.i64(n), int(d), int(K), L.i64(nb))
+    if nbytes == 0:
+        if nb > 1:
+            raise NotImplementedError(f"sums='reference-order' with l = {nb} > 1 problems takes d = 6, K <= 32, 1024 <= N < 2^29, "
+                                      f"l <= 64 (got d={d}, K={K}, N={n})")
+        raise ValueError(f"k-means dimensions out of range: d={d} (<= {L.KMEANS_MAX_D}), K={K} (<= {L.KMEANS_MAX_CLUSTERS})")
+    ws = torch.empty((nbytes,), device=dev, dtype=torch.uint8)
     cen = centroids.clone()
-    labels = torch.empty((n,), device=dev, dtype=torch.int64)
-    trace_t = torch.zeros((max_iter, 2), device=dev) if trace else None
-    st = L.KMeansState()
-    L.check(L.lib().et_kmeans_fit_reforder(L.ptr(X), L.i64(n), d, K, int(max_iter), L.f32(tol), L.ptr(cen), L.ptr(labels),
-                                           L.ptr(trace_t), C.byref(st), L.ptr(ws), C.c_size_t(ws.numel()), L.stream(dev)),
-            "et_kmeans_fit_reforder")
-    return dict(centroids=cen, labels=labels, n_iter=int(st.iter), error=float(st.error), inertia=float(st.inertia),
-                trace=trace_t[:int(st.iter)] if trace else None, done=bool(st.done))
+    labels = torch.empty((nb, n), device=dev, dtype=torch.int64)
+    trace_t = torch.zeros((nb, max_iter, 2), device=dev) if trace else None
+    st = (L.KMeansState * nb)()
+    tm = L.KMeansTiming() if timing else None
+    L.check(L.lib().et_kmeans_fit_reforder_batch(L.ptr(X), L.i64(d * n), L.i64(n), d, K, L.i64(nb), int(max_iter), L.f32(tol),
+                                                 L.ptr(cen), L.ptr(labels), L.ptr(trace_t), st, C.byref(tm) if timing else None,
+                                                 L.ptr(ws), C.c_size_t(ws.numel()), L.stream(dev)),
+            "et_kmeans_fit_reforder_batch")
+    out = []
+    for b in range(nb):
+        r = dict(centroids=cen[b], labels=labels[b], n_iter=int(st[b].iter), error=float(st[b].error),
+                 inertia=float(st[b].inertia), trace=trace_t[b, :int(st[b].iter)] if trace else None, done=bool(st[b].done))
+        if timing:
+            r["timing"] = dict(loop_ms=float(tm.assign_ms), launches=int(tm.assign_launches), iterations=int(tm.iterations))
+        out.append(r)
+    return out
 
 
 # ---------------------------------------------------- sklearn-recipe anchors (anchor.py:65-71)

@@ -325,8 +325,12 @@ int et_kmeans_fit_batch(const float *X, int64_t x_stride, int64_t N, int d, int 
  * count but lets a whole run drift away from the reference's (kmeans.py:180-182 sums fp32 in ATen's cascade order; whole-run
  * label equality with the imported reference: 96/96 runs here against 76/96 with exact sums).  These entry
  * points restate ATen's CPU orders for kmeans.py:73-74 (norms), :180-182 (cluster sums) and :45-51 (error) literally.
- * Single GPU, one problem, any d <= 32, K <= 255; serial where the reference's order is serial -- not a fast path.
- * workspace: et_kmeans_reforder_workspace_bytes. */
+ * Single GPU, any d <= 32, K <= 255.  d = 6, K <= 32, 1024 <= N < 2^29 (the anchor clustering's shape): ONE launch per
+ * Lloyd iteration -- ATen's cascade is a fixed tree over index ranges, so its levels are evaluated in parallel without
+ * changing an addition (level 0: one work item per chunk lane and coordinate; level 1: inside a workgroup; levels 2, 3,
+ * the centroid update and the stop flag: by the workgroups that arrive last) --, no host synchronisation inside the loop.
+ * Any other shape: plain kernels, serial where the reference's order is serial, one synchronisation per iteration.
+ * workspace: et_kmeans_reforder_workspace_bytes (~ 25 B per point for the fast form's permuted copy). */
 size_t et_kmeans_reforder_workspace_bytes(int64_t N, int d, int K);
 /* kmeans.py:59-76 with both norms in torch's order: every bit of the reference's euc_sim. a (d,m), b (d,n) -> y (m,n) */
 int et_euc_sim_reforder(const float *a, const float *b, int d, int64_t m, int64_t n, float *y, et_stream_t stream);
@@ -338,10 +342,20 @@ int et_kmeans_predict_reforder(const float *X, int64_t N, int d, const float *ce
                                float *maxsims, void *workspace, size_t workspace_bytes, et_stream_t stream);
 /* kmeans.py:228-240 from given initial centroids: centroids (d,K) in/out, labels int64 (N) or NULL, trace (max_iter,2) or
  * NULL, *state_host: iter, done, error, inertia (the inertia is this build's fp64 sum: the reference only prints it).
- * Synchronises the stream every iteration, like the reference (kmeans.py:239). */
+ * The fast form synchronises the stream once, at the end; the plain kernels every iteration (kmeans.py:239). */
 int et_kmeans_fit_reforder(const float *X, int64_t N, int d, int K, int max_iter, float tol, float *centroids,
                            int64_t *labels, float *trace, et_kmeans_state *state_host, void *workspace,
                            size_t workspace_bytes, et_stream_t stream);
+/* BatchKMeans.fit's own loop for `batch` (= l) problems (kmeans.py:228-240): all problems iterate together and stop
+ * TOGETHER on the error summed over the whole contiguous (l, d, K) centroid tensor in ATen's inner-sum order.  X: problem
+ * b's points at X + b * x_stride floats; centroids (batch, d, K) in/out; labels (batch, N) int64 or NULL; trace (batch,
+ * max_iter, 2) or NULL (row = joint error, this problem's inertia); states_host[batch]; *timing_host (may be NULL):
+ * assign_ms = the whole loop between two events, assign_launches = launches enqueued.  batch > 1 takes the fast form's
+ * shapes only (d = 6, K <= 32, 1024 <= N < 2^29, batch <= 64; the workspace query returns 0 otherwise). */
+size_t et_kmeans_reforder_batch_workspace_bytes(int64_t N, int d, int K, int64_t batch);
+int et_kmeans_fit_reforder_batch(const float *X, int64_t x_stride, int64_t N, int d, int K, int64_t batch, int max_iter,
+                                 float tol, float *centroids, int64_t *labels, float *trace, et_kmeans_state *states_host,
+                                 et_kmeans_timing *timing_host, void *workspace, size_t workspace_bytes, et_stream_t stream);
 
 /* kmeans.py:261-272 predict: labels int64 (N); maxsims (N) optional */
 int et_kmeans_predict(const float *X, int64_t N, int d, const float *centroids, int K, int64_t *labels,

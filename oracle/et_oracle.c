@@ -932,3 +932,65 @@ int eto_kmeans_fit_reforder(const float *X, int64_t N, int d, int K, const float
     free(cur);
     return ETO_OK;
 }
+
+/* kmeans.py:228-240 for a batch of l problems in the reference's orders: every iteration assigns and updates ALL problems
+ * (eto_kmeans_fit_reforder's step), then ONE error -- `diff.sum()` over the whole contiguous (l, d, K) tensor of squared
+ * centroid differences, ATen's inner-sum order (kmeans.py:45-51, 232) -- is compared with tol (kmeans.py:239): all problems
+ * stop in the same iteration.  X (l,d,N), C_init / centroids (l,d,K), labels (l,N), inertia (l), trace (max_iter,2):
+ * (joint error, mean of the problems' inertias -- kmeans.py:234 is one mean over the batch). */
+int eto_kmeans_fit_reforder_batch(const float *X, int64_t N, int d, int K, int l, const float *C_init, int max_iter, float tol,
+                                  float *centroids, int64_t *labels, int *n_iter, float *error, float *inertia, float *trace)
+{
+    if (K < 1 || K > 255 || d < 1 || d > 64 || N < 1 || l < 1) return ETO_EINVAL;
+    const int dk = d * K;
+    int64_t *sums = (int64_t *)malloc(sizeof(int64_t) * (dk + K));
+    int64_t *counts = sums + dk;
+    float *cur = (float *)malloc(sizeof(float) * dk * (size_t)l * 2 + sizeof(float) * dk);
+    float *sq = cur + (size_t)dk * l, *fs = sq + (size_t)dk * l;
+    double *mx = (double *)malloc(sizeof(double) * l);
+    memcpy(cur, C_init, sizeof(float) * dk * (size_t)l);
+    for (int b = 0; b < l; ++b) {
+        int bad = 0;
+        mx[b] = eto_max_abs(X + (int64_t)b * d * N, (int64_t)d * N, &bad);
+        if (bad) { free(sums); free(cur); free(mx); return ETO_EINVAL; }
+    }
+    int it = 0, done = 0;
+    float err = 0.0f;
+    for (it = 0; it < max_iter; ++it) {
+        double ine_mean = 0.0;
+        for (int b = 0; b < l; ++b) {
+            const float *Xb = X + (int64_t)b * d * N;
+            float *cb = cur + (size_t)b * dk;
+            const int frac = eto_kmeans_frac_bits(mx[b], N);
+            const int sfrac = eto_kmeans_sim_frac_bits(mx[b], eto_max_abs(cb, dk, NULL), d, N);
+            int64_t ss, nn;
+            eto_kmeans_assign_accumulate_impl(Xb, N, d, cb, K, frac, sfrac, labels + (int64_t)b * N, sums, counts, &ss, &nn, 1);
+            eto_kmeans_reforder_sums(Xb, N, d, K, labels + (int64_t)b * N, fs);
+            for (int e = 0; e < dk; ++e) {
+                const float c = fs[e] / (float)counts[e % K];
+                const float diff = cb[e] - c;
+                sq[(size_t)b * dk + e] = diff * diff;
+                cb[e] = c;
+            }
+            inertia[b] = nn > 0 ? NAN : (float)(-(ldexp((double)ss, -sfrac) / (double)N));
+            ine_mean += (double)inertia[b];
+        }
+        err = eto_inner_sum_f32(sq, (int64_t)dk * l);
+        done = (err <= tol) ? 1 : 0;
+        if (trace) {
+            trace[2 * it] = err;
+            trace[2 * it + 1] = (float)(ine_mean / l);
+        }
+        if (done) {
+            ++it;
+            break;
+        }
+    }
+    memcpy(centroids, cur, sizeof(float) * dk * (size_t)l);
+    *n_iter = it;
+    *error = err;
+    free(sums);
+    free(cur);
+    free(mx);
+    return ETO_OK;
+}

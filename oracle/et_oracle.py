@@ -268,6 +268,24 @@ def kmeans_fit(X, C_init, max_iter=100, tol=1e-4, sums="exact"):
                 trace=trace[:it.value].copy())
 
 
+def kmeans_fit_batch_reference_order(Xs, C_inits, max_iter=100, tol=1e-4):
+    """BatchKMeans.fit on l problems in the reference's summation orders (kmeans.py:228-240): one loop, one error over the
+    whole (l, d, K) tensor in ATen's inner-sum order.  -> dict(centroids (l,d,K), labels (l,N), n_iter, error,
+    inertia (l,), trace (n_iter,2) = (joint error, mean inertia))."""
+    Xs, C_inits = _f32(np.stack(Xs)), _f32(np.stack(C_inits))
+    l, d, n = Xs.shape
+    K = C_inits.shape[2]
+    cen = np.empty((l, d, K), np.float32)
+    labels = np.empty((l, n), np.int64)
+    ine = np.zeros((l,), np.float32)
+    trace = np.zeros((max_iter, 2), np.float32)
+    it, err = C.c_int(0), C.c_float(0)
+    _check(lib().eto_kmeans_fit_reforder_batch(_p(Xs, _f32p), C.c_int64(n), d, K, l, _p(C_inits, _f32p), int(max_iter),
+                                               C.c_float(tol), _p(cen, _f32p), _p(labels, _i64p), C.byref(it), C.byref(err),
+                                               _p(ine, _f32p), _p(trace, _f32p)), "kmeans_fit_reforder_batch")
+    return dict(centroids=cen, labels=labels, n_iter=it.value, error=err.value, inertia=ine, trace=trace[:it.value].copy())
+
+
 def kmeans_fit_batch(Xs, C_inits, max_iter=100, tol=1e-4):
     """BatchKMeans.fit on a batch of l problems (kmeans.py:228-240): ONE error -- the sum over all problems -- is
     compared with ``tol`` (kmeans.py:239), so all problems stop in the same iteration.  Restated on the per-problem C

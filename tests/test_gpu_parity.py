@@ -2010,10 +2010,79 @@ def test_reference_order_batchkmeans_module_gauss10000(dev):
     assert km.n_iter_ == [len(z["gauss10000.trace"])]
     ql = km.predict(T(gaussian_points_np(6, 512, seed=12, n_blobs=0), dev)[None].contiguous())
     assert np.array_equal(N_(ql[0]), z["gauss10000.query_labels"].astype(np.int64))
-    with pytest.raises(NotImplementedError):
-        km.fit(torch.cat([x, x], dim=0).contiguous())
+    with pytest.raises(NotImplementedError):  # a batch takes the fast form's shapes only (d = 6, K <= 32, N >= 1024)
+        BatchKMeans(n_clusters=3, sums="reference-order").fit(torch.randn(2, 5, 64, device=dev))
     with pytest.raises(ValueError):
         BatchKMeans(n_clusters=20, sums="fast")
+
+
+def test_reference_order_batch_joint_stop_g7b(ops, oracle, dev):
+    """BatchKMeans(sums="reference-order") on the reference's own l = 3 run (tests/golden/g7b): ONE loop for the batch, the
+    error summed over the whole (l, d, K) tensor in ATen's order -- the reference's iteration count, labels, per-iteration
+    errors and final centroid BITS; and bit for bit the oracle's restatement."""
+    from eigentrajectory_amd import BatchKMeans
+    z = G.load("g7b_batchkmeans_joint_stop.npz")
+    km = BatchKMeans(n_clusters=int(z["K"]), n_redo=1, max_iter=100, tol=1e-4, init_mode="kmeans++", sums="reference-order")
+    np.random.seed(0)
+    labels = km.fit(T(z["x"], dev))
+    assert km.n_iter_ == [len(z["trace"])] * 3
+    assert np.array_equal(N_(labels).astype(np.uint8), z["labels"])
+    assert np.array_equal(N_(km.centroids), z["centroids"])
+    np.testing.assert_allclose(km.inertia_, z["trace"][-1, 1], rtol=1e-5)
+    runs = ops.kmeans_fit_reference_order_batch(T(z["x"], dev), T(z["c0"], dev), 100, 1e-4)
+    ref = oracle.kmeans_fit_batch_reference_order(list(z["x"]), list(z["c0"]), 100, 1e-4)
+    for b, r in enumerate(runs):
+        assert r["n_iter"] == ref["n_iter"]
+        assert np.array_equal(N_(r["labels"]), ref["labels"][b])
+        assert np.array_equal(N_(r["centroids"]), ref["centroids"][b])
+        assert np.array_equal(N_(r["trace"])[:, 0], z["trace"][:, 0].astype(np.float32))
+        np.testing.assert_allclose(r["inertia"], ref["inertia"][b], rtol=1e-5)
+
+
+@pytest.mark.parametrize("n,K,l", [(1024, 20, 2), (5003, 20, 3), (20001, 7, 4), (70000, 32, 2), (131072 + 13, 20, 2), (300000, 20, 2)])
+def test_reference_order_fast_form_vs_oracle(ops, oracle, dev, n, K, l):
+    """The one-launch-per-iteration form of the reference-order fit (csrc/et_kmeans_reforder.hip, namespace fast: parallel
+    levels of ATen's cascade, permuted copy, last-arriver updates) against the oracle's literal restatement, on sizes that
+    exercise every leftover of the cascade (partial chunk / group / block, N mod 4, N mod 32) and on batches: labels, centroid
+    bits, per-iteration errors, iteration count; and problem 0 alone (l = 1: its own stop)."""
+    from eigentrajectory_amd.synth import gaussian_points_np
+    xs = np.stack([gaussian_points_np(6, n, seed=300 + 7 * b + n % 89, n_blobs=(0 if b % 2 else 5)) for b in range(l)])
+    xs[0][:, ::61] *= np.float32(9.0)
+    c0 = np.stack([oracle.kmeans_init_farthest(xs[b], K, (17 * (b + 1)) % n, reference_order=True)[0] for b in range(l)])
+    iters = 12
+    ref = oracle.kmeans_fit_batch_reference_order(list(xs), list(c0), iters, 1e-4)
+    runs = ops.kmeans_fit_reference_order_batch(T(xs, dev), T(c0, dev), iters, 1e-4)
+    for b, r in enumerate(runs):
+        assert r["n_iter"] == ref["n_iter"], (b, r["n_iter"], ref["n_iter"])
+        assert np.array_equal(N_(r["labels"]), ref["labels"][b]), b
+        assert np.array_equal(N_(r["centroids"]), ref["centroids"][b], equal_nan=True), b
+        assert np.array_equal(N_(r["trace"])[:, 0], ref["trace"][:, 0], equal_nan=True)
+        np.testing.assert_allclose(r["inertia"], ref["inertia"][b], rtol=1e-5)
+    one = oracle.kmeans_fit(xs[0], c0[0], iters, 1e-4, sums="reference-order")
+    got = ops.kmeans_fit_reference_order(T(xs[0], dev), T(c0[0], dev), iters, 1e-4)
+    assert got["n_iter"] == one["n_iter"] and np.array_equal(N_(got["labels"]), one["labels"])
+    assert np.array_equal(N_(got["centroids"]), one["centroids"], equal_nan=True)
+    assert np.array_equal(N_(got["trace"])[:, 0], one["trace"][:, 0], equal_nan=True)
+
+
+def test_reference_order_fast_form_nan_centroids_and_huge_values(ops, oracle, dev):
+    """An empty cluster (0/0 = NaN centroid, kmeans.py:182) and magnitudes near the fp32 range take the fast form's
+    NaN-aware arg-max: still the oracle's bits (torch.max: a NaN beats everything, the first one stays)."""
+    from eigentrajectory_amd.synth import gaussian_points_np
+    x = gaussian_points_np(6, 6000, seed=5, n_blobs=4)
+    c0 = x[:, :20].copy()
+    c0[:, 7] = 1e6  # nobody's nearest centroid: empty after the first assignment -> NaN from the second iteration on
+    ref = oracle.kmeans_fit(x, c0, 5, 1e-4, sums="reference-order")
+    got = ops.kmeans_fit_reference_order(T(x, dev), T(c0, dev), 5, 1e-4)
+    assert np.isnan(ref["centroids"]).any()
+    assert got["n_iter"] == ref["n_iter"] and np.array_equal(N_(got["labels"]), ref["labels"])
+    assert np.array_equal(N_(got["centroids"]), ref["centroids"], equal_nan=True)
+    xb = (x * np.float32(3e18)).astype(np.float32)
+    cb = xb[:, 100:120].copy()
+    ref = oracle.kmeans_fit(xb, cb, 4, 1e-4, sums="reference-order")
+    got = ops.kmeans_fit_reference_order(T(xb, dev), T(cb, dev), 4, 1e-4)
+    assert np.array_equal(N_(got["labels"]), ref["labels"])
+    assert np.array_equal(N_(got["centroids"]), ref["centroids"], equal_nan=True)
 
 
 def test_anchor_clustering_relocates_empty_clusters_like_sklearn(dev):

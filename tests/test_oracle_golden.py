@@ -382,6 +382,23 @@ def test_g7b_batch_of_problems_stops_on_the_summed_error(oracle):
     np.testing.assert_allclose(ine, z["trace"][:, 1], rtol=1e-5)
 
 
+def test_g7b_batch_in_reference_order_reproduces_the_reference(oracle):
+    """The same l = 3 run in the reference's summation orders (kmeans.py:228-240 with ONE error over the contiguous
+    (l, d, K) tensor in ATen's inner-sum order): iteration count, labels, the printed error of EVERY iteration and the final
+    centroid BITS of the imported reference."""
+    z = G.load("g7b_batchkmeans_joint_stop.npz")
+    x, c0, K = z["x"], z["c0"], int(z["K"])
+    for b in range(3):
+        r0, _ = oracle.kmeans_init_farthest(x[b], K, int(z["first_index"]), reference_order=True)
+        assert np.array_equal(r0, c0[b])
+    r = oracle.kmeans_fit_batch_reference_order(list(x), list(c0), 100, 1e-4)
+    assert r["n_iter"] == len(z["trace"])
+    assert np.array_equal(r["labels"], z["labels"].astype(np.int64))
+    assert np.array_equal(r["centroids"], z["centroids"])
+    assert np.array_equal(r["trace"][:, 0], z["trace"][:, 0].astype(np.float32))
+    np.testing.assert_allclose(r["trace"][:, 1], z["trace"][:, 1], rtol=1e-5)
+
+
 def test_g7_duplicate_points_nan_propagation(oracle):
     """kmeans.py:180-182: an empty cluster becomes NaN and poisons every later label (no re-seeding)."""
     z = G.load("g7_batchkmeans.npz")
