@@ -130,7 +130,7 @@ def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None,
 
 
 # the dominant kernel of the step: one launch per Lloyd iteration for shards above 32768 points (the chained kernel),
-# ONE persistent launch for all iterations of a fit below that (csrc/et_kmeans.hip: km_persist_wanted; ET_KMEANS_LOOP
+# ONE persistent launch for all iterations of a fit below that (csrc/et_kmeans.hip: km_persist_wanted; ET_OPT_KMEANS_LOOP
 # forces a form).  Which one ran is read off the timing record (iterations per launch).
 CHAIN_KERNEL = "et::kmeans_lloyd_chain_kernel<10, false>"
 PERSIST_KERNEL = "et::kmeans_lloyd_persist_kernel<10, false>"
@@ -419,6 +419,54 @@ def extra_stages(ops, obs, pred, n, K, max_iter, first_index, dev):
     return out, sizes
 
 
+def reference_order_lloyd(ops, dev, n_main, K, max_iter, first_index):
+    """BatchKMeans(sums="reference-order") beside the default on the SAME k-means inputs (the projection of the synthetic
+    trajectories) at N = 1e5 / 1e6 / n_main: the Lloyd loop in ATen's own summation orders (kmeans.py:180-182, 73-74,
+    45-51; csrc/et_kmeans_reforder.hip) -- the path that reproduces the imported reference's whole runs bit for bit
+    (tests/golden/g7c, g7d) -- against the exact-sum loop the headline step times.  Both loops between HIP events on the
+    launch stream, per iteration; `labels_equal`: whether the two fits end with the same labels on this input (they
+    differ by the ~1e-7 summation noise Lloyd iterations amplify: DESIGN 4)."""
+    from eigentrajectory_amd.synth import synthetic_trajectories_torch
+    out = {}
+    for m in sorted({100_000, 1_000_000, int(n_main)}):
+        with torch.no_grad():
+            o, p = synthetic_trajectories_torch(m, dev, seed=0, min_disp=1e-3)
+            g_obs, g_pred, _ = ops.fit_gram(o, p, ops.MODE_MOVING, 0.0, 1)
+            (U_obs, _), (U_pred, _) = ops.eigh_topk_batch([g_obs, g_pred], 6)
+            _, x, _, _ = ops.norm_project(o, p, U_obs, U_pred, None, None, ops.MODE_MOVING, want_flag=False, want_nrm=False)
+            del o, p
+            c0 = ops.kmeans_init_farthest(x, K, first_index % m)
+            best = {}
+            for name in ("reference_order", "exact_sum"):
+                runs = []
+                for rep in range(4):  # (the first one warms up)
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                    r = (ops.kmeans_fit_reference_order(x, c0, max_iter, 1e-4, trace=False) if name == "reference_order"
+                         else ops.kmeans_fit(x, c0, max_iter, 1e-4, trace=False))
+                    ev1.record()
+                    torch.cuda.synchronize()
+                    if rep:
+                        runs.append(ev0.elapsed_time(ev1))
+                best[name] = (min(runs), r)
+            ms_r, r_ref = best["reference_order"]
+            ms_e, r_ex = best["exact_sum"]
+            tag = f"{m:.0e}".replace("+0", "")
+            per_r, per_e = ms_r / max(r_ref["n_iter"], 1) * 1e3, ms_e / max(r_ex["n_iter"], 1) * 1e3
+            out[tag] = dict(fit_ms=round(ms_r, 4), iterations=r_ref["n_iter"], us_per_iteration=round(per_r, 2),
+                            exact_sum_fit_ms=round(ms_e, 4), exact_sum_iterations=r_ex["n_iter"],
+                            exact_sum_us_per_iteration=round(per_e, 2), ratio=round(per_r / per_e, 3),
+                            algorithmic_GBs=round(BYTES["kmeans_iter"] * m / per_r / 1e3, 1),
+                            frac_of_peak=round(BYTES["kmeans_iter"] * m / per_r / 1e3 / HBM_PEAK_GBS, 4),
+                            labels_equal=bool(r_ref["n_iter"] == r_ex["n_iter"] and torch.equal(r_ref["labels"], r_ex["labels"])))
+            del x
+            torch.cuda.empty_cache()
+    out["note"] = ("whole fits (<= max_iter Lloyd iterations, incl. the one-off permuted copy / packed copy of the points) between "
+                   "events; reference_order reads 24 B of coordinates per point and iteration once (assignment and cascade levels in "
+                   "one kernel) + 1.9 KB of partial sums per 1024-4096 points")
+    return out
+
+
 def lloyd_beyond_cache(ops, dev, K, max_iter, first_index, n_big=40_000_000):
     """The dominant kernel on a shard whose working set does NOT fit the 256 MB Infinity Cache: at N = 1e7 an iteration
     streams 140 MB of packed rows + 10 MB of labels -- cache resident, so the headline `roofline` is an algorithmic rate,
@@ -671,6 +719,7 @@ def main():
         if world == 1 and not force_dist and not args.no_extras:
             more, sizes = extra_stages(ops, obs, pred, n, K, args.max_iter, first_index, dev)
             stages.update(more)
+            stages["kmeans_lloyd_reference_order"] = reference_order_lloyd(ops, dev, n, K, args.max_iter, first_index)
             if n == 10_000_000:
                 roofline["beyond_infinity_cache"] = lloyd_beyond_cache(ops, dev, K, args.max_iter, first_index)
             out["scaling_model"] = scaling_model(ops, obs, pred, K, args.max_iter, first_index, dev, ms_per_step,

@@ -18,14 +18,14 @@ LIB_PATH = os.environ.get("ET_LIBETAMD") or os.path.join(_HERE, "libetamd.so")
 
 ET_OK = 0
 ET_ERR_BAD_DATA = 5
-ABI_VERSION = 2  # include/eigentraj.h ET_ABI_VERSION: the struct mirrors below are for this version
+ABI_VERSION = 3  # include/eigentraj.h ET_ABI_VERSION: the struct mirrors below are for this version
 MODE_STATIC, MODE_MOVING, MODE_SPLIT, MODE_IDENTITY = 0, 1, 2, 3
 MAX_T, MAX_K, KMEANS_MAX_D, KMEANS_MAX_CLUSTERS = 32, 32, 32, 255
 SCENE_MAX_N = 16384  # ET_SCENE_MAX_N
 
 #: every symbol include/eigentraj.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "et_abi_version", "et_status_string", "et_compiled_arch",
+    "et_abi_version", "et_status_string", "et_compiled_arch", "et_set_option", "et_get_option",
     "et_norm_params", "et_norm_params_from_nrm", "et_normalize", "et_denormalize",
     "et_norm_project", "et_scene_project", "et_scene_project_train", "et_wrapper_losses_fwd", "et_wrapper_losses_bwd",
     "et_anchor_reconstruct_fwd", "et_anchor_reconstruct_bwd", "et_anchor_reconstruct_metrics",
@@ -84,7 +84,41 @@ def lib():
                      "et_kmeans_reforder_batch_workspace_bytes"):
             getattr(l, name).restype = C.c_size_t
         _lib = l
+        # the library reads nothing from the environment; ET_OPT_<KEY>=value is forwarded once, here (A/B scripts under tools/)
+        for name, value in os.environ.items():
+            if name.startswith("ET_OPT_"):
+                set_option(name[len("ET_OPT_"):].lower(), value)
     return _lib
+
+
+def set_option(key: str, value) -> None:
+    """et_set_option (include/eigentraj.h, "tuning switches"): measurement aids / test levers; never needed for results."""
+    rc = lib().et_set_option(str(key).encode(), str(value).encode())
+    if rc != ET_OK:
+        raise ValueError(f"et_set_option({key!r}, {value!r}): unknown key or value")
+
+
+def get_option(key: str) -> str:
+    buf = C.create_string_buffer(64)
+    if lib().et_get_option(str(key).encode(), buf, C.c_size_t(64)) != ET_OK:
+        raise ValueError(f"et_get_option({key!r}): unknown key")
+    return buf.value.decode()
+
+
+class option:
+    """``with option("kmeans_packed", 0): ...`` -- set a switch for a block and put the old value back."""
+
+    def __init__(self, key, value):
+        self.key, self.value = key, value
+
+    def __enter__(self):
+        self.old = get_option(self.key)
+        set_option(self.key, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.key, self.old)
+        return False
 
 
 def check(rc: int, what: str):

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "et_common.h"
+#include "et_options.h"
 
 namespace et {
 
@@ -184,183 +185,6 @@ __global__ __launch_bounds__(kTile) void project_tile_kernel(
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) C_pred[(int64_t)j * N + n] = acc[j];
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Projection, STREAMING form (one descriptor for all rows: modes STATIC / MOVING / IDENTITY).
-// project_tile_kernel phase-locks a workgroup: load -> barrier -> compute -> store -> exit, and a new workgroup
-// starts from an exposed load latency.  Here the grid is persistent (3 workgroups per CU), every WAVEFRONT owns an
-// LDS slice and walks its own sequence of 64-trajectory passes with no workgroup barrier at all: the rows of pass
-// i + 1 are requested (10 x 16 B per lane, registers) before pass i is computed from the slice, so every wavefront
-// has 10 KB in flight while it computes and stores (120 KB per CU), and the load / compute / store phases of the 12
-// wavefronts of a CU interleave freely.  U is staged once per workgroup.
-// ------------------------------------------------------------------------------------------
-constexpr int kStreamWaves = 4;                      // wavefronts per workgroup
-constexpr int kStreamThreads = kStreamWaves * kWave;
-constexpr int kStreamWgPerCu = 3;                    // 12 wavefronts per CU: 144 KB of LDS slices
-
-template <int K>
-__device__ __forceinline__ void pin_accumulators(float (&acc)[K]) {
-    static_assert(K == 6, "written out for k = 6");
-    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5])::"memory");
-}
-
-// the Q float4 per lane of a 64-row block (row = Q float4) starting at g; rows beyond `left` read as zero
-template <int Q>
-__device__ __forceinline__ void stream_request(const float4 *__restrict__ g, int64_t left, int lane, float4 (&v)[Q]) {
-    const int rows = (int)min((int64_t)kWave, left);
-#pragma unroll
-    for (int j = 0; j < Q; ++j) {
-        const int q = lane + j * kWave;
-        v[j] = q < rows * Q ? g[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
-
-// registers -> the wavefront's LDS slice (row pitch P float4 for rows of Q float4)
-template <int Q, int P>
-__device__ __forceinline__ void stream_stage(float4 *slice, int lane, const float4 (&v)[Q]) {
-#pragma unroll
-    for (int j = 0; j < Q; ++j) {
-        const int q = lane + j * kWave;
-        slice[(q / Q) * P + (q % Q)] = v[j];
-    }
-}
-
-// One 64-trajectory pass of the projection, lane = trajectory, rows in the wavefront's slice.  FULL: all 64 rows exist and
-// every store is unconditional straight-line code -- the compiler can then wait for the NEXT pass's loads (requested
-// before this function) with a counted s_waitcnt that leaves these stores in flight (a store under a branch forces
-// vmcnt(0): the wavefront would sit out its own stores' round trip every pass).
-template <int TO, int TP, int K, bool PRED, bool FULL, int MODE>
-__device__ __forceinline__ void project_pass(const float4 *myObs, const float4 *myPred, const float *sU, int lane, int64_t n0,
-                                             int64_t N, float *__restrict__ C_obs, float *__restrict__ C_pred,
-                                             float *__restrict__ nrm) {
-    constexpr int DO = 2 * TO, DP = 2 * TP, QO = DO / 4, QP = DP / 4, PO = QO + 1, PP = QP + 1;
-    const int64_t n = n0 + lane;
-    const bool live = FULL || n < N;
-    float xo[DO];
-#pragma unroll
-    for (int j = 0; j < QO; ++j) {
-        const float4 v = myObs[lane * PO + j];
-        xo[4 * j] = v.x;
-        xo[4 * j + 1] = v.y;
-        xo[4 * j + 2] = v.z;
-        xo[4 * j + 3] = v.w;
-    }
-    const float ox = xo[DO - 2], oy = xo[DO - 1];
-    const float dx = ox - xo[DO - 6], dy = oy - xo[DO - 5];
-    const RowNorm p = row_norm(ox, oy, dx, dy, MODE, 0.f);
-    if (live) {
-        nrm[n] = ox;
-        nrm[N + n] = oy;
-        nrm[2 * N + n] = dx;
-        nrm[3 * N + n] = dy;
-    }
-    {
-        float acc[K];
-#pragma unroll
-        for (int j = 0; j < K; ++j) acc[j] = 0.f;
-#pragma unroll
-        for (int t = 0; t < TO; ++t) {
-            // (scheduling fence per pair of steps -- the accumulators pass through it, so the fused multiply-adds above
-            // cannot sink below it and the LDS reads below cannot rise above it: the scheduler would otherwise issue all
-            // 60 16-byte reads of U up front and hold them in 200+ registers)
-            if (t % 2 == 0) pin_accumulators(acc);
-            float a, b;
-            normalize_point(p, xo[2 * t], xo[2 * t + 1], a, b);
-#pragma unroll
-            for (int j = 0; j < K; ++j) acc[j] = fmaf(sU[(2 * t) * K + j], a, acc[j]);
-#pragma unroll
-            for (int j = 0; j < K; ++j) acc[j] = fmaf(sU[(2 * t + 1) * K + j], b, acc[j]);
-        }
-        if (live) {
-#pragma unroll
-            for (int j = 0; j < K; ++j) C_obs[(int64_t)j * N + n] = acc[j];
-        }
-    }
-    if (PRED) {
-        const float *up = sU + DO * K;
-        float acc[K];
-#pragma unroll
-        for (int j = 0; j < K; ++j) acc[j] = 0.f;
-#pragma unroll
-        for (int q = 0; q < QP; ++q) {
-            pin_accumulators(acc);
-            const float4 v = myPred[lane * PP + q];
-            float a, b;
-            normalize_point(p, v.x, v.y, a, b);
-#pragma unroll
-            for (int j = 0; j < K; ++j) acc[j] = fmaf(up[(4 * q) * K + j], a, acc[j]);
-#pragma unroll
-            for (int j = 0; j < K; ++j) acc[j] = fmaf(up[(4 * q + 1) * K + j], b, acc[j]);
-            normalize_point(p, v.z, v.w, a, b);
-#pragma unroll
-            for (int j = 0; j < K; ++j) acc[j] = fmaf(up[(4 * q + 2) * K + j], a, acc[j]);
-#pragma unroll
-            for (int j = 0; j < K; ++j) acc[j] = fmaf(up[(4 * q + 3) * K + j], b, acc[j]);
-        }
-        if (live) {
-#pragma unroll
-            for (int j = 0; j < K; ++j) C_pred[(int64_t)j * N + n] = acc[j];
-        }
-    }
-}
-
-template <int TO, int TP, int K, bool PRED, int MODE>
-__global__ __launch_bounds__(kStreamThreads) void project_stream_kernel(
-    const float *__restrict__ obs, const float *__restrict__ pred, int64_t N, const float *__restrict__ U_obs,
-    const float *__restrict__ U_pred, float *__restrict__ C_obs, float *__restrict__ C_pred, float *__restrict__ nrm) {
-    constexpr int DO = 2 * TO, DP = 2 * TP;
-    constexpr int QO = DO / 4, QP = DP / 4;  // float4 per row
-    constexpr int PO = QO + 1, PP = QP + 1;  // padded row pitch (odd: the per-lane row reads are conflict free)
-    static_assert(PO % 2 == 1 && PP % 2 == 1, "padded pitch must be odd in float4 units");
-    __shared__ float4 sObs[kStreamWaves][kWave * PO];
-    __shared__ float4 sPred[PRED ? kStreamWaves : 1][PRED ? kWave * PP : 1];
-    __shared__ float sU[(DO + DP) * K];
-
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int i = threadIdx.x; i < (DO + (PRED ? DP : 0)) * K; i += kStreamThreads) sU[i] = i < DO * K ? U_obs[i] : U_pred[i - DO * K];
-    __syncthreads();  // the only workgroup barrier of the kernel
-
-    float4 *myObs = sObs[wave], *myPred = sPred[PRED ? wave : 0];
-    const int64_t n_full = N / kWave;  // passes with all 64 rows
-    const int64_t stride = (int64_t)gridDim.x * kStreamWaves;
-    const int64_t first = (int64_t)blockIdx.x * kStreamWaves + wave;
-    const float4 *obs4 = reinterpret_cast<const float4 *>(obs), *pred4 = reinterpret_cast<const float4 *>(pred);
-    float4 vo[QO], vp[QP];
-    int64_t pass = first;
-    if (pass < n_full) {
-        stream_request<QO>(obs4 + pass * kWave * QO, kWave, lane, vo);
-        if (PRED) stream_request<QP>(pred4 + pass * kWave * QP, kWave, lane, vp);
-        stream_stage<QO, PO>(myObs, lane, vo);
-        if (PRED) stream_stage<QP, PP>(myPred, lane, vp);
-    }
-    for (; pass < n_full; pass += stride) {
-        // the next pass's rows travel while this one is computed and stored
-        const bool more = pass + stride < n_full;
-        if (more) {
-            stream_request<QO>(obs4 + (pass + stride) * kWave * QO, kWave, lane, vo);
-            if (PRED) stream_request<QP>(pred4 + (pass + stride) * kWave * QP, kWave, lane, vp);
-        }
-        // (compiler barrier: without it the loop-invariant LDS reads of U are hoisted out of the pass loop)
-        asm volatile("" ::: "memory");
-        project_pass<TO, TP, K, PRED, true, MODE>(myObs, myPred, sU, lane, pass * kWave, N, C_obs, C_pred, nrm);
-        // ... and move into the slice once this pass has read it (LDS operations of one wavefront execute in order: no
-        // barrier).  The wait sits here, in line behind this pass's stores, so that it can be a COUNTED wait that leaves
-        // the stores in flight (at the loop head it would merge with the prologue's state and wait for everything).
-        if (more) {
-            stream_stage<QO, PO>(myObs, lane, vo);
-            if (PRED) stream_stage<QP, PP>(myPred, lane, vp);
-        }
-    }
-    // the last N % 64 rows: one masked pass, by the wavefront whose sequence it continues
-    if (n_full * kWave < N && n_full % stride == first) {
-        stream_request<QO>(obs4 + n_full * kWave * QO, N - n_full * kWave, lane, vo);
-        if (PRED) stream_request<QP>(pred4 + n_full * kWave * QP, N - n_full * kWave, lane, vp);
-        stream_stage<QO, PO>(myObs, lane, vo);
-        if (PRED) stream_stage<QP, PP>(myPred, lane, vp);
-        project_pass<TO, TP, K, PRED, false, MODE>(myObs, myPred, sU, lane, n_full * kWave, N, C_obs, C_pred, nrm);
     }
 }
 
@@ -629,103 +453,6 @@ __global__ __launch_bounds__(kTile) void reconstruct_tile_kernel(
         if (tid < rows_next) p = p_next;
         n0 = n0_next;
         rows = rows_next;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Reconstruction S = 1, STREAMING form (one descriptor for all rows, normaliser state from nrm): the same persistent,
-// barrier-free structure as project_stream_kernel.  Lane = trajectory; the 10 input dwords of the next pass (6
-// coefficients + nrm) are requested before this pass is computed; the 64 x 96 B result tile goes through the
-// wavefront's own LDS slice and leaves as 16-B-per-lane row-contiguous stores.
-// ------------------------------------------------------------------------------------------
-constexpr int kRecStreamWgPerCu = 4;  // 16 wavefronts per CU (28 KB of slices per workgroup)
-
-template <int K, bool FULL, int MODE>
-__device__ __forceinline__ void recon_request(const float *__restrict__ C, const float *__restrict__ nrm, int64_t N, int64_t n,
-                                              float (&craw)[K], float (&nr)[4]) {
-    constexpr bool ident = MODE == ET_MODE_IDENTITY;
-    const bool live = FULL || n < N;
-#pragma unroll
-    for (int j = 0; j < K; ++j) craw[j] = live ? C[(int64_t)j * N + n] : 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) nr[j] = (live && !ident) ? nrm[(int64_t)j * N + n] : 0.f;
-}
-
-template <int TP, int K, bool FULL>
-__device__ __forceinline__ void reconstruct_pass(float4 *mine, const float *sU, const float *sA, int lane, int64_t n0, int64_t N,
-                                                 int mode, const float (&craw)[K], const RowNorm &p, float *__restrict__ out) {
-    constexpr int DP = 2 * TP, QP = DP / 4, PP = QP + 1;
-    float c[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) c[j] = sA[j] + craw[j];  // anchor.py:87
-#pragma unroll
-    for (int q = 0; q < QP; ++q) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int f = 4 * q + e;
-            float acc = 0.f;
-#pragma unroll
-            for (int j = 0; j < K; ++j) acc = fmaf(sU[f * K + j], c[j], acc);  // descriptor.py:87
-            v[e] = acc;
-        }
-        float4 o;
-        denormalize_point(p, v[0], v[1], o.x, o.y);
-        denormalize_point(p, v[2], v[3], o.z, o.w);
-        mine[lane * PP + q] = o;
-    }
-    const int rows = FULL ? kWave : (int)(N - n0);
-    float4 *out4 = reinterpret_cast<float4 *>(out + n0 * DP);
-#pragma unroll
-    for (int j = 0; j < QP; ++j) {
-        const int q = lane + j * kWave;
-        if (FULL || q < rows * QP) out4[q] = mine[(q / QP) * PP + (q % QP)];
-    }
-}
-
-template <int TP, int K, int MODE>
-__global__ __launch_bounds__(kStreamThreads) void reconstruct_stream_kernel(
-    const float *__restrict__ C, int64_t N, const float *__restrict__ nrm, const float *__restrict__ A,
-    const float *__restrict__ U, float *__restrict__ out) {
-    constexpr int DP = 2 * TP, QP = DP / 4, PP = QP + 1;
-    __shared__ float4 sOut[kStreamWaves][kWave * PP];
-    __shared__ float sU[DP * K];
-    __shared__ float sA[K];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int i = threadIdx.x; i < DP * K; i += kStreamThreads) sU[i] = U[i];
-    if (threadIdx.x < K) sA[threadIdx.x] = A ? A[threadIdx.x] : 0.f;
-    __syncthreads();
-
-    float4 *mine = sOut[wave];
-    const int64_t n_full = N / kWave;
-    const int64_t stride = (int64_t)gridDim.x * kStreamWaves;
-    const int64_t first = (int64_t)blockIdx.x * kStreamWaves + wave;
-
-    float craw[K], nr[4], cur[K];
-    RowNorm p;
-    int64_t pass = first;
-    if (pass < n_full) {
-        recon_request<K, true, MODE>(C, nrm, N, pass * kWave + lane, craw, nr);
-#pragma unroll
-        for (int j = 0; j < K; ++j) cur[j] = craw[j];
-        p = row_norm(nr[0], nr[1], nr[2], nr[3], MODE, 0.f);
-    }
-    for (; pass < n_full; pass += stride) {
-        const bool more = pass + stride < n_full;
-        if (more) recon_request<K, true, MODE>(C, nrm, N, (pass + stride) * kWave + lane, craw, nr);
-        asm volatile("" ::: "memory");  // (keeps the loop-invariant LDS reads of U inside the pass loop: see project_stream_kernel)
-        reconstruct_pass<TP, K, true>(mine, sU, sA, lane, pass * kWave, N, MODE, cur, p, out);
-        if (more) {  // (consumed here, behind this pass's stores: a counted wait -- see project_stream_kernel)
-#pragma unroll
-            for (int j = 0; j < K; ++j) cur[j] = craw[j];
-            p = row_norm(nr[0], nr[1], nr[2], nr[3], MODE, 0.f);
-        }
-    }
-    if (n_full * kWave < N && n_full % stride == first) {
-        recon_request<K, false, MODE>(C, nrm, N, n_full * kWave + lane, craw, nr);
-        p = row_norm(nr[0], nr[1], nr[2], nr[3], MODE, 0.f);
-        reconstruct_pass<TP, K, false>(mine, sU, sA, lane, n_full * kWave, N, MODE, craw, p, out);
     }
 }
 
@@ -1459,26 +1186,9 @@ __global__ __launch_bounds__(kTile) void reconstruct_bwd_generic_kernel(
 static bool need_m(int mode) { return mode == ET_MODE_MOVING || mode == ET_MODE_SPLIT; }
 static bool need_s(int mode) { return mode != ET_MODE_MOVING; }
 
-// ET_STREAM=1 selects the streaming kernels for one-descriptor calls.  They are NOT the default: built and measured in
-// round 4 (tools/ab_stream.py, profiles/r04a_stream_ab.txt) they lose to the workgroup-tile kernels inside the bench step
-// (project 0.414 against 0.386 ms, reconstruct 0.253 against 0.228 ms at N = 1e7, same box) -- and run at the same
-// speed with ONE workgroup per CU as with three or four: they are not short of bytes in flight, the memory side simply
-// delivers less for 4-KB / 6-KB read pieces and 256-B store pieces from wavefronts that drift apart than for the tile
-// kernel's 16-KB / 24-KB reads and 1-KB stores issued by four wavefronts in step.
-static bool stream_mode() {
-    const char *e = getenv("ET_STREAM");
-    return e && e[0] == '1';
-}
-static int64_t stream_min_rows() {  // ET_STREAM_MIN_ROWS: tests run the streaming form on small inputs
-    const char *e = getenv("ET_STREAM_MIN_ROWS");
-    const long long v = e ? atoll(e) : 0;
-    return v >= 1 ? (int64_t)v : (int64_t)1 << 18;
-}
-static int stream_wgs(int dflt) {  // ET_STREAM_WGS: workgroups per CU of the streaming kernels (measurement aid)
-    const char *e = getenv("ET_STREAM_WGS");
-    const int v = e ? atoi(e) : 0;
-    return v >= 1 && v <= 8 ? v : dflt;
-}
+// (persistent, barrier-free STREAMING forms of the one-descriptor projection / S = 1 reconstruction were built in round 4 and lost
+// to the workgroup-tile kernels -- project 0.414 against 0.386 ms, reconstruct 0.253 against 0.228 ms at N = 1e7, same box,
+// profiles/r04a_stream_ab.txt; their source: tools/lost_forms/project_reconstruct_stream.hip.txt)
 static int cu_count() {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -1507,28 +1217,7 @@ extern "C" int et_norm_project(const float *obs, const float *pred, int64_t N, i
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ceil_div(N, kTile);
     const bool fast = T_obs == 8 && (!pred || T_pred == 12) && k == 6 && aligned16(obs) && (!pred || aligned16(pred));
-    // one descriptor for all rows and enough rows to fill the device: the streaming form
-    if (fast && mode != ET_MODE_SPLIT && C_obs && nrm && stream_mode() && N >= (int64_t)stream_min_rows()) {
-        const bool mv = mode == ET_MODE_MOVING;
-        const unsigned g = (unsigned)min((int64_t)cu_count() * stream_wgs(kStreamWgPerCu), ceil_div(N, kStreamThreads));
-        const float *uo = mv ? U_obs_m : U_obs_s, *up = mv ? U_pred_m : U_pred_s;
-#define ET_PROJECT_STREAM(PRED, MODE)                                                                                         \
-    hipLaunchKernelGGL((project_stream_kernel<8, 12, 6, PRED, MODE>), dim3(g), dim3(kStreamThreads), 0, st, obs,              \
-                       PRED ? pred : nullptr, N, uo, PRED ? up : nullptr, C_obs, PRED ? C_pred : nullptr, nrm)
-        const bool wp = pred && C_pred;
-        if (mode == ET_MODE_MOVING) {
-            if (wp) ET_PROJECT_STREAM(true, ET_MODE_MOVING);
-            else ET_PROJECT_STREAM(false, ET_MODE_MOVING);
-        } else if (mode == ET_MODE_STATIC) {
-            if (wp) ET_PROJECT_STREAM(true, ET_MODE_STATIC);
-            else ET_PROJECT_STREAM(false, ET_MODE_STATIC);
-        } else {
-            if (wp) ET_PROJECT_STREAM(true, ET_MODE_IDENTITY);
-            else ET_PROJECT_STREAM(false, ET_MODE_IDENTITY);
-        }
-#undef ET_PROJECT_STREAM
-        if (flag) ET_HIP_TRY(hipMemsetAsync(flag, mv ? 1 : 0, (size_t)N, st));  // one descriptor: the flag is a constant
-    } else if (fast) {
+    if (fast) {
         hipLaunchKernelGGL((project_tile_kernel<8, 12, 6>), dim3(grid), dim3(kTile), 0, st, obs, pred, N, U_obs_m,
                            U_pred_m, U_obs_s, U_pred_s, mode, static_dist, C_obs, C_pred, nrm, flag);
     } else {
@@ -1562,18 +1251,7 @@ extern "C" int et_anchor_reconstruct_fwd(const float *C, int64_t N, int S, int k
     if ((need_m(mode) && !U_pred_m) || (need_s(mode) && !U_pred_s)) return ET_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     const bool fast = T_pred == 12 && k == 6 && S <= kTile && aligned16(out);
-    if (fast && S == 1 && mode != ET_MODE_SPLIT && (nrm || mode == ET_MODE_IDENTITY) && stream_mode() &&
-        N >= (int64_t)stream_min_rows()) {
-        const bool mv = mode == ET_MODE_MOVING;
-        const unsigned g = (unsigned)min((int64_t)cu_count() * stream_wgs(kRecStreamWgPerCu), ceil_div(N, kStreamThreads));
-        const float *a = mv ? A_m : A_s, *u = mv ? U_pred_m : U_pred_s;
-        if (mode == ET_MODE_MOVING)
-            hipLaunchKernelGGL((reconstruct_stream_kernel<12, 6, ET_MODE_MOVING>), dim3(g), dim3(kStreamThreads), 0, st, C, N, nrm, a, u, out);
-        else if (mode == ET_MODE_STATIC)
-            hipLaunchKernelGGL((reconstruct_stream_kernel<12, 6, ET_MODE_STATIC>), dim3(g), dim3(kStreamThreads), 0, st, C, N, nrm, a, u, out);
-        else
-            hipLaunchKernelGGL((reconstruct_stream_kernel<12, 6, ET_MODE_IDENTITY>), dim3(g), dim3(kStreamThreads), 0, st, C, N, nrm, a, u, out);
-    } else if (fast) {
+    if (fast) {
         const int TN = kTile / S;
         const size_t lds = sizeof(float) * ((size_t)TN * S * 24 + (size_t)TN * kNormStride + 2 * 24 * 6 + 2 * 6 * (size_t)S);
         const int64_t per_wg = (int64_t)TN * (S == 1 ? 1 : kReconTiles);
@@ -1601,11 +1279,12 @@ extern "C" int et_anchor_reconstruct_metrics(const float *C, int64_t N, int S, i
     const bool fast = T_pred == 12 && k == 6 && S <= kTile && aligned16(gt);
     if (fast) {
         const int TN = kTile / S;
-        const char *e = getenv("ET_METRICS_MFMA");  // 0: the vector-ALU workgroup-tile kernel; f32: fp32 matrix instructions only (A/B runs, tests)
-        const int use_f16 = !(e && e[0] == 'f');
+        // option metrics_form (et_set_option; A/B runs, tests): t = the vector-ALU workgroup-tile kernel, f = fp32 matrix instructions only
+        const int form = options().metrics_form.load(std::memory_order_relaxed);
+        const int use_f16 = form != 'f';
         // the matrix-core kernel: a wavefront takes 64 / S trajectories per pass and normalises one ground-truth point
         // per lane, so S <= 64 and (64 / S) * 12 <= 64, i.e. 12 <= S <= 64 (the model form is S = 20)
-        if (!(e && e[0] == '0') && aligned16(gt) && S >= 12 && S <= 64 && N >= 64 / S && N * S < ((int64_t)1 << 29) && N * 24 < ((int64_t)1 << 30)) {
+        if (form != 't' && aligned16(gt) && S >= 12 && S <= 64 && N >= 64 / S && N * S < ((int64_t)1 << 29) && N * 24 < ((int64_t)1 << 30)) {
             const int TNW = 64 / S;
             const int64_t passes = ceil_div(N, TNW);
             const size_t lds = sizeof(float) * metrics_mfma_lds_floats(S, mode == ET_MODE_SPLIT ? 2 : 1);

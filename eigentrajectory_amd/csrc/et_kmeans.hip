@@ -45,6 +45,7 @@
 #include <sched.h>
 
 #include "et_hostring.h"
+#include "et_options.h"
 
 namespace et {
 
@@ -2591,7 +2592,8 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_predict_kernel(const float 
 // update cannot fire and best / nearest stay as they are.  Such a point costs 5 B (best + nearest) instead of
 // 32 B; farthest-first picks are far from everything by construction, so most points qualify.  best[] is only
 // written when it changes.  max|x| is collected by step 1, which reads everything anyway.
-// PERSIST: the body runs inside kmeans_init_persist_kernel, steps separated by a fence-free grid barrier: everything that
+// PERSIST (not instantiated any more: tools/lost_forms/kmeans_init_persist.hip.txt): the body inside ONE launch for all steps,
+// separated by a fence-free grid barrier: everything that
 // crosses workgroups inside the launch -- the workgroup keys, the centroid columns workgroup 0 stores -- is then written
 // and read with device-scope atomics (served by the memory side: no cache fence); best / nearest / the tile summaries
 // are only re-read by the wavefront that wrote them (the tile -> wavefront map is fixed).
@@ -2895,89 +2897,6 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_init_step_kernel(const floa
                              C0_rw, cand, meta, meta_valid);
 }
 
-// Farthest-first steps 2 .. K-1 of a single-GPU initialisation in ONE launch (step 1, the pass that reads every coordinate,
-// keeps its own launch and its own grid).  A step of the launch-per-centroid form is latency: ~12 us at N = 1e7, ~8 us at
-// 1e5, of which the work is a few microseconds -- the rest is the kernel boundary and a prologue that every workgroup
-// starts cold.  Here the grid (<= 2 workgroups per CU, all co-resident) stays and the steps are separated by the same
-// fence-free grid barrier as in kmeans_lloyd_persist_kernel (one relaxed atomic per workgroup after it has drained its
-// own memory operations; one lane polls).  After the last step workgroup 0 reduces the keys into centroid K-1.
-// Every spin carries a time-out (ctl[1] = abort flag): the host then repeats the initialisation with one launch per step.
-template <int D>
-__global__ __launch_bounds__(kKmThreads) void kmeans_init_persist_kernel(const float *__restrict__ X, int64_t N, int d_rt, int K,
-                                                                         float *C0, float *__restrict__ best,
-                                                                         uint8_t *__restrict__ nearest,
-                                                                         unsigned *__restrict__ max_abs_bits,
-                                                                         unsigned long long *keys_odd,
-                                                                         unsigned long long *keys_even, int n_first,
-                                                                         unsigned char *cand,
-                                                                         uint4 *__restrict__ meta, unsigned *ctl) {
-    __shared__ int sAbort;
-    if (threadIdx.x == 0) sAbort = 0;
-    __syncthreads();
-    // a step writes its workgroup keys into the buffer of its parity and reads the other one (step 1, launched before this
-    // kernel, left n_first keys in keys_odd)
-    for (int step = 2; step <= K; ++step) {
-        if (step > 2) {  // ---- grid barrier: every workgroup has stored its key of step - 1 ----
-            if (threadIdx.x == 0) {
-                const unsigned want = (unsigned)(step - 2) * gridDim.x;
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                while (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                    if (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
-                        __builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {  // 0.5 s of the 100 MHz clock
-                        __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        sAbort = 1;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            __syncthreads();
-            if (sAbort) return;
-        }
-        unsigned long long *mine = (step & 1) ? keys_odd : keys_even;
-        const unsigned long long *prev = (step & 1) ? keys_even : keys_odd;
-        const int n_prev = step == 2 ? n_first : (int)gridDim.x;
-        if (step == K) {  // the pick: centroid K-1 from the keys of step K-1
-            if (blockIdx.x != 0) return;
-            __shared__ unsigned long long sKey[kKmThreads / 64];
-            unsigned long long key = ~0ull;
-            for (int b = threadIdx.x; b < n_prev; b += kKmThreads) {
-                const unsigned long long k = __hip_atomic_load(&prev[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                key = k < key ? k : key;
-            }
-            for (int o = 32; o > 0; o >>= 1) {
-                const unsigned long long other = __shfl_xor(key, o);
-                key = other < key ? other : key;
-            }
-            if ((threadIdx.x & 63) == 0) sKey[threadIdx.x >> 6] = key;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                for (int w = 1; w < kKmThreads / 64; ++w) key = sKey[w] < key ? sKey[w] : key;
-                *reinterpret_cast<unsigned long long *>(cand) = key;
-                const int d = D ? D : d_rt;
-                const int64_t local = (int64_t)(unsigned)(key & 0xffffffffull);
-                for (int i = 0; i < d; ++i) {
-                    const float v = (key != ~0ull && local < N) ? X[(int64_t)i * N + local] : __int_as_float(0x7fc00000);
-                    reinterpret_cast<float *>(cand + 8)[i] = v;
-                    C0[i * K + (K - 1)] = v;
-                }
-            }
-            return;
-        }
-        // (the step's inputs pass through an empty asm: nothing derived from them is hoisted out of the step loop)
-        const float *Xi = X;
-        int64_t Ni = N;
-        int Ki = K;
-        asm volatile("" : "+s"(Xi), "+s"(Ni), "+s"(Ki));
-        init_step_body<D, true>(Xi, Ni, d_rt, Ki, step, C0, best, nearest, max_abs_bits, 0, mine, prev, n_prev, C0, cand, meta,
-                                step > 2 ? 1 : 0);
-        // arrival: this workgroup's stores have been performed (see kmeans_lloyd_persist_kernel)
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 // reduce the workgroup keys; candidate record = {key, d floats of the winning local point}
 __global__ __launch_bounds__(kKmThreads) void kmeans_init_pick_kernel(const float *__restrict__ X, int64_t N, int d,
                                                                       const unsigned long long *__restrict__ block_keys,
@@ -3138,10 +3057,9 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // 5e5 1.60 / 1.46, 1e6 1.85 / 1.70, 2e6 2.19 / 2.19, 4e6 2.77 / 2.90, 1e7 4.40 / 5.05 -- the packed body's longer set-up
 // (label table, accumulator copies) costs ~1.4 us per launch, the bytes it saves only count once a launch streams for longer
 constexpr int64_t kPackedMinPoints = (int64_t)1 << 21;
-static int64_t km_packed_min_points() {  // ET_KMEANS_PACKED_MIN: tests run the packed path on small shards
-    const char *e = getenv("ET_KMEANS_PACKED_MIN");
-    const long long v = e ? atoll(e) : 0;
-    return v >= 1024 ? (int64_t)v : kPackedMinPoints;
+static int64_t km_packed_min_points() {  // option kmeans_packed_min: tests run the packed path on small shards
+    const int64_t v = options().kmeans_packed_min.load(std::memory_order_relaxed);
+    return v >= 1024 ? v : kPackedMinPoints;
 }
 static bool km_packed_shape(int64_t N, int d, int K) { return d == 6 && K >= 3 && K <= 32 && N >= km_packed_min_points() && N % 4 == 0; }
 
@@ -3259,32 +3177,18 @@ extern "C" int et_kmeans_begin(et_kmeans_state *state, int64_t n_total, const fl
     return ET_OK;
 }
 
-static char km_argmax_mode() {
-    static const char mode = [] {
-        const char *e = getenv("ET_KMEANS_ARGMAX");
-        return e ? e[0] : 'f';
-    }();
-    return mode;
-}
-
-// ET_KMEANS_PACKED=0: trace-less fits keep the fp32 filter (read per fit: same-process A/B runs and tests)
-static bool km_packed_mode() {
-    const char *e = getenv("ET_KMEANS_PACKED");
-    return !(e && e[0] == '0');
-}
-// ET_KMEANS_INIT_TILES=0: farthest-first steps look at every point's running similarity (A/B runs)
-static bool km_init_tiles_mode() {
-    const char *e = getenv("ET_KMEANS_INIT_TILES");
-    return !(e && e[0] == '0');
-}
-// ET_KMEANS_PACK_FUSED=0: the packed copy is written by a pass of its own before the loop (A/B runs)
-static bool km_pack_fused_mode() {
-    const char *e = getenv("ET_KMEANS_PACK_FUSED");
-    return !(e && e[0] == '0');
-}
+// the switches of et_options.h (et_set_option), read per fit: same-process A/B runs and tests
+static char km_argmax_mode() { return (char)options().kmeans_argmax.load(std::memory_order_relaxed); }
+static bool km_packed_mode() { return options().kmeans_packed.load(std::memory_order_relaxed) != 0; }
+static bool km_init_tiles_mode() { return options().kmeans_init_tiles.load(std::memory_order_relaxed) != 0; }
+static bool km_pack_fused_mode() { return options().kmeans_pack_fused.load(std::memory_order_relaxed) != 0; }
 static std::atomic<long long> g_packed_fits{0};  // fits that iterated on the packed copy (tests: the path under test ran)
+#ifdef ET_TEST_HOOKS  // libetamd_testhooks.so only: problems of et_kmeans_fit_batch to treat as timed out (bit mask)
+static std::atomic<unsigned long long> g_test_abort_mask{0};
+extern "C" void et_testhook_kmeans_abort_mask(unsigned long long mask) { g_test_abort_mask.store(mask, std::memory_order_relaxed); }
+#endif
 
-// matrix-core filter + exact certification (default; ET_KMEANS_ARGMAX=valu disables it)
+// matrix-core filter + exact certification (default; option kmeans_argmax = v disables it)
 static bool km_use_filter(const float *X, int64_t N, int d, int K, const uint8_t *labels_u8) {
     const bool vec4 = (N % 4 == 0) && aligned16(X) && ((reinterpret_cast<uintptr_t>(labels_u8) & 3u) == 0);
     return km_argmax_mode() == 'f' && vec4 && d == 6 && K >= 3 && K <= 32 && N >= 1024 && N <= 0xffffffffll;
@@ -3318,8 +3222,8 @@ static size_t km_filter_lds_bytes(int d, int K, int threads) {
 // 12 or 16 wavefronts per CU for a shard of N points (one workgroup per CU, 256 points per wavefront pass): the
 // launch ends with its slowest wavefront, a pass costs 0.73x as much with three wavefronts per SIMD as with four.
 static int km_filter_threads(int64_t N) {
-    if (const char *e = getenv("ET_KMEANS_FILTER_THREADS")) {  // measurement aid (tools/ab_threads.sh)
-        const int t = atoi(e);
+    {  // option kmeans_filter_threads: measurement aid (tools/ab_threads_sizes.sh)
+        const int t = options().kmeans_filter_threads.load(std::memory_order_relaxed);
         if (t >= 256 && t <= kFilterMaxThreads && t % 64 == 0) return t;
     }
     int dev = 0, n_cu = 256;
@@ -3339,8 +3243,8 @@ static int km_filter_threads(int64_t N) {
 // 1e6 2.65 / 1.97 / 1.65 (1024: 1.69); persistent at 2e4 0.96 / 0.99 / 1.07, at 7e4 1.50 / 1.11 / 1.17.
 // -> the fewest wavefronts that still give every 256-point pass a wavefront of its own twice over.
 static int km_loop_threads(int64_t N, bool persistent) {
-    if (const char *e = getenv("ET_KMEANS_FILTER_THREADS")) {  // measurement aid
-        const int t = atoi(e);
+    {  // option kmeans_filter_threads: measurement aid
+        const int t = options().kmeans_filter_threads.load(std::memory_order_relaxed);
         if (t >= 256 && t <= kFilterMaxThreads && t % 64 == 0) return t;
     }
     const int n_cu = km_cu_count();
@@ -3541,9 +3445,6 @@ extern "C" int et_kmeans_gather_point(const float *X, int64_t N, int d, int64_t 
     return ET_OK;
 }
 
-static int km_init_persist_run(const float *X, int64_t N, int d, int K, float *C0, const KmWorkspace &w, hipStream_t st,
-                               bool *aborted);
-
 extern "C" int et_kmeans_init_farthest(const float *X, int64_t N, int d, int K, int64_t first_index, float *C0,
                                        void *workspace, size_t workspace_bytes, et_stream_t stream) {
     if (!km_dims_ok(d, K) || N < 1 || !X || !C0 || first_index < 0 || first_index >= N || N > 0xffffffffll)
@@ -3555,20 +3456,8 @@ extern "C" int et_kmeans_init_farthest(const float *X, int64_t N, int d, int K, 
                        w.init_maxabs);
     ET_LAUNCH_CHECK();
     int rc = ET_OK;
-    // ET_KMEANS_INIT=persist: steps 2 .. K-1 and the final pick in ONE persistent launch.  NOT the default -- measured in
-    // round 4 (profiles/r04b_init_persist.txt): 0.51 ms against 0.25 ms for the 19 launches at N = 1e7, 1.54 against 1.52 ms
-    // for the whole step at N = 1e5.  A step is a chain of dependent round trips either way (keys -> the new centroid's
-    // coordinates -> tile summaries -> the failing tiles' rows -> key); inside one launch three of them become device-scope
-    // atomics served by the memory side (~2 us each) where the launch form reads its predecessor's stores from L2, and
-    // the barrier (drain stores, arrive, poll) costs what the kernel boundary does.
-    const char *mode = getenv("ET_KMEANS_INIT");
-    if (K >= 3 && mode && mode[0] == 'p') {
-        rc = init_step_impl(X, N, d, K, 1, C0, w.best, 0, w.cand, workspace, workspace_bytes, stream, C0, false);
-        if (rc) return rc;
-        bool aborted = false;
-        rc = km_init_persist_run(X, N, d, K, C0, w, (hipStream_t)stream, &aborted);
-        if (rc || !aborted) return rc;
-    }
+    // (a one-launch form of steps 2 .. K-1 with a fence-free grid barrier was built in round 4 and lost -- 0.51 against 0.25 ms at
+    // 1e7 points, no gain at 1e5: profiles/r04b_init_persist.txt; its source: tools/lost_forms/kmeans_init_persist.hip.txt)
     for (int i = 1; i < K && !rc; ++i)  // one launch per new centroid (+ one pick for the last)
         rc = init_step_impl(X, N, d, K, i, C0, w.best, 0, w.cand, workspace, workspace_bytes, stream, C0, i == K - 1);
     return rc;
@@ -3794,42 +3683,6 @@ class PersistSlots {
 };
 
 }  // namespace et
-// Steps 2 .. K-1 + the final pick of the farthest-first initialisation as one persistent launch (kmeans_init_persist_kernel).
-// *aborted: the grid barrier timed out (another process on the GPU) -- the caller starts over with one launch per step.
-// Synchronises the stream (the abort flag must be read before the result is used; the launch-per-step form does not).
-static int km_init_persist_run(const float *X, int64_t N, int d, int K, float *C0, const et::KmWorkspace &w, hipStream_t st,
-                               bool *aborted) {
-    using namespace et;
-    int dev = 0;
-    const int n_cu = km_cu_count(&dev);
-    // as many workgroups as a step of the launch-per-step form would get, capped at two per CU (all co-resident; the
-    // barrier's cost grows with the number of arrivals)
-    int grid = init_step_grid(N, 2);
-    if (grid > 2 * n_cu) grid = 2 * n_cu;
-    ET_HIP_TRY(hipMemsetAsync(w.persist_ctl, 0, 2 * sizeof(unsigned), st));
-    uint4 *meta = (K <= 32 && km_init_tiles_mode()) ? w.init_meta : nullptr;
-    const int n_first = init_step_grid(N, 1);
-    PersistSlots &slots = PersistSlots::of_device(dev);
-    const int need = (grid + 1) / 2;  // CUs' worth of residency (two workgroups per CU)
-    slots.acquire(need, n_cu);
-    struct Release {
-        PersistSlots &s;
-        int n;
-        ~Release() { s.release(n); }
-    } release_on_exit{slots, need};
-    if (d == 6)
-        hipLaunchKernelGGL((kmeans_init_persist_kernel<6>), dim3(grid), dim3(kKmThreads), 0, st, X, N, d, K, C0, w.best, w.labels_u8,
-                           w.init_maxabs, w.block_keys2, w.block_keys, n_first, w.cand, meta, w.persist_ctl);
-    else
-        hipLaunchKernelGGL((kmeans_init_persist_kernel<0>), dim3(grid), dim3(kKmThreads), 0, st, X, N, d, K, C0, w.best, w.labels_u8,
-                           w.init_maxabs, w.block_keys2, w.block_keys, n_first, w.cand, meta, w.persist_ctl);
-    ET_LAUNCH_CHECK();
-    unsigned ctl[2] = {0u, 0u};
-    ET_HIP_TRY(hipMemcpyAsync(ctl, w.persist_ctl, sizeof ctl, hipMemcpyDeviceToHost, st));
-    ET_HIP_TRY(hipStreamSynchronize(st));
-    *aborted = ctl[1] != 0u;
-    return ET_OK;
-}
 namespace et {
 
 __global__ __launch_bounds__(kKmThreads) void kmeans_persist_prepare_kernel(int plen, long long *l0, long long *l1, long long *l2,
@@ -3860,17 +3713,11 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_persist_prepare_kernel(int 
 // 1e6 20.9 / 15.4, 1e7 56.1 / 49.7 -- the grid barrier + fold + update of the persistent form (~4 us for 33 workgroups,
 // ~7 us + the spread of 256 workgroups' finishing times for a full grid) beats a kernel boundary only while the grid is
 // small; for a full grid the staggered start of a new launch's workgroups happens to hide the uneven pass counts that
-// the barrier exposes.  Hence: persistent up to kPersistMaxPoints, chained above; ET_KMEANS_LOOP=persist / chain forces one.
+// the barrier exposes.  Hence: persistent up to kPersistMaxPoints, chained above; option kmeans_loop = persist / chain forces one.
 // (round 3, later: with 256-thread workgroups the chained loop is ahead from ~3e4 points on -- the table above
 // km_loop_threads; et_kmeans_fit_batch keeps the persistent form for its side-by-side problems at any size it takes)
 constexpr int64_t kPersistMaxPoints = 32768;
-static char km_persist_mode() {  // 'a'uto, 'c'hain, 'p'ersist
-    static const char mode = [] {
-        const char *e = getenv("ET_KMEANS_LOOP");
-        return e ? e[0] : 'a';
-    }();
-    return mode;
-}
+static char km_persist_mode() { return (char)options().kmeans_loop.load(std::memory_order_relaxed); }  // 'a'uto, 'c'hain, 'p'ersist
 static bool km_persist_wanted(int64_t N) {
     const char mode = km_persist_mode();
     if (mode == 'c') return false;
@@ -4131,13 +3978,13 @@ extern "C" int et_kmeans_fit_batch(const float *X, int64_t x_stride, int64_t N, 
             hipLaunchKernelGGL((kmeans_lloyd_persist_kernel<16, false>), g, dim3(threads), lds, st, X + b0 * x_stride, N, K, pa,
                                byte_shift(w.labels_u8, off), tol, (float *)nullptr, max_iter);
         ET_LAUNCH_CHECK();
-        // test hook (tests/test_gpu_parity.py): ET_KMEANS_TEST_ABORT = bit mask of problems to treat as timed out
-        if (const char *env = getenv("ET_KMEANS_TEST_ABORT")) {
-            const unsigned long long mask = strtoull(env, nullptr, 0);
+#ifdef ET_TEST_HOOKS  // libetamd_testhooks.so only (tests/test_gpu_parity.py): bit mask of problems to treat as timed out
+        if (const unsigned long long mask = g_test_abort_mask.load(std::memory_order_relaxed)) {
             for (int64_t b = b0; b < b0 + nb; ++b)
                 if (b < 64 && (mask >> b & 1ull))
                     ET_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(byte_shift(w.persist_ctl, b * (int64_t)one) + 1), 1, 1, st));
         }
+#endif
         // did every problem's barrier hold?  (the slots go back when this chunk has run)
         ET_HIP_TRY(hipMemcpy2DAsync(ctl.data() + 2 * b0, 2 * sizeof(unsigned), byte_shift(w.persist_ctl, off), one,
                                     2 * sizeof(unsigned), (size_t)nb, hipMemcpyDeviceToHost, st));

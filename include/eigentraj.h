@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define ET_ABI_VERSION 2  /* 2: et_kmeans_timing grew `iterations` (32 bytes) */
+#define ET_ABI_VERSION 3  /* 2: et_kmeans_timing grew `iterations` (32 bytes); 3: et_set_option replaces the ET_* environment switches */
 
 #define ET_OK 0
 #define ET_ERR_INVALID_ARG 1  /* bad shape / null pointer / misaligned buffer */
@@ -78,6 +78,24 @@ int et_abi_version(void);
 const char *et_status_string(int status);
 /* name of the GPU arch the kernels were compiled for ("gfx950") */
 const char *et_compiled_arch(void);
+
+/* ---- tuning switches -----------------------------------------------------------------------------
+ * The data path keeps no state between calls and reads nothing from the environment.  The ONE piece of process-wide
+ * mutable configuration is this table of measurement aids / test levers (csrc/et_options.hip): every setting selects
+ * between forms that are tested to give the same bits, the defaults are the shipped configuration, and a switch is read
+ * once at the start of the call it affects (set it before the call, from one thread).  Keys (value as text):
+ *   kmeans_packed_min      >= 1024: shards with at least this many points iterate on the packed f16 copy (default 2^21)
+ *   kmeans_packed          0: trace-less fits keep the fp32 filter body              (default 1)
+ *   kmeans_pack_fused      0: the packed copy is written by a pass of its own         (default 1: inside iteration 0)
+ *   kmeans_argmax          f: matrix-core filter + exact certification (default) | v: the exact scan only
+ *   kmeans_init_tiles      0: farthest-first steps look at every point                (default 1: 256-point tile summaries)
+ *   kmeans_filter_threads  256..1024, multiple of 64: workgroup size of the Lloyd kernels (default 0: chosen per shard)
+ *   kmeans_loop            a: auto (default) | c: one launch per iteration | p: one persistent launch per fit
+ *   metrics_form           a: auto (default) | t: vector-ALU tile kernel for every S | f: fp32 matrix instructions only
+ * et_set_option returns ET_ERR_INVALID_ARG for an unknown key or a value the key does not take; et_get_option writes the
+ * current value as text.  (The Python binding forwards environment variables ET_OPT_<KEY> once, at load.) */
+int et_set_option(const char *key, const char *value);
+int et_get_option(const char *key, char *value, size_t value_bytes);
 
 /* ---- TrajNorm (EigenTrajectory/normalizer.py) -------------------------------------------
  * et_norm_params   normalizer.py:17-29: ori (N,1,2), rot (N,2,2) = [[c,-s],[s,c]], sca (N,1,1)

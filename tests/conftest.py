@@ -26,3 +26,19 @@ def oracle():
     from oracle import et_oracle
     et_oracle.build()
     return et_oracle
+
+
+@pytest.fixture
+def et_option():
+    """et_set_option for the duration of a test (include/eigentraj.h "tuning switches"): et_option("kmeans_packed", 0)."""
+    from eigentrajectory_amd import _lib as L
+    saved = {}
+
+    def set_(key, value):
+        if key not in saved:
+            saved[key] = L.get_option(key)
+        L.set_option(key, value)
+
+    yield set_
+    for key, value in saved.items():
+        L.set_option(key, value)

@@ -29,9 +29,32 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libetamd.so does not export {name}"
     assert sorted(_lib.SYMBOLS) == declared
-    assert lib.et_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.et_abi_version() == _lib.ABI_VERSION == 3
     assert lib.et_compiled_arch() == b"gfx950"
     assert lib.et_status_string(0) == b"ok" and b"workspace" in lib.et_status_string(4)
+
+
+def test_options_table_and_no_environment_reads():
+    """include/eigentraj.h "tuning switches": et_set_option / et_get_option are the library's only mutable configuration
+    -- unknown keys and values are rejected, values round-trip -- and no kernel source reads the environment (the test
+    hook of one GPU test lives in libetamd_testhooks.so, not in the product library)."""
+    from eigentrajectory_amd import _lib
+    assert _lib.get_option("kmeans_loop") == "a" and _lib.get_option("kmeans_packed") == "1"
+    with _lib.option("kmeans_loop", "chain"):
+        assert _lib.get_option("kmeans_loop") == "c"
+    assert _lib.get_option("kmeans_loop") == "a"
+    with _lib.option("kmeans_packed_min", 262144):
+        assert _lib.get_option("kmeans_packed_min") == "262144"
+    for key, value in (("no_such_key", "1"), ("kmeans_loop", "x"), ("kmeans_packed", "yes"), ("kmeans_packed", "")):
+        with pytest.raises(ValueError):
+            _lib.set_option(key, value)
+    csrc = os.path.join(ROOT, "eigentrajectory_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, name)).read(), name
+    import subprocess
+    syms = subprocess.run(["nm", "-D", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "et_testhook" not in syms and "et_debug" not in syms  # (stamp readers exist in -DET_EXP_* variant builds only)
 
 
 def test_state_struct_layout_matches_header():

@@ -9,7 +9,7 @@ for v in "" noload nomfma noboth; do
   [ -n "$v" ] && lib=$R/eigentrajectory_amd/variants/libetamd_$v.so
   [ -f "$lib" ] || continue
   for loop in chain persist; do
-    line=$(ET_LIBETAMD=$lib ET_KMEANS_LOOP=$loop timeout 300 python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | tail -1)
+    line=$(ET_LIBETAMD=$lib ET_OPT_KMEANS_LOOP=$loop timeout 300 python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | tail -1)
     echo "${v:-full} $loop $(echo "$line" | python -c 'import json,sys; j=json.loads(sys.stdin.read()); r=j["roofline"]; print("launch_ms", r["avg_launch_ms"], "iters/launch", r["lloyd_iterations_per_launch"], "us/iter", round(1e3*r["avg_launch_ms"]/r["lloyd_iterations_per_launch"],2), "lloyd_ms", j["stages"]["kmeans_lloyd"]["ms"], "its", j["stages"]["kmeans_lloyd"]["iterations"])')"
   done
 done

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Lloyd loop time per shard size (development aid): run once per loop form, e.g.
-    ET_KMEANS_LOOP=chain python tools/ab_loop_sizes.py ; ET_KMEANS_LOOP=persist python tools/ab_loop_sizes.py
+    ET_OPT_KMEANS_LOOP=chain python tools/ab_loop_sizes.py ; ET_OPT_KMEANS_LOOP=persist python tools/ab_loop_sizes.py
 prints, per N, the wall time of et_kmeans_fit (100 iterations, no trace; median of 7) and the time per iteration."""
 import os, sys, time
 import numpy as np, torch
@@ -10,7 +10,7 @@ from eigentrajectory_amd.synth import synthetic_trajectories_torch
 
 dev = torch.device("cuda:0")
 sizes = [int(float(a)) for a in sys.argv[1:]] or [20_000, 70_000, 100_000, 300_000, 600_000, 1_000_000, 2_000_000, 4_000_000, 10_000_000]
-print("loop form:", os.environ.get("ET_KMEANS_LOOP", "default"))
+print("loop form:", os.environ.get("ET_OPT_KMEANS_LOOP", "default"))
 for n in sizes:
     obs, pred = synthetic_trajectories_torch(n, dev, seed=0, min_disp=1e-3)
     g_obs, g_pred, _ = ops.fit_gram(obs, pred, 1, 0.0, 1)

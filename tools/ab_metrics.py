@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eigentrajectory_amd import ops  # noqa: E402
+from eigentrajectory_amd import _lib as L  # noqa: E402
 from eigentrajectory_amd.synth import synthetic_trajectories_torch  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -39,15 +40,15 @@ def med(fn, reps=10):
 res = {}
 for rnd in range(2):
     for mf in ("0", "f32", "1"):
-        os.environ["ET_METRICS_MFMA"] = mf
+        L.set_option("metrics_form", {"0": "t", "f32": "f", "1": "a"}[mf])
         t_mov = med(lambda: ops.anchor_reconstruct_metrics(C20, pred, A, None, Up, None, ops.MODE_MOVING, nrm=nrm))
         t_spl = med(lambda: ops.anchor_reconstruct_metrics(C20, pred, A, A, Up, Up, ops.MODE_SPLIT, 0.3, nrm=nrm))
         print(f"round {rnd} ET_METRICS_MFMA={mf}: MOVING {t_mov:.3f} ms ({600 * n / t_mov / 1e6 / 8000:.3f} of 8 TB/s)   "
               f"SPLIT {t_spl:.3f} ms ({600 * n / t_spl / 1e6 / 8000:.3f})", flush=True)
-os.environ["ET_METRICS_MFMA"] = "0"
+L.set_option("metrics_form", "t")
 a0, f0 = ops.anchor_reconstruct_metrics(C20, pred, A, A, Up, Up, ops.MODE_SPLIT, 0.3, nrm=nrm)
 for mf in ("f32", "1"):
-    os.environ["ET_METRICS_MFMA"] = mf
+    L.set_option("metrics_form", {"0": "t", "f32": "f", "1": "a"}[mf])
     a1, f1 = ops.anchor_reconstruct_metrics(C20, pred, A, A, Up, Up, ops.MODE_SPLIT, 0.3, nrm=nrm)
     print(mf, "max |ADE diff|", float((a0 - a1).abs().max()), "max |FDE diff|", float((f0 - f1).abs().max()),
           "of max ADE", float(a0.max()), flush=True)

@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Same-process A/B of the projection / S=1 reconstruction kernels at N = 1e7: tile kernels (ET_STREAM=0) against the
+"""HISTORICAL (round 4): the streaming kernels this script compares were taken out of libetamd.so in round 5
+(tools/lost_forms/project_reconstruct_stream.hip.txt; results: profiles/r04a_stream_ab.txt) -- it runs against the library of
+commit 22948e6 only.
+
+Same-process A/B of the projection / S=1 reconstruction kernels at N = 1e7: tile kernels (ET_STREAM=0) against the
 streaming kernels with 1..4 workgroups per CU (ET_STREAM_WGS).  HIP-event medians of 30 launches, alternating."""
 import os
 import sys

@@ -18,7 +18,7 @@ EXTRA=""
 [ "$SRC" = "et_kmeans_reforder.hip" ] && EXTRA="-fno-slp-vectorize"
 /opt/rocm/bin/hipcc $BASE $EXTRA $FLAGS -c "$C/$SRC" -o "$V/${SRC%.hip}_$NAME.o"
 OBJS=""
-for f in et_abi et_trajnorm et_descriptor et_train et_fit et_kmeans et_kmeanspp et_kmeans_reforder et_sharded; do
+for f in et_abi et_options et_trajnorm et_descriptor et_train et_fit et_kmeans et_kmeanspp et_kmeans_reforder et_sharded; do
     if [ "$f.hip" = "$SRC" ]; then OBJS="$OBJS $V/${f}_$NAME.o"; else OBJS="$OBJS $C/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$V/libetamd_$NAME.so" $OBJS -ldl

@@ -9,6 +9,7 @@ import torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 from eigentrajectory_amd import ops  # noqa: E402
+from eigentrajectory_amd import _lib as L  # noqa: E402
 
 dev = torch.device("cuda:0")
 seed0, case = int(sys.argv[1]), int(sys.argv[2])
@@ -40,7 +41,7 @@ print("n", n, "K", K, "iters", iters, flags, "max|x|", float(x.abs().max()), "me
 
 
 def fit(packed, it, trace=False):
-    os.environ["ET_KMEANS_PACKED"] = "1" if packed else "0"
+    L.set_option("kmeans_packed", 1 if packed else 0)
     return ops.kmeans_fit(x, c0, it, tol, trace=trace)
 
 

@@ -15,7 +15,7 @@ import ctypes
 from eigentrajectory_amd import _lib as L
 _pf = L.lib().et_internal_kmeans_packed_fits
 _pf.restype = ctypes.c_longlong
-packed0 = _pf()  # fits that iterated on the packed copy (ET_KMEANS_PACKED_MIN=1024 ET_KMEANS_LOOP=chain ET_SOAK_TRACELESS=1: all of them)
+packed0 = _pf()  # fits that iterated on the packed copy (ET_OPT_KMEANS_PACKED_MIN=1024 ET_OPT_KMEANS_LOOP=chain ET_SOAK_TRACELESS=1: all of them)
 bad = 0
 t0 = time.time()
 for case in range(cases):

@@ -10,6 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eigentrajectory_amd import ops  # noqa: E402
+from eigentrajectory_amd import _lib as L  # noqa: E402
 from eigentrajectory_amd.synth import synthetic_trajectories_torch  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -38,7 +39,7 @@ for it in range(cases):
         kw["obs"] = obs
     out = {}
     for v in ("0", "1"):
-        os.environ["ET_METRICS_MFMA"] = v
+        L.set_option("metrics_form", {"0": "t", "f32": "f", "1": "a"}.get(v, v))
         out[v] = ops.anchor_reconstruct_metrics(c, gt, a_m, a_s, um, us_, mode, 0.3, **kw)
     for name, a, b in (("ade", out["0"][0], out["1"][0]), ("fde", out["0"][1], out["1"][1])):
         na, nb = torch.isnan(a), torch.isnan(b)

@@ -40,9 +40,9 @@ for case in range(cases):
     x = (x * 10.0 ** float(rng.uniform(-6, 6))).contiguous()
     c0 = ops.kmeans_init_farthest(x, K, int(rng.integers(0, n)))
     iters = int(rng.integers(8, 40))
-    os.environ["ET_KMEANS_PACKED"] = "1"
+    L.set_option("kmeans_packed", 1)
     a = ops.kmeans_fit(x, c0, iters, 1e-4 * float(x.var()), trace=False)
-    os.environ["ET_KMEANS_PACKED"] = "0"
+    L.set_option("kmeans_packed", 0)
     b = ops.kmeans_fit(x, c0, iters, 1e-4 * float(x.var()), trace=False)
     ok = (a["n_iter"] == b["n_iter"] and torch.equal(a["labels"], b["labels"])
           and np.array_equal(a["centroids"].cpu().numpy(), b["centroids"].cpu().numpy(), equal_nan=True)

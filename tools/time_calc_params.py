@@ -14,4 +14,4 @@ torch.cuda.synchronize()
 ts = []
 for _ in range(7):
     t0 = time.perf_counter(); model.calculate_parameters(o, p); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-print(os.environ.get("ET_KMEANS_LOOP", "auto"), "calculate_parameters ms:", ["%.2f" % (t * 1e3) for t in sorted(ts)])
+print(os.environ.get("ET_OPT_KMEANS_LOOP", "auto"), "calculate_parameters ms:", ["%.2f" % (t * 1e3) for t in sorted(ts)])
