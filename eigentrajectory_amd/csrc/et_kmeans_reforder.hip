@@ -700,7 +700,19 @@ __device__ unsigned long long g_rf_stamps[4 * 16];
     do {                                                                                                   \
         if (threadIdx.x == 0 && blockIdx.y == 0) atomicMax(&g_rf_stamps[(who) * 16 + (i)], __builtin_amdgcn_s_memrealtime()); \
     } while (0)
+// slot `i` of row 3 += ticks since *t (thread 0 of workgroup 0 only), *t = now
+#define RF_ACC(i, t)                                                                  \
+    do {                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {                 \
+            const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();         \
+            g_rf_stamps[3 * 16 + 8 + (i)] += now_ - (t);                              \
+            (t) = now_;                                                               \
+        }                                                                             \
+    } while (0)
 #else
+#define RF_ACC(i, t) \
+    do {             \
+    } while (0)
 #define RF_STAMP_MAX(who, i) \
     do {                     \
     } while (0)
@@ -713,8 +725,7 @@ __device__ unsigned long long g_rf_stamps[4 * 16];
 //   level 0  wavefront = coordinate, lane = chain (chunk, lane k); the chain's K (+ one dummy) accumulators are the LDS
 //            words [row][chain]; a step = read, add, write of the row its label names;
 //   level 1  work item (coordinate, cluster): adds the results of the chunks < n_l1 in chunk order (four lanes k side by
-//            side in one 16-byte read; the items walk skewed by (cluster mod 8) steps so that a wavefront's reads spread
-//            over all banks); the result of chunk n_l1 (if n_all > n_l1: the lane terms after the last full chunk) is
+//            side in one 16-byte read, four reads in flight); the result of chunk n_l1 (if n_all > n_l1: the lane terms after the last full chunk) is
 //            handed back untouched in acc0.
 // load(tile, rb, lane, coordinate) -> the four values of steps 4 rb .. 4 rb + 3 of chain `lane` of `tile`; sLab: the same
 // steps' labels, one word per (tile, rb, chain); a label = K routes a term that does not exist to the dummy row.
@@ -725,11 +736,20 @@ __device__ __forceinline__ void cascade_levels(Load load, const unsigned *sLab, 
     const int RB = L / 4, rows = K + 1, dk = kD * K;
     const int tiles = (n_all + 15) >> 4;
     const int ci = tid / K, cj = tid % K;
+    // Accumulator word of (row, chain): column chain ^ (4 (row & 7)) of the row's 64 words.  Level 0 (lane = chain, row =
+    // label) stays inside bank  lane mod 4 + a scrambled multiple of 4; level 1 (lane = (coordinate, cluster), a 16-byte
+    // read of the four lanes k of chunk c) finds the rows of eight consecutive clusters in eight different bank groups --
+    // without the swizzle every lane of a wavefront reads the same four banks.
+    [[maybe_unused]] unsigned long long tacc = __builtin_amdgcn_s_memrealtime();
     for (int q0 = 0; q0 < tiles; q0 += TR) {
         const int tr = tiles - q0 < TR ? tiles - q0 : TR;
         for (int ql = 0; ql < tr; ++ql) {
-            float *acc = sAcc + ((size_t)(ql * kD + wave) * rows) * 64 + lane;
-            for (int j = 0; j < rows; ++j) acc[j * 64] = 0.f;
+            float *blk = sAcc + ((size_t)(ql * kD + wave) * rows) * 64;  // this wavefront's (tile, coordinate) block
+            {
+                float4 *z = reinterpret_cast<float4 *>(blk);
+                for (int e = lane; e < rows * 16; e += 64) z[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            RF_ACC(0, tacc);
             const unsigned *lr = sLab + (q0 + ql) * RB * 64 + lane;
             // the chain's values, four 16-byte loads (= 16 steps) in flight at a time: with one load per four steps the loop ran
             // at the latency of its loads, not of its LDS updates (eight in flight cost the registers of a seventh wavefront)
@@ -737,41 +757,66 @@ __device__ __forceinline__ void cascade_levels(Load load, const unsigned *sLab, 
                 float4 xc[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) xc[u] = load(q0 + ql, rb0 + u, lane, wave);
+#ifdef ET_EXP_RFSTAMP
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                RF_ACC(1, tacc);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
+                    // four steps: their accumulators are requested together and the additions chained in registers -- a
+                    // later step whose label repeats an earlier one takes that step's result instead of the (stale) word
+                    // it read, and writes in order, so the row ends with the same sequential sum as read-add-write per
+                    // step, at one LDS round trip per four steps instead of four
                     const float4 xv = xc[u];
                     const unsigned l4 = lr[(rb0 + u) * 64];
-                    float *p0 = acc + (l4 & 255u) * 64;
-                    *p0 = *p0 + xv.x;
-                    float *p1 = acc + ((l4 >> 8) & 255u) * 64;
-                    *p1 = *p1 + xv.y;
-                    float *p2 = acc + ((l4 >> 16) & 255u) * 64;
-                    *p2 = *p2 + xv.z;
-                    float *p3 = acc + (l4 >> 24) * 64;
-                    *p3 = *p3 + xv.w;
+                    const unsigned j0 = l4 & 255u, j1 = (l4 >> 8) & 255u, j2 = (l4 >> 16) & 255u, j3 = l4 >> 24;
+                    float *p0 = blk + j0 * 64 + (lane ^ ((j0 & 7u) << 2)), *p1 = blk + j1 * 64 + (lane ^ ((j1 & 7u) << 2));
+                    float *p2 = blk + j2 * 64 + (lane ^ ((j2 & 7u) << 2)), *p3 = blk + j3 * 64 + (lane ^ ((j3 & 7u) << 2));
+                    const float r0 = *p0, r1 = *p1, r2 = *p2, r3 = *p3;
+                    const float n0 = r0 + xv.x;
+                    const float n1 = (j1 == j0 ? n0 : r1) + xv.y;
+                    const float n2 = (j2 == j1 ? n1 : (j2 == j0 ? n0 : r2)) + xv.z;
+                    const float n3 = (j3 == j2 ? n2 : (j3 == j1 ? n1 : (j3 == j0 ? n0 : r3))) + xv.w;
+                    *p0 = n0;
+                    *p1 = n1;
+                    *p2 = n2;
+                    *p3 = n3;
                 }
+#ifdef ET_EXP_RFSTAMP
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                RF_ACC(2, tacc);
             }
         }
         __syncthreads();
+        RF_ACC(3, tacc);
         if (tid < dk) {
-            const int nch = tr * 16, sk = cj & 7;
-            for (int s = 0; s < nch + 7; ++s) {
-                const int c = s - sk;
-                if (c >= 0 && c < nch) {
-                    const float4 v = *reinterpret_cast<const float4 *>(sAcc + ((size_t)((c >> 4) * kD + ci) * rows + cj) * 64 + (c & 15) * 4);
-                    const int cg = q0 * 16 + c;
-                    if (cg < n_l1) {
-                        acc1.x = acc1.x + v.x;
-                        acc1.y = acc1.y + v.y;
-                        acc1.z = acc1.z + v.z;
-                        acc1.w = acc1.w + v.w;
-                    } else if (cg == n_l1) {
-                        acc0 = v;
+            for (int ql = 0; ql < tr; ++ql) {
+                const float *row = sAcc + ((size_t)(ql * kD + ci) * rows + cj) * 64;
+                const int sw = (cj & 7) << 2;
+#pragma clang loop unroll(disable)
+                for (int h = 0; h < 4; ++h) {  // four chunks' results requested together, added in chunk order
+                    float4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(row + (((4 * h + u) << 2) ^ sw));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int cg = (q0 + ql) * 16 + 4 * h + u;
+                        if (cg < n_l1) {
+                            acc1.x = acc1.x + v[u].x;
+                            acc1.y = acc1.y + v[u].y;
+                            acc1.z = acc1.z + v[u].z;
+                            acc1.w = acc1.w + v[u].w;
+                        } else if (cg == n_l1) {
+                            acc0 = v[u];
+                        }
                     }
                 }
             }
         }
+        RF_ACC(4, tacc);
         __syncthreads();
+        RF_ACC(5, tacc);
     }
 }
 
@@ -1312,7 +1357,9 @@ static int update_rows_cap(const Geo &g, int K, int batch, size_t *lds) {
 
 #ifdef ET_EXP_RFSTAMP
 extern "C" int et_debug_rfstamps(unsigned long long *host) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rf_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : 3;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rf_stamps), sizeof(unsigned long long) * 64) != hipSuccess) return 3;
+    static const unsigned long long zeros[64] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_rf_stamps), zeros, sizeof zeros) == hipSuccess ? 0 : 3;  // (reading resets)
 }
 #endif
 

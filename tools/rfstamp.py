@@ -17,7 +17,9 @@ names = {0: ["start", "prologue", "assign", "levels 0-1 + store", "counts"],
 for n in [int(float(a)) for a in sys.argv[1:]] or [100000, 1000000, 10000000]:
     x = torch.from_numpy(gaussian_points_np(6, n, seed=3, n_blobs=7)).to(dev)
     c0 = ops.kmeans_init_farthest(x, 20, 17)
-    ops.kmeans_fit_reference_order(x, c0, 10, -1.0, trace=False)
+    buf0 = (C.c_ulonglong * 64)()
+    L.lib().et_debug_rfstamps(buf0)  # (reading resets the accumulated slots)
+    ops.kmeans_fit_reference_order(x, c0, 11, -1.0, trace=False)
     torch.cuda.synchronize()
     buf = (C.c_ulonglong * 64)()
     assert L.lib().et_debug_rfstamps(buf) == 0
@@ -30,4 +32,6 @@ for n in [int(float(a)) for a in sys.argv[1:]] or [100000, 1000000, 10000000]:
         print(f"  {label:27s} starts at {(row[0] - t0) / 100:7.2f} us; " +
               ", ".join(f"{names[who][i]} {(row[i] - row[i - 1]) / 100:.2f}" for i in range(1, cnt)) +
               f"; ends at {(row[cnt - 1] - t0) / 100:.2f} us")
+    acc = st[3, 8:14] / 100.0 / 11  # the warm-up call in front + ... : per launch of the 11 launches since the last read
+    print("  workgroup 0, levels 0-1 per launch: zeroing %.2f, loads %.2f, updates %.2f, barrier %.2f, level 1 %.2f, barrier %.2f us" % tuple(acc))
     print(f"  groups kernel, last workgroup to pass: assign {(st[0, 8] - t0) / 100:.2f}, levels {(st[0, 9] - t0) / 100:.2f}, end {(st[0, 10] - t0) / 100:.2f} us")
