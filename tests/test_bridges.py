@@ -150,3 +150,40 @@ def test_sgcn_end_to_end_replay_through_the_oracle_g13(oracle, scene):
         np.testing.assert_allclose(W.batch_fde(out["recon_traj"], pred[s:e]), z[f"{tag}.fde"], atol=1e-5)
         losses = [out["loss_eigentraj"], out["loss_euclidean_ade"], out["loss_euclidean_fde"]]
         np.testing.assert_allclose(losses, z[f"{tag}.losses"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("scene", G.SCENES)
+def test_sgcn_full_splits_replay_through_the_oracle_g14(oracle, scene):
+    """Config 3 at full extent on CPU (tests/golden/g14: every test scene of eth / hotel / zara1 / zara2, every tenth of
+    univ's): oracle projection -> THIS build's sgcn bridge -> the recorded output of the reference's SGCN -> oracle
+    reconstruction: per-pedestrian best-of-20 ADE / FDE and the split-level means within 1e-5 of the reference's."""
+    from eigentrajectory_amd.bridges import get_hook_func
+    from oracle import wrapper_ref as W
+    z = G.load("g14_sgcn_full_splits.npz")
+    g2 = G.load("g2_fit_all_scenes.npz")
+    params = {k[len(scene) + 1:]: g2[k] for k in g2.files if k.startswith(f"{scene}.ET_")}
+    obs, pred, sse = G.dataset(scene, "test")
+    hooks = get_hook_func("sgcn")
+    v_all, out_all = torch.from_numpy(z[f"{scene}.v"]), torch.from_numpy(z[f"{scene}.net_out"])
+    net = ReplaySGCN(None, None, None, 2e-5)
+
+    def predictor(x):  # x = cat(C_obs, obs_ori) (k+2, N), the oracle wrapper's stand-in for the pre-hook input
+        xt = torch.from_numpy(x)
+        data = hooks.model_forward_pre_hook(xt[:6], xt[6:], None)
+        return hooks.model_forward_post_hook(hooks.model_forward(data, net), None).contiguous().numpy()
+
+    ades, fdes, at = [], [], 0
+    for i, n in zip(z[f"{scene}.scene_index"], z[f"{scene}.scene_size"]):
+        s, e = sse[int(i)]
+        n = int(n)
+        net.expect = v_all[:, at:at + n].reshape(1, -1, n, 1)
+        net.eye_shapes = np.asarray([[1, n, n], [n, 1, 1]])
+        net.answer = out_all[:, at:at + n].contiguous()
+        out = W.forward(params, obs[s:e], None, predictor, float(z[f"{scene}.static_dist"]))
+        ades.append(W.batch_ade(out["recon_traj"], pred[s:e]))
+        fdes.append(W.batch_fde(out["recon_traj"], pred[s:e]))
+        at += n
+    ade, fde = np.concatenate(ades), np.concatenate(fdes)
+    np.testing.assert_allclose(ade, z[f"{scene}.ade"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(fde, z[f"{scene}.fde"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose([ade.mean(dtype=np.float64), fde.mean(dtype=np.float64)], z[f"{scene}.ade_fde_mean"], rtol=0, atol=1e-5)

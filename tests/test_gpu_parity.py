@@ -1733,6 +1733,56 @@ def test_sgcn_bridge_end_to_end_replay_g13(dev, scene):
         np.testing.assert_allclose(N_(fde), z[f"{tag}.fde"], atol=1e-5)
 
 
+@pytest.mark.parametrize("scene", G.SCENES)
+def test_sgcn_full_splits_replay_g14(dev, scene):
+    """Config 3 at full extent (BASELINE.json: EigenTrajectory-SGCN inference, 20 samples, all five ETH/UCY splits, ADE/FDE
+    vs the reference): EVERY test scene of eth / hotel / zara1 / zara2 and every tenth of univ's (tools/
+    make_golden_sgcn_full.py: the imported reference's wrapper + sgcn bridge + its seeded SGCN) replayed through the
+    PRODUCT -- wrapper (HIP projection) -> sgcn bridge contract (the network's recorded input is checked, its recorded
+    output answered) -> HIP reconstruction: best-of-20 ADE / FDE per pedestrian within 1e-5 m of the reference's, the
+    split-level means (utils/trainer.py:173-195) within 1e-5, for the fused metrics epilogue AND for the materialised
+    trajectories of the test loop's own call `model(obs)`."""
+    from eigentrajectory_amd import EigenTrajectory
+    from eigentrajectory_amd.bridges import get_hook_func
+    from eigentrajectory_amd.utils import default_hyper_params
+    from .test_bridges import ReplaySGCN
+    z = G.load("g14_sgcn_full_splits.npz")
+    g2 = G.load("g2_fit_all_scenes.npz")
+    obs, pred, sse = G.dataset(scene, "test")
+    net = ReplaySGCN(None, None, None, 2e-5)
+    model = EigenTrajectory(net, get_hook_func("sgcn"), default_hyper_params(static_dist=float(z[f"{scene}.static_dist"])))
+    sd = model.state_dict()
+    for key in list(sd):
+        if key.startswith("ET_"):
+            sd[key] = torch.from_numpy(g2[f"{scene}.{key}"])
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    v_all, out_all = torch.from_numpy(z[f"{scene}.v"]), torch.from_numpy(z[f"{scene}.net_out"]).to(dev)
+    sizes = z[f"{scene}.scene_size"]
+    assert scene == "univ" or len(sizes) == len(sse)  # every scene of the split (univ: index % 10 == 0)
+    fused, plain, at = [], [], 0
+    with torch.no_grad():
+        for i, n in zip(z[f"{scene}.scene_index"], sizes):
+            s, e = sse[int(i)]
+            n = int(n)
+            assert e - s == n
+            net.expect = v_all[:, at:at + n].reshape(1, -1, n, 1)
+            net.eye_shapes = np.asarray([[1, n, n], [n, 1, 1]])
+            net.answer = out_all[:, at:at + n].contiguous()
+            o, p = T(obs[s:e], dev), T(pred[s:e], dev)
+            ade, fde = model.evaluate(o, p)
+            fused.append(torch.stack([ade, fde]))
+            rec = model(o)["recon_traj"]  # (S, n, 12, 2): what the reference's test loop evaluates (utils/trainer.py:183-186)
+            dist = (rec - p[None]).norm(p=2, dim=-1)
+            plain.append(torch.stack([dist.mean(dim=-1).min(dim=0)[0], dist[..., -1].min(dim=0)[0]]))
+            at += n
+    assert at == v_all.shape[1] == len(z[f"{scene}.ade"])
+    ref = np.stack([z[f"{scene}.ade"], z[f"{scene}.fde"]])
+    for got in (N_(torch.cat(fused, dim=1)), N_(torch.cat(plain, dim=1))):
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5)
+        np.testing.assert_allclose(got.mean(axis=1, dtype=np.float64), z[f"{scene}.ade_fde_mean"], rtol=0, atol=1e-5)
+
+
 def test_batchkmeans_batch_of_problems_stops_together(ops, oracle, dev):
     """BatchKMeans.fit on (l, d, n) data (kmeans.py:200-259): the l problems run in lockstep and stop TOGETHER, on the
     error summed over the batch (kmeans.py:232, 239) -- bit for bit what the oracle's restatement of that loop gives."""
