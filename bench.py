@@ -370,6 +370,15 @@ def scene_latency(dev, U_obs, U_pred, n_peds=57, reps=2000):
     return res
 
 
+def step_roofline(n, ms, lloyd_iterations, K):
+    """Algorithmic bytes of one whole step (SURVEY 8(d) per stage: fit 160 + project 208 + reconstruct 136 + (K - 1)
+    farthest-first passes of 32 + 24 per Lloyd iteration + 8 of labels, per trajectory) against the HBM peak."""
+    per = BYTES["fit"] + BYTES["project"] + BYTES["reconstruct"] + (K - 1) * BYTES["kmeans_init_step"] + \
+        BYTES["kmeans_iter"] * lloyd_iterations + BYTES["labels"]
+    gbs = per * n / ms / 1e6
+    return dict(algorithmic_bytes_per_trajectory=round(per, 1), GBs=round(gbs, 1), frac_of_peak=round(gbs / HBM_PEAK_GBS, 4))
+
+
 def extra_stages(ops, obs, pred, n, K, max_iter, first_index, dev):
     """Measurements beside the headline step (single GPU): the model form of the reconstruction (S = 20 samples,
     descriptor.py:162-176: (k,N,20) -> (20,N,12,2), 2416 B per trajectory) forward, backward and with the fused
@@ -415,7 +424,7 @@ def extra_stages(ops, obs, pred, n, K, max_iter, first_index, dev):
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps
             sizes[tag] = dict(value=round(m / dt, 1), unit="trajectories/s", ms_per_step=round(dt * 1e3, 4),
-                              lloyd_iterations=float(np.mean(its)))
+                              lloyd_iterations=float(np.mean(its)), **step_roofline(m, dt * 1e3, float(np.mean(its)), K))
     return out, sizes
 
 
@@ -725,7 +734,8 @@ def main():
             out["scaling_model"] = scaling_model(ops, obs, pred, K, args.max_iter, first_index, dev, ms_per_step,
                                                  float(np.mean(iters)))
             sizes[f"{n:.0e}".replace("+0", "")] = dict(value=round(out["value"], 1), unit="trajectories/s",
-                                                       ms_per_step=out["ms_per_step"], lloyd_iterations=float(np.mean(iters)))
+                                                       ms_per_step=out["ms_per_step"], lloyd_iterations=float(np.mean(iters)),
+                                                       **step_roofline(n, ms_per_step, float(np.mean(iters)), K))
             out["sizes"] = sizes
         if world == 1 and not args.no_cpu_baseline:
             del obs, pred

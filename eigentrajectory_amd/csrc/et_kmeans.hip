@@ -3575,7 +3575,11 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
         if (timed(it)) ET_HIP_TRY(hipEventRecord((*events)[2 * it], st));
 #define ET_LAUNCH_CHAIN(NR, SIM)                                                                                          \
     do {                                                                                                                  \
-        if (!grid) grid = km_resident_grid(kmeans_lloyd_chain_kernel<NR, SIM>, lds, work_items, threads);                 \
+        if (!grid) {                                                                                                      \
+            grid = km_resident_grid(kmeans_lloyd_chain_kernel<NR, SIM>, lds, work_items, threads);                        \
+            const int cap = options().kmeans_loop_grid.load(std::memory_order_relaxed);                                   \
+            if (cap > 0 && grid > cap) grid = cap;                                                                        \
+        }                                                                                                                 \
         hipLaunchKernelGGL((kmeans_lloyd_chain_kernel<NR, SIM>), dim3(grid), dim3(threads), lds, st, X, N, K, ch,          \
                            labels_u8, tol, trace, it > 0 ? 1 : 0);                                                        \
     } while (0)

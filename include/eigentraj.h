@@ -90,6 +90,7 @@ const char *et_compiled_arch(void);
  *   kmeans_argmax          f: matrix-core filter + exact certification (default) | v: the exact scan only
  *   kmeans_init_tiles      0: farthest-first steps look at every point                (default 1: 256-point tile summaries)
  *   kmeans_filter_threads  256..1024, multiple of 64: workgroup size of the Lloyd kernels (default 0: chosen per shard)
+ *   kmeans_loop_grid       > 0: at most this many workgroups for the one-launch-per-iteration Lloyd kernel (default 0)
  *   kmeans_loop            a: auto (default) | c: one launch per iteration | p: one persistent launch per fit
  *   metrics_form           a: auto (default) | t: vector-ALU tile kernel for every S | f: fp32 matrix instructions only
  * et_set_option returns ET_ERR_INVALID_ARG for an unknown key or a value the key does not take; et_get_option writes the

@@ -337,9 +337,16 @@ def test_kmeans_bit_exact_vs_oracle_and_golden_g7(ops, oracle, dev, tag):
     assert np.array_equal(N_(res["labels"]), ref["labels"])            # bit-exact assignments
     assert np.array_equal(N_(res["centroids"]), ref["centroids"])      # bit-exact centroids
     assert np.array_equal(N_(res["trace"]), ref["trace"])
-    if tag != "gauss10000":  # whole-run equality with the reference is ill-conditioned there (see G7 notes)
-        assert np.array_equal(N_(res["labels"]), z[f"{tag}.labels"].astype(np.int64))
-        assert res["n_iter"] == len(z[f"{tag}.trace"])
+    # whole-run equality with the imported REFERENCE: the reference-order fit reproduces every case -- labels, iteration count,
+    # centroid bits, the error of every iteration; the exact-sum fit (above: bit-exact against the oracle) every case but
+    # gauss10000, where the ~1e-7 difference of the summation orders sends Lloyd to another fixed point (a rate)
+    ro = ops.kmeans_fit_reference_order(T(x, dev), c0, 100, 1e-4)
+    assert np.array_equal(N_(ro["labels"]), z[f"{tag}.labels"].astype(np.int64))
+    assert ro["n_iter"] == len(z[f"{tag}.trace"])
+    assert np.array_equal(N_(ro["centroids"]), z[f"{tag}.centroids"])
+    assert np.array_equal(N_(ro["trace"])[:, 0], z[f"{tag}.trace"][:, 0].astype(np.float32))
+    same = np.array_equal(N_(res["labels"]), z[f"{tag}.labels"].astype(np.int64)) and res["n_iter"] == len(z[f"{tag}.trace"])
+    assert same == (tag != "gauss10000")
     # step-wise parity with the reference from ITS centroids (teacher forcing), first/last iterations
     hist = z[f"{tag}.history"]
     for i in (0, 1, len(hist) - 2):
