@@ -33,6 +33,8 @@
 
 #include "et_common.h"
 #include "et_hostring.h"
+#include "et_mfma_filter.h"
+#include "et_options.h"
 
 namespace et {
 namespace reforder {
@@ -820,8 +822,231 @@ __device__ __forceinline__ void cascade_levels(Load load, const unsigned *sLab, 
     }
 }
 
+// ---- the assignment of a group by CERTIFICATION (iterations >= 1, no NaN possible): csrc/et_kmeans.hip's matrix-core filter
+//      ("Lloyd half-step for iterations >= 1": that is where the bounds are derived) on the quads of the permuted copy.  Per
+//      point the second largest of the f16-MFMA upper bounds u_j >= Y_j + |x|^2 is compared with the exact Y_l + |x|^2 of the
+//      point's OLD label l (one fmaf chain, kmeans.py:71-74 with the norms in ATen's orders -- the bound E1 on the chain's
+//      rounding holds for any order of the six-term norm sums): if it exceeds every other cluster's bound the reference's
+//      arg-max is l, strictly, and Y_l is its maximum similarity.  Every other point (1-3 % per iteration) goes on a
+//      workgroup queue and gets the exact scan afterwards, four threads per point.  The same labels as the exact scan of
+//      every point, by construction; what it saves is the scan: ~300 vector + 16 matrix instructions per 256 points
+//      instead of ~720 vector instructions. ----
+#ifdef ET_EXP_RF_CHECK
+__device__ unsigned g_rf_check[64];
+#endif
+// split_f16 (et_mfma_filter.h) as plain expressions: (a, b) * sg -> packed {hi(a), hi(b)}, {lo(a), lo(b)}, round to nearest
+// (a sg is exact, sg being a power of two; the residual a sg - hi has at most 13 significant bits: exact as well).  The
+// inline-assembly form writes registers the hazard recogniser cannot see: in this kernel the register allocator handed it
+// the B operands of the previous point's matrix instructions while those were still being read, and the second point of
+// every quad was certified on garbage -- wrong labels in 0.5 % of the points, found by the oracle; a variant build with
+// more code in between happened to be right.  Ten instructions per pair instead of four.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_f16_visible(float a, float b, float sg, unsigned &hi, unsigned &lo) {
+    const float as = a * sg, bs = b * sg;
+    const f16x2_t h = {(_Float16)as, (_Float16)bs};
+    const f16x2_t l = {(_Float16)(as - (float)h.x), (_Float16)(bs - (float)h.y)};
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+template <int NREGS>
+__device__ __forceinline__ double assign_group_filter(const float4 *__restrict__ x4, int L2, const float *sC, int K, float sg,
+                                                      unsigned *sLab, unsigned *__restrict__ LTg, unsigned short *sQ, int q_cap,
+                                                      int *sQn, bool &ok) {
+    const int tid = (int)threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    constexpr float kUp = 1.001953125f, kTiny = 1.1920928955078125e-7f;  // (1 + 2^-9) v + 2^-23 survives the rtz to f16
+    const float sg2 = sg * sg;
+    const float4 *s4 = reinterpret_cast<const float4 *>(sC);
+    // A operands (loop invariant): this lane feeds accumulator row m = col, k-half = half; cluster j sits in register j >> 1
+    // of half j & 1 (rows of clusters >= K: -60000) -- csrc/et_kmeans.hip, filter_assign_body
+    u32x4 a1 = {0u, 0u, 0u, 0u}, a2 = {0u, 0u, 0u, 0u};
+    {
+        const int j = 2 * (4 * (col >> 3) + (col & 3)) + ((col >> 2) & 1);
+        unsigned ch[3] = {0u, 0u, 0u}, cl[3] = {0u, 0u, 0u};
+        float nb = -60000.0f;
+        if (j < K) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) split_f16_visible(sC[j * 8 + 2 * p], sC[j * 8 + 2 * p + 1], 2.0f * sg, ch[p], cl[p]);
+            nb = -sC[j * 8 + 6] * sg2;
+        }
+        const auto nh = __builtin_amdgcn_cvt_pkrtz(nb, 0.f);
+        const unsigned bnd = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(nb, (nb - (float)nh[0]) * 1024.0f));
+        unsigned ebd = 0u;
+        if (j < K) {
+            const float cj = sqrtf(sC[j * 8 + 6]) * sg * 1.001f;
+            ebd = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(fmaf(3.0517578125e-5f * cj, kUp, kTiny),
+                                                                           fmaf(fmaf(cj, 1.52587890625e-5f, 9.5367431640625e-7f) * cj, kUp, kTiny)));
+        }
+        a1 = u32x4{ch[0], ch[1], ch[2], half == 0 ? bnd : ebd};
+        a2 = u32x4{cl[0], cl[1], cl[2], 0u};
+    }
+    const f16x8 A1 = __builtin_bit_cast(f16x8, a1), A2 = __builtin_bit_cast(f16x8, a2);
+    double sim = 0.0;
+    for (int qi = tid; qi < L2; qi += kFThreads) {  // (L2 mod 384 = 256: whole wavefronts run the last round)
+        float4 v[kD];
+#pragma unroll
+        for (int i = 0; i < kD; ++i) v[i] = x4[i * L2 + qi];
+        const unsigned old_packed = LTg[qi];
+        unsigned undecided = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x[kD];
+#pragma unroll
+            for (int i = 0; i < kD; ++i) x[i] = q == 0 ? v[i].x : (q == 1 ? v[i].y : (q == 2 ? v[i].z : v[i].w));
+            float an = x[0] * x[0];  // kmeans.py:73, a full block's column: rows in sequence
+#pragma unroll
+            for (int i = 1; i < kD; ++i) an = an + x[i] * x[i];
+            const float rs = fmaf(__builtin_amdgcn_sqrtf(an) * sg, kUp, kTiny);  // >= sg ||x||
+            unsigned w[7];  // {xh01, xh23, xh45, xl01, xl23, xl45, (r, 1)}
+#pragma unroll
+            for (int p = 0; p < 3; ++p) split_f16_visible(x[2 * p], x[2 * p + 1], sg, w[p], w[3 + p]);
+            w[6] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(fmaf(rs, kUp, kTiny), 1.0f));
+            const unsigned ones = 0x14003c00u;  // {1, 2^-10}: partners of {hi, lo * 2^10} of -|c|^2
+            u32x4 bLo, bUp;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const auto r = p < 3 ? __builtin_amdgcn_permlane32_swap(w[p], w[3 + p], false, false)
+                                     : __builtin_amdgcn_permlane32_swap(ones, w[6], false, false);
+                bLo[p] = r[0];
+                bUp[p] = r[1];
+            }
+            const f16x8 BL = __builtin_bit_cast(f16x8, bLo), BU = __builtin_bit_cast(f16x8, bUp);
+            f32x16 accL, accU;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accL[r] = accU[r] = 0.f;
+            accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, BL, accL, 0, 0, 0);
+            accU = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, BU, accU, 0, 0, 0);
+            accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, BL, accL, 0, 0, 0);
+            accU = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, BU, accU, 0, 0, 0);
+            float bL, sL, bU, sU;
+            top2<NREGS>(accL, bL, sL);
+            top2<NREGS>(accU, bU, sU);
+            const auto rb = __builtin_amdgcn_permlane32_swap(__float_as_uint(bL), __float_as_uint(bU), false, false);
+            const auto rq = __builtin_amdgcn_permlane32_swap(__float_as_uint(sL), __float_as_uint(sU), false, false);
+            const float b0 = __uint_as_float(rb[0]), b1 = __uint_as_float(rb[1]);
+            const float s0 = __uint_as_float(rq[0]), s1 = __uint_as_float(rq[1]);
+            const float second = vmed3(b0, b1, vmax(s0, s1));  // second largest upper bound u_j
+            // exact similarity to the old label's centroid, kmeans.py:71-74
+            const int ol = (int)((old_packed >> (8 * q)) & 0xffu);
+            const float4 r0 = s4[2 * ol], r1 = s4[2 * ol + 1];
+            float y = fmaf(x[0], r0.x, 0.f);
+            y = fmaf(x[1], r0.y, y);
+            y = fmaf(x[2], r0.z, y);
+            y = fmaf(x[3], r0.w, y);
+            y = fmaf(x[4], r1.x, y);
+            y = fmaf(x[5], r1.y, y);
+            y = y * 2.0f;
+            y = y - an;
+            y = y - r1.z;
+            // keep <=> (Y_l + |x|^2) sg^2 exceeds every other cluster's upper bound: w - second > eps(r) + rounding of w
+            const float wv = (y + an) * sg2;
+            const float th = fmaf(fabsf(wv), 2.384185791015625e-7f,
+                                  fmaf(rs, fmaf(rs, 1.52587890625e-5f, 9.5367431640625e-7f), 2.3283064365386963e-10f));
+#ifdef ET_EXP_RF_ALL_UNDECIDED
+            const bool keep = false;
+#else
+            const bool keep = wv - second > th;
+#endif
+#ifdef ET_EXP_RF_CHECK
+            {
+                float bestv = -__builtin_inff(), secv = -__builtin_inff();
+                int bj = -1;
+                for (int j = 0; j < K; ++j) {
+                    const float4 t0 = s4[2 * j], t1 = s4[2 * j + 1];
+                    float yy = fmaf(x[0], t0.x, 0.f);
+                    yy = fmaf(x[1], t0.y, yy);
+                    yy = fmaf(x[2], t0.z, yy);
+                    yy = fmaf(x[3], t0.w, yy);
+                    yy = fmaf(x[4], t1.x, yy);
+                    yy = fmaf(x[5], t1.y, yy);
+                    yy = yy * 2.0f;
+                    yy = yy - an;
+                    yy = yy - t1.z;
+                    if (yy > bestv) {
+                        secv = bestv;
+                        bestv = yy;
+                        bj = j;
+                    } else if (yy > secv) secv = yy;
+                }
+                if (keep && bj != ol && atomicAdd(&g_rf_check[0], 1u) == 0u) {
+                    float *o = reinterpret_cast<float *>(&g_rf_check[1]);
+                    o[0] = (float)qi; o[1] = (float)q; o[2] = (float)ol; o[3] = (float)bj; o[4] = y; o[5] = bestv; o[6] = secv;
+                    o[7] = wv; o[8] = second; o[9] = th; o[10] = b0; o[11] = b1; o[12] = s0; o[13] = s1; o[14] = sg; o[15] = an;
+                    o[16] = (float)lane; o[17] = rs;
+                    for (int i = 0; i < 6; ++i) o[18 + i] = x[i];
+                }
+            }
+#endif
+            sim = sim + (keep ? (double)y : 0.0);
+            undecided |= keep ? 0u : (1u << q);
+        }
+        sLab[qi] = old_packed;  // (the bytes of undecided points are replaced below)
+        if (undecided) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((undecided >> q) & 1u) {
+                    const int slot = atomicAdd(sQn, 1);
+                    if (slot < q_cap) sQ[slot] = (unsigned short)(qi * 4 + q);
+                }
+        }
+    }
+    __syncthreads();
+    // ---- the undecided points: exact arg-max, four threads per point (clusters sub, sub + 4, ...; first maximum wins) ----
+    const int nq = *sQn, sub = tid & 3;
+    ok = nq <= q_cap;  // (more undecided points than the queue holds: the caller runs the exact scan of the whole group)
+    if (!ok) return 0.0;
+    for (int base = 0; base < nq; base += kFThreads / 4) {
+        const int e = base + (tid >> 2);
+        const bool act = e < nq;
+        const int pid = sQ[act ? e : 0], qi = pid >> 2, q = pid & 3;
+        float x[kD];
+#pragma unroll
+        for (int i = 0; i < kD; ++i) x[i] = reinterpret_cast<const float *>(x4 + i * L2 + qi)[q];
+        float an = x[0] * x[0];
+#pragma unroll
+        for (int i = 1; i < kD; ++i) an = an + x[i] * x[i];
+        float best = -__builtin_inff();
+        int lb = 0x7fffffff;
+        for (int j = sub; j < K; j += 4) {
+            const float4 r0 = s4[2 * j], r1 = s4[2 * j + 1];
+            float y = fmaf(x[0], r0.x, 0.f);
+            y = fmaf(x[1], r0.y, y);
+            y = fmaf(x[2], r0.z, y);
+            y = fmaf(x[3], r0.w, y);
+            y = fmaf(x[4], r1.x, y);
+            y = fmaf(x[5], r1.y, y);
+            y = y * 2.0f;
+            y = y - an;
+            y = y - r1.z;
+            if (y > best) {
+                best = y;
+                lb = j;
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 4; o <<= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int ol = __shfl_xor(lb, o);
+            if (ob > best || (ob == best && ol < lb)) {
+                best = ob;
+                lb = ol;
+            }
+        }
+        if (act && sub == 0) {
+            reinterpret_cast<uint8_t *>(sLab)[pid] = (uint8_t)lb;
+            reinterpret_cast<uint8_t *>(LTg)[pid] = (uint8_t)lb;
+            sim = sim + (double)best;
+        }
+    }
+    __syncthreads();
+    return sim;
+}
+
 // ---- one Lloyd iteration, first half: assignment + levels 0 and 1.  Workgroup g < G: group g; workgroup G: the tail ----
-__global__ __launch_bounds__(kFThreads, 7) void reforder_groups_kernel(const Args a) {
+// NREGS = 0: the exact scan of every point (L = 16: four workgroups per CU); 10 / 16 (K <= 20 / 32): iterations >= 1 certify
+// the labels with the matrix-core filter (L >= 32; more registers: fewer wavefronts per CU, far fewer instructions)
+template <int NREGS>
+__global__ __launch_bounds__(kFThreads, NREGS ? 4 : 7) void reforder_groups_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, dk = kD * K;
@@ -834,7 +1059,7 @@ __global__ __launch_bounds__(kFThreads, 7) void reforder_groups_kernel(const Arg
 #pragma unroll
         for (int i = 0; i < kD; ++i) cpre[i] = cen0[i * K + (tid < K ? tid : 0)];
     }
-    const int64_t done0 = state->done;
+    const int64_t done0 = state->done, iter0 = state->iter;
     const double max_abs_x = state->max_abs_x;
     if (done0) return;  // the whole batch stopped in an earlier launch (kmeans.py:239), or bad input was flagged
     const float *X = a.X + (int64_t)blockIdx.y * a.x_stride;
@@ -875,7 +1100,20 @@ __global__ __launch_bounds__(kFThreads, 7) void reforder_groups_kernel(const Arg
         sC[tid * 8 + 6] = sqnorm_at(sq, kD, tid, K);
         sC[tid * 8 + 7] = 0.f;
     }
+    __shared__ unsigned sMaxC;
+    __shared__ int sQn;
     if (tid < kFMaxK) sCnt[tid] = 0u;
+    if (tid == 0) {
+        sMaxC = 0u;
+        sQn = 0;
+    }
+    __syncthreads();
+    if (tid < K) {
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < kD; ++i) m = fmaxf(m, fabsf(cpre[i]));
+        atomicMax(&sMaxC, __float_as_uint(m));  // (non-negative floats order like their bit patterns; a NaN sets `bad`)
+    }
     const bool nans = __syncthreads_or(bad) != 0 || !(max_abs_x < 1e18);
     double sim = 0.0;
     float4 acc1 = make_float4(0.f, 0.f, 0.f, 0.f), acc0 = acc1;
@@ -884,7 +1122,19 @@ __global__ __launch_bounds__(kFThreads, 7) void reforder_groups_kernel(const Arg
     if (!is_tail) {
         // ---- assignment of the group's 4 L^2 points (kmeans.py:143-158): a quad = four consecutive steps of one chain ----
         const float4 *x4 = XT4 + gidx * kD * L2;
-        for (int qi = tid; qi < L2; qi += kFThreads) {
+        bool filtered = false;
+        if constexpr (NREGS > 0) {
+            // power-of-two scale: every |x| sg, |c| sg < 32 (csrc/et_kmeans.hip, filter_assign_body); the first iteration (no
+            // labels yet), a possible NaN or a scale whose square leaves the fp32 range: the exact scan decides
+            const int e_max = exponent_above(fmax(max_abs_x, (double)__uint_as_float(sMaxC)));
+            if (iter0 > 0 && !nans && K >= 3 && e_max >= -40 && e_max <= 60) {
+                const int q_cap = min(4 * L2, (int)((size_t)TR * kD * (K + 1) * 64 * sizeof(float) / sizeof(unsigned short)));
+                sim = assign_group_filter<NREGS>(x4, L2, sC, K, ldexpf(1.0f, 5 - e_max), sLab, LT32 + gidx * L2,
+                                                 reinterpret_cast<unsigned short *>(sAcc), q_cap, &sQn, filtered);
+                if (!filtered) sim = 0.0;
+            }
+        }
+        for (int qi = tid; qi < L2 && !filtered; qi += kFThreads) {
             float4 xv[kD];
 #pragma unroll
             for (int i = 0; i < kD; ++i) xv[i] = x4[i * L2 + qi];
@@ -912,12 +1162,16 @@ __global__ __launch_bounds__(kFThreads, 7) void reforder_groups_kernel(const Arg
             sLab[qi] = packed;
             LT32[gidx * L2 + qi] = packed;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                atomicAdd(&sCnt[lb[p]], 1u);
-                sim = sim + (double)bv[p];
-            }
+            for (int p = 0; p < 4; ++p) sim = sim + (double)bv[p];
         }
         __syncthreads();
+        for (int qi = tid; qi < L2; qi += kFThreads) {  // points per cluster, from the final labels
+            const unsigned l4 = sLab[qi];
+            atomicAdd(&sCnt[l4 & 255u], 1u);
+            atomicAdd(&sCnt[(l4 >> 8) & 255u], 1u);
+            atomicAdd(&sCnt[(l4 >> 16) & 255u], 1u);
+            atomicAdd(&sCnt[l4 >> 24], 1u);
+        }
         RF_STAMP(who, 2);
         RF_STAMP_MAX(0, 8);
         cascade_levels([&](int q, int rb, int ln, int i) { return x4[i * L2 + (q * RB + rb) * 64 + ln]; }, sLab, sAcc, K, L, TR, L, L,
@@ -1336,6 +1590,7 @@ static bool fast_shape(int64_t N, int d, int K) {
 // level-0 tiles (16 chunks) whose accumulators are in LDS at a time: ONE -- at L = 32 two tiles (73 KB, two workgroups per
 // CU) took 123 us per iteration at 1e7 points against 111 us with one (38 KB, four per CU), same box
 static int fast_tiles_per_round(const Geo &) { return 1; }
+static int fast_filter_min_lp() { return options().reforder_filter_min_lp.load(std::memory_order_relaxed); }
 static size_t fast_lds_bytes(const Geo &g, int K, int TR) {
     const int L = 1 << g.lp;
     // level-0 accumulators (K rows + a dummy one), a group's label words, the tail's label bytes
@@ -1355,6 +1610,11 @@ static int update_rows_cap(const Geo &g, int K, int batch, size_t *lds) {
     return want;
 }
 
+#ifdef ET_EXP_RF_CHECK
+extern "C" int et_debug_rfcheck(unsigned *host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rf_check), sizeof(unsigned) * 64) == hipSuccess ? 0 : 3;
+}
+#endif
 #ifdef ET_EXP_RFSTAMP
 extern "C" int et_debug_rfstamps(unsigned long long *host) {
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rf_stamps), sizeof(unsigned long long) * 64) != hipSuccess) return 3;
@@ -1424,8 +1684,9 @@ static int fast_fit(const float *X, int64_t x_stride, int64_t N, int K, int64_t 
         int dev_id = 0;
         ET_HIP_TRY(hipGetDevice(&dev_id));
         if (!lds_set[dev_id & 63]) {
-            ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(reforder_groups_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            for (const void *f : {reinterpret_cast<const void *>(reforder_groups_kernel<0>), reinterpret_cast<const void *>(reforder_groups_kernel<10>),
+                                  reinterpret_cast<const void *>(reforder_groups_kernel<16>)})
+                ET_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
             ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(reforder_update_kernel2),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUMaxLds));
             lds_set[dev_id & 63] = true;
@@ -1449,13 +1710,17 @@ static int fast_fit(const float *X, int64_t x_stride, int64_t N, int K, int64_t 
         ET_HIP_TRY(hipEventCreate(&ev[1]));
         ET_HIP_TRY(hipEventRecord(ev[0], st));
     }
+    // the matrix-core label filter pays where the exact scan is what a launch waits for: L >= 32 (N > 4.2e6)
+    const bool use_filter = a.geo.lp >= fast_filter_min_lp() && K >= 3;
     constexpr int kAhead = 16, kEvery = 4;
     et_kmeans_state *state0 = (et_kmeans_state *)(a.ws + a.lay.state);
     int launched = 0;
     bool done = false;
     const dim3 grid((unsigned)(a.geo.G + 1), (unsigned)batch), ugrid((unsigned)a.geo.n_blk, (unsigned)batch);
     for (int it = 0; it < max_iter && !done; ++it) {
-        hipLaunchKernelGGL(reforder_groups_kernel, grid, dim3(kFThreads), lds, st, a);
+        if (!use_filter) hipLaunchKernelGGL(reforder_groups_kernel<0>, grid, dim3(kFThreads), lds, st, a);
+        else if (K <= 20) hipLaunchKernelGGL(reforder_groups_kernel<10>, grid, dim3(kFThreads), lds, st, a);
+        else hipLaunchKernelGGL(reforder_groups_kernel<16>, grid, dim3(kFThreads), lds, st, a);
         hipLaunchKernelGGL(reforder_update_kernel2, ugrid, dim3(kUThreads), ulds, st, a, rows_cap);
         ET_LAUNCH_CHECK();
         launched = it + 1;

@@ -1,0 +1,81 @@
+// et_mfma_filter.h -- the pieces of the matrix-core label filter (csrc/et_kmeans.hip: "Lloyd half-step for iterations >= 1",
+// where the bounds are derived) that the reference-order Lloyd kernel (csrc/et_kmeans_reforder.hip) shares with it: the f16
+// (hi, lo) split, the top-2 of an accumulator, v_med3-based max / min on raw MFMA results.
+#pragma once
+
+#include "et_common.h"
+
+namespace et {
+
+__device__ __forceinline__ int exponent_above(double m) {  // smallest E with m < 2^E; 0 for m == 0
+    if (!(m > 0.0)) return 0;
+    const unsigned long long b = (unsigned long long)__double_as_longlong(m);
+    return (int)((b >> 52) & 0x7ff) - 1022;
+}
+
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// (a, b) * sg (a power of two) -> packed f16 {hi(a), hi(b)} and {lo(a), lo(b)} with sg a ~ hi + lo, round to nearest:
+// |sg a - hi - lo| <= 2^-22 |sg a| + 2^-25 (inside the 2^-20 relative + 2^-24 absolute the bounds below are derived
+// with).  Four instructions per pair: v_fma_mixlo/mixhi_f16 scale and round in one step (a sg is exact in fp32, sg
+// being a power of two) and evaluate the residual a sg - hi exactly (it has at most 13 significant bits) before
+// rounding it to f16 -- no separate scaling multiplies and no pack instructions.  (Inline asm: from the C expression the
+// compiler rounds the second hi twice, five instructions; none of the operands is an MFMA result.)
+__device__ __forceinline__ void split_f16(float a, float b, float sg, unsigned &hi, unsigned &lo) {
+    unsigned h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=&v"(h) : "v"(a), "v"(sg));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+&v"(h) : "v"(b), "v"(sg));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=&v"(l) : "v"(a), "v"(sg), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+&v"(l) : "v"(b), "v"(sg), "v"(h));
+    hi = h;
+    lo = l;
+}
+
+// max(|a|, |b|, |c|) in one instruction (from fmaxf(fmaxf(fabsf ...)) the compiler canonicalises two of the operands
+// with a v_max x,x each)
+__device__ __forceinline__ float max3_abs(float a, float b, float c) {
+    float m;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+    return m;
+}
+
+// max / min as v_med3_f32 against +-inf: fmaxf on a raw MFMA result would first be "canonicalised" by a
+// v_max x,x (the compiler cannot prove it quiet), one extra VALU op per value.  (Inline asm is not an option:
+// the compiler does not insert the MFMA -> VALU wait states in front of instructions it cannot see.)
+__device__ __forceinline__ float opaque_inf() {  // +inf the optimiser cannot see through (no instruction is emitted)
+    unsigned u = 0x7f800000u;
+    asm volatile("" : "+s"(u));
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ float vmax(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, opaque_inf()); }
+__device__ __forceinline__ float vmin(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -opaque_inf()); }
+__device__ __forceinline__ float vmed3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+
+// largest and second largest (as a multiset) of acc[0..NREGS), NREGS >= 3: (max3, med3) per triple, two ops to
+// merge the maxima and one more for the seconds
+template <int NREGS>
+__device__ __forceinline__ void top2(const f32x16 &acc, float &b, float &s) {
+    b = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
+    s = vmed3(acc[0], acc[1], acc[2]);
+    int r = 3;
+#pragma unroll
+    for (; r + 2 < NREGS; r += 3) {
+        const float gs = vmed3(acc[r], acc[r + 1], acc[r + 2]);  // second of the triple
+        const float gm = __builtin_fmaxf(__builtin_fmaxf(acc[r], acc[r + 1]), acc[r + 2]);
+        s = vmed3(b, gm, vmax(s, gs));
+        b = vmax(b, gm);
+    }
+#pragma unroll
+    for (; r < NREGS; ++r) {
+        s = vmed3(b, s, acc[r]);
+        b = vmax(b, acc[r]);
+    }
+}
+
+
+}  // namespace et

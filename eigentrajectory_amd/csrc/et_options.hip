@@ -32,6 +32,7 @@ const Key *keys(int *n) {
         {"kmeans_filter_threads", Key::kInt, &o.kmeans_filter_threads, nullptr},
         {"kmeans_loop_grid", Key::kInt, &o.kmeans_loop_grid, nullptr},
         {"kmeans_loop", Key::kChar, &o.kmeans_loop, "acp"},
+        {"reforder_filter_min_lp", Key::kInt, &o.reforder_filter_min_lp, nullptr},
         {"metrics_form", Key::kChar, &o.metrics_form, "atf"},
     };
     *n = (int)(sizeof(table) / sizeof(table[0]));

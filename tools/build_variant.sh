@@ -15,7 +15,7 @@ EXTRA=""
 [ "$SRC" = "et_kmeans.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize"
 [ "$SRC" = "et_descriptor.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize"
 [ "$SRC" = "et_fit.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize"
-[ "$SRC" = "et_kmeans_reforder.hip" ] && EXTRA="-fno-slp-vectorize"
+[ "$SRC" = "et_kmeans_reforder.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize"
 /opt/rocm/bin/hipcc $BASE $EXTRA $FLAGS -c "$C/$SRC" -o "$V/${SRC%.hip}_$NAME.o"
 OBJS=""
 for f in et_abi et_options et_trajnorm et_descriptor et_train et_fit et_kmeans et_kmeanspp et_kmeans_reforder et_sharded; do
