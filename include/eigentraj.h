@@ -93,7 +93,9 @@ const char *et_compiled_arch(void);
  *   kmeans_loop_grid       > 0: at most this many workgroups for the one-launch-per-iteration Lloyd kernel (default 0)
  *   kmeans_loop            a: auto (default) | c: one launch per iteration | p: one persistent launch per fit
  *   reforder_filter_min_lp 4..9: the reference-order Lloyd kernel certifies labels with the matrix-core filter from this cascade level
- *                          power on (L = 2^lp; default 5: N > 4.2e6; 4: always, 9: never)
+ *                          power on (L = 2^lp; 4: always, 5: N > 4.2e6, 9: never = default -- built and tested equal, but at 1e7 points
+ *                          the launch is bound by its vector instructions either way and the filter's registers halve the
+ *                          wavefronts per CU: 138 against 119 us per iteration)
  *   metrics_form           a: auto (default) | t: vector-ALU tile kernel for every S | f: fp32 matrix instructions only
  * et_set_option returns ET_ERR_INVALID_ARG for an unknown key or a value the key does not take; et_get_option writes the
  * current value as text.  (The Python binding forwards environment variables ET_OPT_<KEY> once, at load.) */
