@@ -14,7 +14,7 @@ BENCH="python $R/bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1"
 
 # 0. the plain bench line (default command) next to the profiles, the box's bandwidth ceilings, and the sharded path
 #    forced onto one GPU (RCCL world 1): native entry points vs the torch.distributed step API
-python $R/bench.py > "$OUT/${TAG}_bench_line.json" 2> "$OUT/bench.err"
+python $R/bench.py 2> "$OUT/bench.err" | tail -1 > "$OUT/${TAG}_bench_line.json"
 python $R/tools/bw_ceiling.py > "$OUT/${TAG}_bw_ceiling.json" 2>/dev/null
 for mode in native torch; do
     ET_BENCH_FORCE_DIST=1 ET_BENCH_DIST=$mode python $R/bench.py --no-cpu-baseline --no-extras --steps 5 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_line_forced_dist_$mode.json"
