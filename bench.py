@@ -445,6 +445,18 @@ def reference_order_lloyd(ops, dev, n_main, K, max_iter, first_index):
             _, x, _, _ = ops.norm_project(o, p, U_obs, U_pred, None, None, ops.MODE_MOVING, want_flag=False, want_nrm=False)
             del o, p
             c0 = ops.kmeans_init_farthest(x, K, first_index % m)
+            inits = {}
+            for name, fn in (("reference_order", ops.kmeans_init_farthest_reference_order), ("exact_sum", ops.kmeans_init_farthest)):
+                ts = []
+                for rep in range(3):
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                    c_init = fn(x, K, first_index % m)
+                    ev1.record()
+                    torch.cuda.synchronize()
+                    if rep:
+                        ts.append(ev0.elapsed_time(ev1))
+                inits[name] = (min(ts), c_init)
             best = {}
             for name in ("reference_order", "exact_sum"):
                 runs = []
@@ -467,7 +479,9 @@ def reference_order_lloyd(ops, dev, n_main, K, max_iter, first_index):
                             exact_sum_us_per_iteration=round(per_e, 2), ratio=round(per_r / per_e, 3),
                             algorithmic_GBs=round(BYTES["kmeans_iter"] * m / per_r / 1e3, 1),
                             frac_of_peak=round(BYTES["kmeans_iter"] * m / per_r / 1e3 / HBM_PEAK_GBS, 4),
-                            labels_equal=bool(r_ref["n_iter"] == r_ex["n_iter"] and torch.equal(r_ref["labels"], r_ex["labels"])))
+                            labels_equal=bool(r_ref["n_iter"] == r_ex["n_iter"] and torch.equal(r_ref["labels"], r_ex["labels"])),
+                            farthest_first_ms=round(inits["reference_order"][0], 4), exact_sum_farthest_first_ms=round(inits["exact_sum"][0], 4),
+                            same_initial_centroids=bool(torch.equal(inits["reference_order"][1], inits["exact_sum"][1])))
             del x
             torch.cuda.empty_cache()
     out["note"] = ("whole fits (<= max_iter Lloyd iterations, incl. the one-off permuted copy / packed copy of the points) between "

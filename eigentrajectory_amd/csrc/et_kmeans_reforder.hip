@@ -343,26 +343,152 @@ __global__ __launch_bounds__(kThreads) void reforder_init_step_kernel(const floa
         cands[blockIdx.x].idx = sI[0];
     }
 }
-// the winner of the blocks' candidates becomes column `col`; col = 0: the given first index
-__global__ void reforder_init_pick_kernel(const float *__restrict__ X, int64_t N, int d, int K, int col,
-                                          const Cand *__restrict__ cands, int n_cands, int64_t first_index,
-                                          float *__restrict__ C0) {
-    __shared__ long long sIdx;
+// ---- the same step, incrementally (d < 8, K <= 32): the reference re-evaluates euc_sim against ALL `count` current
+// centroids, but which of the two norm orders a centroid's |b|^2 takes depends on (column, count) in a way that leaves only two
+// regimes for count <= 31: every column in the 4-lane order ("R"), except count = 4 .. 7, where columns 0 .. 3 are summed in
+// sequence ("S") (column_is_sequential).  So a running maximum over the R-order similarities (bestR: all centroids; bestR4:
+// centroids >= 4) is exact -- max is order independent, NaN sticky -- and a step evaluates ONE new centroid per point (plus,
+// in the four steps count = 4 .. 7, the S-order similarities of centroids 0 .. 3) instead of `count`:
+//   count in 1..3, 8..31:  value = bestR;      count in 4..7:  value = max(max_{j<4} sim_S(x, c_j), bestR4)
+// 9.0 -> ~1.5 ms for the 19 steps at 1e7 points; the same picks bit for bit (tests: every G7c / G7d case, odd shapes).
+template <int D>  // D = 6: the coordinates in registers; 0: any d < 8 (run-time loops)
+__global__ __launch_bounds__(kThreads) void reforder_init_step_inc_kernel(const float *__restrict__ X, int64_t N, int d_rt, int K,
+                                                                          int count, const float *__restrict__ C0,
+                                                                          float *__restrict__ bestR, float *__restrict__ bestR4,
+                                                                          Cand *__restrict__ cands) {
+    constexpr int DM = D ? D : 8;
+    const int d = D ? D : d_rt;
+    __shared__ float sNew[DM + 1];      // the newest centroid (column count - 1) and its R-order norm
+    __shared__ float sS[4 * (DM + 1)];  // count in 4..7: centroids 0..3 and their S-order norms
+    const bool window = count >= 4 && count <= 7;
     if (threadIdx.x == 0) {
-        long long bi = first_index;
-        if (col > 0) {
-            float bv = 0.f;
-            bi = -1;
-            for (int b = 0; b < n_cands; ++b)
-                if (cands[b].idx >= 0 && (bi < 0 || argmin_ahead(cands[b].v, cands[b].idx, bv, bi))) {
-                    bv = cands[b].v;
-                    bi = cands[b].idx;
-                }
+        float sq[kMaxD];
+        for (int i = 0; i < d; ++i) {
+            const float v = C0[i * K + (count - 1)];
+            sNew[i] = v;
+            sq[i] = v * v;
         }
-        sIdx = bi;
+        sNew[DM] = row_sum_f32(sq, d);
+    }
+    if (window && threadIdx.x >= 64 && threadIdx.x < 68) {
+        const int j = threadIdx.x - 64;
+        float sq[kMaxD];
+        for (int i = 0; i < d; ++i) {
+            const float v = C0[i * K + j];
+            sS[j * (DM + 1) + i] = v;
+            sq[i] = v * v;
+        }
+        sS[j * (DM + 1) + DM] = cascade_f32(sq, 1, d);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < d; i += blockDim.x) C0[i * K + col] = X[(int64_t)i * N + sIdx];
+    float bv = 0.f;
+    long long bi = -1;
+    const int64_t seq_cols = N < 8 ? N / 4 * 4 : N / 32 * 32;  // column_is_sequential(n, N)
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        float x[DM];
+#pragma unroll
+        for (int i = 0; i < DM; ++i) x[i] = i < d ? X[(int64_t)i * N + n] : 0.f;
+        float an;
+        if (n < seq_cols) {  // rows in sequence (0 + s0 = s0)
+            an = x[0] * x[0];
+#pragma unroll
+            for (int i = 1; i < DM; ++i)
+                if (i < d) an = an + x[i] * x[i];
+        } else {
+            float sq[kMaxD];
+            for (int i = 0; i < d; ++i) sq[i] = x[i] * x[i];
+            an = sqnorm_at(sq, d, n, N);
+        }
+        auto sim = [&](const float *c) {
+            float y = 0.f;
+#pragma unroll
+            for (int i = 0; i < DM; ++i)
+                if (i < d) y = fmaf(x[i], c[i], y);
+            y = y * 2.0f;
+            y = y - an;
+            y = y - c[DM];
+            return y;
+        };
+        const float yn = sim(sNew);
+        float r = count == 1 ? yn : bestR[n];
+        if (count > 1 && gt_nanmax(yn, r)) r = yn;
+        if (count == 1 || r == yn || isnan(yn)) bestR[n] = r;  // (written when it may have changed)
+        float value = r;
+        if (count >= 5 && count <= 7) {  // (bestR4 is only ever read inside the window)
+            float r4 = count == 5 ? yn : bestR4[n];
+            if (count > 5 && gt_nanmax(yn, r4)) r4 = yn;
+            bestR4[n] = r4;
+            value = r4;
+        }
+        if (window) {
+            float v = sim(sS);
+            for (int j = 1; j < 4; ++j) {
+                const float y = sim(sS + j * (DM + 1));
+                if (gt_nanmax(y, v)) v = y;
+            }
+            if (count >= 5 && gt_nanmax(value, v)) v = value;
+            value = v;
+        }
+        if (bi < 0 || argmin_ahead(value, n, bv, bi)) {
+            bv = value;
+            bi = n;
+        }
+    }
+    __shared__ float sV[kThreads];
+    __shared__ long long sI[kThreads];
+    sV[threadIdx.x] = bv;
+    sI[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = kThreads / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const float v2 = sV[threadIdx.x + o];
+            const long long i2 = sI[threadIdx.x + o];
+            if (i2 >= 0 && (sI[threadIdx.x] < 0 || argmin_ahead(v2, i2, sV[threadIdx.x], sI[threadIdx.x]))) {
+                sV[threadIdx.x] = v2;
+                sI[threadIdx.x] = i2;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        cands[blockIdx.x].v = sV[0];
+        cands[blockIdx.x].idx = sI[0];
+    }
+}
+// the winner of the blocks' candidates becomes column `col`; col = 0: the given first index
+__global__ __launch_bounds__(kThreads) void reforder_init_pick_kernel(const float *__restrict__ X, int64_t N, int d, int K, int col,
+                                                                      const Cand *__restrict__ cands, int n_cands,
+                                                                      int64_t first_index, float *__restrict__ C0) {
+    __shared__ float sV[kThreads];
+    __shared__ long long sI[kThreads];
+    // (all candidates requested side by side: one thread walking up to 1024 of them was ~200 us of every step)
+    float bv = 0.f;
+    long long bi = col > 0 ? -1 : first_index;
+    if (col > 0)
+        for (int b = threadIdx.x; b < n_cands; b += kThreads) {
+            const float v = cands[b].v;
+            const long long i = cands[b].idx;
+            if (i >= 0 && (bi < 0 || argmin_ahead(v, i, bv, bi))) {
+                bv = v;
+                bi = i;
+            }
+        }
+    sV[threadIdx.x] = bv;
+    sI[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = kThreads / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const float v2 = sV[threadIdx.x + o];
+            const long long i2 = sI[threadIdx.x + o];
+            if (i2 >= 0 && (sI[threadIdx.x] < 0 || argmin_ahead(v2, i2, sV[threadIdx.x], sI[threadIdx.x]))) {
+                sV[threadIdx.x] = v2;
+                sI[threadIdx.x] = i2;
+            }
+        }
+        __syncthreads();
+    }
+    const long long idx = sI[0];
+    for (int i = threadIdx.x; i < d; i += kThreads) C0[i * K + col] = X[(int64_t)i * N + idx];
 }
 
 // kmeans.py:59-76 with both norms in torch's order: a (d,m), b (d,n) -> y (m,n)
@@ -390,6 +516,7 @@ struct Workspace {
     et_kmeans_state *state;
     uint8_t *labels_u8;
     float *maxsims;
+    float *best4;  // farthest-first, incremental form: running maximum over centroids >= 4
     unsigned long long *counts;
     float *sums;
     float *lanes;
@@ -410,6 +537,8 @@ static Workspace carve(void *base, int64_t N, int d, int K) {
     w.labels_u8 = p + off;
     off = up(off + (size_t)N + 4);
     w.maxsims = (float *)(p + off);
+    off = up(off + sizeof(float) * (size_t)N);
+    w.best4 = (float *)(p + off);
     off = up(off + sizeof(float) * (size_t)N);
     w.counts = (unsigned long long *)(p + off);
     off = up(off + sizeof(unsigned long long) * 256);
@@ -1782,13 +1911,21 @@ extern "C" int et_kmeans_init_farthest_reforder(const float *X, int64_t N, int d
     const Workspace w = carve(workspace, N, d, K);
     hipStream_t st = (hipStream_t)stream;
     const int grid = grid_for(N);
-    hipLaunchKernelGGL(reforder_init_pick_kernel, dim3(1), dim3(64), 0, st, X, N, d, K, 0, (const Cand *)w.cands, 0,
+    hipLaunchKernelGGL(reforder_init_pick_kernel, dim3(1), dim3(kThreads), 0, st, X, N, d, K, 0, (const Cand *)w.cands, 0,
                        first_index, C0);
+    const bool incremental = d < 8 && K <= 32;  // (see reforder_init_step_inc_kernel)
     for (int i = 1; i < K; ++i) {
         const size_t lds = sizeof(float) * ((size_t)d * i + (size_t)i);
-        hipLaunchKernelGGL(reforder_init_step_kernel, dim3(grid), dim3(kThreads), lds, st, X, N, d, K, i, (const float *)C0,
-                           w.cands);
-        hipLaunchKernelGGL(reforder_init_pick_kernel, dim3(1), dim3(64), 0, st, X, N, d, K, i, (const Cand *)w.cands, grid,
+        if (incremental && d == 6)
+            hipLaunchKernelGGL(reforder_init_step_inc_kernel<6>, dim3(grid), dim3(kThreads), 0, st, X, N, d, K, i, (const float *)C0,
+                               w.maxsims, w.best4, w.cands);
+        else if (incremental)
+            hipLaunchKernelGGL(reforder_init_step_inc_kernel<0>, dim3(grid), dim3(kThreads), 0, st, X, N, d, K, i, (const float *)C0,
+                               w.maxsims, w.best4, w.cands);
+        else
+            hipLaunchKernelGGL(reforder_init_step_kernel, dim3(grid), dim3(kThreads), lds, st, X, N, d, K, i, (const float *)C0,
+                               w.cands);
+        hipLaunchKernelGGL(reforder_init_pick_kernel, dim3(1), dim3(kThreads), 0, st, X, N, d, K, i, (const Cand *)w.cands, grid,
                            (int64_t)0, C0);
     }
     ET_LAUNCH_CHECK();
