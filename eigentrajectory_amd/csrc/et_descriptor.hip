@@ -24,6 +24,8 @@
 
 namespace et {
 
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
 constexpr int kTile = 256;  // trajectories (or pairs) per workgroup = threads per workgroup
 
 // workgroup -> tile.  Workgroup b runs on XCD b % 8, so the identity map deals consecutive tiles round-robin over the
@@ -52,6 +54,8 @@ __device__ __forceinline__ int64_t tile_of_block() {
 //            by 16 B so that the per-lane row reads below are bank-conflict free)
 //   phase 2  lane = trajectory: normaliser state, normalise, U^T x (U from LDS), k-major stores
 // ------------------------------------------------------------------------------------------
+// (round 5: staging the rows memory -> LDS directly, `buffer_load_dwordx4 ... lds`, default and non-temporal policy, measured
+// no faster: profiles/r05d_project_dma_ab.txt; source: tools/lost_forms/project_lds_dma.hip.txt)
 template <int TO, int TP, int K>
 __global__ __launch_bounds__(kTile) void project_tile_kernel(
     const float *__restrict__ obs, const float *__restrict__ pred, int64_t N,
@@ -772,8 +776,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
     constexpr int DP = 2 * TP, D = kMetStages;
     constexpr bool SPLIT = MODE == ET_MODE_SPLIT;
     constexpr int ND = SPLIT ? 2 : 1;  // descriptors in play: SPLIT 0 static / 1 moving, else the mode's own
-    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
