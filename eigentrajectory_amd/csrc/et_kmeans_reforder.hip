@@ -1012,102 +1012,85 @@ __device__ __forceinline__ double assign_group_filter(const float4 *__restrict__
     const f16x8 A1 = __builtin_bit_cast(f16x8, a1), A2 = __builtin_bit_cast(f16x8, a2);
     double sim = 0.0;
     for (int qi = tid; qi < L2; qi += kFThreads) {  // (L2 mod 384 = 256: whole wavefronts run the last round)
-        float4 v[kD];
-#pragma unroll
-        for (int i = 0; i < kD; ++i) v[i] = x4[i * L2 + qi];
         const unsigned old_packed = LTg[qi];
         unsigned undecided = 0u;
+        // Register-lean on purpose (the first form held the quad's 24 coordinates and both tiles' 32 accumulators: 122
+        // registers = two workgroups per CU, and lost to the exact scan): two points at a time from 8-byte loads (the lines
+        // are in the L1 after the first), the two 32-point tiles of a step one after the other.
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float x[kD];
+        for (int hq = 0; hq < 2; ++hq) {
+            float2 v[kD];
 #pragma unroll
-            for (int i = 0; i < kD; ++i) x[i] = q == 0 ? v[i].x : (q == 1 ? v[i].y : (q == 2 ? v[i].z : v[i].w));
-            float an = x[0] * x[0];  // kmeans.py:73, a full block's column: rows in sequence
+            for (int i = 0; i < kD; ++i) v[i] = reinterpret_cast<const float2 *>(x4 + i * L2 + qi)[hq];
 #pragma unroll
-            for (int i = 1; i < kD; ++i) an = an + x[i] * x[i];
-            const float rs = fmaf(__builtin_amdgcn_sqrtf(an) * sg, kUp, kTiny);  // >= sg ||x||
-            unsigned w[7];  // {xh01, xh23, xh45, xl01, xl23, xl45, (r, 1)}
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q = 2 * hq + qq;
+                float x[kD];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) split_f16_visible(x[2 * p], x[2 * p + 1], sg, w[p], w[3 + p]);
-            w[6] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(fmaf(rs, kUp, kTiny), 1.0f));
-            const unsigned ones = 0x14003c00u;  // {1, 2^-10}: partners of {hi, lo * 2^10} of -|c|^2
-            u32x4 bLo, bUp;
+                for (int i = 0; i < kD; ++i) x[i] = qq == 0 ? v[i].x : v[i].y;
+                float an = x[0] * x[0];  // kmeans.py:73, a full block's column: rows in sequence
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const auto r = p < 3 ? __builtin_amdgcn_permlane32_swap(w[p], w[3 + p], false, false)
-                                     : __builtin_amdgcn_permlane32_swap(ones, w[6], false, false);
-                bLo[p] = r[0];
-                bUp[p] = r[1];
-            }
-            const f16x8 BL = __builtin_bit_cast(f16x8, bLo), BU = __builtin_bit_cast(f16x8, bUp);
-            f32x16 accL, accU;
+                for (int i = 1; i < kD; ++i) an = an + x[i] * x[i];
+                const float rs = fmaf(__builtin_amdgcn_sqrtf(an) * sg, kUp, kTiny);  // >= sg ||x||
+                unsigned w[7];  // {xh01, xh23, xh45, xl01, xl23, xl45, (r, 1)}
 #pragma unroll
-            for (int r = 0; r < 16; ++r) accL[r] = accU[r] = 0.f;
-            accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, BL, accL, 0, 0, 0);
-            accU = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, BU, accU, 0, 0, 0);
-            accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, BL, accL, 0, 0, 0);
-            accU = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, BU, accU, 0, 0, 0);
-            float bL, sL, bU, sU;
-            top2<NREGS>(accL, bL, sL);
-            top2<NREGS>(accU, bU, sU);
-            const auto rb = __builtin_amdgcn_permlane32_swap(__float_as_uint(bL), __float_as_uint(bU), false, false);
-            const auto rq = __builtin_amdgcn_permlane32_swap(__float_as_uint(sL), __float_as_uint(sU), false, false);
-            const float b0 = __uint_as_float(rb[0]), b1 = __uint_as_float(rb[1]);
-            const float s0 = __uint_as_float(rq[0]), s1 = __uint_as_float(rq[1]);
-            const float second = vmed3(b0, b1, vmax(s0, s1));  // second largest upper bound u_j
-            // exact similarity to the old label's centroid, kmeans.py:71-74
-            const int ol = (int)((old_packed >> (8 * q)) & 0xffu);
-            const float4 r0 = s4[2 * ol], r1 = s4[2 * ol + 1];
-            float y = fmaf(x[0], r0.x, 0.f);
-            y = fmaf(x[1], r0.y, y);
-            y = fmaf(x[2], r0.z, y);
-            y = fmaf(x[3], r0.w, y);
-            y = fmaf(x[4], r1.x, y);
-            y = fmaf(x[5], r1.y, y);
-            y = y * 2.0f;
-            y = y - an;
-            y = y - r1.z;
-            // keep <=> (Y_l + |x|^2) sg^2 exceeds every other cluster's upper bound: w - second > eps(r) + rounding of w
-            const float wv = (y + an) * sg2;
-            const float th = fmaf(fabsf(wv), 2.384185791015625e-7f,
-                                  fmaf(rs, fmaf(rs, 1.52587890625e-5f, 9.5367431640625e-7f), 2.3283064365386963e-10f));
+                for (int p = 0; p < 3; ++p) split_f16_visible(x[2 * p], x[2 * p + 1], sg, w[p], w[3 + p]);
+                w[6] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(fmaf(rs, kUp, kTiny), 1.0f));
+                const unsigned ones = 0x14003c00u;  // {1, 2^-10}: partners of {hi, lo * 2^10} of -|c|^2
+                u32x4 bLo, bUp;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const auto r = p < 3 ? __builtin_amdgcn_permlane32_swap(w[p], w[3 + p], false, false)
+                                         : __builtin_amdgcn_permlane32_swap(ones, w[6], false, false);
+                    bLo[p] = r[0];
+                    bUp[p] = r[1];
+                }
+                float bL, sL, bU, sU;
+                {
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, __builtin_bit_cast(f16x8, bLo), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, __builtin_bit_cast(f16x8, bLo), acc, 0, 0, 0);
+                    top2<NREGS>(acc, bL, sL);
+                }
+                {
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, __builtin_bit_cast(f16x8, bUp), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, __builtin_bit_cast(f16x8, bUp), acc, 0, 0, 0);
+                    top2<NREGS>(acc, bU, sU);
+                }
+                const auto rb = __builtin_amdgcn_permlane32_swap(__float_as_uint(bL), __float_as_uint(bU), false, false);
+                const auto rq = __builtin_amdgcn_permlane32_swap(__float_as_uint(sL), __float_as_uint(sU), false, false);
+                const float b0 = __uint_as_float(rb[0]), b1 = __uint_as_float(rb[1]);
+                const float s0 = __uint_as_float(rq[0]), s1 = __uint_as_float(rq[1]);
+                const float second = vmed3(b0, b1, vmax(s0, s1));  // second largest upper bound u_j
+                // exact similarity to the old label's centroid, kmeans.py:71-74
+                const int ol = (int)((old_packed >> (8 * q)) & 0xffu);
+                const float4 r0 = s4[2 * ol], r1 = s4[2 * ol + 1];
+                float y = fmaf(x[0], r0.x, 0.f);
+                y = fmaf(x[1], r0.y, y);
+                y = fmaf(x[2], r0.z, y);
+                y = fmaf(x[3], r0.w, y);
+                y = fmaf(x[4], r1.x, y);
+                y = fmaf(x[5], r1.y, y);
+                y = y * 2.0f;
+                y = y - an;
+                y = y - r1.z;
+                // keep <=> (Y_l + |x|^2) sg^2 exceeds every other cluster's upper bound: w - second > eps(r) + rounding of w
+                const float wv = (y + an) * sg2;
+                const float th = fmaf(fabsf(wv), 2.384185791015625e-7f,
+                                      fmaf(rs, fmaf(rs, 1.52587890625e-5f, 9.5367431640625e-7f), 2.3283064365386963e-10f));
 #ifdef ET_EXP_RF_ALL_UNDECIDED
-            const bool keep = false;
+                const bool keep = false;
 #else
-            const bool keep = wv - second > th;
+                const bool keep = wv - second > th;
 #endif
-#ifdef ET_EXP_RF_CHECK
-            {
-                float bestv = -__builtin_inff(), secv = -__builtin_inff();
-                int bj = -1;
-                for (int j = 0; j < K; ++j) {
-                    const float4 t0 = s4[2 * j], t1 = s4[2 * j + 1];
-                    float yy = fmaf(x[0], t0.x, 0.f);
-                    yy = fmaf(x[1], t0.y, yy);
-                    yy = fmaf(x[2], t0.z, yy);
-                    yy = fmaf(x[3], t0.w, yy);
-                    yy = fmaf(x[4], t1.x, yy);
-                    yy = fmaf(x[5], t1.y, yy);
-                    yy = yy * 2.0f;
-                    yy = yy - an;
-                    yy = yy - t1.z;
-                    if (yy > bestv) {
-                        secv = bestv;
-                        bestv = yy;
-                        bj = j;
-                    } else if (yy > secv) secv = yy;
-                }
-                if (keep && bj != ol && atomicAdd(&g_rf_check[0], 1u) == 0u) {
-                    float *o = reinterpret_cast<float *>(&g_rf_check[1]);
-                    o[0] = (float)qi; o[1] = (float)q; o[2] = (float)ol; o[3] = (float)bj; o[4] = y; o[5] = bestv; o[6] = secv;
-                    o[7] = wv; o[8] = second; o[9] = th; o[10] = b0; o[11] = b1; o[12] = s0; o[13] = s1; o[14] = sg; o[15] = an;
-                    o[16] = (float)lane; o[17] = rs;
-                    for (int i = 0; i < 6; ++i) o[18 + i] = x[i];
-                }
+                sim = sim + (keep ? (double)y : 0.0);
+                undecided |= keep ? 0u : (1u << q);
             }
-#endif
-            sim = sim + (keep ? (double)y : 0.0);
-            undecided |= keep ? 0u : (1u << q);
         }
         sLab[qi] = old_packed;  // (the bytes of undecided points are replaced below)
         if (undecided) {
@@ -1175,7 +1158,7 @@ __device__ __forceinline__ double assign_group_filter(const float4 *__restrict__
 // NREGS = 0: the exact scan of every point (L = 16: four workgroups per CU); 10 / 16 (K <= 20 / 32): iterations >= 1 certify
 // the labels with the matrix-core filter (L >= 32; more registers: fewer wavefronts per CU, far fewer instructions)
 template <int NREGS>
-__global__ __launch_bounds__(kFThreads, NREGS ? 4 : 7) void reforder_groups_kernel(const Args a) {
+__global__ __launch_bounds__(kFThreads, NREGS ? 6 : 7) void reforder_groups_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, dk = kD * K;
