@@ -126,13 +126,16 @@ def _lloyd_relocating(X, c0, max_iter, tol):
     sh.scan()
     sh.begin(n, cen)
     frac = int(sh.read_state().frac)
-    rows = np.ascontiguousarray(X.T.cpu().numpy())
+    rows = None  # (the points come to the host when an empty cluster first appears: most repeated fits never need them)
     for _ in range(max_iter):
         part = sh.assign(cen)
-        host = part.cpu().numpy().copy()
-        counts = host[d * K:d * K + K]
+        counts = part[d * K:d * K + K].cpu().numpy()  # K integers per iteration; everything else only on an empty cluster
         empty = np.where(counts == 0)[0]
         if empty.size:
+            if rows is None:
+                rows = np.ascontiguousarray(X.T.cpu().numpy())
+            host = part.cpu().numpy().copy()
+            counts = host[d * K:d * K + K]
             labels = sh.labels().cpu().numpy()
             old = np.ascontiguousarray(cen.T.cpu().numpy())
             dist = ((rows - old[labels]) ** 2).sum(axis=1)

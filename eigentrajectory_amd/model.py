@@ -250,6 +250,34 @@ class EigenTrajectory(nn.Module):
     # Memory: every captured graph owns a private allocator pool (>= one 2 MB segment) plus its output buffers, so the
     # cache is bounded and evicts the least recently used scene; a test split is <= ~1000 scenes (~2-4 GB).
     _SCENE_GRAPH_LIMIT = 1024
+    _PREDICTOR_STAMP_EVERY = 64
+
+    def _predictor_stamp(self):
+        """Addresses of the predictor's parameters and buffers -- walking them costs more host time than the ~21 us replay
+        they protect once a predictor has hundreds of tensors, so the walk is redone when this wrapper saw something that
+        can move them (``_apply``: .to() / .cuda() / .half(); ``load_state_dict``; ``train()`` / ``eval()``) and otherwise only
+        every 64th call.  Blind spots, by construction of a pointer-keyed cache: a predictor moved or re-allocated behind the
+        wrapper's back is noticed up to 63 replays late; an in-place ``.data`` swap that keeps the storage is not noticed at
+        all (neither was it before)."""
+        d = self.__dict__
+        n = d.get("_pstamp_calls", 0)
+        d["_pstamp_calls"] = n + 1
+        if d.get("_pstamp") is None or n % self._PREDICTOR_STAMP_EVERY == 0:
+            d["_pstamp"] = (tuple(p.data_ptr() for p in self.baseline_model.parameters()),
+                            tuple(b.data_ptr() for b in self.baseline_model.buffers()))
+        return d["_pstamp"]
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__["_pstamp"] = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.__dict__["_pstamp"] = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def train(self, mode=True):
+        self.__dict__["_pstamp"] = None
+        return super().train(mode)
 
     def _graph_for(self, kind, obs_traj, pred_traj, run):
         params = (self.ET_m_descriptor.U_obs_trunc, self.ET_m_descriptor.U_pred_trunc, self.ET_s_descriptor.U_obs_trunc,
@@ -258,9 +286,7 @@ class EigenTrajectory(nn.Module):
                None if pred_traj is None else tuple(pred_traj.shape))
         # (calculate_parameters / load_state_dict may re-register the parameters, the predictor may be moved, re-allocated
         # or switched between train() and eval(): a graph holds raw pointers and the code path taken at capture time)
-        stamp = (tuple(p.data_ptr() for p in params), self.training, self.baseline_model.training,
-                 tuple(p.data_ptr() for p in self.baseline_model.parameters()),
-                 tuple(b.data_ptr() for b in self.baseline_model.buffers()))
+        stamp = (tuple(p.data_ptr() for p in params), self.training, self.baseline_model.training, self._predictor_stamp())
         cache = self.__dict__.setdefault("_scene_graphs", {})
         entry = cache.get(key)
         if entry is not None and entry["stamp"] == stamp:
