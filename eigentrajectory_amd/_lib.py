@@ -39,6 +39,7 @@ SYMBOLS = [
     "et_center_columns", "et_kmeanspp_workspace_bytes", "et_kmeanspp_seed", "et_kmeanspp_batch_workspace_bytes", "et_kmeanspp_seed_batch",
     "et_comm_load", "et_comm_unique_id", "et_comm_init_rank", "et_comm_destroy", "et_comm_info",
     "et_fit_gram_sharded", "et_kmeans_sharded_workspace_bytes", "et_kmeans_init_farthest_sharded", "et_kmeans_fit_sharded",
+    "et_kmeans_reforder_shard_block", "et_kmeans_reforder_sharded_workspace_bytes", "et_kmeans_fit_reforder_sharded",
 ]
 
 
@@ -81,8 +82,9 @@ def lib():
         for name in ("et_fit_gram_workspace_bytes", "et_kmeans_partials_len", "et_kmeans_workspace_bytes",
                      "et_kmeanspp_workspace_bytes", "et_kmeans_sharded_workspace_bytes", "et_kmeans_batch_workspace_bytes",
                      "et_kmeanspp_batch_workspace_bytes", "et_kmeans_reforder_workspace_bytes",
-                     "et_kmeans_reforder_batch_workspace_bytes"):
+                     "et_kmeans_reforder_batch_workspace_bytes", "et_kmeans_reforder_sharded_workspace_bytes"):
             getattr(l, name).restype = C.c_size_t
+        l.et_kmeans_reforder_shard_block.restype = C.c_int64
         _lib = l
         # the library reads nothing from the environment; ET_OPT_<KEY>=value is forwarded once, here (A/B scripts under tools/)
         for name, value in os.environ.items():

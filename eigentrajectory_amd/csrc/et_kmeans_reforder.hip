@@ -610,10 +610,10 @@ struct Geo {
     int64_t full_chunks;  // (N / 4) / L
     int n_blk, full_blk;  // level-2 blocks (a partial last one included) / complete ones
 };
-static Geo make_geo(int64_t N) {
+static Geo make_geo(int64_t N, int lp_forced = 0) {  // lp_forced: a shard takes the level step of the WHOLE array
     Geo g;
     g.N = N;
-    g.lp = level_power(N / 4);
+    g.lp = lp_forced ? lp_forced : level_power(N / 4);
     const int64_t L = (int64_t)1 << g.lp;
     g.full_chunks = N / 4 / L;
     g.G = g.full_chunks / L;
@@ -1650,6 +1650,221 @@ __global__ __launch_bounds__(kUThreads) void reforder_update_kernel2(const Args 
     RF_STAMP(3, 4);
 }
 
+// =====================================================================================================================
+// The reference-order iteration over SHARDS (one process per GPU; not in the reference).  The order of a cascade sum is a
+// property of the whole array, but its tree is made of index ranges: with every shard boundary on a multiple of a level-2
+// block (4 L^3 points, L from the TOTAL number of points) a rank owns whole blocks, runs levels 0 .. 2 of its own rows
+// exactly as above, and what has to travel is one row of d K sums (+ K counts) per block -- 2 KB per 16 384 points at
+// L = 16, per 1 048 576 at L = 64 -- plus the last rank's leftovers: ONE all-gather per iteration; then every rank runs
+// the same sequential level 3 over the ranks' rows in rank order (= global block order), the lane combination, the update
+// and the stop flag: identical centroids everywhere without a broadcast, and the same bits as the single-GPU fit.
+// Record of a rank (16-byte words): rows[max_rows][d K + 8] | T1[d K] | T0[d K] | leftover labels | leftover coordinates
+// (3 points x 6, 5 words) | tail counts (8) | similarity sum (fp64 in one word).
+// =====================================================================================================================
+struct ShardRec {
+    int max_rows, rowlen, dk;
+    __host__ __device__ int t1() const { return max_rows * rowlen; }
+    __host__ __device__ int t0() const { return t1() + dk; }
+    __host__ __device__ int lab() const { return t0() + dk; }
+    __host__ __device__ int coords() const { return lab() + 1; }
+    __host__ __device__ int tailcnt() const { return coords() + 5; }
+    __host__ __device__ int sin() const { return tailcnt() + kFMaxK / 4; }
+    __host__ __device__ int words() const { return sin() + 1; }
+};
+
+// levels 2 of this rank's blocks -> its record (plain stores: the all-gather follows the kernel); workgroup 0 adds the
+// tail's rows, the leftover points, the tail's counts and the rank's similarity sum
+__global__ __launch_bounds__(kUThreads) void reforder_level2_sharded_kernel(const Args a, ShardRec rec, int rows_local,
+                                                                           float4 *__restrict__ send, int rows_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K, dk = kD * K;
+    unsigned char *ws = a.ws;
+    const et_kmeans_state *state = at<et_kmeans_state>(ws, a.lay.state);
+    if (state->done) return;
+    const Geo &geo = a.geo;
+    const int lp = geo.lp, L = 1 << lp;
+    const float4 *S1 = at<const float4>(ws, a.lay.S1);
+    const uint4 *cnt4 = at<const uint4>(ws, a.lay.cnt);
+    float4 *sRows = reinterpret_cast<float4 *>(smem);
+    const int blk = (int)blockIdx.x, rowlen = rec.rowlen;
+    if (blk < rows_local) {
+        const int64_t g0 = (int64_t)blk << lp;
+        const int ng = (int)((geo.G - g0) < L ? (geo.G - g0) : L);
+        float4 a2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint4 c2 = make_uint4(0u, 0u, 0u, 0u);
+        for (int r0 = 0; r0 < ng; r0 += rows_cap) {
+            const int nr = ng - r0 < rows_cap ? ng - r0 : rows_cap;
+            const float4 *src = S1 + (g0 + r0) * dk;
+            const uint4 *csrc = cnt4 + (g0 + r0) * (kFMaxK / 4);
+            for (int r8 = 0; r8 < nr; r8 += 16) {
+                if (tid < rowlen) {
+                    float4 v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int r = r8 + u < nr ? r8 + u : r8;
+                        v[u] = tid < dk ? src[r * dk + tid] : __builtin_bit_cast(float4, csrc[r * (kFMaxK / 4) + (tid - dk)]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (r8 + u < nr) sRows[(r8 + u) * rowlen + tid] = v[u];
+                }
+            }
+            __syncthreads();
+            if (tid < dk) {
+                for (int g = 0; g < nr; ++g) {
+                    const float4 v = sRows[g * rowlen + tid];
+                    a2.x = a2.x + v.x;
+                    a2.y = a2.y + v.y;
+                    a2.z = a2.z + v.z;
+                    a2.w = a2.w + v.w;
+                }
+            } else if (tid < rowlen) {
+                for (int g = 0; g < nr; ++g) {
+                    const uint4 v = __builtin_bit_cast(uint4, sRows[g * rowlen + tid]);
+                    c2.x += v.x;
+                    c2.y += v.y;
+                    c2.z += v.z;
+                    c2.w += v.w;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid < dk) send[(int64_t)blk * rowlen + tid] = a2;
+        else if (tid < rowlen) send[(int64_t)blk * rowlen + tid] = __builtin_bit_cast(float4, c2);
+    }
+    if (blk != 0) return;
+    const float4 *T = at<const float4>(ws, a.lay.T);
+    const double *Sin = at<const double>(ws, a.lay.Sin);
+    if (tid < dk) {
+        send[rec.t1() + tid] = T[tid];
+        send[rec.t0() + tid] = T[dk + tid];
+    }
+    if (tid == 0) send[rec.lab()] = T[2 * dk];
+    if (tid < 5) {  // the N mod 4 points after the lanes' ranges: their coordinates travel with the record
+        const int64_t N = geo.N, n0 = N / 4 * 4;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = 4 * tid + u, pnt = e / kD, i = e % kD;
+            v[u] = (e < 3 * kD && n0 + pnt < N) ? a.X[(int64_t)i * N + n0 + pnt] : 0.f;
+        }
+        send[rec.coords() + tid] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    if (tid >= 64 && tid < 64 + kFMaxK / 4) send[rec.tailcnt() + (tid - 64)] = __builtin_bit_cast(float4, cnt4[geo.G * (kFMaxK / 4) + (tid - 64)]);
+    __shared__ double sWsum[8];
+    double part = 0.0;
+    for (int64_t g = tid; g <= geo.G; g += kUThreads) part = part + Sin[g];
+    part = wave_sum_f64(part);
+    if (lane == 0) sWsum[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+        double sum = sWsum[0];
+        for (int w = 1; w < kUThreads / 64; ++w) sum = sum + sWsum[w];
+        const unsigned long long b = (unsigned long long)__double_as_longlong(sum);
+        send[rec.sin()] = make_float4(__uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)), 0.f, 0.f);
+    }
+}
+
+// every rank, identically: level 3 over the ranks' complete blocks in rank order, the tail rank's partial block / tail /
+// leftovers, lane combination, new centroids (kmeans.py:180-182), error (ATen's inner sum), stop flag
+__global__ __launch_bounds__(kUThreads) void reforder_finish_sharded_kernel(const Args a, ShardRec rec, int P, const int *__restrict__ rows_of,
+                                                                           int tail_rank, int tail_full_rows, int64_t N_total,
+                                                                           const float4 *__restrict__ table, int rows_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = (int)threadIdx.x;
+    const int K = a.K, dk = kD * K, rowlen = rec.rowlen;
+    et_kmeans_state *state = at<et_kmeans_state>(a.ws, a.lay.state);
+    if (state->done) return;
+    float *cen = at<float>(a.ws, a.lay.cen);
+    __shared__ unsigned sCntTot[kFMaxK];
+    __shared__ float sScr[40];
+    float4 *sRows = reinterpret_cast<float4 *>(smem);
+    float4 a3 = make_float4(0.f, 0.f, 0.f, 0.f), p2 = a3;
+    unsigned ctot[4] = {0u, 0u, 0u, 0u};
+    const int words = rec.words();
+    for (int r = 0; r < P; ++r) {
+        const float4 *rr = table + (int64_t)r * words;
+        const int nrows = rows_of[r], nfull = r == tail_rank ? tail_full_rows : nrows;
+        for (int r0 = 0; r0 < nrows; r0 += rows_cap) {
+            const int nr = nrows - r0 < rows_cap ? nrows - r0 : rows_cap;
+            for (int e = tid; e < nr * rowlen; e += kUThreads) sRows[e] = rr[r0 * rowlen + e];
+            __syncthreads();
+            if (tid < dk) {
+                for (int b = 0; b < nr; ++b) {
+                    const float4 v = sRows[b * rowlen + tid];
+                    if (r0 + b < nfull) {
+                        a3.x = a3.x + v.x;
+                        a3.y = a3.y + v.y;
+                        a3.z = a3.z + v.z;
+                        a3.w = a3.w + v.w;
+                    } else {
+                        p2 = v;  // (the partial block: the tail rank's last row)
+                    }
+                }
+            } else if (tid < rowlen) {
+                for (int b = 0; b < nr; ++b) {
+                    const uint4 v = __builtin_bit_cast(uint4, sRows[b * rowlen + tid]);
+                    ctot[0] += v.x;
+                    ctot[1] += v.y;
+                    ctot[2] += v.z;
+                    ctot[3] += v.w;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid >= dk && tid < rowlen) {
+            const uint4 t = __builtin_bit_cast(uint4, rr[rec.tailcnt() + (tid - dk)]);
+            ctot[0] += t.x;
+            ctot[1] += t.y;
+            ctot[2] += t.z;
+            ctot[3] += t.w;
+        }
+    }
+    if (tid >= dk && tid < rowlen) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sCntTot[4 * (tid - dk) + u] = ctot[u];
+    }
+    __syncthreads();
+    const float4 *last = table + (int64_t)tail_rank * words;  // (the rank that owns the end of the array)
+    float *sSq = reinterpret_cast<float *>(smem);
+    if (tid < dk) {
+        const int j = tid % K, i = tid / K;
+        const float4 p1 = last[rec.t1() + tid], p0 = last[rec.t0() + tid];
+        const unsigned lw = __float_as_uint(last[rec.lab()].x);
+        const float *lc = reinterpret_cast<const float *>(last + rec.coords());
+        float p = ((p0.x + p1.x) + p2.x) + a3.x;
+        for (int pnt = 0; pnt < (int)(N_total & 3); ++pnt)  // the N mod 4 terms after the lanes' ranges go onto lane 0
+            if (((lw >> (8 * pnt)) & 255u) == (unsigned)j) p = p + lc[pnt * kD + i];
+        p = p + (((p0.y + p1.y) + p2.y) + a3.y);
+        p = p + (((p0.z + p1.z) + p2.z) + a3.z);
+        p = p + (((p0.w + p1.w) + p2.w) + a3.w);
+        const float c = p / (float)sCntTot[j];  // 0/0 = NaN for an empty cluster (kmeans.py:182)
+        const float diff = cen[tid] - c;
+        cen[tid] = c;
+        sSq[tid] = diff * diff;
+    }
+    __syncthreads();
+    const float error = inner_sum_parallel(sSq, dk, sScr);
+    if (tid == 0) {
+        double sum = 0.0;
+        for (int r = 0; r < P; ++r) {
+            const float4 w = table[(int64_t)r * words + rec.sin()];
+            sum = sum + __longlong_as_double((long long)(((unsigned long long)__float_as_uint(w.y) << 32) | __float_as_uint(w.x)));
+        }
+        const float inertia = (float)(-(sum / (double)N_total));
+        const int64_t it = state->iter;
+        if (a.trace) {
+            a.trace[2 * it] = error;
+            a.trace[2 * it + 1] = inertia;
+        }
+        state->inertia = (double)inertia;
+        state->error = (double)error;
+        state->iter = it + 1;
+        state->done = (error <= a.tol) ? 1 : 0;
+    }
+}
+
 // before the loop: state, working centroids, counters
 __global__ __launch_bounds__(kThreads) void reforder_fast_prepare_kernel(const Args a, const float *__restrict__ cen_in) {
     unsigned char *ws = a.ws + (int64_t)blockIdx.x * a.ws_stride;
@@ -1876,6 +2091,179 @@ static int fast_fit(const float *X, int64_t x_stride, int64_t N, int K, int64_t 
     for (int64_t b = 0; b < batch; ++b)
         if (states_host[b].bad_input) return ET_ERR_BAD_DATA;
     return ET_OK;
+}
+
+// ---- shards (see "The reference-order iteration over SHARDS" above) ----
+namespace {
+struct ShardPlan {
+    int P = 0, rank = 0, tail_rank = 0, tail_full = 0, max_rows = 0, lp = 0;
+    int64_t N_total = 0;
+    int rows[ET_REFORDER_MAX_RANKS] = {};
+    fast::Geo geo;
+    fast::ShardRec rec;
+    size_t off_send = 0, off_table = 0, off_rows = 0, bytes = 0;
+};
+int shard_plan(const int64_t *n_locals, int P, int rank, int K, ShardPlan *p) {
+    using namespace fast;
+    if (!n_locals || P < 1 || P > ET_REFORDER_MAX_RANKS || rank < 0 || rank >= P || K < 1 || K > kFMaxK) return ET_ERR_INVALID_ARG;
+    int64_t total = 0;
+    int tail_rank = 0;
+    for (int r = 0; r < P; ++r) {
+        if (n_locals[r] < 0) return ET_ERR_INVALID_ARG;
+        total += n_locals[r];
+        if (n_locals[r] > 0) tail_rank = r;
+    }
+    if (!fast_shape(total, kD, K)) return ET_ERR_UNSUPPORTED;
+    p->lp = level_power(total / 4);
+    const int64_t block = (int64_t)4 << (3 * p->lp);
+    p->P = P;
+    p->rank = rank;
+    p->tail_rank = tail_rank;
+    p->N_total = total;
+    p->max_rows = 1;
+    for (int r = 0; r < P; ++r) {
+        if (r != tail_rank && n_locals[r] % block != 0) return ET_ERR_INVALID_ARG;  // whole level-2 blocks before the tail rank
+        const Geo g = make_geo(n_locals[r], p->lp);
+        p->rows[r] = g.n_blk;
+        if (r == tail_rank) p->tail_full = g.full_blk;
+        if (g.n_blk > p->max_rows) p->max_rows = g.n_blk;
+    }
+    p->geo = make_geo(n_locals[rank], p->lp);
+    p->rec.max_rows = p->max_rows;
+    p->rec.dk = kD * K;
+    p->rec.rowlen = kD * K + kFMaxK / 4;
+    size_t off = shared_bytes(K, 1) + make_layout(p->geo, K).bytes;
+    p->off_send = off;
+    off = up(off + sizeof(float4) * (size_t)p->rec.words());
+    p->off_table = off;
+    off = up(off + sizeof(float4) * (size_t)p->rec.words() * P);
+    p->off_rows = off;
+    off = up(off + sizeof(int) * ET_REFORDER_MAX_RANKS);
+    p->bytes = off;
+    return ET_OK;
+}
+}  // namespace
+
+extern "C" int64_t et_kmeans_reforder_shard_block(int64_t N_total, int d, int K) {
+    if (!fast::fast_shape(N_total, d, K)) return 0;
+    return (int64_t)4 << (3 * level_power(N_total / 4));
+}
+
+extern "C" size_t et_kmeans_reforder_sharded_workspace_bytes(const int64_t *n_locals, int nranks, int rank, int d, int K) {
+    ShardPlan p;
+    if (d != fast::kD || shard_plan(n_locals, nranks, rank, K, &p) != ET_OK) return 0;
+    return p.bytes;
+}
+
+// `gather(ctx, send, recv, bytes, stream)`: every rank's `bytes` at send -> recv[rank * bytes ...] on every rank (in stream
+// order); `agree(ctx, state, stream)`: MAX over ranks of state->max_abs_x / bad_input.  Both nullptr: one rank.
+extern "C" int et_internal_kmeans_reforder_sharded_run(const float *X, const int64_t *n_locals, int nranks, int rank, int K,
+                                                       int max_iter, float tol, float *centroids, int64_t *labels, float *trace,
+                                                       et_kmeans_state *state_host, void *workspace, size_t workspace_bytes,
+                                                       int (*gather)(void *, const void *, void *, size_t, hipStream_t),
+                                                       int (*agree)(void *, et_kmeans_state *, hipStream_t), void *ctx,
+                                                       et_stream_t stream) {
+    using namespace fast;
+    ShardPlan p;
+    int rc = shard_plan(n_locals, nranks, rank, K, &p);
+    if (rc) return rc;
+    if (!centroids || !state_host || !workspace || max_iter < 1 || (p.geo.N > 0 && !X)) return ET_ERR_INVALID_ARG;
+    if (nranks > 1 && !gather) return ET_ERR_INVALID_ARG;
+    if (workspace_bytes < p.bytes) return ET_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Args a;
+    a.geo = p.geo;
+    a.lay = make_layout(a.geo, K);
+    unsigned char *base = (unsigned char *)workspace;
+    a.batch_arrive = (unsigned *)base;
+    a.sq_all = (float *)(base + 256);
+    a.ws = base + shared_bytes(K, 1);
+    a.ws_stride = (int64_t)a.lay.bytes;
+    a.X = X;
+    a.x_stride = 0;
+    a.K = K;
+    a.batch = 1;
+    a.tol = tol;
+    a.trace = trace;
+    a.max_iter = max_iter;
+    a.mail = nullptr;
+    a.tiles_per_round = fast_tiles_per_round(a.geo);
+    float4 *send = (float4 *)(base + p.off_send), *table = (float4 *)(base + p.off_table);
+    int *rows_dev = (int *)(base + p.off_rows);
+    et::StateRing *ring = et::StateRing::get(&rc);
+    if (!ring) return rc;
+    const size_t lds = fast_lds_bytes(a.geo, K, a.tiles_per_round);
+    size_t l2lds = 0;
+    const int l2cap = update_rows_cap(a.geo, K, 1, &l2lds);
+    const size_t rowb = sizeof(float4) * (size_t)p.rec.rowlen;
+    const int fcap = (int)std::min<size_t>((size_t)p.max_rows, kUMaxLds / rowb);
+    const size_t flds = std::max<size_t>((size_t)fcap * rowb, sizeof(float) * (size_t)kD * K);
+    {
+        static bool lds_set[64] = {};
+        int dev_id = 0;
+        ET_HIP_TRY(hipGetDevice(&dev_id));
+        if (!lds_set[dev_id & 63]) {
+            for (const void *f : {reinterpret_cast<const void *>(reforder_groups_kernel<0>), reinterpret_cast<const void *>(reforder_groups_kernel<10>),
+                                  reinterpret_cast<const void *>(reforder_groups_kernel<16>)})
+                ET_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            for (const void *f : {reinterpret_cast<const void *>(reforder_level2_sharded_kernel), reinterpret_cast<const void *>(reforder_finish_sharded_kernel)})
+                ET_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUMaxLds));
+            lds_set[dev_id & 63] = true;
+        }
+    }
+    et_kmeans_state *state = (et_kmeans_state *)(a.ws + a.lay.state);
+    rc = et_kmeans_scan(X, a.geo.N, kD, state, stream);
+    if (rc) return rc;
+    if (agree) {
+        rc = agree(ctx, state, st);
+        if (rc) return rc;
+    }
+    ET_HIP_TRY(hipMemcpyAsync(rows_dev, p.rows, sizeof(int) * (size_t)p.P, hipMemcpyHostToDevice, st));  // (p outlives the copy: this call ends with a synchronize)
+    ET_HIP_TRY(hipMemsetAsync(send, 0, sizeof(float4) * (size_t)p.rec.words(), st));
+    hipLaunchKernelGGL(reforder_fast_prepare_kernel, dim3(1), dim3(kThreads), 0, st, a, (const float *)centroids);
+    if (a.geo.G > 0) {
+        const int64_t quads = a.geo.G << (2 * a.geo.lp);
+        const int pg = (int)std::min<int64_t>((quads + kThreads - 1) / kThreads, 2048);
+        hipLaunchKernelGGL(reforder_permute_kernel, dim3(pg, 1), dim3(kThreads), 0, st, X, (int64_t)0, a.ws, a.ws_stride, a.lay.XT,
+                           a.geo);
+    }
+    ET_LAUNCH_CHECK();
+    const bool use_filter = a.geo.lp >= fast_filter_min_lp() && K >= 3;
+    constexpr int kEvery = 4;
+    bool done = false;
+    const dim3 grid((unsigned)(a.geo.G + 1), 1), l2grid((unsigned)std::max(p.rows[rank], 1), 1);
+    const size_t rec_bytes = sizeof(float4) * (size_t)p.rec.words();
+    for (int it = 0; it < max_iter && !done; ++it) {
+        if (!use_filter) hipLaunchKernelGGL(reforder_groups_kernel<0>, grid, dim3(kFThreads), lds, st, a);
+        else if (K <= 20) hipLaunchKernelGGL(reforder_groups_kernel<10>, grid, dim3(kFThreads), lds, st, a);
+        else hipLaunchKernelGGL(reforder_groups_kernel<16>, grid, dim3(kFThreads), lds, st, a);
+        hipLaunchKernelGGL(reforder_level2_sharded_kernel, l2grid, dim3(kUThreads), l2lds, st, a, p.rec, p.rows[rank], send, l2cap);
+        ET_LAUNCH_CHECK();
+        if (gather) {
+            rc = gather(ctx, send, table, rec_bytes, st);
+            if (rc) return rc;
+        } else {
+            ET_HIP_TRY(hipMemcpyAsync(table, send, rec_bytes, hipMemcpyDeviceToDevice, st));
+        }
+        hipLaunchKernelGGL(reforder_finish_sharded_kernel, dim3(1), dim3(kUThreads), flds, st, a, p.rec, p.P, (const int *)rows_dev,
+                           p.tail_rank, p.tail_full, p.N_total, (const float4 *)table, fcap);
+        ET_LAUNCH_CHECK();
+        // the stop flag is read one post late, by a blocking wait on that specific copy: which copy a rank sees must not
+        // depend on timing, or the ranks would stop enqueueing collectives at different iterations (et_sharded.hip)
+        if ((it + 1) % kEvery == 0) {
+            rc = ring->post(state, st, &done);
+            if (!rc && ring->pending() > 1) rc = ring->wait_oldest(&done);
+            if (rc) return rc;
+        }
+    }
+    const int64_t fgrid = std::max<int64_t>(1, std::min<int64_t>((a.geo.N + kThreads - 1) / kThreads, 2048));
+    hipLaunchKernelGGL(reforder_fast_finish_kernel, dim3((unsigned)fgrid, 1), dim3(kThreads), 0, st, a, centroids,
+                       a.geo.N > 0 ? labels : nullptr);
+    ET_LAUNCH_CHECK();
+    ET_HIP_TRY(hipMemcpyAsync(state_host, state, sizeof(et_kmeans_state), hipMemcpyDeviceToHost, st));
+    ET_HIP_TRY(hipStreamSynchronize(st));
+    state_host->n_total = p.N_total;
+    return state_host->bad_input ? ET_ERR_BAD_DATA : ET_OK;
 }
 
 extern "C" int et_euc_sim_reforder(const float *a, const float *b, int d, int64_t m, int64_t n, float *y,

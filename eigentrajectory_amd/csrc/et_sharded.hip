@@ -313,3 +313,45 @@ extern "C" int et_kmeans_fit_sharded(const float *X, int64_t N_local, int64_t N_
     ET_HIP_TRY(hipStreamSynchronize(st));
     return state_host->bad_input ? ET_ERR_BAD_DATA : ET_OK;
 }
+
+extern "C" int et_internal_kmeans_reforder_sharded_run(const float *X, const int64_t *n_locals, int nranks, int rank, int K,
+                                                       int max_iter, float tol, float *centroids, int64_t *labels, float *trace,
+                                                       et_kmeans_state *state_host, void *workspace, size_t workspace_bytes,
+                                                       int (*gather)(void *, const void *, void *, size_t, hipStream_t),
+                                                       int (*agree)(void *, et_kmeans_state *, hipStream_t), void *ctx,
+                                                       et_stream_t stream);
+namespace {
+int gather_over_ranks(void *ctx, const void *send, void *recv, size_t bytes, hipStream_t st) {
+    const ncclResult_t r = et::g_rccl.AllGather(send, recv, bytes, ncclUint8, static_cast<ReduceCtx *>(ctx)->comm, st);
+    return r == ncclSuccess ? ET_OK : ET_ERR_RCCL;
+}
+int agree_over_ranks(void *ctx, et_kmeans_state *state, hipStream_t st) {  // the scan's scale and non-finite flag: MAX
+    ncclComm_t c = static_cast<ReduceCtx *>(ctx)->comm;
+    if (et::g_rccl.GroupStart() != ncclSuccess) return ET_ERR_RCCL;
+    const ncclResult_t r1 = et::g_rccl.AllReduce(&state->max_abs_x, &state->max_abs_x, 1, ncclDouble, ncclMax, c, st);
+    const ncclResult_t r2 = et::g_rccl.AllReduce(&state->bad_input, &state->bad_input, 1, ncclInt64, ncclMax, c, st);
+    if (et::g_rccl.GroupEnd() != ncclSuccess || r1 != ncclSuccess || r2 != ncclSuccess) return ET_ERR_RCCL;
+    return ET_OK;
+}
+}  // namespace
+
+extern "C" int et_kmeans_fit_reforder_sharded(const float *X, const int64_t *n_locals, int nranks, int rank, int d, int K,
+                                              int max_iter, float tol, float *centroids, int64_t *labels, float *trace,
+                                              et_kmeans_state *state_host, void *workspace, size_t workspace_bytes,
+                                              et_comm_t comm, et_stream_t stream) {
+    if (d != 6) return ET_ERR_UNSUPPORTED;
+    if (!comm) {
+        if (nranks != 1 || rank != 0) return ET_ERR_INVALID_ARG;
+        return et_internal_kmeans_reforder_sharded_run(X, n_locals, 1, 0, K, max_iter, tol, centroids, labels, trace, state_host,
+                                                       workspace, workspace_bytes, nullptr, nullptr, nullptr, stream);
+    }
+    if (!g_rccl.ok) return ET_ERR_RCCL;
+    int cn = 0, cr = 0;
+    ET_RCCL_TRY(g_rccl.CommCount((ncclComm_t)comm, &cn));
+    ET_RCCL_TRY(g_rccl.CommUserRank((ncclComm_t)comm, &cr));
+    if (cn != nranks || cr != rank) return ET_ERR_INVALID_ARG;
+    ReduceCtx ctx{(ncclComm_t)comm};
+    return et_internal_kmeans_reforder_sharded_run(X, n_locals, nranks, rank, K, max_iter, tol, centroids, labels, trace,
+                                                   state_host, workspace, workspace_bytes, &gather_over_ranks, &agree_over_ranks,
+                                                   &ctx, stream);
+}

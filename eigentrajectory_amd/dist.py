@@ -190,12 +190,25 @@ class ShardedKMeans:
             self.shard.init_select(gathered, self.world, rec_bytes, i, C0)
         return C0
 
-    def fit(self, centroids, max_iter=100, tol=1e-4, trace=None):
+    def fit(self, centroids, max_iter=100, tol=1e-4, trace=None, sums="exact"):
         """kmeans.py:228-240 over all ranks.  ``centroids`` (d,K) is updated in place (identical on every rank).
+
+        sums="reference-order": the reference's own fp32 summation orders (ops.kmeans_fit_reference_order on the whole
+        array, bit for bit); needs the shard sizes of ops.reference_order_shard_sizes and, beyond one rank, a Communicator.
 
         Returns dict(centroids, labels (local, int64), n_iter, error, inertia, done).
         """
         sh = self.shard
+        if sums == "reference-order":
+            if self.world > 1 and self.comm is None:
+                raise NotImplementedError("sums='reference-order' over several ranks runs as one native call: pass comm=Communicator(...)")
+            res = ops.kmeans_fit_reference_order_sharded(sh.X, centroids, self.counts, self.rank, self.comm, max_iter, tol,
+                                                         trace=False)
+            centroids.copy_(res["centroids"])
+            res["centroids"] = centroids
+            return res
+        if sums != "exact":
+            raise ValueError(f"sums must be 'exact' or 'reference-order', got {sums!r}")
         if self.comm is not None:
             ws = self._native_workspace()
             st = L.KMeansState()

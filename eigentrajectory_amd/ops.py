@@ -472,6 +472,52 @@ def kmeans_fit_reference_order_batch(X, centroids, max_iter=100, tol=1e-4, trace
     return out
 
 
+def reference_order_shard_sizes(n_total, world, d=6, K=20):
+    """How to split n_total points over `world` ranks so that sums="reference-order" gives the single-GPU bits: every
+    rank before the last non-empty one holds whole level-2 blocks of ATen's cascade (include/eigentraj.h,
+    et_kmeans_fit_reforder_sharded); as even as that allows.  -> list of `world` sizes (trailing ranks may be empty)."""
+    block = int(L.lib().et_kmeans_reforder_shard_block(L.i64(n_total), int(d), int(K)))
+    if block == 0:
+        raise NotImplementedError(f"sharded sums='reference-order' takes d = 6, K <= 32, 1024 <= N < 2^29 (got d={d}, K={K}, N={n_total})")
+    blocks = -(-int(n_total) // block)
+    per = -(-blocks // int(world))
+    sizes, left = [], int(n_total)
+    for _ in range(int(world)):
+        take = min(left, per * block)
+        sizes.append(take)
+        left -= take
+    return sizes
+
+
+def kmeans_fit_reference_order_sharded(X_local, centroids, n_locals, rank, comm=None, max_iter=100, tol=1e-4, trace=True):
+    """kmeans.py:228-240 in the reference's fp32 summation orders over points split across ranks (n_locals: every rank's
+    size, see :func:`reference_order_shard_sizes`; comm: a dist.Communicator or None for one rank).  The same centroids,
+    labels, error and iteration count as :func:`kmeans_fit_reference_order` on the whole array, on every rank."""
+    dev = L.require_device(centroids)
+    X_local, centroids = _dev_args(dev, X_local, centroids)
+    d, n = X_local.shape
+    K = centroids.shape[1]
+    sizes = (C.c_int64 * len(n_locals))(*[int(v) for v in n_locals])
+    if int(n_locals[rank]) != n:
+        raise ValueError(f"n_locals[{rank}] = {n_locals[rank]} but this rank holds {n} points")
+    nbytes = L.lib().et_kmeans_reforder_sharded_workspace_bytes(sizes, len(n_locals), int(rank), int(d), int(K))
+    if nbytes == 0:
+        raise NotImplementedError("sharded sums='reference-order': d = 6, K <= 32, 1024 <= N_total < 2^29 and whole level-2 "
+                                  f"blocks on every rank before the last (got d={d}, K={K}, sizes={list(n_locals)})")
+    ws = torch.empty((nbytes,), device=dev, dtype=torch.uint8)
+    cen = centroids.clone()
+    labels = torch.empty((n,), device=dev, dtype=torch.int64)
+    trace_t = torch.zeros((max_iter, 2), device=dev) if trace else None
+    st = L.KMeansState()
+    L.check(L.lib().et_kmeans_fit_reforder_sharded(L.ptr(X_local) if n else None, sizes, len(n_locals), int(rank), int(d), int(K),
+                                                   int(max_iter), L.f32(tol), L.ptr(cen), L.ptr(labels) if n else None,
+                                                   L.ptr(trace_t), C.byref(st), L.ptr(ws), C.c_size_t(ws.numel()),
+                                                   comm.handle if comm is not None else None, L.stream(dev)),
+            "et_kmeans_fit_reforder_sharded")
+    return dict(centroids=cen, labels=labels, n_iter=int(st.iter), error=float(st.error), inertia=float(st.inertia),
+                trace=trace_t[:int(st.iter)] if trace else None, done=bool(st.done))
+
+
 # ---------------------------------------------------- sklearn-recipe anchors (anchor.py:65-71)
 def center_columns(X, rel_tol=1e-4):
     """KMeans.fit's pre-processing on a COPY of X (d,N): -> (X - mean (d,N), mean (d,), tol (1,) = rel_tol * mean(var))

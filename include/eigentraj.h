@@ -457,6 +457,24 @@ int et_kmeans_fit_sharded(const float *X, int64_t N_local, int64_t N_total, int 
                           et_kmeans_state *state_host, void *workspace, size_t workspace_bytes,
                           et_comm_t comm, et_stream_t stream);
 
+/* The REFERENCE-ORDER Lloyd iterations (et_kmeans_fit_reforder above) over shards, d = 6, K <= 32, 1024 <= N_total < 2^29.
+ * The order of ATen's cascade sum is a property of the whole array, but its tree is made of index ranges: rank r holds the
+ * points [sum of n_locals[0..r), + n_locals[r]) and every rank before the last non-empty one holds a whole number of
+ * level-2 blocks (n_locals[r] a multiple of et_kmeans_reforder_shard_block(N_total, d, K) = 4 L^3 points, L the level
+ * step of N_total: 16 384 / 131 072 / 1 048 576 points for L = 16 / 32 / 64; zero is a multiple); ranks after it are empty.  Each rank runs
+ * levels 0 .. 2 over its own blocks; per iteration ONE all-gather of a record per rank (a row of d K sums + K counts per
+ * block, the end of the array's partial sums) and the same sequential level 3 on every rank: centroids, labels, error and
+ * iteration count equal et_kmeans_fit_reforder on the whole array bit for bit (inertia: to fp32 rounding).  n_locals is a
+ * HOST array of nranks sizes, identical on every rank; labels (n_locals[rank]) int64 or NULL; *state_host the final
+ * state.  comm == NULL: nranks must be 1.  Anything else than the shapes above: ET_ERR_UNSUPPORTED / ET_ERR_INVALID_ARG. */
+#define ET_REFORDER_MAX_RANKS 64
+int64_t et_kmeans_reforder_shard_block(int64_t N_total, int d, int K); /* 0: shape not taken */
+size_t et_kmeans_reforder_sharded_workspace_bytes(const int64_t *n_locals, int nranks, int rank, int d, int K);
+int et_kmeans_fit_reforder_sharded(const float *X, const int64_t *n_locals, int nranks, int rank, int d, int K, int max_iter,
+                                   float tol, float *centroids, int64_t *labels, float *trace,
+                                   et_kmeans_state *state_host, void *workspace, size_t workspace_bytes,
+                                   et_comm_t comm, et_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -537,6 +537,135 @@ def test_native_two_shards_equal_the_rccl_world1_run(ops, dev, tmp_path, cut):
     assert np.array_equal(labels, r0["labels"])
 
 
+def _reference_order_shards_native(dev, x, c0, sizes, max_iter, tol):
+    """et_kmeans_fit_reforder_sharded's loop (csrc/et_kmeans_reforder.hip: et_internal_kmeans_reforder_sharded_run) on
+    len(sizes) shards of ONE GPU: one host thread and stream per shard, and a test all-gather (barrier, copy of every
+    shard's record) in place of ncclAllGather.  -> per shard: dict(centroids, labels, trace, state)."""
+    import ctypes as C
+    import threading
+    from eigentrajectory_amd import _lib as L
+    lib = L.lib()
+    P = len(sizes)
+    GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+    AGREE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+    run = lib.et_internal_kmeans_reforder_sharded_run
+    run.restype = C.c_int
+    run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                    C.c_void_p, C.c_void_p, C.c_size_t, GATHER, AGREE, C.c_void_p, C.c_void_p]
+    K = c0.shape[1]
+    arr = (C.c_int64 * P)(*sizes)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    out = [None] * P
+    barrier = threading.Barrier(P)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(P)]
+    sends = [None] * P
+    errors = []
+
+    def worker(r):
+        try:
+            n = sizes[r]
+            X = T(np.ascontiguousarray(x[:, offs[r]:offs[r + 1]]), dev) if n else None
+            nbytes = lib.et_kmeans_reforder_sharded_workspace_bytes(arr, P, r, 6, K)
+            assert nbytes > 0
+            ws = torch.empty((nbytes,), device=dev, dtype=torch.uint8)
+            cen = T(c0, dev).clone()
+            labels = torch.empty((max(n, 1),), device=dev, dtype=torch.int64)
+            trace = torch.zeros((max_iter, 2), device=dev)
+            st = L.KMeansState()
+
+            def gather(ctx, send, recv, nb, stream):
+                with torch.cuda.stream(streams[r]):
+                    streams[r].synchronize()
+                    off = send - ws.data_ptr()
+                    assert 0 <= off and off + nb <= ws.numel()
+                    sends[r] = ws[off:off + nb]
+                    barrier.wait()  # every shard's record is complete and published
+                    roff = recv - ws.data_ptr()
+                    for q in range(P):
+                        assert sends[q].numel() == nb  # the same collective on every "rank"
+                        ws[roff + q * nb:roff + (q + 1) * nb].copy_(sends[q])
+                    streams[r].synchronize()
+                    barrier.wait()  # everybody has read everybody's
+                return 0
+
+            def agree(ctx, state, stream):
+                return 0
+
+            g, a = GATHER(gather), AGREE(agree)
+            with torch.cuda.stream(streams[r]):
+                rc = run(L.ptr(X), arr, P, r, K, max_iter, L.f32(tol), L.ptr(cen), L.ptr(labels) if n else None, L.ptr(trace),
+                         C.byref(st), L.ptr(ws), C.c_size_t(ws.numel()), g, a, None, C.c_void_p(streams[r].cuda_stream))
+                streams[r].synchronize()
+            assert rc == 0, rc
+            out[r] = dict(centroids=N_(cen), labels=N_(labels)[:n], trace=N_(trace)[:int(st.iter)], state=st)
+        except BaseException as exc:  # noqa: BLE001
+            errors.append(exc)
+            barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(P)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    if errors:
+        raise errors[0]
+    assert all(o is not None for o in out)
+    return out
+
+
+@pytest.mark.parametrize("n,blocks", [(40000, (1, 1)), (40000, (2, 0)), (40000, (1, 1, 1)), (100000, (2, 2, 2, 1)),
+                                      (32768, (1, 1)), (5000, (1, 0)), (4300000, (16, 17)), (4300000, (32, 1, 0))])
+def test_reference_order_shards_equal_the_single_gpu_fit(ops, dev, oracle, n, blocks):
+    """sums="reference-order" over shards cut at level-2 blocks of ATen's cascade: every shard ends with the centroids,
+    the error trace and the iteration count of the single-GPU reference-order fit on the whole array, bit for bit, and
+    the shards' labels together are its labels; for the small cases that fit is checked against the oracle as well.
+    Cases: the end of the array inside the last shard's first block / nothing left for the last shard / an empty trailing
+    rank / N a multiple of a block / L = 32 (4.3e6 points: blocks of 131 072)."""
+    import ctypes as C
+    from eigentrajectory_amd import _lib as L
+    from eigentrajectory_amd.synth import gaussian_points_np
+    K, max_iter, tol = 20, 12, 1e-4
+    x = gaussian_points_np(6, n, seed=17, n_blobs=9)
+    x[:, ::61] *= 25.0
+    block = int(L.lib().et_kmeans_reforder_shard_block(L.i64(n), 6, K))
+    assert block == (16384 if n <= 4 << 19 else 131072)
+    sizes, left = [], n
+    for b in blocks:
+        sizes.append(min(left, b * block))
+        left -= sizes[-1]
+    sizes[[i for i, b in enumerate(blocks) if b][-1]] += left  # the last non-empty shard takes the end of the array
+    assert sum(sizes) == n
+    c0 = N_(ops.kmeans_init_farthest_reference_order(T(x, dev), K, 5))
+    whole = ops.kmeans_fit_reference_order(T(x, dev), T(c0, dev), max_iter, tol)
+    if n <= 100000:
+        ref = oracle.kmeans_fit(x, c0, max_iter, tol, sums="reference-order")
+        assert np.array_equal(N_(whole["centroids"]), ref["centroids"]) and np.array_equal(N_(whole["labels"]), ref["labels"])
+    shards = _reference_order_shards_native(dev, x, c0, sizes, max_iter, tol)
+    for r, sh in enumerate(shards):
+        assert np.array_equal(sh["centroids"], N_(whole["centroids"])), r
+        assert int(sh["state"].iter) == whole["n_iter"] and bool(sh["state"].done) == whole["done"]
+        assert np.float32(sh["state"].error) == np.float32(whole["error"])
+        assert np.array_equal(sh["trace"][:, 0], N_(whole["trace"])[:, 0])
+        np.testing.assert_allclose(sh["trace"][:, 1], N_(whole["trace"])[:, 1], rtol=1e-6)  # (the inertia: fp32 rounding of an fp64 sum)
+    assert np.array_equal(np.concatenate([sh["labels"] for sh in shards]), N_(whole["labels"]))
+
+
+def test_reference_order_sharded_entry_point_one_rank(ops, dev):
+    """et_kmeans_fit_reforder_sharded without a communicator (one rank: the record is copied instead of gathered) and
+    the shard-size helper; sizes that cut inside a block are refused."""
+    from eigentrajectory_amd.synth import gaussian_points_np
+    x = gaussian_points_np(6, 50000, seed=3, n_blobs=6)
+    c0 = x[:, :20].copy()
+    whole = ops.kmeans_fit_reference_order(T(x, dev), T(c0, dev), 10, 1e-4)
+    one = ops.kmeans_fit_reference_order_sharded(T(x, dev), T(c0, dev), [50000], 0, None, 10, 1e-4)
+    assert torch.equal(one["centroids"], whole["centroids"]) and torch.equal(one["labels"], whole["labels"])
+    assert one["n_iter"] == whole["n_iter"] and torch.equal(one["trace"][:, 0], whole["trace"][:, 0])
+    assert ops.reference_order_shard_sizes(50000, 2) == [32768, 17232]
+    assert ops.reference_order_shard_sizes(50000, 8) == [16384, 16384, 16384, 848, 0, 0, 0, 0]
+    with pytest.raises(NotImplementedError):
+        ops.kmeans_fit_reference_order_sharded(T(x[:, :25000], dev), T(c0, dev), [25000, 25000], 0, None, 10, 1e-4)
+
+
 def _two_rank_gpu_worker(rank, world, port, cuts, out_dir):
     import os
     import torch.distributed as dist
@@ -600,6 +729,11 @@ def _nccl_world1_worker(rank, port, out_dir):
         assert torch.equal(c0n, c0) and resn["n_iter"] == res["n_iter"] and resn["done"] == res["done"]
         assert torch.equal(resn["centroids"], res["centroids"]) and torch.equal(resn["labels"], res["labels"])
         assert resn["inertia"] == res["inertia"] and resn["error"] == res["error"]
+        # sums="reference-order" over shards: per iteration one ncclAllGather of the rank's record (world 1: from itself)
+        rf = kn.fit(c0n.clone(), max_iter=30, tol=1e-4, sums="reference-order")
+        one = ops.kmeans_fit_reference_order(torch.from_numpy(x).to(dev), c0n, 30, 1e-4, trace=False)
+        assert torch.equal(rf["centroids"], one["centroids"]) and torch.equal(rf["labels"], one["labels"])
+        assert rf["n_iter"] == one["n_iter"] and rf["error"] == one["error"]
         comm.close()
         np.savez(os.path.join(out_dir, "rank0.npz"), U_pred=U_pred.cpu().numpy(), count=count, c0=c0.cpu().numpy(),
                  centroids=res["centroids"].cpu().numpy(), labels=res["labels"].cpu().numpy(), n_iter=res["n_iter"])

@@ -190,3 +190,33 @@ def test_round2_entry_points_validate_arguments_on_the_host():
     assert lib.et_kmeans_fit_sharded(null, i64(10), i64(5), 6, 20, 100, f32(1e-4), null, null, null, null, null, null, null,
                                      null, ctypes.c_size_t(0), null, null) == 1   # N_total < N_local
     assert b"RCCL" in lib.et_status_string(6)
+
+
+def test_reference_order_shard_geometry_on_the_host():
+    """The shard rule of et_kmeans_fit_reforder_sharded (include/eigentraj.h) is host arithmetic: block = 4 L^3 points
+    with L the level step of ATen's cascade for N_total / 4 items per lane (SumKernel.cpp: 2^max(4, ceil_log2(n) / 4));
+    every rank before the last non-empty one holds whole blocks; anything else has no workspace (= is refused)."""
+    import ctypes as C
+    from eigentrajectory_amd import _lib as L
+    from eigentrajectory_amd import ops
+    lib = L.lib()
+    block = lambda n: int(lib.et_kmeans_reforder_shard_block(L.i64(n), 6, 20))
+    assert block(1023) == 0 and block(1024) == 4 * 16 ** 3
+    assert block(4 << 19) == 4 * 16 ** 3 and block((4 << 19) + 4) == 4 * 32 ** 3  # ceil_log2(N / 4) 19 -> 20
+    assert block(4 << 23) == 4 * 32 ** 3 and block((4 << 23) + 4) == 4 * 64 ** 3
+    assert block(1 << 29) == 0 and int(lib.et_kmeans_reforder_shard_block(L.i64(100000), 5, 20)) == 0
+
+    def ws(sizes, rank, K=20):
+        arr = (C.c_int64 * len(sizes))(*sizes)
+        return int(lib.et_kmeans_reforder_sharded_workspace_bytes(arr, len(sizes), rank, 6, K))
+
+    for n, world in [(100000, 8), (1000000, 8), (10000000, 8), (50000, 3), (16384, 2), (1024, 4)]:
+        sizes = ops.reference_order_shard_sizes(n, world)
+        assert sum(sizes) == n and len(sizes) == world
+        last = max(i for i, v in enumerate(sizes) if v)
+        assert all(v % block(n) == 0 for v in sizes[:last]) and all(v == 0 for v in sizes[last + 1:])
+        assert all(ws(sizes, r) > 0 for r in range(world))
+    assert ws([25000, 25000], 0) == 0          # a cut inside a block
+    assert ws([16384, 0, 1000], 1) > 0         # (an empty rank holds zero blocks wherever it sits)
+    assert ws([16384, 1000], 2) == 0 and ws([16384, 1000], 0, K=33) == 0
+    assert ws([16384, 16384, 0], 2) > 0        # trailing empty ranks take part in the collectives
