@@ -20,7 +20,7 @@ for case in range(cases):
         n = int(rng.randint(1024, 60000))
     K = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 20, 20, 20, 31, 32]))
     l = int(rng.choice([1, 1, 2, 3]))
-    iters = int(rng.randint(2, 9))
+    iters = int(rng.randint(2, 9)) if rng.rand() < 0.7 else int(rng.randint(9, 40))  # (some long fits)
     scale = float(10.0 ** rng.uniform(-8, 8)) if rng.rand() < 0.3 else 1.0
     xs = []
     for b in range(l):
