@@ -187,3 +187,41 @@ def test_sgcn_full_splits_replay_through_the_oracle_g14(oracle, scene):
     np.testing.assert_allclose(ade, z[f"{scene}.ade"], rtol=0, atol=1e-5)
     np.testing.assert_allclose(fde, z[f"{scene}.fde"], rtol=0, atol=1e-5)
     np.testing.assert_allclose([ade.mean(dtype=np.float64), fde.mean(dtype=np.float64)], z[f"{scene}.ade_fde_mean"], rtol=0, atol=1e-5)
+
+
+def test_agentformer_tenth_of_univ_replay_through_the_oracle_g15(oracle):
+    """Config 5's data path at G14's extent on CPU (tests/golden/g15: every tenth test scene of univ, 2 471 pedestrians;
+    tools/make_golden_agentformer_full.py): oracle projection -> THIS build's agentformer bridge -> the recorded output of
+    the reference's AgentFormerLight -> oracle reconstruction: per-pedestrian best-of-20 ADE / FDE and their means within
+    1e-5 of the reference's."""
+    from eigentrajectory_amd.bridges import get_hook_func
+    from oracle import wrapper_ref as W
+    z = G.load("g15_agentformer_univ_tenth.npz")
+    g2 = G.load("g2_fit_all_scenes.npz")
+    params = {k[len("univ."):]: g2[k] for k in g2.files if k.startswith("univ.ET_")}
+    obs, pred, sse = G.dataset("univ", "test")
+    hooks = get_hook_func("agentformer")
+    assert int(z["pre_axis"]) == 1 and int(z["dec_axis"]) == 0 and int(z["dec_per_pedestrian"]) == 1
+    pre_all, dec_all = torch.from_numpy(z["pre_motion"]), torch.from_numpy(z["dec_motion"])
+    net = ReplayAgentFormer(None, None, 2e-5)
+
+    def predictor(x):  # x = cat(C_obs, obs_ori) (k+2, N), the oracle wrapper's stand-in for the pre-hook input
+        xt = torch.from_numpy(x)
+        data = hooks.model_forward_pre_hook(xt[:6], xt[6:], None)
+        return hooks.model_forward_post_hook(hooks.model_forward(data, net), None).contiguous().numpy()
+
+    ades, fdes, at = [], [], 0
+    for i, n in zip(z["scene_index"], z["scene_size"]):
+        s, e = sse[int(i)]
+        n = int(n)
+        assert e - s == n
+        net.expect, net.answer = pre_all[:, at:at + n], dec_all[at:at + n]
+        out = W.forward(params, obs[s:e], None, predictor, float(z["static_dist"]))
+        ades.append(W.batch_ade(out["recon_traj"], pred[s:e]))
+        fdes.append(W.batch_fde(out["recon_traj"], pred[s:e]))
+        at += n
+    assert at == len(z["ade"])
+    ade, fde = np.concatenate(ades), np.concatenate(fdes)
+    np.testing.assert_allclose(ade, z["ade"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(fde, z["fde"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose([ade.mean(dtype=np.float64), fde.mean(dtype=np.float64)], z["ade_fde_mean"], rtol=0, atol=1e-5)

@@ -1924,6 +1924,51 @@ def test_sgcn_full_splits_replay_g14(dev, scene):
         np.testing.assert_allclose(got.mean(axis=1, dtype=np.float64), z[f"{scene}.ade_fde_mean"], rtol=0, atol=1e-5)
 
 
+def test_agentformer_tenth_of_univ_replay_g15(dev):
+    """Config 5's data path (BASELINE.json: EigenTrajectory-AgentFormer, univ) at G14's extent through the PRODUCT: every tenth
+    test scene of univ (95 scenes, 2 471 pedestrians; tools/make_golden_agentformer_full.py: the imported reference's wrapper
+    + agentformer bridge + its seeded AgentFormerLight) -- wrapper (HIP projection) -> agentformer bridge contract (the
+    predictor's recorded input is checked, its recorded output answered) -> HIP reconstruction: best-of-20 ADE / FDE per
+    pedestrian and their means within 1e-5 of the reference's, for the fused metrics epilogue and for the materialised
+    trajectories of the test loop's own call `model(obs)`."""
+    from eigentrajectory_amd import EigenTrajectory
+    from eigentrajectory_amd.bridges import get_hook_func
+    from eigentrajectory_amd.utils import default_hyper_params
+    from .test_bridges import ReplayAgentFormer
+    z = G.load("g15_agentformer_univ_tenth.npz")
+    g2 = G.load("g2_fit_all_scenes.npz")
+    obs, pred, sse = G.dataset("univ", "test")
+    net = ReplayAgentFormer(None, None, 2e-5)
+    model = EigenTrajectory(net, get_hook_func("agentformer"), default_hyper_params(static_dist=float(z["static_dist"])))
+    sd = model.state_dict()
+    for key in list(sd):
+        if key.startswith("ET_"):
+            sd[key] = torch.from_numpy(g2[f"univ.{key}"])
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    pre_all, dec_all = torch.from_numpy(z["pre_motion"]), torch.from_numpy(z["dec_motion"]).to(dev)
+    assert list(z["scene_index"]) == list(range(0, len(sse), 10))
+    fused, plain, at = [], [], 0
+    with torch.no_grad():
+        for i, n in zip(z["scene_index"], z["scene_size"]):
+            s, e = sse[int(i)]
+            n = int(n)
+            assert e - s == n
+            net.expect, net.answer = pre_all[:, at:at + n], dec_all[at:at + n]
+            o, p = T(obs[s:e], dev), T(pred[s:e], dev)
+            ade, fde = model.evaluate(o, p)
+            fused.append(torch.stack([ade, fde]))
+            rec = model(o)["recon_traj"]  # (S, n, 12, 2): what the reference's test loop evaluates (utils/trainer.py:183-186)
+            dist = (rec - p[None]).norm(p=2, dim=-1)
+            plain.append(torch.stack([dist.mean(dim=-1).min(dim=0)[0], dist[..., -1].min(dim=0)[0]]))
+            at += n
+    assert at == len(z["ade"]) == 2471
+    ref = np.stack([z["ade"], z["fde"]])
+    for got in (N_(torch.cat(fused, dim=1)), N_(torch.cat(plain, dim=1))):
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5)
+        np.testing.assert_allclose(got.mean(axis=1, dtype=np.float64), z["ade_fde_mean"], rtol=0, atol=1e-5)
+
+
 def test_batchkmeans_batch_of_problems_stops_together(ops, oracle, dev):
     """BatchKMeans.fit on (l, d, n) data (kmeans.py:200-259): the l problems run in lockstep and stop TOGETHER, on the
     error summed over the batch (kmeans.py:232, 239) -- bit for bit what the oracle's restatement of that loop gives."""
