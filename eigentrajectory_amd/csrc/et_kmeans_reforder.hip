@@ -623,6 +623,13 @@ static Geo make_geo(int64_t N, int lp_forced = 0) {  // lp_forced: a shard takes
     return g;
 }
 
+// LDS of the groups kernel: [level-0 accumulators (K rows + a dummy one per coordinate and tile) | a group's label words];
+// the tail's label bytes (4 L^2 + 4 L + 16) alias the accumulators until level 0 clears them
+__host__ __device__ inline size_t acc_region_bytes(int K, int L, int TR) {
+    const size_t acc = sizeof(float) * (size_t)TR * kD * (K + 1) * 64, tail = ((size_t)(4 * L * L + 4 * L + 16) + 15) / 16 * 16;
+    return acc > tail ? acc : tail;
+}
+
 // byte offsets inside one problem's block of the workspace.  S1 / S2 / T hold one float4 = the four lanes k of a (group |
 // block | tail part, coordinate, cluster) entry.
 struct Layout {
@@ -1192,8 +1199,10 @@ __global__ __launch_bounds__(kFThreads, NREGS ? 6 : 7) void reforder_groups_kern
     __shared__ double sWsum[8];
     const int TR = a.tiles_per_round;
     float *sAcc = reinterpret_cast<float *>(smem);                                          // [tile in round][coordinate][row][64 chains]
-    unsigned *sLab = reinterpret_cast<unsigned *>(sAcc + (size_t)TR * kD * (K + 1) * 64);   // a group's labels, one word per quad
-    const int64_t gidx = blockIdx.x;
+    unsigned *sLab = reinterpret_cast<unsigned *>(smem + acc_region_bytes(K, 1 << a.geo.lp, TR));  // a group's labels, one word per quad
+    // the tail's workgroup is dispatched FIRST: it is as long as any other and at the highest index it used to start when the
+    // last slot freed up, alone on the chip for its whole 20 us (N = 1e7: the launch ended 113 us after it began, the groups 93)
+    const int64_t gidx = blockIdx.x == 0 ? geo.G : (int64_t)blockIdx.x - 1;
     const bool is_tail = gidx == geo.G;
     [[maybe_unused]] const int who = is_tail ? 1 : (gidx == 0 ? 0 : 9);
     RF_STAMP(who, 0);
@@ -1300,7 +1309,9 @@ __global__ __launch_bounds__(kFThreads, NREGS ? 6 : 7) void reforder_groups_kern
         const int pc = (int)(geo.full_chunks - geo.G * L);    // full chunks of the partial group (< L)
         const int rem = (int)(size - geo.full_chunks * L);    // lane terms after them (< L)
         const int n_all = pc + (rem > 0 ? 1 : 0);
-        uint8_t *sTail = reinterpret_cast<uint8_t *>(sLab + L2);
+        // (the tail's label bytes live in the accumulators' space until level 0 clears it: a region of their own made the
+        // launch's LDS 41.9 KB at L = 32 -- three workgroups per CU instead of four)
+        uint8_t *sTail = reinterpret_cast<uint8_t *>(sAcc);
         for (int m0 = 2 * tid; m0 < nt; m0 += 2 * kFThreads) {  // two points per thread side by side
             float x[2][kD], an[2];
 #pragma unroll
@@ -1344,6 +1355,9 @@ __global__ __launch_bounds__(kFThreads, NREGS ? 6 : 7) void reforder_groups_kern
             }
             sLab[w] = word;
         }
+        unsigned lw = 0u;  // labels of the N mod 4 leftover points, for the workgroup that combines the lanes
+        if (tid == 0)
+            for (int64_t n = size * 4; n < N; ++n) lw |= (unsigned)sTail[n - tail0] << (8 * (int)(n & 3));
         __syncthreads();
         const int64_t lim = N - tail0;
         cascade_levels(
@@ -1362,11 +1376,7 @@ __global__ __launch_bounds__(kFThreads, NREGS ? 6 : 7) void reforder_groups_kern
             T[tid] = acc1;
             T[dk + tid] = acc0;
         }
-        if (tid == 0) {  // labels of the N mod 4 leftover points, for the workgroup that combines the lanes
-            unsigned lw = 0u;
-            for (int64_t n = size * 4; n < N; ++n) lw |= (unsigned)sTail[n - tail0] << (8 * (int)(n & 3));
-            T[2 * dk] = make_float4(__uint_as_float(lw), 0.f, 0.f, 0.f);
-        }
+        if (tid == 0) T[2 * dk] = make_float4(__uint_as_float(lw), 0.f, 0.f, 0.f);
         RF_STAMP(who, 3);
     }
     // ---- this workgroup's counts and similarity sum (read by the next kernel) ----
@@ -1920,8 +1930,7 @@ static int fast_tiles_per_round(const Geo &) { return 1; }
 static int fast_filter_min_lp() { return options().reforder_filter_min_lp.load(std::memory_order_relaxed); }
 static size_t fast_lds_bytes(const Geo &g, int K, int TR) {
     const int L = 1 << g.lp;
-    // level-0 accumulators (K rows + a dummy one), a group's label words, the tail's label bytes
-    const size_t body = sizeof(float) * (size_t)TR * kD * (K + 1) * 64 + sizeof(unsigned) * (size_t)L * L + (size_t)(4 * L * L + 4 * L + 16);
+    const size_t body = acc_region_bytes(K, L, TR) + sizeof(unsigned) * (size_t)L * L;
     return (body + 15) / 16 * 16;
 }
 // rows of d K float4 the update kernel stages at a time, and its dynamic LDS
