@@ -633,7 +633,7 @@ __host__ __device__ inline size_t acc_region_bytes(int K, int L, int TR) {
 // byte offsets inside one problem's block of the workspace.  S1 / S2 / T hold one float4 = the four lanes k of a (group |
 // block | tail part, coordinate, cluster) entry.
 struct Layout {
-    size_t state, cen, arrive, cnt, S1, S2, T, Sin, XT, LT, tail, LB, gflag, bytes;
+    size_t state, cen, arrive, cnt, S1, S2, T, Sin, XT, LT, tail, bytes;
 };
 static Layout make_layout(const Geo &g, int K) {
     Layout l;
@@ -661,10 +661,6 @@ static Layout make_layout(const Geo &g, int K) {
     off = up(off + (size_t)g.tail0 + 4);
     l.tail = off;
     off = up(off + (size_t)(g.N - g.tail0) + 4);
-    l.LB = off;  // per point of the full groups (XT's order): lower bound on the distance to every OTHER centroid, + the drift sum at its refresh
-    off = up(off + sizeof(float) * (size_t)g.tail0);
-    l.gflag = off;  // per group: 1 = the next launch scans every point (too many undecided ones last time / bounds not valid)
-    off = up(off + sizeof(unsigned) * (size_t)(g.G + 1));
     l.bytes = off;
     return l;
 }
@@ -775,10 +771,7 @@ __device__ __forceinline__ void points_best(const float (&x)[NP][kD], const floa
 // same IEEE operations, two points per instruction).  No similarity can be NaN or infinite here (the caller checked the
 // magnitudes), so "the first row always wins" is `y > -inf`.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// SECOND: sv = the largest similarity among the clusters that are not the arg-max (a tie for the maximum: the maximum).
-template <bool SECOND>
-__device__ __forceinline__ void quad_best(const float4 (&xv)[kD], const float *sC, int K, int (&lb)[4], float (&bv)[4],
-                                          float (&sv)[4]) {
+__device__ __forceinline__ void quad_best(const float4 (&xv)[kD], const float *sC, int K, int (&lb)[4], float (&bv)[4]) {
     f32x2 xa[kD], xb[kD];
 #pragma unroll
     for (int i = 0; i < kD; ++i) {
@@ -797,7 +790,6 @@ __device__ __forceinline__ void quad_best(const float4 (&xv)[kD], const float *s
     float4 n0 = s4[0], n1 = s4[1];
     lb[0] = lb[1] = lb[2] = lb[3] = 0;
     bv[0] = bv[1] = bv[2] = bv[3] = -__builtin_inff();
-    sv[0] = sv[1] = sv[2] = sv[3] = -__builtin_inff();
     const f32x2 zero = {0.f, 0.f};
 #pragma clang loop unroll(disable)
     for (int j = 0; j < K; ++j) {
@@ -822,7 +814,6 @@ __device__ __forceinline__ void quad_best(const float4 (&xv)[kD], const float *s
         const float y[4] = {ya.x, ya.y, yb.x, yb.y};
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            if constexpr (SECOND) sv[p] = fmaxf(sv[p], fminf(bv[p], y[p]));
             const bool take = y[p] > bv[p];
             bv[p] = take ? y[p] : bv[p];
             lb[p] = take ? j : lb[p];
@@ -1170,142 +1161,11 @@ __device__ __forceinline__ double assign_group_filter(const float4 *__restrict__
     return sim;
 }
 
-// ---- labels by DISTANCE BOUNDS (Hamerly's test made rigorous for the reference's fp32 similarity) -------------------------
-// Per point the fit keeps lb = a lower bound on the true distance to every centroid but its own, stored as lc = lb + D
-// with D = the sum of the largest centroid movement of every update so far (rounded up): centroids that moved by at most
-// D' - D since the bound was taken are at least lc - D' away (triangle inequality), with no write per iteration.  With Y
-// the reference's similarity (kmeans.py:71-74) to the point's OLD centroid, computed exactly as the reference does, and E >=
-// the rounding error of that formula for any centroid (|Y_j + |x - c_j|^2| <= 10 u (|x| + |c_j|)^2, u = 2^-24: six fma, the
-// two norms in any order, two subtractions; E = 2^-20 * 6 (max|x_i| + max|c_ij|)^2 + 1e-37), every other cluster has
-// Y_j <= -lb^2 + E, so Y + lb^2 > E proves that the reference's arg-max is the old label -- strictly, so ties never get
-// here -- for ~26 instructions instead of 8 per cluster.  The other points go through the workgroup's queue to the exact
-// scan (four threads per point), which also takes the new bound from the second-largest similarity: d_j^2 >= -Y_j - E.
-constexpr float kDown = 0.99999976158142089844f;  // 1 - 2^-22: covers v_sqrt_f32's ulp and one rounding
-__device__ __forceinline__ float bound_from_second(float second, float E, float cum) {
-    const float l2 = -second - E;                           // (second = -inf for K = 1: +inf, every later test passes)
-    const float l = __builtin_amdgcn_sqrtf(fmaxf(l2, 0.f)) * kDown;
-    return (l + cum) * kDown;
-}
-__device__ __forceinline__ double assign_group_skip(const float4 *__restrict__ x4, int L2, const float *sC, int K, float cum, float E,
-                                                    unsigned *sLab, unsigned *__restrict__ LTg, float4 *__restrict__ LBg,
-                                                    unsigned short *sQ, int q_cap, int *sQn, bool &ok, int &nq_out) {
-    const int tid = (int)threadIdx.x;
-    const float4 *s4 = reinterpret_cast<const float4 *>(sC);
-    double sim = 0.0;
-    for (int qi = tid; qi < L2; qi += kFThreads) {
-        const unsigned old_packed = LTg[qi];
-        const float4 lc4 = LBg[qi];
-        float4 xv[kD];
-#pragma unroll
-        for (int i = 0; i < kD; ++i) xv[i] = x4[i * L2 + qi];
-        unsigned undecided = 0u;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float x[kD];
-#pragma unroll
-            for (int i = 0; i < kD; ++i) x[i] = q == 0 ? xv[i].x : (q == 1 ? xv[i].y : (q == 2 ? xv[i].z : xv[i].w));
-            float an = x[0] * x[0];  // kmeans.py:73, a full block's column: rows in sequence
-#pragma unroll
-            for (int i = 1; i < kD; ++i) an = an + x[i] * x[i];
-            const int ol = (int)((old_packed >> (8 * q)) & 0xffu);
-            const float4 r0 = s4[2 * ol], r1 = s4[2 * ol + 1];
-            float y = fmaf(x[0], r0.x, 0.f);
-            y = fmaf(x[1], r0.y, y);
-            y = fmaf(x[2], r0.z, y);
-            y = fmaf(x[3], r0.w, y);
-            y = fmaf(x[4], r1.x, y);
-            y = fmaf(x[5], r1.y, y);
-            y = y * 2.0f;
-            y = y - an;
-            y = y - r1.z;
-            const float lc = q == 0 ? lc4.x : (q == 1 ? lc4.y : (q == 2 ? lc4.z : lc4.w));
-            const float le = lc - cum;          // (NaN / -inf: not kept)
-            const float ld = le * kDown;
-            const float t = fmaf(ld, ld, y);   // (Y + lb^2)(1 + delta): one rounding
-#ifdef ET_EXP_RF_ALL_UNDECIDED
-            const bool keep = false;
-#else
-            const bool keep = le > 0.f && t > E;
-#endif
-            sim = sim + (keep ? (double)y : 0.0);
-            undecided |= keep ? 0u : (1u << q);
-        }
-        sLab[qi] = old_packed;  // (the bytes of undecided points are replaced below)
-        if (undecided) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if ((undecided >> q) & 1u) {
-                    const int slot = atomicAdd(sQn, 1);
-                    if (slot < q_cap) sQ[slot] = (unsigned short)(qi * 4 + q);
-                }
-        }
-    }
-    RF_STAMP(blockIdx.x == 0 ? 0 : 9, 5);
-    __syncthreads();
-    RF_STAMP(blockIdx.x == 0 ? 0 : 9, 6);
-    // ---- the undecided points: exact arg-max + second-largest similarity, four threads per point (clusters sub, sub + 4, ...) ----
-    const int nq = *sQn, sub = tid & 3;
-    nq_out = nq;
-    ok = nq <= q_cap;  // (more undecided points than the queue holds: the caller scans the whole group)
-    if (!ok) return 0.0;
-    float *LBf = reinterpret_cast<float *>(LBg);
-    for (int base = 0; base < nq; base += kFThreads / 4) {
-        const int e = base + (tid >> 2);
-        const bool act = e < nq;
-        const int pid = sQ[act ? e : 0], qi = pid >> 2, q = pid & 3;
-        float x[kD];
-#pragma unroll
-        for (int i = 0; i < kD; ++i) x[i] = reinterpret_cast<const float *>(x4 + i * L2 + qi)[q];
-        float an = x[0] * x[0];
-#pragma unroll
-        for (int i = 1; i < kD; ++i) an = an + x[i] * x[i];
-        float best = -__builtin_inff(), second = -__builtin_inff();
-        int lb = 0x7fffffff;
-        for (int j = sub; j < K; j += 4) {
-            const float4 r0 = s4[2 * j], r1 = s4[2 * j + 1];
-            float y = fmaf(x[0], r0.x, 0.f);
-            y = fmaf(x[1], r0.y, y);
-            y = fmaf(x[2], r0.z, y);
-            y = fmaf(x[3], r0.w, y);
-            y = fmaf(x[4], r1.x, y);
-            y = fmaf(x[5], r1.y, y);
-            y = y * 2.0f;
-            y = y - an;
-            y = y - r1.z;
-            second = fmaxf(second, fminf(best, y));
-            if (y > best) {
-                best = y;
-                lb = j;
-            }
-        }
-#pragma unroll
-        for (int o = 1; o < 4; o <<= 1) {
-            const float ob = __shfl_xor(best, o), os = __shfl_xor(second, o);
-            const int ol = __shfl_xor(lb, o);
-            second = fmaxf(fmaxf(second, os), fminf(best, ob));
-            if (ob > best || (ob == best && ol < lb)) {
-                best = ob;
-                lb = ol;
-            }
-        }
-        if (act && sub == 0) {
-            reinterpret_cast<uint8_t *>(sLab)[pid] = (uint8_t)lb;
-            reinterpret_cast<uint8_t *>(LTg)[pid] = (uint8_t)lb;
-            LBf[pid] = bound_from_second(second, E, cum);
-            sim = sim + (double)best;
-        }
-    }
-    __syncthreads();
-    return sim;
-}
-
 // ---- one Lloyd iteration, first half: assignment + levels 0 and 1.  Workgroup g < G: group g; workgroup G: the tail ----
 // NREGS = 0: the exact scan of every point (L = 16: four workgroups per CU); 10 / 16 (K <= 20 / 32): iterations >= 1 certify
 // the labels with the matrix-core filter (L >= 32; more registers: fewer wavefronts per CU, far fewer instructions)
-// NREGS = -1: the exact scan only for the points that the distance bounds do not certify (assign_group_skip).
 template <int NREGS>
-__global__ __launch_bounds__(kFThreads, NREGS > 0 ? 6 : 7) void reforder_groups_kernel(const Args a) {
-    constexpr bool SKIP = NREGS < 0;
+__global__ __launch_bounds__(kFThreads, NREGS ? 6 : 7) void reforder_groups_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, dk = kD * K;
@@ -1320,8 +1180,6 @@ __global__ __launch_bounds__(kFThreads, NREGS > 0 ? 6 : 7) void reforder_groups_
     }
     const int64_t done0 = state->done, iter0 = state->iter;
     const double max_abs_x = state->max_abs_x;
-    [[maybe_unused]] const float cum = SKIP ? at<const float>(ws, a.lay.arrive)[4] : 0.f;
-    [[maybe_unused]] const unsigned gflag0 = SKIP ? at<const unsigned>(ws, a.lay.gflag)[blockIdx.x] : 0u;
     if (done0) return;  // the whole batch stopped in an earlier launch (kmeans.py:239), or bad input was flagged
     const float *X = a.X + (int64_t)blockIdx.y * a.x_stride;
     const Geo &geo = a.geo;
@@ -1386,28 +1244,6 @@ __global__ __launch_bounds__(kFThreads, NREGS > 0 ? 6 : 7) void reforder_groups_
         // ---- assignment of the group's 4 L^2 points (kmeans.py:143-158): a quad = four consecutive steps of one chain ----
         const float4 *x4 = XT4 + gidx * kD * L2;
         bool filtered = false;
-        [[maybe_unused]] unsigned gflag1 = 0u;  // what the next launch finds in gflag
-        [[maybe_unused]] float E = 0.f;
-        if constexpr (SKIP) {
-            const float s = ((float)max_abs_x + __uint_as_float(sMaxC)) * 1.001f;
-            E = fmaf(s * s, 5.7792664e-6f, 1e-37f);  // 6 * 2^-20 * 1.01
-            float4 *LBg = at<float4>(ws, a.lay.LB) + gidx * L2;
-            if (iter0 > 0 && !nans && gflag0 == 0u) {
-                const int q_cap = min(4 * L2, (int)((size_t)TR * kD * (K + 1) * 64 * sizeof(float) / sizeof(unsigned short)));
-                int nq = 0;
-                sim = assign_group_skip(x4, L2, sC, K, cum, E, sLab, LT32 + gidx * L2, LBg, reinterpret_cast<unsigned short *>(sAcc),
-                                        q_cap, &sQn, filtered, nq);
-                if (!filtered) sim = 0.0;
-                gflag1 = nq > L2 ? 1u : 0u;  // more than a quarter undecided: the plain scan of everything is cheaper next time
-#ifdef ET_EXP_RF_CHECK
-                if (tid == 0) atomicAdd(&g_rf_check[iter0 < 31 ? iter0 : 31], (unsigned)nq);
-#endif
-            }
-#ifdef ET_EXP_RF_CHECK
-            else if (tid == 0) atomicAdd(&g_rf_check[32 + (iter0 < 31 ? iter0 : 31)], 1u);
-#endif
-            if (nans) gflag1 = 1u;  // (the NaN rule's scan below keeps no bounds)
-        }
         if constexpr (NREGS > 0) {
             // power-of-two scale: every |x| sg, |c| sg < 32 (csrc/et_kmeans.hip, filter_assign_body); the first iteration (no
             // labels yet), a possible NaN or a scale whose square leaves the fp32 range: the exact scan decides
@@ -1425,12 +1261,8 @@ __global__ __launch_bounds__(kFThreads, NREGS > 0 ? 6 : 7) void reforder_groups_
             for (int i = 0; i < kD; ++i) xv[i] = x4[i * L2 + qi];
             int lb[4];
             float bv[4];
-            [[maybe_unused]] float sv[4];
             if (!nans) {
-                quad_best<SKIP>(xv, sC, K, lb, bv, sv);
-                if constexpr (SKIP)
-                    at<float4>(ws, a.lay.LB)[gidx * L2 + qi] = make_float4(bound_from_second(sv[0], E, cum), bound_from_second(sv[1], E, cum),
-                                                                            bound_from_second(sv[2], E, cum), bound_from_second(sv[3], E, cum));
+                quad_best(xv, sC, K, lb, bv);
             } else {  // (an empty cluster's NaN centroid, or magnitudes near the fp32 range: torch.max's NaN rule, point by point)
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
@@ -1453,8 +1285,6 @@ __global__ __launch_bounds__(kFThreads, NREGS > 0 ? 6 : 7) void reforder_groups_
 #pragma unroll
             for (int p = 0; p < 4; ++p) sim = sim + (double)bv[p];
         }
-        if constexpr (SKIP)
-            if (tid == 0) at<unsigned>(ws, a.lay.gflag)[gidx] = gflag1;
         __syncthreads();
         for (int qi = tid; qi < L2; qi += kFThreads) {  // points per cluster, from the final labels
             const unsigned l4 = sLab[qi];
@@ -1699,9 +1529,6 @@ __global__ __launch_bounds__(kUThreads) void reforder_update_kernel2(const Args 
     float4 a3 = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned ctot[4] = {0u, 0u, 0u, 0u};
     __shared__ unsigned sCntTot[kFMaxK];
-    __shared__ float sDr[kD * kFMaxK];
-    __shared__ unsigned sDrMax;
-    if (tid == 0) sDrMax = 0u;
     for (int r0 = 0; r0 < geo.full_blk; r0 += rows_cap) {
         const int nr = geo.full_blk - r0 < rows_cap ? geo.full_blk - r0 : rows_cap;
         const unsigned base = (unsigned)((int64_t)r0 * rowlen * sizeof(float4));
@@ -1784,26 +1611,14 @@ __global__ __launch_bounds__(kUThreads) void reforder_update_kernel2(const Args 
         const float c = p / (float)sCntTot[j];  // 0/0 = NaN for an empty cluster (kmeans.py:182)
         const float diff = cen[tid] - c;
         cen[tid] = c;
-        sDr[tid] = diff * diff;
         if (a.batch > 1) __hip_atomic_store(&sq_mine[tid], diff * diff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else sSq[tid] = diff * diff;
     }
     __syncthreads();
-    if (tid < K) {  // how far this cluster's centroid moved (an empty cluster's NaN orders above everything: the bounds die)
-        float m2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < kD; ++i) m2 = m2 + sDr[i * K + tid];
-        atomicMax(&sDrMax, __float_as_uint(__builtin_amdgcn_sqrtf(m2)));
-    }
     if (tid == 0) {
         double s = sWsum[0];
         for (int w = 1; w < kUThreads / 64; ++w) s = s + sWsum[w];
         __hip_atomic_store(&state->inertia, (double)(float)(-(s / (double)N)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (tid == 0) {  // D += the largest movement, rounded up (assign_group_skip)
-        float *D = at<float>(ws, a.lay.arrive) + 4;
-        *D = fmaf(__uint_as_float(sDrMax), 1.000001f, *D) * 1.000001f + 4e-19f;
     }
     RF_STAMP(3, 1);
     if (a.batch > 1) {
@@ -2073,10 +1888,7 @@ __global__ __launch_bounds__(kThreads) void reforder_fast_prepare_kernel(const A
         st->inertia = 0.0;
     }
     for (int e = threadIdx.x; e < dk; e += blockDim.x) at<float>(ws, a.lay.cen)[e] = cen_in[(int64_t)blockIdx.x * dk + e];
-    if (threadIdx.x == 0) {
-        at<unsigned>(ws, a.lay.arrive)[0] = 0u;
-        at<float>(ws, a.lay.arrive)[4] = 0.f;  // the drift sum of assign_group_skip
-    }
+    if (threadIdx.x == 0) at<unsigned>(ws, a.lay.arrive)[0] = 0u;
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.batch_arrive = 0u;
 }
 
@@ -2209,7 +2021,7 @@ static int fast_fit(const float *X, int64_t x_stride, int64_t N, int K, int64_t 
         ET_HIP_TRY(hipGetDevice(&dev_id));
         if (!lds_set[dev_id & 63]) {
             for (const void *f : {reinterpret_cast<const void *>(reforder_groups_kernel<0>), reinterpret_cast<const void *>(reforder_groups_kernel<10>),
-                                  reinterpret_cast<const void *>(reforder_groups_kernel<16>), reinterpret_cast<const void *>(reforder_groups_kernel<-1>)})
+                                  reinterpret_cast<const void *>(reforder_groups_kernel<16>)})
                 ET_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
             ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(reforder_update_kernel2),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUMaxLds));
@@ -2236,15 +2048,13 @@ static int fast_fit(const float *X, int64_t x_stride, int64_t N, int K, int64_t 
     }
     // the matrix-core label filter pays where the exact scan is what a launch waits for: L >= 32 (N > 4.2e6)
     const bool use_filter = a.geo.lp >= fast_filter_min_lp() && K >= 3;
-    const bool use_skip = !use_filter && et::options().reforder_skip.load(std::memory_order_relaxed) != 0;
     constexpr int kAhead = 16, kEvery = 4;
     et_kmeans_state *state0 = (et_kmeans_state *)(a.ws + a.lay.state);
     int launched = 0;
     bool done = false;
     const dim3 grid((unsigned)(a.geo.G + 1), (unsigned)batch), ugrid((unsigned)a.geo.n_blk, (unsigned)batch);
     for (int it = 0; it < max_iter && !done; ++it) {
-        if (use_skip) hipLaunchKernelGGL(reforder_groups_kernel<-1>, grid, dim3(kFThreads), lds, st, a);
-        else if (!use_filter) hipLaunchKernelGGL(reforder_groups_kernel<0>, grid, dim3(kFThreads), lds, st, a);
+        if (!use_filter) hipLaunchKernelGGL(reforder_groups_kernel<0>, grid, dim3(kFThreads), lds, st, a);
         else if (K <= 20) hipLaunchKernelGGL(reforder_groups_kernel<10>, grid, dim3(kFThreads), lds, st, a);
         else hipLaunchKernelGGL(reforder_groups_kernel<16>, grid, dim3(kFThreads), lds, st, a);
         hipLaunchKernelGGL(reforder_update_kernel2, ugrid, dim3(kUThreads), ulds, st, a, rows_cap);
