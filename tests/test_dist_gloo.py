@@ -192,3 +192,67 @@ def test_sharded_fit_and_kmeans_two_ranks_gloo(tmp_path, oracle, cuts):
     assert int(r0["n_iter"]) == ref["n_iter"]
     assert np.array_equal(r0["centroids"], ref["centroids"])          # exact integer sums: bit-identical
     assert np.array_equal(np.concatenate([r0["labels"], r1["labels"]]), ref["labels"])
+
+
+def _reforder_exchange_worker(rank, world, port, sizes, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ._reforder_shard_np import level_step, replay, shard_record
+        n = sum(sizes)
+        rng = np.random.RandomState(7)
+        d, K = 6, 5
+        x = (rng.standard_normal((d, n)) * np.array([[1], [30], [1e-2], [1], [5], [1]])).astype(np.float32)
+        lab = rng.randint(K, size=n)
+        lab[rng.rand(n) < 0.3] = 2  # uneven clusters, one of them big
+        lo = sum(sizes[:rank])
+        L = level_step(n)
+        rec = shard_record(x[:, lo:lo + sizes[rank]], lab[lo:lo + sizes[rank]], K, L)
+        # the record as the kernels lay it out: max_rows rows | T1 | T0 | leftovers (3 points) | full_rows
+        block = 4 * L ** 3
+        max_rows = max(1, max(-(-(s // (4 * L * L)) // L) for s in sizes))
+        rows = np.zeros((max_rows, d, K, 4), np.float32)
+        rows[:len(rec["rows"])] = rec["rows"]
+        left = np.zeros((d, K, 3), np.float32)
+        left[:, :, :rec["left"].shape[2]] = rec["left"]
+        flat = np.concatenate([rows.ravel(), rec["T1"].ravel(), rec["T0"].ravel(), left.ravel(),
+                               np.asarray([len(rec["rows"]), rec["full_rows"], rec["left"].shape[2]], np.float32)])
+        mine = torch.from_numpy(flat)
+        table = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(table, mine)  # ONE all-gather per iteration: what ncclAllGather does in et_kmeans_fit_reforder_sharded
+        records = []
+        for t in table:
+            a = t.numpy()
+            o = 0
+            r_ = a[o:o + rows.size].reshape(rows.shape); o += rows.size
+            t1 = a[o:o + d * K * 4].reshape(d, K, 4); o += d * K * 4
+            t0 = a[o:o + d * K * 4].reshape(d, K, 4); o += d * K * 4
+            lf = a[o:o + d * K * 3].reshape(d, K, 3); o += d * K * 3
+            nrows, nfull, nleft = (int(v) for v in a[o:o + 3])
+            records.append(dict(rows=r_[:nrows], full_rows=nfull, T1=t1, T0=t0, left=lf[:, :, :nleft]))
+        tail_rank = max(i for i, s in enumerate(sizes) if s > 0)
+        assert all(s % block == 0 for s in sizes[:tail_rank])
+        sums = replay(records, tail_rank)
+        np.save(os.path.join(out_dir, f"sums{rank}.npy"), sums)
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "data.npz"), x=x, lab=lab, K=K)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sizes", [(16384, 23616), (32768, 7235), (40000, 0)])
+def test_reference_order_shard_exchange_two_ranks_gloo(tmp_path, oracle, sizes):
+    """The exchange of the sharded reference-order k-means (et_kmeans_fit_reforder_sharded) with two gloo ranks on CPU: every
+    rank restates its levels 0 .. 2 in numpy (tests/_reforder_shard_np.py: the kernels' additions in the kernels' order),
+    ONE all-gather of the records, the same level-3 replay on both ranks -> the cluster sums of the oracle's literal ATen-order
+    sum over the WHOLE array, bit for bit, on every rank.  Shards: the end of the array inside the second shard / a shard
+    that ends on N mod 4 != 0 / an empty trailing rank."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_reforder_exchange_worker, args=(2, port, sizes, str(tmp_path)), nprocs=2, join=True)
+    z = np.load(tmp_path / "data.npz")
+    ref = oracle.kmeans_reforder_sums(z["x"], z["lab"], int(z["K"]))
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"sums{r}.npy"), ref), r
