@@ -355,12 +355,32 @@ template <int D>  // D = 6: the coordinates in registers; 0: any d < 8 (run-time
 __global__ __launch_bounds__(kThreads) void reforder_init_step_inc_kernel(const float *__restrict__ X, int64_t N, int d_rt, int K,
                                                                           int count, const float *__restrict__ C0,
                                                                           float *__restrict__ bestR, float *__restrict__ bestR4,
-                                                                          Cand *__restrict__ cands) {
+                                                                          uint8_t *__restrict__ nearest, unsigned *__restrict__ max_abs_bits,
+                                                                          int skip_ok, Cand *__restrict__ cands) {
     constexpr int DM = D ? D : 8;
     const int d = D ? D : d_rt;
     __shared__ float sNew[DM + 1];      // the newest centroid (column count - 1) and its R-order norm
     __shared__ float sS[4 * (DM + 1)];  // count in 4..7: centroids 0..3 and their S-order norms
+    __shared__ float sDelta[ET_KMEANS_MAX_CLUSTERS];  // lower bounds of ||c_new - c_j||^2, j < count - 1
+    __shared__ unsigned sMabs;
     const bool window = count >= 4 && count <= 7;
+    // Outside the window the step's value IS bestR, and a point whose nearest centroid c_l (the arg-max behind bestR) is
+    // closer than half the distance from c_l to the new centroid cannot get a larger similarity from the new one -- the test
+    // of csrc/et_kmeans.hip's farthest-first (init_step_body: ||c_new - c_l||^2 >= 4 (E - b), E >= twice the rounding error
+    // of the similarity formula in ANY summation order of the norms), on the reference-order values: such a point costs
+    // 5 bytes (bestR, nearest) instead of 28, and its value is bit for bit what the full evaluation would leave.
+    // (skip_ok: only for big shards -- below ~2e6 points a step is two dependent round trips instead of one and nothing else)
+    const bool can_skip = count >= 2 && !window && skip_ok != 0;
+    if (threadIdx.x == 0) sMabs = 0u;
+    if (can_skip && (int)threadIdx.x >= 128 && (int)threadIdx.x < 128 + count - 1) {
+        const int j = (int)threadIdx.x - 128;
+        double s2 = 0.0;
+        for (int i = 0; i < d; ++i) {
+            const double t = (double)C0[i * K + (count - 1)] - (double)C0[i * K + j];
+            s2 += t * t;
+        }
+        sDelta[j] = (float)(s2 * (1.0 - 4e-6)) * (1.0f - 1e-6f);
+    }
     if (threadIdx.x == 0) {
         float sq[kMaxD];
         for (int i = 0; i < d; ++i) {
@@ -383,11 +403,33 @@ __global__ __launch_bounds__(kThreads) void reforder_init_step_inc_kernel(const 
     __syncthreads();
     float bv = 0.f;
     long long bi = -1;
+    float E = __int_as_float(0x7f800000);  // (unknown: nothing is skipped)
+    if (can_skip) {
+        const float R = 2.0f * sqrtf((float)d) * __uint_as_float(*max_abs_bits) * 1.0001f;  // every centroid is a point
+        E = R * R * 1.9073486328125e-6f;                                                   // 2^-19 (|x| + |c|)^2
+        if (!(E <= 3.0e38f)) E = __int_as_float(0x7f800000);
+    }
+    float mabs = 0.f;
     const int64_t seq_cols = N < 8 ? N / 4 * 4 : N / 32 * 32;  // column_is_sequential(n, N)
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        if (can_skip) {
+            const float b = bestR[n];
+            const float w = E - b;  // (a NaN or +inf anywhere makes a comparison false: full evaluation)
+            if (w >= 0.0f && sDelta[nearest[n]] >= 4.0001f * w) {
+                if (bi < 0 || argmin_ahead(b, n, bv, bi)) {
+                    bv = b;
+                    bi = n;
+                }
+                continue;
+            }
+        }
         float x[DM];
 #pragma unroll
         for (int i = 0; i < DM; ++i) x[i] = i < d ? X[(int64_t)i * N + n] : 0.f;
+        if (count == 1) {
+#pragma unroll
+            for (int i = 0; i < DM; ++i) mabs = fmaxf(mabs, fabsf(x[i]));  // (a NaN is ignored here and never skipped later)
+        }
         float an;
         if (n < seq_cols) {  // rows in sequence (0 + s0 = s0)
             an = x[0] * x[0];
@@ -411,8 +453,12 @@ __global__ __launch_bounds__(kThreads) void reforder_init_step_inc_kernel(const 
         };
         const float yn = sim(sNew);
         float r = count == 1 ? yn : bestR[n];
-        if (count > 1 && gt_nanmax(yn, r)) r = yn;
-        if (count == 1 || r == yn || isnan(yn)) bestR[n] = r;  // (written when it may have changed)
+        const bool took = count == 1 || gt_nanmax(yn, r);
+        if (took) {
+            r = yn;
+            bestR[n] = r;
+            nearest[n] = (uint8_t)(count - 1);
+        }
         float value = r;
         if (count >= 5 && count <= 7) {  // (bestR4 is only ever read inside the window)
             float r4 = count == 5 ? yn : bestR4[n];
@@ -438,6 +484,7 @@ __global__ __launch_bounds__(kThreads) void reforder_init_step_inc_kernel(const 
     __shared__ long long sI[kThreads];
     sV[threadIdx.x] = bv;
     sI[threadIdx.x] = bi;
+    if (count == 1 && mabs > 0.f) atomicMax(&sMabs, __float_as_uint(mabs));  // (non-negative floats order like their bits)
     __syncthreads();
     for (int o = kThreads / 2; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) {
@@ -453,6 +500,7 @@ __global__ __launch_bounds__(kThreads) void reforder_init_step_inc_kernel(const 
     if (threadIdx.x == 0) {
         cands[blockIdx.x].v = sV[0];
         cands[blockIdx.x].idx = sI[0];
+        if (count == 1 && sMabs) atomicMax(max_abs_bits, sMabs);
     }
 }
 // the winner of the blocks' candidates becomes column `col`; col = 0: the given first index
@@ -2294,14 +2342,17 @@ extern "C" int et_kmeans_init_farthest_reforder(const float *X, int64_t N, int d
     hipLaunchKernelGGL(reforder_init_pick_kernel, dim3(1), dim3(kThreads), 0, st, X, N, d, K, 0, (const Cand *)w.cands, 0,
                        first_index, C0);
     const bool incremental = d < 8 && K <= 32;  // (see reforder_init_step_inc_kernel)
+    unsigned *max_abs_bits = reinterpret_cast<unsigned *>(w.counts);  // (free until a fit uses the workspace)
+    const int skip_ok = N >= et::options().reforder_init_skip_min.load(std::memory_order_relaxed) ? 1 : 0;
+    if (incremental) ET_HIP_TRY(hipMemsetAsync(max_abs_bits, 0, sizeof(unsigned), st));
     for (int i = 1; i < K; ++i) {
         const size_t lds = sizeof(float) * ((size_t)d * i + (size_t)i);
         if (incremental && d == 6)
             hipLaunchKernelGGL(reforder_init_step_inc_kernel<6>, dim3(grid), dim3(kThreads), 0, st, X, N, d, K, i, (const float *)C0,
-                               w.maxsims, w.best4, w.cands);
+                               w.maxsims, w.best4, w.labels_u8, max_abs_bits, skip_ok, w.cands);
         else if (incremental)
             hipLaunchKernelGGL(reforder_init_step_inc_kernel<0>, dim3(grid), dim3(kThreads), 0, st, X, N, d, K, i, (const float *)C0,
-                               w.maxsims, w.best4, w.cands);
+                               w.maxsims, w.best4, w.labels_u8, max_abs_bits, skip_ok, w.cands);
         else
             hipLaunchKernelGGL(reforder_init_step_kernel, dim3(grid), dim3(kThreads), lds, st, X, N, d, K, i, (const float *)C0,
                                w.cands);

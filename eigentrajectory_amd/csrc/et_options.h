@@ -20,6 +20,7 @@ struct Options {
     std::atomic<int> kmeans_loop_grid{0};         // > 0: at most this many workgroups for the chained Lloyd kernel (grid sweep); 0: one resident round
     std::atomic<int> kmeans_loop{'a'};            // 'a'uto, 'c'hain (one launch per iteration), 'p'ersist (one launch per fit)
     std::atomic<int> reforder_filter_min_lp{9};  // reference-order Lloyd: level power from which the matrix-core label filter is used (4: always, 9: never = default: it measured slower)
+    std::atomic<int64_t> reforder_init_skip_min{(int64_t)1 << 21};  // reference-order farthest-first: shards of at least this many points test (bestR, nearest) before reading a point's coordinates
     std::atomic<int> metrics_form{'a'};           // 'a'uto, 't'ile (vector-ALU workgroup-tile kernel), 'f' (fp32 matrix instructions)
 };
 

@@ -33,6 +33,7 @@ const Key *keys(int *n) {
         {"kmeans_loop_grid", Key::kInt, &o.kmeans_loop_grid, nullptr},
         {"kmeans_loop", Key::kChar, &o.kmeans_loop, "acp"},
         {"reforder_filter_min_lp", Key::kInt, &o.reforder_filter_min_lp, nullptr},
+        {"reforder_init_skip_min", Key::kI64, &o.reforder_init_skip_min, nullptr},
         {"metrics_form", Key::kChar, &o.metrics_form, "atf"},
     };
     *n = (int)(sizeof(table) / sizeof(table[0]));

@@ -1969,6 +1969,32 @@ def test_agentformer_tenth_of_univ_replay_g15(dev):
         np.testing.assert_allclose(got.mean(axis=1, dtype=np.float64), z["ade_fde_mean"], rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("n,K,kind", [(1024, 20, 0), (5003, 32, 1), (30000, 20, 2), (30000, 8, 3), (70001, 20, 4), (200000, 20, 2)])
+def test_reference_order_farthest_first_with_the_point_skip_vs_oracle(ops, dev, oracle, et_option, n, K, kind):
+    """kmeans.py:88-112 in the reference's orders with the big-shard form forced on (reforder_init_skip_min = 0: a point whose
+    nearest centroid is closer than half the way to the new one is not read): the oracle's literal picks -- every step's
+    euc_sim against ALL current centroids -- bit for bit, on blobs, outliers x 1000 (new centroids far from everything: most
+    points skip), far-from-origin data (the error bound E dominates: nothing skips), duplicated points (ties), NaN-free
+    tiny scales; and the same picks with the skip off."""
+    rng = np.random.RandomState(100 + kind)
+    x = rng.standard_normal((6, n)).astype(np.float32)
+    if kind == 1:
+        x += np.float32(200.0)
+    elif kind == 2:
+        x[:, ::97] *= np.float32(1000.0)
+    elif kind == 3:
+        x[:, n // 2:] = x[:, :n - n // 2]
+    elif kind == 4:
+        x *= np.float32(1e-12)
+    first = int(rng.randint(n))
+    ref, _ = oracle.kmeans_init_farthest(x, K, first, reference_order=True)
+    et_option("reforder_init_skip_min", 0)
+    got = N_(ops.kmeans_init_farthest_reference_order(T(x, dev), K, first))
+    et_option("reforder_init_skip_min", 1 << 40)
+    plain = N_(ops.kmeans_init_farthest_reference_order(T(x, dev), K, first))
+    assert np.array_equal(got, ref) and np.array_equal(plain, ref)
+
+
 def test_batchkmeans_batch_of_problems_stops_together(ops, oracle, dev):
     """BatchKMeans.fit on (l, d, n) data (kmeans.py:200-259): the l problems run in lockstep and stop TOGETHER, on the
     error summed over the batch (kmeans.py:232, 239) -- bit for bit what the oracle's restatement of that loop gives."""

@@ -37,7 +37,16 @@ for case in range(cases):
             x[:, n // 2:] = x[:, : n - n // 2]                                    # every point twice: exact ties
         xs.append((x * np.float32(scale)).astype(np.float32))
     xs = np.stack(xs)
-    c0 = np.stack([eo.kmeans_init_farthest(xs[b], K, int(rng.randint(n)), reference_order=True)[0] for b in range(l)])
+    firsts = [int(rng.randint(n)) for _ in range(l)]
+    c0 = np.stack([eo.kmeans_init_farthest(xs[b], K, firsts[b], reference_order=True)[0] for b in range(l)])
+    for skip_min in (0, 1 << 40):  # the farthest-first picks, with and without the big-shard point skip
+        L.set_option("reforder_init_skip_min", skip_min)
+        for b in range(l):
+            got = ops.kmeans_init_farthest_reference_order(torch.from_numpy(xs[b]).to(dev), K, firsts[b]).cpu().numpy()
+            if not np.array_equal(got, c0[b], equal_nan=True):
+                bad += 1
+                print(f"MISMATCH (farthest-first) case {case}: n={n} K={K} scale={scale:g} skip_min={skip_min}", flush=True)
+    L.set_option("reforder_init_skip_min", 1 << 21)
     ref = eo.kmeans_fit_batch_reference_order(list(xs), list(c0), iters, 1e-4)
     for flt in (9, 4):
         L.set_option("reforder_filter_min_lp", flt)
