@@ -356,9 +356,13 @@ __global__ __launch_bounds__(kThreads) void reforder_init_step_inc_kernel(const 
                                                                           int count, const float *__restrict__ C0,
                                                                           float *__restrict__ bestR, float *__restrict__ bestR4,
                                                                           uint8_t *__restrict__ nearest, unsigned *__restrict__ max_abs_bits,
-                                                                          int skip_ok, Cand *__restrict__ cands) {
+                                                                          int skip_ok, Cand *__restrict__ cands,
+                                                                          const Cand *__restrict__ prev_cands, int n_prev,
+                                                                          float *__restrict__ C0_rw) {
     constexpr int DM = D ? D : 8;
     const int d = D ? D : d_rt;
+    __shared__ float sV[kThreads];
+    __shared__ long long sI[kThreads];
     __shared__ float sNew[DM + 1];      // the newest centroid (column count - 1) and its R-order norm
     __shared__ float sS[4 * (DM + 1)];  // count in 4..7: centroids 0..3 and their S-order norms
     __shared__ float sDelta[ET_KMEANS_MAX_CLUSTERS];  // lower bounds of ||c_new - c_j||^2, j < count - 1
@@ -372,29 +376,63 @@ __global__ __launch_bounds__(kThreads) void reforder_init_step_inc_kernel(const 
     // (skip_ok: only for big shards -- below ~2e6 points a step is two dependent round trips instead of one and nothing else)
     const bool can_skip = count >= 2 && !window && skip_ok != 0;
     if (threadIdx.x == 0) sMabs = 0u;
+    // Centroid count - 1 is the winner of the PREVIOUS step's workgroup candidates: every workgroup derives it itself (the same
+    // reduction everywhere; workgroup 0 also stores it into C0) -- two short round trips in the prologue instead of a pick
+    // launch between two steps (19 launches and their boundaries per seeding).  prev_cands == nullptr: it is in C0 already.
+    if (prev_cands) {
+        float pv = 0.f;
+        long long pi = -1;
+        for (int b = threadIdx.x; b < n_prev; b += kThreads) {
+            const float v = prev_cands[b].v;
+            const long long i = prev_cands[b].idx;
+            if (i >= 0 && (pi < 0 || argmin_ahead(v, i, pv, pi))) {
+                pv = v;
+                pi = i;
+            }
+        }
+        sV[threadIdx.x] = pv;
+        sI[threadIdx.x] = pi;
+        __syncthreads();
+        for (int o = kThreads / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) {
+                const float v2 = sV[threadIdx.x + o];
+                const long long i2 = sI[threadIdx.x + o];
+                if (i2 >= 0 && (sI[threadIdx.x] < 0 || argmin_ahead(v2, i2, sV[threadIdx.x], sI[threadIdx.x]))) {
+                    sV[threadIdx.x] = v2;
+                    sI[threadIdx.x] = i2;
+                }
+            }
+            __syncthreads();
+        }
+        if ((int)threadIdx.x < d) {
+            const float v = X[(int64_t)threadIdx.x * N + sI[0]];
+            sNew[threadIdx.x] = v;
+            if (blockIdx.x == 0) C0_rw[threadIdx.x * K + (count - 1)] = v;
+        }
+        __syncthreads();
+    } else if ((int)threadIdx.x < d) {
+        sNew[threadIdx.x] = C0[threadIdx.x * K + (count - 1)];
+    }
+    if (!prev_cands) __syncthreads();
     if (can_skip && (int)threadIdx.x >= 128 && (int)threadIdx.x < 128 + count - 1) {
         const int j = (int)threadIdx.x - 128;
         double s2 = 0.0;
         for (int i = 0; i < d; ++i) {
-            const double t = (double)C0[i * K + (count - 1)] - (double)C0[i * K + j];
+            const double t = (double)sNew[i] - (double)C0[i * K + j];
             s2 += t * t;
         }
         sDelta[j] = (float)(s2 * (1.0 - 4e-6)) * (1.0f - 1e-6f);
     }
     if (threadIdx.x == 0) {
         float sq[kMaxD];
-        for (int i = 0; i < d; ++i) {
-            const float v = C0[i * K + (count - 1)];
-            sNew[i] = v;
-            sq[i] = v * v;
-        }
+        for (int i = 0; i < d; ++i) sq[i] = sNew[i] * sNew[i];
         sNew[DM] = row_sum_f32(sq, d);
     }
     if (window && threadIdx.x >= 64 && threadIdx.x < 68) {
         const int j = threadIdx.x - 64;
         float sq[kMaxD];
         for (int i = 0; i < d; ++i) {
-            const float v = C0[i * K + j];
+            const float v = j == count - 1 ? sNew[i] : C0[i * K + j];  // (count = 4: column 3 is being stored by workgroup 0 right now)
             sS[j * (DM + 1) + i] = v;
             sq[i] = v * v;
         }
@@ -480,8 +518,6 @@ __global__ __launch_bounds__(kThreads) void reforder_init_step_inc_kernel(const 
             bi = n;
         }
     }
-    __shared__ float sV[kThreads];
-    __shared__ long long sI[kThreads];
     sV[threadIdx.x] = bv;
     sI[threadIdx.x] = bi;
     if (count == 1 && mabs > 0.f) atomicMax(&sMabs, __float_as_uint(mabs));  // (non-negative floats order like their bits)
@@ -596,8 +632,8 @@ static Workspace carve(void *base, int64_t N, int d, int K) {
     off = up(off + sizeof(float) * 4 * dk);
     w.partial = (double *)(p + off);
     off = up(off + sizeof(double) * kMaxBlocks);
-    w.cands = (Cand *)(p + off);
-    off = up(off + sizeof(Cand) * kMaxBlocks);
+    w.cands = (Cand *)(p + off);  // (two buffers: the incremental farthest-first reads one step's while it writes the next's)
+    off = up(off + sizeof(Cand) * 2 * kMaxBlocks);
     const int lp = level_power(N / 4);
     const int64_t L = (int64_t)1 << lp;
     const int64_t groups = (N / 4 / L + L - 1) / L + 1;
@@ -2347,17 +2383,22 @@ extern "C" int et_kmeans_init_farthest_reforder(const float *X, int64_t N, int d
     if (incremental) ET_HIP_TRY(hipMemsetAsync(max_abs_bits, 0, sizeof(unsigned), st));
     for (int i = 1; i < K; ++i) {
         const size_t lds = sizeof(float) * ((size_t)d * i + (size_t)i);
+        // (incremental form: step i reads the candidates step i - 1 wrote -- two buffers, a late workgroup of this launch must
+        // not see this launch's records -- and picks centroid i - 1 itself; only the last centroid needs the pick launch)
+        Cand *mine = w.cands + (size_t)(i & 1) * kMaxBlocks;
+        const Cand *prev = i > 1 ? w.cands + (size_t)((i - 1) & 1) * kMaxBlocks : nullptr;
         if (incremental && d == 6)
             hipLaunchKernelGGL(reforder_init_step_inc_kernel<6>, dim3(grid), dim3(kThreads), 0, st, X, N, d, K, i, (const float *)C0,
-                               w.maxsims, w.best4, w.labels_u8, max_abs_bits, skip_ok, w.cands);
+                               w.maxsims, w.best4, w.labels_u8, max_abs_bits, skip_ok, mine, prev, grid, C0);
         else if (incremental)
             hipLaunchKernelGGL(reforder_init_step_inc_kernel<0>, dim3(grid), dim3(kThreads), 0, st, X, N, d, K, i, (const float *)C0,
-                               w.maxsims, w.best4, w.labels_u8, max_abs_bits, skip_ok, w.cands);
+                               w.maxsims, w.best4, w.labels_u8, max_abs_bits, skip_ok, mine, prev, grid, C0);
         else
             hipLaunchKernelGGL(reforder_init_step_kernel, dim3(grid), dim3(kThreads), lds, st, X, N, d, K, i, (const float *)C0,
                                w.cands);
-        hipLaunchKernelGGL(reforder_init_pick_kernel, dim3(1), dim3(kThreads), 0, st, X, N, d, K, i, (const Cand *)w.cands, grid,
-                           (int64_t)0, C0);
+        if (!incremental || i == K - 1)
+            hipLaunchKernelGGL(reforder_init_pick_kernel, dim3(1), dim3(kThreads), 0, st, X, N, d, K, i,
+                               (const Cand *)(incremental ? mine : w.cands), grid, (int64_t)0, C0);
     }
     ET_LAUNCH_CHECK();
     return ET_OK;
