@@ -449,17 +449,14 @@ __global__ __launch_bounds__(kThreads) void reforder_init_step_inc_kernel(const 
     }
     float mabs = 0.f;
     const int64_t seq_cols = N < 8 ? N / 4 * 4 : N / 32 * 32;  // column_is_sequential(n, N)
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
-        if (can_skip) {
-            const float b = bestR[n];
-            const float w = E - b;  // (a NaN or +inf anywhere makes a comparison false: full evaluation)
-            if (w >= 0.0f && sDelta[nearest[n]] >= 4.0001f * w) {
-                if (bi < 0 || argmin_ahead(b, n, bv, bi)) {
-                    bv = b;
-                    bi = n;
-                }
-                continue;
+    // one point: `known` = its bestR is in b already and the skip test has been made (passed: skip)
+    auto visit = [&](int64_t n, bool known, float b, bool skip) {
+        if (skip) {
+            if (bi < 0 || argmin_ahead(b, n, bv, bi)) {
+                bv = b;
+                bi = n;
             }
+            return;
         }
         float x[DM];
 #pragma unroll
@@ -490,7 +487,7 @@ __global__ __launch_bounds__(kThreads) void reforder_init_step_inc_kernel(const 
             return y;
         };
         const float yn = sim(sNew);
-        float r = count == 1 ? yn : bestR[n];
+        float r = count == 1 ? yn : (known ? b : bestR[n]);
         const bool took = count == 1 || gt_nanmax(yn, r);
         if (took) {
             r = yn;
@@ -517,6 +514,30 @@ __global__ __launch_bounds__(kThreads) void reforder_init_step_inc_kernel(const 
             bv = value;
             bi = n;
         }
+    };
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gstride = (int64_t)gridDim.x * blockDim.x;
+    if (can_skip) {
+        // four points per lane through one 16-byte load of bestR and one 4-byte load of nearest (one point per lane and trip
+        // was a chain of ~38 dependent round trips per thread at 1e7 points: 48 us per step whatever it skipped)
+        const int64_t n4 = N / 4;
+        for (int64_t g = gtid; g < n4; g += gstride) {
+            const float4 b4 = reinterpret_cast<const float4 *>(bestR)[g];
+            const unsigned l4 = reinterpret_cast<const unsigned *>(nearest)[g];
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float w = E - bb[v];  // (a NaN or +inf anywhere makes a comparison false: full evaluation)
+                const bool skip = w >= 0.0f && sDelta[(l4 >> (8 * v)) & 0xffu] >= 4.0001f * w;
+                visit(4 * g + v, true, bb[v], skip);
+            }
+        }
+        for (int64_t n = 4 * n4 + gtid; n < N; n += gstride) {
+            const float b = bestR[n];
+            const float w = E - b;
+            visit(n, true, b, w >= 0.0f && sDelta[nearest[n]] >= 4.0001f * w);
+        }
+    } else {
+        for (int64_t n = gtid; n < N; n += gstride) visit(n, false, 0.f, false);
     }
     sV[threadIdx.x] = bv;
     sI[threadIdx.x] = bi;
