@@ -1535,7 +1535,11 @@ __device__ __forceinline__ float inner_sum_parallel(const float *v, int size, fl
 //      level 3, the leftovers, the lane combination, the new centroids (kmeans.py:180-182); the last one of the batch: the
 //      error over the whole (l, d, K) tensor in ATen's order (kmeans.py:45-51, 232), the stop flag, the next launch's
 //      counters.  Rows travel memory -> LDS with every load of a pass in flight at once. ----
-__global__ __launch_bounds__(kUThreads) void reforder_update_kernel2(const Args a, int rows_cap) {
+// SINGLE (TT = 1024 threads, one workgroup per problem): shards of at most `1024 / slot` blocks (N <= 131 072 at K <= 20) --
+// thread group b folds block b straight from memory into LDS and the same workgroup goes on with level 3: no arrival, no
+// rows through memory, one small workgroup instead of a grid (-1.5 us per iteration where an iteration is 20 us).
+template <int TT, bool SINGLE>
+__global__ __launch_bounds__(TT) void reforder_update_kernel2(const Args a, int rows_cap, int slot) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, dk = kD * K;
@@ -1556,7 +1560,7 @@ __global__ __launch_bounds__(kUThreads) void reforder_update_kernel2(const Args 
     float4 *S2 = at<float4>(ws, a.lay.S2);
     const float4 *T = at<const float4>(ws, a.lay.T);
     const double *Sin = at<const double>(ws, a.lay.Sin);
-    __shared__ double sWsum[8];
+    __shared__ double sWsum[16];
     __shared__ int sFlag[2];
     __shared__ float sScr[40];
     float4 *sRows = reinterpret_cast<float4 *>(smem);
@@ -1564,70 +1568,114 @@ __global__ __launch_bounds__(kUThreads) void reforder_update_kernel2(const Args 
     RF_STAMP(who, 0);
 
     // ---- level 2 ----
-    const int blk = (int)blockIdx.x;
+    const int blk = SINGLE ? tid / slot : (int)blockIdx.x;
+    [[maybe_unused]] const int ltid = SINGLE ? tid % slot : tid;  // column of the row this thread folds
     const int64_t g0 = (int64_t)blk << lp;
     const int ng = (int)((geo.G - g0) < L ? (geo.G - g0) : L);
     float4 a2 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int rowlen = dk + kFMaxK / 4;  // float4 per row of S2: the sums, then the block's points per cluster (bit patterns)
     uint4 c2 = make_uint4(0u, 0u, 0u, 0u);
     const uint4 *cnt4 = at<const uint4>(ws, a.lay.cnt);  // rows of kFMaxK counts = kFMaxK / 4 words of 16 bytes
-    for (int r0 = 0; r0 < ng; r0 += rows_cap) {
-        const int nr = ng - r0 < rows_cap ? ng - r0 : rows_cap;
-        const float4 *src = S1 + (g0 + r0) * dk;
-        const uint4 *csrc = cnt4 + (g0 + r0) * (kFMaxK / 4);
-        for (int r8 = 0; r8 < nr; r8 += 16) {  // sixteen rows' loads in flight per thread: thread = column, rows in sequence
-            if (tid < rowlen) {
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rS2 = rsrc_of(S2, (int64_t)sizeof(float4) * (geo.n_blk + 1) * rowlen);
+    if constexpr (SINGLE) {
+        // thread group `blk` (slot threads, ltid = column): its block's rows straight from memory, sixteen in flight, added in
+        // row order; the result is row `blk` of the LDS table level 3 reads below
+        if (blk < geo.n_blk && ltid < rowlen) {
+            const float4 *src = S1 + g0 * dk;
+            const uint4 *csrc = cnt4 + g0 * (kFMaxK / 4);
+            for (int r8 = 0; r8 < ng; r8 += 16) {
                 float4 v[16];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
-                    const int r = r8 + u < nr ? r8 + u : r8;
-                    v[u] = tid < dk ? src[r * dk + tid] : __builtin_bit_cast(float4, csrc[r * (kFMaxK / 4) + (tid - dk)]);
+                    const int r = r8 + u < ng ? r8 + u : r8;
+                    v[u] = ltid < dk ? src[r * dk + ltid] : __builtin_bit_cast(float4, csrc[r * (kFMaxK / 4) + (ltid - dk)]);
                 }
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (r8 + u < nr) sRows[(r8 + u) * rowlen + tid] = v[u];
+                for (int u = 0; u < 16; ++u) {
+                    if (r8 + u < ng) {
+                        if (ltid < dk) {
+                            a2.x = a2.x + v[u].x;
+                            a2.y = a2.y + v[u].y;
+                            a2.z = a2.z + v[u].z;
+                            a2.w = a2.w + v[u].w;
+                        } else {
+                            const uint4 c = __builtin_bit_cast(uint4, v[u]);
+                            c2.x += c.x;
+                            c2.y += c.y;
+                            c2.z += c.z;
+                            c2.w += c.w;
+                        }
+                    }
+                }
             }
-        }
-        __syncthreads();
-        if (tid < dk) {
-            for (int g = 0; g < nr; ++g) {
-                const float4 v = sRows[g * rowlen + tid];
-                a2.x = a2.x + v.x;
-                a2.y = a2.y + v.y;
-                a2.z = a2.z + v.z;
-                a2.w = a2.w + v.w;
-            }
-        } else if (tid < rowlen) {  // (integers: any order)
-            for (int g = 0; g < nr; ++g) {
-                const uint4 v = __builtin_bit_cast(uint4, sRows[g * rowlen + tid]);
+            if (ltid >= dk && blk == 0) {  // block 0 takes the tail's counts along
+                const uint4 v = cnt4[geo.G * (kFMaxK / 4) + (ltid - dk)];
                 c2.x += v.x;
                 c2.y += v.y;
                 c2.z += v.z;
                 c2.w += v.w;
             }
+            sRows[blk * rowlen + ltid] = ltid < dk ? a2 : __builtin_bit_cast(float4, c2);
         }
         __syncthreads();
-    }
-    const __amdgpu_buffer_rsrc_t rS2 = rsrc_of(S2, (int64_t)sizeof(float4) * (geo.n_blk + 1) * rowlen);
-    if (tid < dk) st16_sc1(rS2, (unsigned)(((int64_t)blk * rowlen + tid) * sizeof(float4)), a2);
-    if (tid >= dk && tid < rowlen) {
-        if (blk == 0) {  // block 0 takes the tail's counts along
-            const uint4 v = cnt4[geo.G * (kFMaxK / 4) + (tid - dk)];
-            c2.x += v.x;
-            c2.y += v.y;
-            c2.z += v.z;
-            c2.w += v.w;
+    } else {
+        for (int r0 = 0; r0 < ng; r0 += rows_cap) {
+            const int nr = ng - r0 < rows_cap ? ng - r0 : rows_cap;
+            const float4 *src = S1 + (g0 + r0) * dk;
+            const uint4 *csrc = cnt4 + (g0 + r0) * (kFMaxK / 4);
+            for (int r8 = 0; r8 < nr; r8 += 16) {  // sixteen rows' loads in flight per thread: thread = column, rows in sequence
+                if (tid < rowlen) {
+                    float4 v[16];
+    #pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int r = r8 + u < nr ? r8 + u : r8;
+                        v[u] = tid < dk ? src[r * dk + tid] : __builtin_bit_cast(float4, csrc[r * (kFMaxK / 4) + (tid - dk)]);
+                    }
+    #pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (r8 + u < nr) sRows[(r8 + u) * rowlen + tid] = v[u];
+                }
+            }
+            __syncthreads();
+            if (tid < dk) {
+                for (int g = 0; g < nr; ++g) {
+                    const float4 v = sRows[g * rowlen + tid];
+                    a2.x = a2.x + v.x;
+                    a2.y = a2.y + v.y;
+                    a2.z = a2.z + v.z;
+                    a2.w = a2.w + v.w;
+                }
+            } else if (tid < rowlen) {  // (integers: any order)
+                for (int g = 0; g < nr; ++g) {
+                    const uint4 v = __builtin_bit_cast(uint4, sRows[g * rowlen + tid]);
+                    c2.x += v.x;
+                    c2.y += v.y;
+                    c2.z += v.z;
+                    c2.w += v.w;
+                }
+            }
+            __syncthreads();
         }
-        st16_sc1(rS2, (unsigned)(((int64_t)blk * rowlen + tid) * sizeof(float4)), __builtin_bit_cast(float4, c2));
+        if (tid < dk) st16_sc1(rS2, (unsigned)(((int64_t)blk * rowlen + tid) * sizeof(float4)), a2);
+        if (tid >= dk && tid < rowlen) {
+            if (blk == 0) {  // block 0 takes the tail's counts along
+                const uint4 v = cnt4[geo.G * (kFMaxK / 4) + (tid - dk)];
+                c2.x += v.x;
+                c2.y += v.y;
+                c2.z += v.z;
+                c2.w += v.w;
+            }
+            st16_sc1(rS2, (unsigned)(((int64_t)blk * rowlen + tid) * sizeof(float4)), __builtin_bit_cast(float4, c2));
+        }
+        RF_STAMP(who, 1);
+        // ---- arrival: the stores have been performed at the memory side ----
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) sFlag[0] = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)geo.n_blk - 1u;
+        __syncthreads();
+        RF_STAMP(who, 2);
+        if (!sFlag[0]) return;
     }
-    RF_STAMP(who, 1);
-    // ---- arrival: the stores have been performed at the memory side ----
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (tid == 0) sFlag[0] = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)geo.n_blk - 1u;
-    __syncthreads();
-    RF_STAMP(who, 2);
-    if (!sFlag[0]) return;
 
     // ---- last workgroup of this problem: level 3 over the complete blocks, in block order ----
     RF_STAMP(3, 0);
@@ -1637,20 +1685,22 @@ __global__ __launch_bounds__(kUThreads) void reforder_update_kernel2(const Args 
     for (int r0 = 0; r0 < geo.full_blk; r0 += rows_cap) {
         const int nr = geo.full_blk - r0 < rows_cap ? geo.full_blk - r0 : rows_cap;
         const unsigned base = (unsigned)((int64_t)r0 * rowlen * sizeof(float4));
-        for (int e0 = 0; e0 < nr * rowlen; e0 += 16 * kUThreads) {  // sixteen 16-byte loads per lane in flight
-            float4 v[16];
+        if constexpr (!SINGLE) {
+            for (int e0 = 0; e0 < nr * rowlen; e0 += 16 * TT) {  // sixteen 16-byte loads per lane in flight
+                float4 v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int e = e0 + u * kUThreads + tid;
-                v[u] = ld16_sc1(rS2, base + (unsigned)((e < nr * rowlen ? e : 0) * sizeof(float4)));
-            }
+                for (int u = 0; u < 16; ++u) {
+                    const int e = e0 + u * TT + tid;
+                    v[u] = ld16_sc1(rS2, base + (unsigned)((e < nr * rowlen ? e : 0) * sizeof(float4)));
+                }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int e = e0 + u * kUThreads + tid;
-                if (e < nr * rowlen) sRows[e] = v[u];
+                for (int u = 0; u < 16; ++u) {
+                    const int e = e0 + u * TT + tid;
+                    if (e < nr * rowlen) sRows[e] = v[u];
+                }
             }
-        }
-        __syncthreads();
+            __syncthreads();
+        }  // (SINGLE: the rows are in the table already, all of them: rows_cap >= n_blk)
         if (tid < dk) {
             for (int b = 0; b < nr; ++b) {
                 const float4 v = sRows[b * rowlen + tid];
@@ -1670,9 +1720,13 @@ __global__ __launch_bounds__(kUThreads) void reforder_update_kernel2(const Args 
         }
         __syncthreads();
     }
+    float4 part_row = make_float4(0.f, 0.f, 0.f, 0.f);  // the partial block's row, this thread's column
+    if (geo.n_blk > geo.full_blk && tid < rowlen)
+        part_row = SINGLE ? sRows[geo.full_blk * rowlen + tid]
+                          : ld16_sc1(rS2, (unsigned)(((int64_t)geo.full_blk * rowlen + tid) * sizeof(float4)));
     if (tid >= dk && tid < rowlen) {
         if (geo.n_blk > geo.full_blk) {
-            const float4 v = ld16_sc1(rS2, (unsigned)(((int64_t)geo.full_blk * rowlen + tid) * sizeof(float4)));
+            const float4 v = part_row;
             ctot[0] += __float_as_uint(v.x);
             ctot[1] += __float_as_uint(v.y);
             ctot[2] += __float_as_uint(v.z);
@@ -1682,17 +1736,20 @@ __global__ __launch_bounds__(kUThreads) void reforder_update_kernel2(const Args 
         for (int u = 0; u < 4; ++u) sCntTot[4 * (tid - dk) + u] = ctot[u];
     }
     // the inertia of this assignment (kmeans.py:234; only printed by the reference): fp64, a fixed order
+    // (always as kUThreads = 256 threads would do it -- four wavefronts' partial sums --, so that both forms give the same bits)
     double part = 0.0;
-    for (int64_t gb = 0; gb <= geo.G; gb += 8 * kUThreads) {  // eight loads in flight; a fixed order per thread
-        double v[8];
+    if (tid < kUThreads) {
+        for (int64_t gb = 0; gb <= geo.G; gb += 8 * kUThreads) {  // eight loads in flight; a fixed order per thread
+            double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int64_t g = gb + (int64_t)u * kUThreads + tid;
-            v[u] = Sin[g <= geo.G ? g : 0];
+            for (int u = 0; u < 8; ++u) {
+                const int64_t g = gb + (int64_t)u * kUThreads + tid;
+                v[u] = Sin[g <= geo.G ? g : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (gb + (int64_t)u * kUThreads + tid <= geo.G) part = part + v[u];
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (gb + (int64_t)u * kUThreads + tid <= geo.G) part = part + v[u];
     }
     part = wave_sum_f64(part);
     if (lane == 0) sWsum[wave] = part;
@@ -1702,8 +1759,7 @@ __global__ __launch_bounds__(kUThreads) void reforder_update_kernel2(const Args 
     if (tid < dk) {
         const int j = tid % K;
         const float *x = X + (int64_t)(tid / K) * N;
-        const float4 p2 = geo.n_blk > geo.full_blk ? ld16_sc1(rS2, (unsigned)(((int64_t)geo.full_blk * rowlen + tid) * sizeof(float4)))
-                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 p2 = part_row;
         const float4 p1 = T[tid], p0 = T[dk + tid];
         const unsigned lw = __float_as_uint(T[2 * dk].x);
         float p = ((p0.x + p1.x) + p2.x) + a3.x;
@@ -1734,14 +1790,14 @@ __global__ __launch_bounds__(kUThreads) void reforder_update_kernel2(const Args 
         __syncthreads();
         if (!sFlag[1]) return;
         const int tot = a.batch * dk;
-        for (int e = tid; e < tot; e += kUThreads) sSq[e] = __hip_atomic_load(&a.sq_all[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int e = tid; e < tot; e += TT) sSq[e] = __hip_atomic_load(&a.sq_all[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
     }
     RF_STAMP(3, 2);
     const float error = inner_sum_parallel(sSq, a.batch * dk, sScr);
     const int done = (error <= a.tol) ? 1 : 0;
     RF_STAMP(3, 3);
-    for (int b = tid; b < a.batch; b += kUThreads) {
+    for (int b = tid; b < a.batch; b += TT) {
         et_kmeans_state *st = at<et_kmeans_state>(a.ws + (int64_t)b * a.ws_stride, a.lay.state);
         const int64_t it = st->iter;
         const double ine = __hip_atomic_load(&st->inertia, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2128,8 +2184,9 @@ static int fast_fit(const float *X, int64_t x_stride, int64_t N, int K, int64_t 
             for (const void *f : {reinterpret_cast<const void *>(reforder_groups_kernel<0>), reinterpret_cast<const void *>(reforder_groups_kernel<10>),
                                   reinterpret_cast<const void *>(reforder_groups_kernel<16>)})
                 ET_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-            ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(reforder_update_kernel2),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUMaxLds));
+            for (const void *f : {reinterpret_cast<const void *>(reforder_update_kernel2<kUThreads, false>),
+                                  reinterpret_cast<const void *>(reforder_update_kernel2<1024, true>)})
+                ET_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUMaxLds));
             lds_set[dev_id & 63] = true;
         }
     }
@@ -2158,11 +2215,17 @@ static int fast_fit(const float *X, int64_t x_stride, int64_t N, int K, int64_t 
     int launched = 0;
     bool done = false;
     const dim3 grid((unsigned)(a.geo.G + 1), (unsigned)batch), ugrid((unsigned)a.geo.n_blk, (unsigned)batch);
+    // few blocks (N <= 131 072 at K <= 20): one 1024-thread workgroup per problem folds them side by side (no arrival hop)
+    const int uslot = (kD * K + kFMaxK / 4 + 63) / 64 * 64;
+    const bool single_update = a.geo.n_blk <= 1024 / uslot && et::options().reforder_single_update.load(std::memory_order_relaxed) != 0;
     for (int it = 0; it < max_iter && !done; ++it) {
         if (!use_filter) hipLaunchKernelGGL(reforder_groups_kernel<0>, grid, dim3(kFThreads), lds, st, a);
         else if (K <= 20) hipLaunchKernelGGL(reforder_groups_kernel<10>, grid, dim3(kFThreads), lds, st, a);
         else hipLaunchKernelGGL(reforder_groups_kernel<16>, grid, dim3(kFThreads), lds, st, a);
-        hipLaunchKernelGGL(reforder_update_kernel2, ugrid, dim3(kUThreads), ulds, st, a, rows_cap);
+        if (single_update)
+            hipLaunchKernelGGL((reforder_update_kernel2<1024, true>), dim3(1, (unsigned)batch), dim3(1024), ulds, st, a, rows_cap, uslot);
+        else
+            hipLaunchKernelGGL((reforder_update_kernel2<kUThreads, false>), ugrid, dim3(kUThreads), ulds, st, a, rows_cap, 0);
         ET_LAUNCH_CHECK();
         launched = it + 1;
         if (a.mail) {  // stay at most kAhead launches ahead of the device's report; stop when it carries the flag

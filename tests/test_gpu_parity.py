@@ -2344,16 +2344,20 @@ def test_reference_order_batch_joint_stop_g7b(ops, oracle, dev):
         np.testing.assert_allclose(r["inertia"], ref["inertia"][b], rtol=1e-5)
 
 
-@pytest.mark.parametrize("filter_lp", [9, 4])
+@pytest.mark.parametrize("filter_lp", [9, 4, -1])
 @pytest.mark.parametrize("n,K,l", [(1024, 20, 2), (5003, 20, 3), (20001, 7, 4), (70000, 32, 2), (131072 + 13, 20, 2), (300000, 20, 2)])
 def test_reference_order_fast_form_vs_oracle(ops, oracle, dev, et_option, n, K, l, filter_lp):
     """The one-launch-per-iteration form of the reference-order fit (csrc/et_kmeans_reforder.hip, namespace fast: parallel
     levels of ATen's cascade, permuted copy, last-arriver updates) against the oracle's literal restatement, on sizes that
     exercise every leftover of the cascade (partial chunk / group / block, N mod 4, N mod 32) and on batches: labels, centroid
     bits, per-iteration errors, iteration count; and problem 0 alone (l = 1: its own stop).  filter_lp = 4 switches the
-    matrix-core label certification on (built, tested equal, off by default: DESIGN 3.8): the same bits."""
+    matrix-core label certification on (built, tested equal, off by default: DESIGN 3.8): the same bits; -1: the update kernel's grid
+    form on the small shards that take the single-workgroup form by default."""
     from eigentrajectory_amd.synth import gaussian_points_np
-    et_option("reforder_filter_min_lp", filter_lp)
+    if filter_lp < 0:  # (-1: the update as a grid of block workgroups + last arriver also where one workgroup would do)
+        et_option("reforder_single_update", 0)
+    else:
+        et_option("reforder_filter_min_lp", filter_lp)
     xs = np.stack([gaussian_points_np(6, n, seed=300 + 7 * b + n % 89, n_blobs=(0 if b % 2 else 5)) for b in range(l)])
     xs[0][:, ::61] *= np.float32(9.0)
     c0 = np.stack([oracle.kmeans_init_farthest(xs[b], K, (17 * (b + 1)) % n, reference_order=True)[0] for b in range(l)])

@@ -50,6 +50,7 @@ for case in range(cases):
     ref = eo.kmeans_fit_batch_reference_order(list(xs), list(c0), iters, 1e-4)
     for flt in (9, 4):
         L.set_option("reforder_filter_min_lp", flt)
+        L.set_option("reforder_single_update", 1 if flt == 9 else int(rng.randint(2)))  # (both forms of the update kernel)
         runs = ops.kmeans_fit_reference_order_batch(torch.from_numpy(xs).to(dev), torch.from_numpy(c0).to(dev), iters, 1e-4)
         ok = True
         for b, r in enumerate(runs):
@@ -63,4 +64,5 @@ for case in range(cases):
     if case % 20 == 19:
         print(f"{case + 1} cases, {bad} mismatches", flush=True)
 L.set_option("reforder_filter_min_lp", 9)
+L.set_option("reforder_single_update", 1)
 print(f"done: {cases} cases x 2 forms, {bad} mismatches")
