@@ -59,7 +59,10 @@ constexpr int kKmThreads = 256;
 // not of wavefronts), but a wavefront then has 4/3 as many passes to do, and the count is an integer.  Per Lloyd
 // launch at N = 1e7 (same box): 256 threads 60.3 us, 512: 58.0, 640: 60.5, 704: 57.1, 768: 54.7, 832: 59.3, 896: 57.8,
 // 960: 58.7, 1024: 57.2 (sizes that load the four SIMDs unevenly lose); at N = 1e6 768 needs two passes, 1024 one.
-constexpr int kFilterMaxThreads = 1024;
+#ifndef ET_KM_MAXTHREADS
+#define ET_KM_MAXTHREADS 1024
+#endif
+constexpr int kFilterMaxThreads = ET_KM_MAXTHREADS;
 constexpr int kFilterMinThreads = 768;
 constexpr int kKmMaxBlocks = 4096;
 
@@ -1299,14 +1302,44 @@ __device__ __forceinline__ void packed_drain(const unsigned *q, int cnt, int K, 
     }
 }
 
-__device__ __forceinline__ void packed_issue(const LloydPacked &pk, int64_t N, const uint8_t *__restrict__ labels, int64_t gg,
-                                             int half, int col, uint4 (&vn)[3], uint2 &rn, unsigned &lpn) {
-    const int64_t n = gg * 256 + 128 * half + 4 * col;
-    const int64_t nl = n < N ? n : 0;  // lanes past the end read points 0..3: finite data, discarded through `valid`
+// Dual form of a pass's loads: BOTH lanes of a column request the rows of the column's point in the lower 128-point block
+// (-> the B operand of tile L) and in the upper block (tile U) -- the two half-waves ask for the same addresses, the memory
+// side sees the bytes once -- instead of exchanging their own rows with v_permlane32_swap (2 issue slots + 2 copies per
+// dword).  A lane's own point is the lower block's for half 0, the upper block's for half 1.  Buffer loads: a pass index
+// past the end (g < 0: offset 0xfffffff0) or rows past N are out of range, return zeros and cost no traffic, so the request
+// needs no branch around it and the two register sets of the loop (unrolled by two: no copies) are waited for by count.
+struct PkRows {
+    u32x4 vL[3], vU[3];
+    unsigned rL[2], rU[2];
+    unsigned lp;
+};
+struct PkSrc {
+    __amdgpu_buffer_rsrc_t row[3], rr, lab;
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pk_rsrc(const void *base, int64_t bytes) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const int nb = __builtin_amdgcn_readfirstlane((int)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, nb, 0x00020000);
+}
+constexpr int64_t kPkDualMaxN = 1ll << 28;  // 4 N bytes per row and every byte offset stay below 2^31
+__device__ __forceinline__ void packed_issue_dual(const PkSrc &src, int64_t gg, unsigned lane_off, unsigned own_off, PkRows &o) {
+    // byte offset of the lower block's four points of this column inside a row of dwords
+    const unsigned oL = gg >= 0 ? (unsigned)gg * 1024u + lane_off : 0xfffffff0u;
+    const unsigned oU = gg >= 0 ? oL + 512u : 0xfffffff0u;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) vn[p] = *reinterpret_cast<const uint4 *>(pk.xh + (int64_t)p * N + nl);
-    rn = *reinterpret_cast<const uint2 *>(pk.rr + nl);
-    lpn = *reinterpret_cast<const unsigned *>(labels + nl);
+    for (int p = 0; p < 3; ++p) {
+        o.vL[p] = __builtin_amdgcn_raw_buffer_load_b128(src.row[p], oL, 0, 0);
+        o.vU[p] = __builtin_amdgcn_raw_buffer_load_b128(src.row[p], oU, 0, 0);
+    }
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t a = __builtin_amdgcn_raw_buffer_load_b64(src.rr, oL >> 1, 0, 0);
+    const u32x2_t b = __builtin_amdgcn_raw_buffer_load_b64(src.rr, gg >= 0 ? oU >> 1 : 0xfffffff0u, 0, 0);
+    o.rL[0] = a.x;
+    o.rL[1] = a.y;
+    o.rU[0] = b.x;
+    o.rU[1] = b.y;
+    o.lp = __builtin_amdgcn_raw_buffer_load_b32(src.lab, gg >= 0 ? (oL >> 2) + own_off : 0xfffffff0u, 0, 0);
 }
 
 // ---- the per-launch tables of packed_assign_body, as functions of a cluster's centroid (c[0..5], |c|^2 as stage_centroids
@@ -1324,11 +1357,14 @@ __device__ __forceinline__ void pk_table_row(const float (&c)[6], float bn, cons
     }
     // (v_sqrt_f32, 1 ulp: both are upper bounds with a 1e-3 margin)
     const float Q = __builtin_amdgcn_sqrtf(qq) * s * 1.001f + 1e-30f, M = m_up + __builtin_amdgcn_sqrtf(bn) * s * 1.001f;
-    row[6] = qq * s2;
-    // th(R) = R^2 k1 + R thr_r + thr_1:  epsR + Ew_l + E1_l  (header comment), coefficients rounded up
-    row[7] = fmaf(9.86e-4f, Q, 9.7e-7f * M) * kUp + 1e-30f;
-    row[8] = (fmaf(9.6e-7f * Q, Q, 2.4e-7f * Q) + fmaf(4.85e-7f * M, M, 1e-12f)) * kUp;
+    row[6] = -(qq * s2);  // (negated: the chain starts from it)
+    // th(R) = R^2 k1 + R thr_r + thr_1:  epsR + Ew_l + E1_l  (header comment), coefficients rounded up -- twice: the
+    // second (1 + 2^-9), which covers the roundings of th's own evaluation, used to be a multiplication per point
+    row[7] = (fmaf(9.86e-4f, Q, 9.7e-7f * M) * kUp + 1e-30f) * kUp;
+    row[8] = ((fmaf(9.6e-7f * Q, Q, 2.4e-7f * Q) + fmaf(4.85e-7f * M, M, 1e-12f)) * kUp) * kUp;
 }
+// th's two cluster-independent coefficients with the same factor inside: 2^-22 |y| (the chain's rounding) and 7.4e-6 R^2
+constexpr float kThY = 2.384185791015625e-7f * 1.001953125f, kThR2 = 7.4e-6f * 1.001953125f;
 
 // A operand of a lane's cluster (layout as in filter_assign_body): lower half-wave lanes carry k-slots 0..7 =
 // {hi(2 q)_0..5, -|q|^2 + const as hi, lo * 2^10}, upper half-wave lanes k-slots 8..15 = {lo(2 q)_0..5, slope, 0}
@@ -1434,6 +1470,7 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
         return;
     }
     bool fallback = st_iter <= 0 || !st_fast_ok || pk_ok == 0u;
+    fallback = fallback || N > kPkDualMaxN || (N & 3) != 0;  // (the rows are requested through 32-bit buffer offsets, 16 bytes at a time)
     if (!fallback) {  // every |s (c - mu)| inside the packed range?  (cen: d x K floats in LDS, the same in every workgroup)
         if (range_bad >= 0) {  // (the caller's update has looked already: uniform over the workgroup)
             fallback = range_bad != 0;
@@ -1454,7 +1491,6 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
     float *sL = sC + K * 8;                                                                    // K * kPkRow: label table
     const int lane = tx & 63, wave = tx >> 6, half = lane >> 5, col = lane & 31;
     unsigned *queue = reinterpret_cast<unsigned *>(sL + K * kPkRow) + wave * kPkQueue;
-    constexpr float kUp = 1.001953125f;  // (1 + 2^-9): rounding the thresholds up
     u32x4 a1;
     __shared__ int sNext;
     if (tables) {
@@ -1510,50 +1546,45 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
         }
         return g < n_groups ? g : -1;
     };
-    uint4 vn[3];
-    uint2 rn = make_uint2(0u, 0u);
-    unsigned lpn = 0u;
-    int64_t g = take();
-    if (g >= 0) packed_issue(pk, N, labels, g, half, col, vn, rn, lpn);
-#ifdef ET_EXP_WAITSTAMP
-    unsigned long long ws_wait = 0, ws_pass = 0, ws_drain = 0, ws_n = 0, ws_nd = 0;
-#endif
-    while (g >= 0) {
-#ifdef ET_EXP_WAITSTAMP
-        const unsigned long long ws_t0 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this pass's rows (requested one pass ago) have arrived
-        const unsigned long long ws_t1 = __builtin_amdgcn_s_memtime();
-        ws_wait += ws_t1 - ws_t0;
-        ++ws_n;
-#endif
-        const int64_t n = g * 256 + 128 * half + 4 * col;
-        const bool valid = n < N;
-        uint4 v[3];
+    PkSrc src;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) v[p] = vn[p];
-        const uint2 rv = rn;
-        const unsigned old_packed = lpn;
-        // the next pass's rows are in flight during this pass's arithmetic and its queue drain
-        g = take();
-        if (g >= 0) packed_issue(pk, N, labels, g, half, col, vn, rn, lpn);
+    for (int p = 0; p < 3; ++p) src.row[p] = pk_rsrc(pk.xh + (int64_t)p * N, 4 * N);
+    src.rr = pk_rsrc(pk.rr, 2 * N);
+    src.lab = pk_rsrc(labels, N);
+    const unsigned lane_off = 16u * (unsigned)col, own_off = 128u * (unsigned)half;
+    const unsigned ones = 0x14003c00u;  // {1, 2^-10}: partners of {hi, lo * 2^10} of -|q|^2 + const
+    // one pass on the rows in `cu` (pass index gc); the other register set is in flight meanwhile
+    auto process = [&](const PkRows &cu, int64_t gc) __attribute__((always_inline)) {
+        const int64_t n = gc * 256 + 128 * half + 4 * col;
+        const bool valid = n < N;
+        const unsigned old_packed = cu.lp;
         unsigned undecided = 0u;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             unsigned w[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) w[p] = q == 0 ? v[p].x : (q == 1 ? v[p].y : (q == 2 ? v[p].z : v[p].w));
-            const unsigned rpair = q < 2 ? rv.x : rv.y;
-            const unsigned r16 = (q & 1) ? (rpair >> 16) : rpair;  // low half: this point's R (the high half meets a zero)
-            const float R = (float)__builtin_bit_cast(_Float16, (unsigned short)(r16 & 0xffffu));
-            const unsigned ones = 0x14003c00u;  // {1, 2^-10}: partners of {hi, lo * 2^10} of -|q|^2 + const
             u32x4 bLo, bUp;
+            const unsigned rpL = cu.rL[q >> 1], rpU = cu.rU[q >> 1];
+            // low half: the point's R (the high half meets a zero of the A operand)
+            const unsigned r16L = (q & 1) ? (rpL >> 16) : rpL, r16U = (q & 1) ? (rpU >> 16) : rpU;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const auto r = p < 3 ? __builtin_amdgcn_permlane32_swap(w[p], w[p], false, false)
-                                     : __builtin_amdgcn_permlane32_swap(ones, r16, false, false);
-                bLo[p] = r[0];
-                bUp[p] = r[1];
+            for (int p = 0; p < 3; ++p) {
+                bLo[p] = cu.vL[p][q];
+                bUp[p] = cu.vU[p][q];
+                w[p] = half ? bUp[p] : bLo[p];
             }
+            bLo[3] = half ? r16L : ones;
+            bUp[3] = half ? r16U : ones;
+            const unsigned r16 = half ? r16U : r16L;
+            // certified lower bound of the old label's value: fp32 chain on the f16 coordinates
+            const int ol = (int)((old_packed >> (8 * q)) & 0xffu);
+            const float4 r0 = l4[3 * ol], r1 = l4[3 * ol + 1], r2 = l4[3 * ol + 2];
+            float y = r1.z;  // -|q_l|^2 s^2
+            y = fma_mix_lo(w[0], r0.x, y);
+            y = fma_mix_hi(w[0], r0.y, y);
+            y = fma_mix_lo(w[1], r0.z, y);
+            y = fma_mix_hi(w[1], r0.w, y);
+            y = fma_mix_lo(w[2], r1.x, y);
+            y = fma_mix_hi(w[2], r1.y, y);
             const f16x8 BL = __builtin_bit_cast(f16x8, bLo), BU = __builtin_bit_cast(f16x8, bUp);
             f32x16 accL, accU;
 #pragma unroll
@@ -1568,17 +1599,9 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
             const float b0 = __uint_as_float(rb[0]), b1 = __uint_as_float(rb[1]);
             const float s0 = __uint_as_float(rq[0]), s1 = __uint_as_float(rq[1]);
             const float second = vmed3(b0, b1, vmax(s0, s1));  // second largest upper bound
-            // certified lower bound of the old label's value: fp32 chain on the f16 coordinates
-            const int ol = (int)((old_packed >> (8 * q)) & 0xffu);
-            const float4 r0 = l4[3 * ol], r1 = l4[3 * ol + 1], r2 = l4[3 * ol + 2];
-            float y = -r1.z;
-            y = fma_mix_lo(w[0], r0.x, y);
-            y = fma_mix_hi(w[0], r0.y, y);
-            y = fma_mix_lo(w[1], r0.z, y);
-            y = fma_mix_hi(w[1], r0.w, y);
-            y = fma_mix_lo(w[2], r1.x, y);
-            y = fma_mix_hi(w[2], r1.y, y);
-            const float th = fmaf(fabsf(y), 2.384185791015625e-7f, fmaf(R, fmaf(R, 7.4e-6f, r1.w), r2.x)) * kUp;
+            // th(R) (1 + 2^-9): the factor is inside the coefficients (pk_table_row: r1.w, r2.x; kThY, kThR2 here)
+            const float R = (float)__builtin_bit_cast(_Float16, (unsigned short)(r16 & 0xffffu));
+            const float th = fmaf(fabsf(y), kThY, fmaf(R, fmaf(R, kThR2, r1.w), r2.x));
             const bool keep = y - second > th;
             undecided |= (valid && !keep) ? (1u << q) : 0u;
         }
@@ -1598,22 +1621,37 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
 #endif
                 if (qn >= 64) {
                     qn -= 64;
-#ifdef ET_EXP_WAITSTAMP
-                    const unsigned long long ws_d0 = __builtin_amdgcn_s_memtime();
-#endif
                     packed_drain(queue + qn, 64, K, sC, pk.xa, labels, sAcc, frac, lane);
-#ifdef ET_EXP_WAITSTAMP
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    ws_drain += __builtin_amdgcn_s_memtime() - ws_d0;
-                    ++ws_nd;
-#endif
                 }
             }
         }
-#ifdef ET_EXP_WAITSTAMP
-        ws_pass += __builtin_amdgcn_s_memtime() - ws_t0;
+    };
+    // the loop, unrolled by two over the register sets ra / rb: a set is requested one pass ahead and never copied
+    PkRows ra, rb;
+#ifdef ET_EXP_WAITSTAMP  // (passes and their cycles only: the exposed wait and the drains are no longer separable)
+    unsigned long long ws_wait = 0, ws_pass = 0, ws_drain = 0, ws_n = 0, ws_nd = 0;
+#define KM_WS_PASS(call)                                             \
+    do {                                                             \
+        const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); \
+        call;                                                        \
+        ws_pass += __builtin_amdgcn_s_memtime() - t0_;               \
+        ++ws_n;                                                      \
+    } while (0)
+#else
+#define KM_WS_PASS(call) call
 #endif
+    int64_t g = take();
+    packed_issue_dual(src, g, lane_off, own_off, ra);
+    while (g >= 0) {
+        const int64_t g2 = take();
+        packed_issue_dual(src, g2, lane_off, own_off, rb);
+        KM_WS_PASS(process(ra, g));
+        if (g2 < 0) break;
+        g = take();
+        packed_issue_dual(src, g, lane_off, own_off, ra);
+        KM_WS_PASS(process(rb, g2));
     }
+#undef KM_WS_PASS
 #ifdef ET_EXP_WAITSTAMP
     if (lane == 0) {  // (into LDS: six device atomics per wavefront here made the build's launches 4-5x slower)
         atomicAdd(&s_ws_acc[0], ws_n);

@@ -56,22 +56,36 @@ __device__ __forceinline__ float vmax(float a, float b) { return __builtin_amdgc
 __device__ __forceinline__ float vmin(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -opaque_inf()); }
 __device__ __forceinline__ float vmed3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 
-// largest and second largest (as a multiset) of acc[0..NREGS), NREGS >= 3: (max3, med3) per triple, two ops to
-// merge the maxima and one more for the seconds
+// largest and second largest (as a multiset) of acc[0..NREGS), NREGS >= 3: (max3, med3) per triple; the triples' pairs
+// are merged two at a time into the running pair -- largest = max3 of the three maxima, second = the largest of their
+// median and the three seconds (four instructions for two triples) --, a last odd pair with three instructions, left-over
+// values with two each.  Ten values: 12 instructions (the pairwise merge this replaces: 14).
 template <int NREGS>
 __device__ __forceinline__ void top2(const f32x16 &acc, float &b, float &s) {
+    constexpr int T = NREGS / 3;
     b = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);
     s = vmed3(acc[0], acc[1], acc[2]);
-    int r = 3;
+    int i = 1;
 #pragma unroll
-    for (; r + 2 < NREGS; r += 3) {
-        const float gs = vmed3(acc[r], acc[r + 1], acc[r + 2]);  // second of the triple
+    for (; i + 1 < T; i += 2) {
+        const int r = 3 * i;
+        const float m1 = __builtin_fmaxf(__builtin_fmaxf(acc[r], acc[r + 1]), acc[r + 2]);
+        const float t1 = vmed3(acc[r], acc[r + 1], acc[r + 2]);
+        const float m2 = __builtin_fmaxf(__builtin_fmaxf(acc[r + 3], acc[r + 4]), acc[r + 5]);
+        const float t2 = vmed3(acc[r + 3], acc[r + 4], acc[r + 5]);
+        const float mid = vmed3(b, m1, m2);
+        s = __builtin_fmaxf(__builtin_fmaxf(mid, s), vmax(t1, t2));
+        b = __builtin_fmaxf(__builtin_fmaxf(b, m1), m2);
+    }
+    if (i < T) {
+        const int r = 3 * i;
+        const float gs = vmed3(acc[r], acc[r + 1], acc[r + 2]);
         const float gm = __builtin_fmaxf(__builtin_fmaxf(acc[r], acc[r + 1]), acc[r + 2]);
         s = vmed3(b, gm, vmax(s, gs));
         b = vmax(b, gm);
     }
 #pragma unroll
-    for (; r < NREGS; ++r) {
+    for (int r = 3 * T; r < NREGS; ++r) {
         s = vmed3(b, s, acc[r]);
         b = vmax(b, acc[r]);
     }
