@@ -59,10 +59,10 @@ constexpr int kKmThreads = 256;
 // not of wavefronts), but a wavefront then has 4/3 as many passes to do, and the count is an integer.  Per Lloyd
 // launch at N = 1e7 (same box): 256 threads 60.3 us, 512: 58.0, 640: 60.5, 704: 57.1, 768: 54.7, 832: 59.3, 896: 57.8,
 // 960: 58.7, 1024: 57.2 (sizes that load the four SIMDs unevenly lose); at N = 1e6 768 needs two passes, 1024 one.
-constexpr int kFilterMaxThreads = 1024;
-// the chained Lloyd kernel: at most 12 wavefronts per workgroup, so that its packed pass may hold two sets of eight 16-byte
-// records (64 VGPRs) beside the accumulators -- 170 VGPRs per lane instead of 128
-constexpr int kChainMaxThreads = 768;
+#ifndef ET_KM_MAXTHREADS
+#define ET_KM_MAXTHREADS 1024
+#endif
+constexpr int kFilterMaxThreads = ET_KM_MAXTHREADS;
 constexpr int kFilterMinThreads = 768;
 constexpr int kKmMaxBlocks = 4096;
 
@@ -447,7 +447,8 @@ struct PackedHeader {  // written by kmeans_pack_kernel
     int pad[7];
 };
 struct LloydPacked {
-    const unsigned *xh;  // N records of 16 B (see "PACKED copy" below); nullptr: no packed copy
+    const unsigned *xh;
+    const unsigned short *rr;
     const float4 *xa;
     const PackedHeader *hdr;
     int fused;  // the exact first iteration of the fit writes the copy (default); 0: kmeans_pack_kernel did, before the loop
@@ -457,6 +458,7 @@ constexpr int kPackSamples = 1024;
 // where the exact first iteration of a fit (assign_body_valu<6, 4>) writes the packed copy of the points it reads anyway
 struct PackOut {
     unsigned *xh;
+    unsigned short *rr;
     float4 *xa;
     float mu[6];
     float s;
@@ -515,9 +517,10 @@ __device__ __forceinline__ bool packed_header(const float *__restrict__ X, int64
 // the packed form of the four points n .. n + 3 (x[v][i]: coordinate i of point n + v)
 __device__ __forceinline__ void pack_quad(const float (&x)[4][6], int64_t n, int64_t N, const PackOut &po) {
     constexpr float kUp = 1.001953125f, kTiny = 1.1920928955078125e-7f;
+    unsigned hw[3][4];
+    unsigned short rh[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        unsigned hw[4];
         float xc[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) xc[i] = x[q][i] - po.mu[i];
@@ -526,18 +529,22 @@ __device__ __forceinline__ void pack_quad(const float (&x)[4][6], int64_t n, int
         for (int i = 0; i < 6; ++i) an = fmaf(xc[i], xc[i], an);
         const float rs = fmaf(__builtin_amdgcn_sqrtf(an) * po.s, kUp, kTiny);
         const auto rp = __builtin_amdgcn_cvt_pkrtz(fmaf(rs, kUp, kTiny), 0.f);  // survives the rounding toward zero
-        hw[3] = __builtin_bit_cast(unsigned, rp) & 0xffffu;  // {R, 0}
+        rh[q] = (unsigned short)(__builtin_bit_cast(unsigned, rp) & 0xffffu);
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             unsigned h;
             asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=&v"(h) : "v"(xc[2 * p]), "v"(po.s));
             asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+&v"(h) : "v"(xc[2 * p + 1]), "v"(po.s));
-            hw[p] = h;
+            hw[p][q] = h;
         }
-        *reinterpret_cast<uint4 *>(po.xh + 4 * (n + q)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
         po.xa[2 * (n + q)] = make_float4(x[q][0], x[q][1], x[q][2], x[q][3]);
         po.xa[2 * (n + q) + 1] = make_float4(x[q][4], x[q][5], 0.f, 0.f);
     }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+        *reinterpret_cast<uint4 *>(po.xh + (int64_t)p * N + n) = make_uint4(hw[p][0], hw[p][1], hw[p][2], hw[p][3]);
+    *reinterpret_cast<uint2 *>(po.rr + n) =
+        make_uint2((unsigned)rh[0] | ((unsigned)rh[1] << 16), (unsigned)rh[2] | ((unsigned)rh[3] << 16));
 }
 
 template <int D, int VEC>
@@ -545,7 +552,7 @@ __device__ __forceinline__ void assign_body_valu(
     const float *__restrict__ X, int64_t N, int d_rt, int K, const et_kmeans_state *__restrict__ state,
     const float *__restrict__ cen, const int64_t *__restrict__ given, uint8_t *__restrict__ labels,
     long long *__restrict__ block_partials, long long *__restrict__ lanes = nullptr, int copy_mask = kAccLanes - 1,
-    const PackOut pack = PackOut{nullptr, nullptr, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0.f}) {
+    const PackOut pack = PackOut{nullptr, nullptr, nullptr, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0.f}) {
     const unsigned tx = thread_x();  // (opaque per call: see thread_x)
     const int d = D ? D : d_rt;
     const int plen = d * K + K + 2;
@@ -1218,11 +1225,12 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
 __global__ __launch_bounds__(kKmThreads) void kmeans_pack_kernel(const float *__restrict__ X, int64_t N,
                                                                  const et_kmeans_state *__restrict__ state,
                                                                  PackedHeader *__restrict__ hdr, unsigned *__restrict__ xh,
-                                                                 float4 *__restrict__ xa) {
+                                                                 unsigned short *__restrict__ rr, float4 *__restrict__ xa) {
     // (stand-alone form, ET_KMEANS_PACK_FUSED=0: by default the exact first iteration of the fit writes the copy)
     constexpr int d = 6;
     PackOut po;
     po.xh = xh;
+    po.rr = rr;
     po.xa = xa;
     if (!packed_header(X, N, state, hdr, po.mu, po.s)) return;
     const int tid = threadIdx.x;
@@ -1294,21 +1302,19 @@ __device__ __forceinline__ void packed_drain(const unsigned *q, int cnt, int K, 
     }
 }
 
-// A pass's requests.  The B operand of the matrix instruction for a point is the point's 16-byte record as it lies in
-// memory ({x0 x1, x2 x3, x4 x5, R 0} as f16), and BOTH lanes of a column hold it: lane (col, half) requests the records of
-// points 32 i + col of the pass's lower 128-point block (tiles L0..L3) and of its upper block (U0..U3), i = 0..3 -- 512
-// contiguous bytes per request and half-wave, the two half-waves asking for the same addresses (the memory side sees the
-// bytes once).  No exchange between the half-waves (v_permlane32_swap: two issue slots and two copies per dword), no
-// assembling of operands from rows.  A lane's own points -- whose old labels it reads and which it certifies -- are the
-// lower block's for half 0, the upper block's for half 1.  Buffer requests: a pass index past the end (g < 0) or a record
-// past N is out of range, returns zeros and costs no traffic, so no request sits under a branch and the two register sets
-// of the loop (unrolled by two: a set is never copied) are waited for by count.
+// Dual form of a pass's loads: BOTH lanes of a column request the rows of the column's point in the lower 128-point block
+// (-> the B operand of tile L) and in the upper block (tile U) -- the two half-waves ask for the same addresses, the memory
+// side sees the bytes once -- instead of exchanging their own rows with v_permlane32_swap (2 issue slots + 2 copies per
+// dword).  A lane's own point is the lower block's for half 0, the upper block's for half 1.  Buffer loads: a pass index
+// past the end (g < 0: offset 0xfffffff0) or rows past N are out of range, return zeros and cost no traffic, so the request
+// needs no branch around it and the two register sets of the loop (unrolled by two: no copies) are waited for by count.
 struct PkRows {
-    u32x4 vL[4], vU[4];
-    unsigned lb[4];  // old labels of the own points
+    u32x4 vL[3], vU[3];
+    unsigned rL[2], rU[2];
+    unsigned lp;
 };
 struct PkSrc {
-    __amdgpu_buffer_rsrc_t rec, lab;
+    __amdgpu_buffer_rsrc_t row[3], rr, lab;
 };
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t pk_rsrc(const void *base, int64_t bytes) {
     const unsigned long long b = reinterpret_cast<unsigned long long>(base);
@@ -1316,18 +1322,24 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pk_rsrc(const void *base, int6
     const int nb = __builtin_amdgcn_readfirstlane((int)bytes);
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, nb, 0x00020000);
 }
-constexpr int64_t kPkMaxN = 1ll << 26;  // 16 N bytes of records, every byte offset below 2^31
-__device__ __forceinline__ void packed_issue(const PkSrc &src, int64_t gg, unsigned lane_off, unsigned own_off, PkRows &o) {
-    constexpr unsigned kOut = 0xfffffff0u;
-    const unsigned oL = gg >= 0 ? (unsigned)gg * 4096u + lane_off : kOut;  // record of point 256 g + col
+constexpr int64_t kPkDualMaxN = 1ll << 28;  // 4 N bytes per row and every byte offset stay below 2^31
+__device__ __forceinline__ void packed_issue_dual(const PkSrc &src, int64_t gg, unsigned lane_off, unsigned own_off, PkRows &o) {
+    // byte offset of the lower block's four points of this column inside a row of dwords
+    const unsigned oL = gg >= 0 ? (unsigned)gg * 1024u + lane_off : 0xfffffff0u;
+    const unsigned oU = gg >= 0 ? oL + 512u : 0xfffffff0u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        o.vL[i] = __builtin_amdgcn_raw_buffer_load_b128(src.rec, gg >= 0 ? oL + 512u * i : kOut, 0, 0);
-        o.vU[i] = __builtin_amdgcn_raw_buffer_load_b128(src.rec, gg >= 0 ? oL + 2048u + 512u * i : kOut, 0, 0);
+    for (int p = 0; p < 3; ++p) {
+        o.vL[p] = __builtin_amdgcn_raw_buffer_load_b128(src.row[p], oL, 0, 0);
+        o.vU[p] = __builtin_amdgcn_raw_buffer_load_b128(src.row[p], oU, 0, 0);
     }
-    const unsigned ol = gg >= 0 ? (oL >> 4) + own_off : kOut;  // own point 256 g + 128 half + col (+ 32 i)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o.lb[i] = __builtin_amdgcn_raw_buffer_load_b8(src.lab, gg >= 0 ? ol + 32u * i : kOut, 0, 0);
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t a = __builtin_amdgcn_raw_buffer_load_b64(src.rr, oL >> 1, 0, 0);
+    const u32x2_t b = __builtin_amdgcn_raw_buffer_load_b64(src.rr, gg >= 0 ? oU >> 1 : 0xfffffff0u, 0, 0);
+    o.rL[0] = a.x;
+    o.rL[1] = a.y;
+    o.rU[0] = b.x;
+    o.rU[1] = b.y;
+    o.lp = __builtin_amdgcn_raw_buffer_load_b32(src.lab, gg >= 0 ? (oL >> 2) + own_off : 0xfffffff0u, 0, 0);
 }
 
 // ---- the per-launch tables of packed_assign_body, as functions of a cluster's centroid (c[0..5], |c|^2 as stage_centroids
@@ -1350,21 +1362,18 @@ __device__ __forceinline__ void pk_table_row(const float (&c)[6], float bn, cons
     // second (1 + 2^-9), which covers the roundings of th's own evaluation, used to be a multiplication per point
     row[7] = (fmaf(9.86e-4f, Q, 9.7e-7f * M) * kUp + 1e-30f) * kUp;
     row[8] = ((fmaf(9.6e-7f * Q, Q, 2.4e-7f * Q) + fmaf(4.85e-7f * M, M, 1e-12f)) * kUp) * kUp;
-    // the constant of the matrix estimate's upper bound,  u_j - epsR(R) = t'_j + R ebd_r + ebd_1  with  t'_j = 2 p.q_j - |q_j|^2:
-    // -|q_j|^2 + ebd_1, exact in fp32 -- it is the accumulator the matrix instruction starts from (pk_a_operand has ebd_r)
-    const float ebd_1 = fmaf(5.4e-6f * Q, Q, 4.8e-7f * Q) + fmaf(4.85e-7f * M, M, 2e-10f);
-    const float nb = fmaf(-qq, s2, ebd_1 * kUp);
-    row[9] = fmaf(fabsf(nb), 3.814697265625e-6f, nb) + 1e-12f;
 }
 // th's two cluster-independent coefficients with the same factor inside: 2^-22 |y| (the chain's rounding) and 7.4e-6 R^2
 constexpr float kThY = 2.384185791015625e-7f * 1.001953125f, kThR2 = 7.4e-6f * 1.001953125f;
 
 // A operand of a lane's cluster (layout as in filter_assign_body): lower half-wave lanes carry k-slots 0..7 =
-// {hi(2 q)_0..5, 0, 0}, upper half-wave lanes k-slots 8..15 = {lo(2 q)_0..5, slope (against the record's R), 0}
+// {hi(2 q)_0..5, -|q|^2 + const as hi, lo * 2^10}, upper half-wave lanes k-slots 8..15 = {lo(2 q)_0..5, slope, 0}
 __device__ __forceinline__ u32x4 pk_a_operand(const float (&c)[6], float bn, bool valid, const float *hdr, float s, float m_up,
                                               int half) {
     constexpr float kUp = 1.001953125f, kTiny = 1.1920928955078125e-7f;  // (1 + 2^-9) v + 2^-23 survives the rtz to f16
+    const float s2 = s * s;
     unsigned ch[3] = {0u, 0u, 0u}, cl[3] = {0u, 0u, 0u};
+    float nb = -60000.0f;
     unsigned ebd = 0u;
     if (valid) {
         float ct[6], qq = 0.f;
@@ -1376,11 +1385,18 @@ __device__ __forceinline__ u32x4 pk_a_operand(const float (&c)[6], float bn, boo
 #pragma unroll
         for (int p = 0; p < 3; ++p) split_f16(ct[2 * p], ct[2 * p + 1], 2.0f * s, ch[p], cl[p]);
         const float Q = sqrtf(qq) * s * 1.001f + 1e-30f, M = m_up + sqrtf(bn) * s * 1.001f;
-        // u_j - epsR(R) = t'_j + R ebd_r + ebd_1  (ebd_1: pk_table_row)
+        // u_j - epsR(R) = t'_j + R ebd_r + ebd_1
         const float ebd_r = fmaf(9.95e-4f, Q, fmaf(9.7e-7f, M, 4.8e-7f));
+        // (+ 2e-10: the 2^-34 of E2 and, for a cluster so close to mu that -|q|^2 + const is positive, what the
+        // round-toward-zero hi / lo pair below can fall short of it: < 2^-24 / 1024 = 5.8e-11)
+        const float ebd_1 = fmaf(5.4e-6f * Q, Q, 4.8e-7f * Q) + fmaf(4.85e-7f * M, M, 2e-10f);
+        nb = fmaf(-qq, s2, ebd_1 * kUp);
+        nb = fmaf(fabsf(nb), 3.814697265625e-6f, nb) + 1e-12f;  // + 2^-18 |nb|: the hi / lo pair below never rounds it down
         ebd = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(fmaf(ebd_r, kUp, kTiny), 0.f));
     }
-    return half == 0 ? u32x4{ch[0], ch[1], ch[2], 0u} : u32x4{cl[0], cl[1], cl[2], ebd};
+    const auto nh = __builtin_amdgcn_cvt_pkrtz(nb, 0.f);
+    const unsigned bnd = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(nb, (nb - (float)nh[0]) * 1024.0f));
+    return half == 0 ? u32x4{ch[0], ch[1], ch[2], bnd} : u32x4{cl[0], cl[1], cl[2], ebd};
 }
 
 // The tables above from the NEW centroids `cen` (d x K, LDS) while the update that made them is still reducing its error and
@@ -1447,13 +1463,14 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
         // its own over X, kmeans_pack_kernel, costs 175-190 us)
         PackOut po;
         po.xh = const_cast<unsigned *>(pk.xh);
+        po.rr = const_cast<unsigned short *>(pk.rr);
         po.xa = const_cast<float4 *>(pk.xa);
         if (!packed_header(X, N, state, const_cast<PackedHeader *>(pk.hdr), po.mu, po.s)) po.xh = nullptr;
         assign_body_valu<6, 4>(X, N, d, K, state, cen, nullptr, labels, nullptr, lanes, copy_mask, po);
         return;
     }
     bool fallback = st_iter <= 0 || !st_fast_ok || pk_ok == 0u;
-    fallback = fallback || N > kPkMaxN;  // (the records are requested through 32-bit buffer offsets)
+    fallback = fallback || N > kPkDualMaxN || (N & 3) != 0;  // (the rows are requested through 32-bit buffer offsets, 16 bytes at a time)
     if (!fallback) {  // every |s (c - mu)| inside the packed range?  (cen: d x K floats in LDS, the same in every workgroup)
         if (range_bad >= 0) {  // (the caller's update has looked already: uniform over the workgroup)
             fallback = range_bad != 0;
@@ -1529,38 +1546,51 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
         }
         return g < n_groups ? g : -1;
     };
-    // the accumulator a tile starts from: -|q_j|^2 + const of the lane's clusters (register r of half h: cluster
-    // 8 (r / 4) + 2 (r % 4) + h), exact in fp32; clusters that do not exist lose against everything
-    f32x16 c0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int j = 8 * (r >> 2) + 2 * (r & 3) + half;
-        c0[r] = (r < NREGS && j < K) ? sL[j * kPkRow + 9] : -1e30f;
-    }
     PkSrc src;
-    src.rec = pk_rsrc(pk.xh, 16 * N);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) src.row[p] = pk_rsrc(pk.xh + (int64_t)p * N, 4 * N);
+    src.rr = pk_rsrc(pk.rr, 2 * N);
     src.lab = pk_rsrc(labels, N);
     const unsigned lane_off = 16u * (unsigned)col, own_off = 128u * (unsigned)half;
-    // one pass on the records in `cu` (pass index gc); the other register set is in flight meanwhile
+    const unsigned ones = 0x14003c00u;  // {1, 2^-10}: partners of {hi, lo * 2^10} of -|q|^2 + const
+    // one pass on the rows in `cu` (pass index gc); the other register set is in flight meanwhile
     auto process = [&](const PkRows &cu, int64_t gc) __attribute__((always_inline)) {
-        const int64_t n0 = gc * 256 + 128 * half + col;  // own points: n0 + 32 i
-        unsigned long long um[4];  // wave-uniform masks of the lanes whose i-th own point stays undecided
+        const int64_t n = gc * 256 + 128 * half + 4 * col;
+        const bool valid = n < N;
+        const unsigned old_packed = cu.lp;
+        unsigned undecided = 0u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u32x4 own = half ? cu.vU[i] : cu.vL[i];
+        for (int q = 0; q < 4; ++q) {
+            unsigned w[3];
+            u32x4 bLo, bUp;
+            const unsigned rpL = cu.rL[q >> 1], rpU = cu.rU[q >> 1];
+            // low half: the point's R (the high half meets a zero of the A operand)
+            const unsigned r16L = (q & 1) ? (rpL >> 16) : rpL, r16U = (q & 1) ? (rpU >> 16) : rpU;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                bLo[p] = cu.vL[p][q];
+                bUp[p] = cu.vU[p][q];
+                w[p] = half ? bUp[p] : bLo[p];
+            }
+            bLo[3] = half ? r16L : ones;
+            bUp[3] = half ? r16U : ones;
+            const unsigned r16 = half ? r16U : r16L;
             // certified lower bound of the old label's value: fp32 chain on the f16 coordinates
-            const int ol = (int)cu.lb[i];
+            const int ol = (int)((old_packed >> (8 * q)) & 0xffu);
             const float4 r0 = l4[3 * ol], r1 = l4[3 * ol + 1], r2 = l4[3 * ol + 2];
             float y = r1.z;  // -|q_l|^2 s^2
-            y = fma_mix_lo(own[0], r0.x, y);
-            y = fma_mix_hi(own[0], r0.y, y);
-            y = fma_mix_lo(own[1], r0.z, y);
-            y = fma_mix_hi(own[1], r0.w, y);
-            y = fma_mix_lo(own[2], r1.x, y);
-            y = fma_mix_hi(own[2], r1.y, y);
-            const f16x8 BL = __builtin_bit_cast(f16x8, cu.vL[i]), BU = __builtin_bit_cast(f16x8, cu.vU[i]);
-            const f32x16 accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, BL, c0, 0, 0, 0);
-            const f32x16 accU = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, BU, c0, 0, 0, 0);
+            y = fma_mix_lo(w[0], r0.x, y);
+            y = fma_mix_hi(w[0], r0.y, y);
+            y = fma_mix_lo(w[1], r0.z, y);
+            y = fma_mix_hi(w[1], r0.w, y);
+            y = fma_mix_lo(w[2], r1.x, y);
+            y = fma_mix_hi(w[2], r1.y, y);
+            const f16x8 BL = __builtin_bit_cast(f16x8, bLo), BU = __builtin_bit_cast(f16x8, bUp);
+            f32x16 accL, accU;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accL[r] = accU[r] = 0.f;
+            accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, BL, accL, 0, 0, 0);
+            accU = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, BU, accU, 0, 0, 0);
             float bL, sL_, bU, sU;
             top2<NREGS>(accL, bL, sL_);
             top2<NREGS>(accU, bU, sU);
@@ -1569,25 +1599,21 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
             const float b0 = __uint_as_float(rb[0]), b1 = __uint_as_float(rb[1]);
             const float s0 = __uint_as_float(rq[0]), s1 = __uint_as_float(rq[1]);
             const float second = vmed3(b0, b1, vmax(s0, s1));  // second largest upper bound
-            // th(R) (1 + 2^-9): the factor is inside the coefficients (pk_table_row: r1.w, r2.x; kThY, kThR2)
-            const float R = (float)__builtin_bit_cast(_Float16, (unsigned short)(own[3] & 0xffffu));
+            // th(R) (1 + 2^-9): the factor is inside the coefficients (pk_table_row: r1.w, r2.x; kThY, kThR2 here)
+            const float R = (float)__builtin_bit_cast(_Float16, (unsigned short)(r16 & 0xffffu));
             const float th = fmaf(fabsf(y), kThY, fmaf(R, fmaf(R, kThR2, r1.w), r2.x));
             const bool keep = y - second > th;
-            um[i] = __builtin_amdgcn_ballot_w64(!keep);
+            undecided |= (valid && !keep) ? (1u << q) : 0u;
         }
-        if (gc * 256 + 256 > N) {  // (the shard's last pass: own points past the end decide nothing)
+        if (__ballot(undecided != 0u)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) um[i] &= __builtin_amdgcn_ballot_w64(n0 + 32 * i < N);
-        }
-        if ((um[0] | um[1] | um[2] | um[3]) != 0ull) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned long long m = um[i];
-                const bool push = (m >> lane) & 1ull;
+            for (int q = 0; q < 4; ++q) {
+                const bool push = (undecided >> q) & 1u;
+                const unsigned long long m = __ballot(push);
                 if (push) {
                     unsigned *e = queue + qn + __popcll(m & ((1ull << lane) - 1ull));
-                    e[0] = (unsigned)(n0 + 32 * i);
-                    e[kFilterSlots] = cu.lb[i];
+                    e[0] = (unsigned)(n + q);
+                    e[kFilterSlots] = (old_packed >> (8 * q)) & 0xffu;
                 }
                 qn += __popcll(m);
 #ifdef ET_FILTER_DEBUG
@@ -1615,14 +1641,14 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
 #define KM_WS_PASS(call) call
 #endif
     int64_t g = take();
-    packed_issue(src, g, lane_off, own_off, ra);
+    packed_issue_dual(src, g, lane_off, own_off, ra);
     while (g >= 0) {
         const int64_t g2 = take();
-        packed_issue(src, g2, lane_off, own_off, rb);
+        packed_issue_dual(src, g2, lane_off, own_off, rb);
         KM_WS_PASS(process(ra, g));
         if (g2 < 0) break;
         g = take();
-        packed_issue(src, g, lane_off, own_off, ra);
+        packed_issue_dual(src, g, lane_off, own_off, ra);
         KM_WS_PASS(process(rb, g2));
     }
 #undef KM_WS_PASS
@@ -2015,7 +2041,7 @@ __device__ __forceinline__ void fold_lanes(const long long *__restrict__ lanes, 
 }
 
 template <int NREGS, bool SIM>
-__global__ __launch_bounds__(kChainMaxThreads) void kmeans_lloyd_chain_kernel(
+__global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     const float *__restrict__ X, int64_t N, int K, const LloydChain ch, uint8_t *__restrict__ labels, float tol,
     float *trace, int has_pending) {
     constexpr int d = 6;
@@ -2990,6 +3016,7 @@ struct KmWorkspace {
     // packed copy of the points for the trace-less chained loop (kmeans_pack_kernel); nullptr when the shape has none
     PackedHeader *pk_hdr;
     unsigned *pk_xh;
+    unsigned short *pk_rr;
     float4 *pk_xa;
     size_t bytes;
 };
@@ -3055,12 +3082,15 @@ static KmWorkspace km_carve(void *base, int64_t N, int d, int K) {
     off = align_up(off + 2 * sizeof(unsigned), 256);
     w.pk_hdr = nullptr;
     w.pk_xh = nullptr;
+    w.pk_rr = nullptr;
     w.pk_xa = nullptr;
-    if (km_packed_shape(N, d, K)) {  // 48 B per point
+    if (km_packed_shape(N, d, K)) {  // 46 B per point
         w.pk_hdr = (PackedHeader *)(p + off);
         off = align_up(off + sizeof(PackedHeader), 256);
         w.pk_xh = (unsigned *)(p + off);
-        off = align_up(off + 16 * (size_t)N, 256);
+        off = align_up(off + 12 * (size_t)N, 256);
+        w.pk_rr = (unsigned short *)(p + off);
+        off = align_up(off + 2 * (size_t)N, 256);
         w.pk_xa = (float4 *)(p + off);
         off = align_up(off + 32 * (size_t)N, 256);
     }
@@ -3442,7 +3472,7 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
     StateRing *ring = StateRing::get(&rc);
     if (!ring) return rc;
     const bool want_sim = trace != nullptr;
-    const int threads = std::min(km_loop_threads(N, false), kChainMaxThreads);
+    const int threads = km_loop_threads(N, false);
     const size_t plen = km_plen(d, K), lds = km_filter_lds_bytes(d, K, threads);
     // rows that allow 16-byte loads and enough points: the filter body; any other shard of a sharded fit: the exact scan,
     // one point per lane, inside the same kernel (a single-GPU fit only comes here with vec_ok)
@@ -3473,7 +3503,7 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
         const int64_t quads = N / 4;
         const int pgrid = (int)std::min<int64_t>((quads + kKmThreads - 1) / kKmThreads, 1024);
         hipLaunchKernelGGL(kmeans_pack_kernel, dim3(pgrid), dim3(kKmThreads), 0, st, X, N, (const et_kmeans_state *)state,
-                           w.pk_hdr, w.pk_xh, w.pk_xa);
+                           w.pk_hdr, w.pk_xh, w.pk_rr, w.pk_xa);
         ET_LAUNCH_CHECK();
     }
     auto chain_for = [&](int t) {
@@ -3495,7 +3525,7 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
         // memory side), and it is what a sharded fit puts on the wire
         ch.compact = 1;
         ch.vec_ok = vec_ok ? 1 : 0;
-        ch.pk = packed ? LloydPacked{w.pk_xh, w.pk_xa, w.pk_hdr, pack_fused ? 1 : 0} : LloydPacked{nullptr, nullptr, nullptr, 0};
+        ch.pk = packed ? LloydPacked{w.pk_xh, w.pk_rr, w.pk_xa, w.pk_hdr, pack_fused ? 1 : 0} : LloydPacked{nullptr, nullptr, nullptr, nullptr, 0};
         return ch;
     };
     int grid = 0, launched = 0;
