@@ -1250,16 +1250,14 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_pack_kernel(const float *__
     }
 }
 
-// a += f16(w.lo or w.hi) * b, one v_fma_mix_f32 (the f16 operand is converted exactly)
+// a += f16(w.lo or w.hi) * b: the compiler folds the (exact) conversion into one v_fma_mix_f32.  Compiler-visible on
+// purpose: these instructions sit between matrix instructions, and the hazard recogniser does not look inside inline
+// assembly (an asm helper's output once landed in a register an earlier v_mfma was still reading).
 __device__ __forceinline__ float fma_mix_lo(unsigned w, float b, float a) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(b), "v"(a));
-    return r;
+    return fmaf((float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)), b, a);
 }
 __device__ __forceinline__ float fma_mix_hi(unsigned w, float b, float a) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(b), "v"(a));
-    return r;
+    return fmaf((float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)), b, a);
 }
 
 constexpr int kPkQueue = 2 * kFilterSlots;  // per wavefront: point index, old label
