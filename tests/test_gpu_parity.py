@@ -940,6 +940,30 @@ def test_kmeans_packed_copy_short_fits(ops, oracle, dev, et_option, max_iter):
     assert np.array_equal(N_(plain["centroids"]), N_(res["centroids"]), equal_nan=True)
 
 
+@pytest.mark.parametrize("extra", [4, 124, 128, 132, 252])
+def test_kmeans_packed_copy_shard_tails(ops, oracle, dev, et_option, extra):
+    """A pass of the packed body is 256 points: both lanes of a column request the column's rows of the lower AND of the
+    upper 128-point block through buffer requests whose out-of-range offsets return zeros.  Shards whose last pass has one
+    quad, an almost full lower block, no upper block, one quad of the upper block, all but one quad: against the oracle
+    and the fp32 filter, bit for bit."""
+    from eigentrajectory_amd.synth import gaussian_points_np
+    et_option("kmeans_packed_min", 1024)
+    et_option("kmeans_loop", "chain")
+    n = 256 * 37 + extra
+    x = gaussian_points_np(6, n, seed=100 + extra, n_blobs=9)
+    x[:, n - 3:] *= np.float32(3.0)  # the shard's last points are ones whose labels move
+    x_dev = T(x, dev)
+    c0, _ = oracle.kmeans_init_farthest(x, 20, n - 1)
+    ref = oracle.kmeans_fit(x, c0, 15, 1e-4)
+    res = ops.kmeans_fit(x_dev, T(c0, dev), 15, 1e-4, trace=False)
+    assert res["n_iter"] == ref["n_iter"]
+    assert np.array_equal(N_(res["labels"]), ref["labels"])
+    assert np.array_equal(N_(res["centroids"]), ref["centroids"])
+    et_option("kmeans_packed", 0)
+    plain = ops.kmeans_fit(x_dev, T(c0, dev), 15, 1e-4, trace=False)
+    assert torch.equal(plain["labels"], res["labels"])
+
+
 def test_kmeans_packed_copy_vs_oracle(ops, oracle, dev, et_option):
     """the packed path against the CPU oracle itself (one case: the oracle needs ~1 s per iteration at this size)"""
     import ctypes as C
