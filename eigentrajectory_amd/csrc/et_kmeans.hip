@@ -2070,7 +2070,10 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     const unsigned st_word = reinterpret_cast<const unsigned *>(ch.st_rd)[(int)threadIdx.x < kStateWords ? (int)threadIdx.x : 0];
     const float cen0 = ch.cen_rd[(int)threadIdx.x < d * K ? (int)threadIdx.x : 0];
     FoldRegs fr;
-    fold_issue(ch.lanes_rd, ch.tot_rd, plen, fr, ch.compact != 0);  // (the filter kernels' launch sizes always fit: fold_fits())
+    // (the delta table of the chained loop is ALWAYS the compact one-copy form -- host side, chain_for() --: a constant here,
+    // so that the sweeps of the 16-copy form are not compiled in; their register arrays, indexed under a runtime flag, ended
+    // up in scratch memory: a store -> load round trip in every launch's prologue and a private segment per wavefront)
+    fold_issue(ch.lanes_rd, ch.tot_rd, plen, fr, true);
     if (done0) {  // converged earlier (or bad input flagged before the loop): keep the published copies in step
         if (wg0) {
             if (threadIdx.x == 0) {
@@ -2092,7 +2095,7 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     if (!SIM && threadIdx.x < 9) sPkHdr[threadIdx.x] = pk_word;
     if ((int)threadIdx.x < kStateWords) reinterpret_cast<unsigned *>(&sSt)[threadIdx.x] = st_word;  // the state block, word by word
     if (has_pending) {
-        fold_combine(fr, iter0 > 0, plen, sTot, ch.compact != 0);
+        fold_combine(fr, iter0 > 0, plen, sTot, true);
         __syncthreads();
         KM_PSTAMP(2);
         // (trace-less fit on the packed copy: the next assignment's tables are made by wavefronts 2, 3 and 4 beside the
@@ -2119,15 +2122,14 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
         for (int e = threadIdx.x; e < d * K; e += (int)blockDim.x) ch.cen_wr[e] = sCen[e];
         if (has_pending)
             for (int e = threadIdx.x; e < plen; e += (int)blockDim.x) ch.tot_wr[e] = sTot[e];
-        const int total = plen * kAccLanes;
-        for (int i = threadIdx.x; i < total; i += (int)blockDim.x) ch.lanes_zero[i] = 0;
+        for (int i = threadIdx.x; i < plen; i += (int)blockDim.x) ch.lanes_zero[i] = 0;  // (compact: plen entries in use)
         // sCen / sTot lie inside the area the assignment bodies clear for their accumulators: this workgroup's other
         // wavefronts must not start clearing while the ones above still read (uniform per workgroup: only workgroup 0 waits)
         __syncthreads();
     }
     KM_PSTAMP(4);
     if (done1) return;  // the update just applied met the tolerance: no further assignment (kmeans.py:239)
-    const int copy_mask = ch.compact ? -1 : kAccLanes - 1;
+    const int copy_mask = -1;
     // a shard whose rows do not allow 16-byte loads (sharded runs cut the points anywhere), or a tiny one: the plain exact
     // scan, one point per lane, inside the same launch -- which loop form a sharded fit takes then depends on (d, K)
     // alone and every rank knows it without asking the others
