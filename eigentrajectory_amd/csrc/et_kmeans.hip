@@ -418,6 +418,9 @@ __global__ void kmeans_begin_kernel(et_kmeans_state *state, int64_t n_total, con
 // arrivals per address, nothing to fold afterwards except kAccLanes values per entry, and no arrivals at all for the
 // entries a workgroup did not change.
 constexpr int kAccLanes = 16;
+// entries between two compact copies of the delta table (a table has room for kAccLanes * plen entries: the host side
+// lowers the number of copies until they fit)
+__host__ __device__ __forceinline__ int compact_pitch(int plen) { return (plen + 31) & ~31; }
 
 __device__ __forceinline__ void emit_partials(const long long *sAcc, int plen, int n_threads,
                                               long long *__restrict__ block_partials, long long *__restrict__ lanes,
@@ -426,11 +429,14 @@ __device__ __forceinline__ void emit_partials(const long long *sAcc, int plen, i
     if (lanes) {
         // copy_mask = 15: sixteen copies per entry, [entry][copy]; 0: one copy at the same stride (small persistent
         // grids); -1: one copy, entries adjacent (the sharded loop's wire format)
+        // ... -C (C = 2, 4, 8): C compact copies, kCompactPitch entries apart, workgroup b adds onto copy b % C (the chained
+        // loop on one GPU: 256 workgroups' arrivals on one address are served one after the other, ~15 ns each)
         const int stride = copy_mask < 0 ? 1 : kAccLanes, mask = copy_mask < 0 ? 0 : copy_mask;
+        const int base = copy_mask < -1 ? (int)(blockIdx.x & (unsigned)(-copy_mask - 1)) * compact_pitch(plen) : 0;
         for (int i = tx; i < plen; i += n_threads) {
             const long long v = sAcc[i];
             if (v != 0)
-                atomicAdd(reinterpret_cast<unsigned long long *>(&lanes[i * stride + (blockIdx.x & mask)]),
+                atomicAdd(reinterpret_cast<unsigned long long *>(&lanes[base + i * stride + (blockIdx.x & mask)]),
                           (unsigned long long)v);
         }
     } else {
@@ -1959,6 +1965,7 @@ struct LloydChain {
     // sharded loop: ONE copy of the delta table, entries adjacent (what travels over the wire between two launches is
     // then the d K + K + 2 int64 that carry the information, 1.1 KB, not the 16-copy table)
     int compact;
+    int copies;  // compact copies of the delta table in use (1: sharded loop -- the wire format; a power of two <= 8 else)
     int vec_ok;  // this shard's rows allow 16-byte loads (N % 4 == 0, aligned) and it has >= 1024 points: filter body
     LloydPacked pk;  // pk.xh != nullptr: trace-less iterations run on the packed copy (packed_assign_body)
 };
@@ -1975,11 +1982,21 @@ struct FoldRegs {
 };
 __device__ __forceinline__ bool fold_fits(int plen) { return kFoldSweeps * (int)blockDim.x >= plen * kAccLanes; }
 __device__ __forceinline__ void fold_issue(const long long *__restrict__ lanes, const long long *__restrict__ tot_prev,
-                                           int plen, FoldRegs &r, bool compact = false) {
+                                           int plen, FoldRegs &r, bool compact = false, int copies = 1) {
     const int total = plen * kAccLanes, n_threads = (int)blockDim.x;
-    if (compact) {  // one copy, entries adjacent: one load per entry (plen <= 226 <= blockDim.x)
+    if (compact) {  // entries adjacent: one load per entry and copy (plen <= 226 <= blockDim.x), all requested together
         const int ci = (int)threadIdx.x < plen ? (int)threadIdx.x : 0;
-        r.v[0] = lanes[ci];
+        const int pitch = compact_pitch(plen);
+        long long v = lanes[ci];
+        long long x[3] = {0, 0, 0};
+        if (copies > 1) x[0] = lanes[ci + pitch];
+        if (copies > 2) {
+            x[1] = lanes[ci + 2 * pitch];
+            x[2] = lanes[ci + 3 * pitch];
+        }
+        long long y = 0;
+        for (int c = 4; c < copies; ++c) y += lanes[ci + c * pitch];
+        r.v[0] = ((v + x[0]) + (x[1] + x[2])) + y;  // (integers: any order)
         r.prev[0] = tot_prev[ci];
         return;
     }
@@ -2013,10 +2030,13 @@ __device__ __forceinline__ void fold_combine(const FoldRegs &r, bool have_prev, 
     }
 }
 __device__ __forceinline__ void fold_lanes(const long long *__restrict__ lanes, const long long *__restrict__ tot_prev,
-                                           bool have_prev, int plen, long long *sTot, bool compact = false) {
+                                           bool have_prev, int plen, long long *sTot, bool compact = false, int copies = 1) {
     if (compact) {
-        for (int e = threadIdx.x; e < plen; e += (int)blockDim.x)
-            sTot[e] = ((have_prev && e < plen - 2) ? tot_prev[e] : 0) + lanes[e];
+        for (int e = threadIdx.x; e < plen; e += (int)blockDim.x) {
+            long long v = lanes[e];
+            for (int c = 1; c < copies; ++c) v += lanes[e + c * compact_pitch(plen)];
+            sTot[e] = ((have_prev && e < plen - 2) ? tot_prev[e] : 0) + v;
+        }
         return;
     }
     if (fold_fits(plen)) {
@@ -2073,7 +2093,7 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     // (the delta table of the chained loop is ALWAYS the compact one-copy form -- host side, chain_for() --: a constant here,
     // so that the sweeps of the 16-copy form are not compiled in; their register arrays, indexed under a runtime flag, ended
     // up in scratch memory: a store -> load round trip in every launch's prologue and a private segment per wavefront)
-    fold_issue(ch.lanes_rd, ch.tot_rd, plen, fr, true);
+    fold_issue(ch.lanes_rd, ch.tot_rd, plen, fr, true, ch.copies);
     if (done0) {  // converged earlier (or bad input flagged before the loop): keep the published copies in step
         if (wg0) {
             if (threadIdx.x == 0) {
@@ -2122,14 +2142,14 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
         for (int e = threadIdx.x; e < d * K; e += (int)blockDim.x) ch.cen_wr[e] = sCen[e];
         if (has_pending)
             for (int e = threadIdx.x; e < plen; e += (int)blockDim.x) ch.tot_wr[e] = sTot[e];
-        for (int i = threadIdx.x; i < plen; i += (int)blockDim.x) ch.lanes_zero[i] = 0;  // (compact: plen entries in use)
+        for (int i = threadIdx.x; i < ch.copies * compact_pitch(plen); i += (int)blockDim.x) ch.lanes_zero[i] = 0;  // (the compact copies in use)
         // sCen / sTot lie inside the area the assignment bodies clear for their accumulators: this workgroup's other
         // wavefronts must not start clearing while the ones above still read (uniform per workgroup: only workgroup 0 waits)
         __syncthreads();
     }
     KM_PSTAMP(4);
     if (done1) return;  // the update just applied met the tolerance: no further assignment (kmeans.py:239)
-    const int copy_mask = -1;
+    const int copy_mask = -ch.copies;  // (-1: one compact copy)
     // a shard whose rows do not allow 16-byte loads (sharded runs cut the points anywhere), or a tiny one: the plain exact
     // scan, one point per lane, inside the same launch -- which loop form a sharded fit takes then depends on (d, K)
     // alone and every rank knows it without asking the others
@@ -2165,7 +2185,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_chain_finalize_kernel(const
         for (int e = threadIdx.x; e < plen; e += kKmThreads) partials[e] = ch.tot_rd[e];
         return;
     }
-    fold_lanes(ch.lanes_rd, ch.tot_rd, ch.st_rd->iter > 0, plen, sTot, ch.compact != 0);
+    fold_lanes(ch.lanes_rd, ch.tot_rd, ch.st_rd->iter > 0, plen, sTot, ch.compact != 0, ch.copies);
     __syncthreads();
     for (int e = threadIdx.x; e < plen; e += kKmThreads) partials[e] = sTot[e];
     if (threadIdx.x == 0) *state = *ch.st_rd;
@@ -3508,6 +3528,9 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
                            w.pk_hdr, w.pk_xh, w.pk_rr, w.pk_xa);
         ET_LAUNCH_CHECK();
     }
+    int chain_copies = options().kmeans_chain_copies.load(std::memory_order_relaxed);
+    if (chain_copies != 1 && chain_copies != 2 && chain_copies != 4 && chain_copies != 8) chain_copies = 2;
+    while (chain_copies > 1 && (size_t)chain_copies * compact_pitch((int)plen) > plen * kAccLanes) chain_copies >>= 1;
     auto chain_for = [&](int t) {
         LloydChain ch;
         ch.st_rd = w.chain_state[t & 1];
@@ -3526,6 +3549,9 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
         // instead of folding 2272, and <= 256 arrivals per address spread over the launch's tail are absorbed by the
         // memory side), and it is what a sharded fit puts on the wire
         ch.compact = 1;
+        // ... and on one GPU a few of them (option kmeans_chain_copies, default 2): a launch's 256 workgroups add their deltas
+        // within a few microseconds of each other, and arrivals on one address are served one after the other
+        ch.copies = hook.reduce ? 1 : chain_copies;
         ch.vec_ok = vec_ok ? 1 : 0;
         ch.pk = packed ? LloydPacked{w.pk_xh, w.pk_rr, w.pk_xa, w.pk_hdr, pack_fused ? 1 : 0} : LloydPacked{nullptr, nullptr, nullptr, nullptr, 0};
         return ch;

@@ -17,6 +17,7 @@ struct Options {
     std::atomic<int> kmeans_init_tiles{1};        // 0: farthest-first steps look at every point's running similarity
     std::atomic<int> kmeans_pack_fused{1};        // 0: the packed copy is written by a pass of its own before the loop
     std::atomic<int> kmeans_filter_threads{0};    // 256 .. 1024 (multiple of 64): threads per workgroup of the Lloyd kernels; 0: chosen per shard
+    std::atomic<int> kmeans_chain_copies{2};      // 1, 2, 4, 8: compact copies of the delta table the chained Lloyd kernel of a single-GPU fit adds its deltas onto
     std::atomic<int> kmeans_loop_grid{0};         // > 0: at most this many workgroups for the chained Lloyd kernel (grid sweep); 0: one resident round
     std::atomic<int> kmeans_loop{'a'};            // 'a'uto, 'c'hain (one launch per iteration), 'p'ersist (one launch per fit)
     std::atomic<int> reforder_filter_min_lp{9};  // reference-order Lloyd: level power from which the matrix-core label filter is used (4: always, 9: never = default: it measured slower)

@@ -30,6 +30,7 @@ const Key *keys(int *n) {
         {"kmeans_init_tiles", Key::kInt, &o.kmeans_init_tiles, nullptr},
         {"kmeans_pack_fused", Key::kInt, &o.kmeans_pack_fused, nullptr},
         {"kmeans_filter_threads", Key::kInt, &o.kmeans_filter_threads, nullptr},
+        {"kmeans_chain_copies", Key::kInt, &o.kmeans_chain_copies, nullptr},
         {"kmeans_loop_grid", Key::kInt, &o.kmeans_loop_grid, nullptr},
         {"kmeans_loop", Key::kChar, &o.kmeans_loop, "acp"},
         {"reforder_filter_min_lp", Key::kInt, &o.reforder_filter_min_lp, nullptr},

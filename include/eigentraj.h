@@ -90,6 +90,8 @@ const char *et_compiled_arch(void);
  *   kmeans_argmax          f: matrix-core filter + exact certification (default) | v: the exact scan only
  *   kmeans_init_tiles      0: farthest-first steps look at every point                (default 1: 256-point tile summaries)
  *   kmeans_filter_threads  256..1024, multiple of 64: workgroup size of the Lloyd kernels (default 0: chosen per shard)
+ *   kmeans_chain_copies    1 / 2 / 4 / 8 copies of the per-iteration delta table in a single-GPU fit's one-launch-per-iteration loop (default 2;
+ *                          a sharded fit always uses one: its wire format)
  *   kmeans_loop_grid       > 0: at most this many workgroups for the one-launch-per-iteration Lloyd kernel (default 0)
  *   kmeans_loop            a: auto (default) | c: one launch per iteration | p: one persistent launch per fit
  *   reforder_filter_min_lp 4..9: the reference-order Lloyd kernel certifies labels with the matrix-core filter from this cascade level
