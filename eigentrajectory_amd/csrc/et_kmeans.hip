@@ -153,14 +153,16 @@ __device__ __forceinline__ void best_centroid(const float *x, int d_rt, const fl
 // nothing else to hide latencies behind: four centroids per step, their rows requested from LDS together and their
 // fmaf chains interleaved (the plain loop is one LDS round trip + nine dependent operations per centroid: 2.7 us for
 // K = 20 against 0.9 us).  The same operations per centroid and the comparisons in centroid order => the same result.
-__device__ __forceinline__ void best_centroid6_drain(const float *x, const float *sC, int K, int &label, float &best) {
+// (j0 .. K: the centroids of a range, in order -- the half-wave form of packed_drain splits the K centroids between two
+// lanes and merges their results with the same comparison, earlier range first)
+__device__ __forceinline__ void best_centroid6_drain(const float *x, const float *sC, int K, int &label, float &best, int j0 = 0) {
     float an = 0.f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) an = an + x[i] * x[i];  // kmeans.py:73 |a|^2
-    int lb = 0;
+    int lb = j0;
     float bv = 0.f;
     const float4 *s4 = reinterpret_cast<const float4 *>(sC);  // rows of 8 floats: c[0..5], |c|^2, -
-    int j = 0;
+    int j = j0;
     for (; j + 4 <= K; j += 4) {
         float4 lo[4], hi[4];
 #pragma unroll
@@ -189,7 +191,7 @@ __device__ __forceinline__ void best_centroid6_drain(const float *x, const float
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (j + u == 0 || gt_nanmax(y[u], bv)) {
+            if (j + u == j0 || gt_nanmax(y[u], bv)) {
                 bv = y[u];
                 lb = j + u;
             }
@@ -206,7 +208,7 @@ __device__ __forceinline__ void best_centroid6_drain(const float *x, const float
         y = y * 2.0f;
         y = y - an;
         y = y - c1.z;
-        if (j == 0 || gt_nanmax(y, bv)) {
+        if (j == j0 || gt_nanmax(y, bv)) {
             bv = y;
             lb = j;
         }
@@ -1279,15 +1281,31 @@ constexpr int kPkAccPitch = 228;   // int64 per copy: >= d K + K + 2 = 226 for K
 __device__ __forceinline__ void packed_drain(const unsigned *q, int cnt, int K, const float *sC, const float4 *__restrict__ xa,
                                              uint8_t *__restrict__ labels, long long *sAcc, int frac, int lane) {
     constexpr int d = 6;
-    if (lane >= cnt) return;
-    const int64_t n = (int64_t)q[lane];
-    const int old = (int)q[kFilterSlots + lane];
+    // At most 32 queued points (the usual case of a wavefront's LAST drain, which sits on the launch's tail with nothing to
+    // hide behind): lanes e and e + 32 both fetch point e and scan about half of the centroids each -- the first kh (a multiple
+    // of four) and the rest --, then the lower lane merges: the later range wins only by the scan's own comparison
+    // (strictly larger, or NaN against non-NaN), i.e. the result is the one of the scan over all K in order.
+    const bool halves = __builtin_amdgcn_readfirstlane(cnt) <= 32 && K >= 8;  // (wave-uniform, and known to be)
+    const int e = halves ? (lane & 31) : lane;
+    const bool mine = e < cnt;
+    const int ec = mine ? e : 0;
+    const int64_t n = (int64_t)q[ec];
+    const int old = (int)q[kFilterSlots + ec];
     const float4 a = xa[2 * n], b = xa[2 * n + 1];
     const float x[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
     int lb;
     float best;
-    best_centroid6_drain(x, sC, K, lb, best);
-    if (lb != old) {
+    const bool up = halves && lane >= 32;
+    const int kh = ((K + 4) / 8) * 4;  // K = 20: twelve and eight
+    best_centroid6_drain(x, sC, (halves && !up) ? kh : K, lb, best, up ? kh : 0);
+    if (halves) {
+        const auto rb = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+        const auto rl = __builtin_amdgcn_permlane32_swap((unsigned)lb, (unsigned)lb, false, false);
+        const float ub = __uint_as_float(rb[1]);  // (second result, lower lanes: the upper partner's value)
+        const bool take = gt_nanmax(ub, best);
+        lb = take ? (int)rl[1] : lb;
+    }
+    if (mine && !up && lb != old) {
         labels[n] = (uint8_t)lb;
         // kPkAccCopies copies of the accumulators, a lane adds onto copy lane % kPkAccCopies: the points that change in
         // one iteration move between a handful of clusters, so the 64 lanes of a drain hit a few addresses each, and LDS
