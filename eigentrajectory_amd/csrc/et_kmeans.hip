@@ -1462,7 +1462,9 @@ __device__ __forceinline__ void packed_tables_side(int role, int lane, const flo
     }
 }
 
-template <int NREGS>
+// (FIRST: the instantiation a fit's first launch takes -- the only one that can meet iteration 0, i.e. the exact scan that
+// also writes the packed copy; the launches after it do not carry that code)
+template <int NREGS, bool FIRST>
 __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const float *hdr,
                                                    const float *__restrict__ X, int64_t N, int K,
                                                    const et_kmeans_state *state, const float *cen,
@@ -1479,7 +1481,7 @@ __device__ __forceinline__ void packed_assign_body(const LloydPacked pk, const f
     const int frac = (int)state->frac;
     const float s = hdr[6], m_up = hdr[7];
     const unsigned pk_ok = __float_as_uint(hdr[8]);
-    if (st_iter <= 0 && pk.fused) {
+    if (FIRST && st_iter <= 0 && pk.fused) {
         // the fit's first launch: the exact scan of every point -- which also writes the packed copy, from the rows it reads
         // anyway (the scan is bound by its arithmetic, ~130 us at 1e7 points, and has the memory side to spare: a pass of
         // its own over X, kmeans_pack_kernel, costs 175-190 us)
@@ -2076,7 +2078,7 @@ __device__ __forceinline__ void fold_lanes(const long long *__restrict__ lanes, 
     }
 }
 
-template <int NREGS, bool SIM>
+template <int NREGS, bool SIM, bool FIRST = false>
 __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     const float *__restrict__ X, int64_t N, int K, const LloydChain ch, uint8_t *__restrict__ labels, float tol,
     float *trace, int has_pending) {
@@ -2174,7 +2176,7 @@ __global__ __launch_bounds__(kFilterMaxThreads) void kmeans_lloyd_chain_kernel(
     if (ch.vec_ok) {
         if constexpr (!SIM) {
             if (ch.pk.xh) {
-                packed_assign_body<NREGS>(ch.pk, sPkHdr, X, N, K, &sSt, sCen, labels, ch.lanes_wr, copy_mask, range_bad,
+                packed_assign_body<NREGS, FIRST>(ch.pk, sPkHdr, X, N, K, &sSt, sCen, labels, ch.lanes_wr, copy_mask, range_bad,
                                           tables_ready ? sPkTab : nullptr);
                 return;
             }
@@ -3217,7 +3219,11 @@ static int km_fat_lds_attribute() {
         reinterpret_cast<const void *>(KERNEL<16, true>), reinterpret_cast<const void *>(KERNEL<16, false>)
     const void *fat[] = {reinterpret_cast<const void *>(kmeans_assign_filter_kernel<10>),
                          reinterpret_cast<const void *>(kmeans_assign_filter_kernel<16>),
-                         ET_FAT4(kmeans_lloyd_chain_kernel), ET_FAT4(kmeans_lloyd_persist_kernel)};
+                         ET_FAT4(kmeans_lloyd_chain_kernel), ET_FAT4(kmeans_lloyd_persist_kernel),
+                         reinterpret_cast<const void *>(kmeans_lloyd_chain_kernel<10, true, true>),
+                         reinterpret_cast<const void *>(kmeans_lloyd_chain_kernel<10, false, true>),
+                         reinterpret_cast<const void *>(kmeans_lloyd_chain_kernel<16, true, true>),
+                         reinterpret_cast<const void *>(kmeans_lloyd_chain_kernel<16, false, true>)};
 #undef ET_FAT4
     for (const void *f : fat) ET_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     lds_ok = true;
@@ -3597,8 +3603,12 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
             const int cap = options().kmeans_loop_grid.load(std::memory_order_relaxed);                                   \
             if (cap > 0 && grid > cap) grid = cap;                                                                        \
         }                                                                                                                 \
-        hipLaunchKernelGGL((kmeans_lloyd_chain_kernel<NR, SIM>), dim3(grid), dim3(threads), lds, st, X, N, K, ch,          \
-                           labels_u8, tol, trace, it > 0 ? 1 : 0);                                                        \
+        if (it == 0)                                                                                                      \
+            hipLaunchKernelGGL((kmeans_lloyd_chain_kernel<NR, SIM, true>), dim3(grid), dim3(threads), lds, st, X, N, K,   \
+                               ch, labels_u8, tol, trace, 0);                                                             \
+        else                                                                                                              \
+            hipLaunchKernelGGL((kmeans_lloyd_chain_kernel<NR, SIM, false>), dim3(grid), dim3(threads), lds, st, X, N, K,  \
+                               ch, labels_u8, tol, trace, 1);                                                             \
     } while (0)
         if (K <= 20) {
             if (sim_now) ET_LAUNCH_CHAIN(10, true);
