@@ -522,6 +522,16 @@ __device__ __forceinline__ bool packed_header(const float *__restrict__ X, int64
     return ok;
 }
 
+// Where point n's exact coordinates (a row of 32 B) lie in the side-by-side copy `xa`: blocks of 256 points = four planes of
+// 64 rows, plane q holding the q-th point of every quad of the block.  The copy is WRITTEN by lanes that own consecutive
+// quads, so the two store instructions of a wavefront for its q-th points fill one plane = 2 KB contiguous (rows in point
+// order made every store instruction 64 pieces of 16 B, 128 B apart: the pack pass ran at 3.2 TB/s); a queued point's gather
+// still reads one 32-byte row.  (Eight planes of 16-byte pieces -- every store instruction 1 KB contiguous -- write as
+// fast, but the gather's two pieces 1 KB apart cost the steady launches 0.4 us each.)
+__device__ __forceinline__ int64_t xa_index(int64_t n) {
+    return (n >> 8) * 512 + (int64_t)(n & 3) * 128 + (int64_t)((n & 255) >> 2) * 2;
+}
+
 // the packed form of the four points n .. n + 3 (x[v][i]: coordinate i of point n + v)
 __device__ __forceinline__ void pack_quad(const float (&x)[4][6], int64_t n, int64_t N, const PackOut &po) {
     constexpr float kUp = 1.001953125f, kTiny = 1.1920928955078125e-7f;
@@ -545,8 +555,9 @@ __device__ __forceinline__ void pack_quad(const float (&x)[4][6], int64_t n, int
             asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+&v"(h) : "v"(xc[2 * p + 1]), "v"(po.s));
             hw[p][q] = h;
         }
-        po.xa[2 * (n + q)] = make_float4(x[q][0], x[q][1], x[q][2], x[q][3]);
-        po.xa[2 * (n + q) + 1] = make_float4(x[q][4], x[q][5], 0.f, 0.f);
+        const int64_t ia = xa_index(n + q);
+        po.xa[ia] = make_float4(x[q][0], x[q][1], x[q][2], x[q][3]);
+        po.xa[ia + 1] = make_float4(x[q][4], x[q][5], 0.f, 0.f);
     }
 #pragma unroll
     for (int p = 0; p < 3; ++p)
@@ -1207,7 +1218,7 @@ __device__ __forceinline__ void filter_assign_body(const float *__restrict__ X, 
 //        mu = the mean of 1024 evenly spaced points (any vector would do: arg-max_j -|x - c_j|^2 does not depend on the
 //        origin), s = the power of two that brings every |s (x - mu)| below 16
 //   rr   N f16: an upper bound R of  s ||x - mu||
-//   xa   N rows of 32 B: the exact coordinates of a point side by side, for the few points the test cannot decide
+//   xa   32 B per point: the exact coordinates of a point side by side (where: xa_index), for the few points the test cannot decide
 // = 14 B per point and iteration instead of 24, and the 1-3 % of undecided points cost one 64-B sector each instead of
 // six.  The rounding of x is now by far the largest error of the matrix-core estimate, so the bounds are re-derived
 // (scaled units; p = s (x - mu), q_j = s (c_j - mu) exact, R >= ||p||, Q_j >= ||q_j||; r = s ||x|| <= R + m with
@@ -1291,7 +1302,8 @@ __device__ __forceinline__ void packed_drain(const unsigned *q, int cnt, int K, 
     const int ec = mine ? e : 0;
     const int64_t n = (int64_t)q[ec];
     const int old = (int)q[kFilterSlots + ec];
-    const float4 a = xa[2 * n], b = xa[2 * n + 1];
+    const int64_t ia = xa_index(n);
+    const float4 a = xa[ia], b = xa[ia + 1];
     const float x[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
     int lb;
     float best;
@@ -3134,7 +3146,7 @@ static KmWorkspace km_carve(void *base, int64_t N, int d, int K) {
         w.pk_rr = (unsigned short *)(p + off);
         off = align_up(off + 2 * (size_t)N, 256);
         w.pk_xa = (float4 *)(p + off);
-        off = align_up(off + 32 * (size_t)N, 256);
+        off = align_up(off + 8192 * (((size_t)N + 255) / 256), 256);  // (whole blocks of 256 points: xa_index)
     }
     w.bytes = off;
     return w;
