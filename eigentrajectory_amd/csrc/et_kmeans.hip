@@ -2008,6 +2008,7 @@ struct LloydChain {
 // put its other loads between them: fold_issue() requests every value (clamped indices keep the register arrays out
 // of scratch memory), fold_combine() sums.  d = 6, K <= 32 with the filter kernels' 768 / 1024 threads needs 3 ... 5
 // sweeps of blockDim.x entries; fold_lanes() is the plain loop for any other shape.
+constexpr int kTimedRun = 4;  // launches between the two events of a timed sample of the chained loop
 constexpr int kFoldSweeps = 5;
 struct FoldRegs {
     long long v[kFoldSweeps], prev[kFoldSweeps];
@@ -3525,7 +3526,7 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
                         uint8_t *labels_u8, float *trace, et_kmeans_state *state, long long *partials, const KmWorkspace &w,
                         hipStream_t st, ChainHook hook, std::vector<hipEvent_t> *events, int time_every, int *launched_out) {
     constexpr int kEvery = 4;
-    auto timed = [&](int it) { return events && (it == 0 || it % time_every == 1); };
+    auto timed = [&](int it) { return events && (it == 0 || it % time_every == 1); };  // (time_every >= kTimedRun)
     int rc = ET_OK;
     StateRing *ring = StateRing::get(&rc);
     if (!ring) return rc;
@@ -3631,7 +3632,12 @@ static int km_chain_run(const float *X, int64_t N, int d, int K, int max_iter, f
         }
 #undef ET_LAUNCH_CHAIN
         ET_LAUNCH_CHECK();
-        if (timed(it)) ET_HIP_TRY(hipEventRecord((*events)[2 * it + 1], st));
+        // (the end event of a timed launch: right after the first launch -- the exact scan --, after the FOURTH launch of a
+        // sampled run of the others: an event between two kernels costs a dispatch gap on each side, and a bracket around
+        // one 33-us launch measured 37.5 us where rocprofv3 saw 32.8; four launches per bracket measure the period)
+        if (events && it == 0) ET_HIP_TRY(hipEventRecord((*events)[1], st));
+        if (events && it >= kTimedRun && timed(it - (kTimedRun - 1)) && it - (kTimedRun - 1) != 0)
+            ET_HIP_TRY(hipEventRecord((*events)[2 * (it - (kTimedRun - 1)) + 1], st));
         // sharded: the deltas this launch added onto its (one-copy, compact) table become the sum over all ranks' before
         // the next launch reads them: d K + K + 2 int64, 1.1 KB for d = 6, K = 20
         if (hook.reduce) {
@@ -4186,13 +4192,14 @@ extern "C" int et_kmeans_fit(const float *X, int64_t N, int d, int K, int max_it
         int samples = 0;
         for (int it = 0; it < worked; ++it) {
             if (!timed(it)) continue;
+            if (it > 0 && it + kTimedRun - 1 >= worked) continue;  // (a run that the fit's end cut short has no end event)
             float ms = 0.f;
             ET_HIP_TRY(hipEventElapsedTime(&ms, events[2 * it], events[2 * it + 1]));
             if (it == 0) {
                 first = (double)ms;
             } else {
                 total += (double)ms;
-                ++samples;
+                samples += kTimedRun;
             }
         }
         timing_host->assign_ms = total;
