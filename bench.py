@@ -115,7 +115,7 @@ def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None,
         res = ops.kmeans_fit(c_pred, c0, max_iter, 1e-4, timing=True, trace=os.environ.get("ET_BENCH_TRACE") == "1")
         sw.stop("kmeans_lloyd")
         # the first launch of a fit is the plain exact scan (kmeans_assign_kernel<6,4>, full accumulation); the
-        # others are the filter kernel, the dominant kernel of the path, of which every 8th launch is timed
+        # others are the filter kernel, the dominant kernel of the path, of which four launches out of every eight are timed
         timing.append((res["assign_ms"], res["assign_launches"], res["assign_iterations"]))
     else:
         skm = km(c_pred, K)
@@ -702,7 +702,7 @@ def main():
                                              frac_of_peak=round(344.0 * n / pr / 1e6 / HBM_PEAK_GBS, 4))
         # dominant kernel by time: the Lloyd kernel (kmeans_lloyd_chain_kernel<10,false>: one launch per iteration), timed
         # with HIP events recorded on the launch stream around a sample of the launches inside the timed steps
-        # (et_kmeans_fit: the first launch and every 8th of the others)
+        # (et_kmeans_fit: the first launch, and of the others runs of four out of every eight between one pair of events)
         if timing and sum(c for _, c, _ in timing) > 0:
             launches = sum(c for _, c, _ in timing)
             avg_ms = sum(m for m, _, _ in timing) / launches

@@ -315,8 +315,9 @@ int et_kmeans_labels_i64(const uint8_t *labels_u8, int64_t N, int64_t *labels, e
 /* optional kernel timing of et_kmeans_fit: HIP events recorded on `stream` around the dominant kernel of the path.
  * Default (all iterations of the fit in ONE persistent launch, kmeans_lloyd_persist_kernel): the duration of that
  * launch, assign_launches = 1, iterations = the Lloyd iterations it ran.  One launch per iteration (ET_KMEANS_LOOP=chain,
- * shapes the persistent kernel does not take): a sample of the launches -- the first one separately, then every 8th
- * (an event record between two kernels costs a dispatch gap on both sides).  Filled after the final sync. */
+ * shapes the persistent kernel does not take): a sample of the launches -- the first one separately, then of every eight
+ * launches a run of four between one pair of events (an event record between two kernels costs a dispatch gap on both
+ * sides; assign_launches counts the launches inside the pairs).  Filled after the final sync. */
 typedef struct et_kmeans_timing {
     double assign_ms;        /* summed duration of the timed launches                                                 */
     int64_t assign_launches; /* number of launches in assign_ms                                                       */

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Average duration of the Lloyd kernels of the bench step under rocprofv3 (ON THE GPU BOX), for same-box comparisons of
-# library variants / environment switches where the event-based lloyd_us/iter is too coarse (it averages every 8th
+# library variants / environment switches where the event-based lloyd_us/iter is too coarse (it averages runs of four launches out of eight; until round 5: every 8th
 # launch INCLUDING the exact first iteration):
 #     tools/kstat.sh <label> [VAR=value ...]
 LABEL=$1; shift
