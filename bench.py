@@ -134,7 +134,7 @@ def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None,
 # forces a form).  Which one ran is read off the timing record (iterations per launch).
 CHAIN_KERNEL = "et::kmeans_lloyd_chain_kernel<10, false>"
 PERSIST_KERNEL = "et::kmeans_lloyd_persist_kernel<10, false>"
-# trace-less fits of shards >= 1.25 * 2^20 points iterate on a packed f16 copy of the points (14 B per point instead of 24,
+# trace-less fits of shards >= 2^17 points iterate on a packed f16 copy of the points (14 B per point instead of 24,
 # csrc/et_kmeans.hip: kPackedMinPoints)
 PACKED_KERNEL = CHAIN_KERNEL  # (the same kernel: the packed body is a branch of it)
 

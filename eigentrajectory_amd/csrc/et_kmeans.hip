@@ -15,7 +15,7 @@
 //                                                    points that provably keep their running maximum, steps >= 3 whole
 //                                                    tiles of 256 points on a 16-byte summary
 //   iteration 0      kmeans_assign_kernel body      exact scan + full accumulation (inside the loop kernel's launch); for
-//                                                    shards >= 1.25 * 2^20 points it also writes the packed copy (pack_quad)
+//                                                    shards >= 2^17 points it also writes the packed copy (pack_quad)
 //   iterations >= 1  kmeans_assign_filter_kernel    f16 MFMA upper bounds + exact certification of the old label,
 //                                                    undecided points through an LDS queue; deltas leave as atomics
 //                    kmeans_lloyd_chain_kernel      ... one launch per iteration: every workgroup applies the PREVIOUS
@@ -3082,7 +3082,9 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // (label table, accumulator copies) costs ~1.4 us per launch, the bytes it saves only count once a launch streams for longer
 // (same-box sweep after the pass was rebuilt in round 5, bench step of 100 iterations, packed against fp32 filter: 1.0e6 points
 // 2.14 / 2.06 ms, 1.5e6 2.33 / 2.43, 2.0e6 2.51 / 2.64 -- profiles/r05m)
-constexpr int64_t kPackedMinPoints = 1310720;  // 1.25 * 2^20
+// (... and again at the round's end -- two delta-table copies, the half-wave last drain, no private segment: 1.5e5 points 1.44 /
+// 1.53 ms, 2e5 1.45 / 1.54, 4e5 1.55 / 1.62, 1e6 1.86 / 1.95; 7e4 and 1e5 level, 4e4 1.24 / 1.26 -- profiles/r05m item 14)
+constexpr int64_t kPackedMinPoints = 131072;  // 2^17
 static int64_t km_packed_min_points() {  // option kmeans_packed_min: tests run the packed path on small shards
     const int64_t v = options().kmeans_packed_min.load(std::memory_order_relaxed);
     return v >= 1024 ? v : kPackedMinPoints;

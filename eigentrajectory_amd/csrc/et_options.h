@@ -11,7 +11,7 @@
 namespace et {
 
 struct Options {
-    std::atomic<int64_t> kmeans_packed_min{0};   // >= 1024: shards of at least this many points iterate on the packed copy (default 1310720 = 1.25 * 2^20)
+    std::atomic<int64_t> kmeans_packed_min{0};   // >= 1024: shards of at least this many points iterate on the packed copy (default 131072 = 2^17)
     std::atomic<int> kmeans_argmax{'f'};          // 'f': matrix-core filter + exact certification; 'v': the exact scan only
     std::atomic<int> kmeans_packed{1};            // 0: trace-less fits keep the fp32 filter
     std::atomic<int> kmeans_init_tiles{1};        // 0: farthest-first steps look at every point's running similarity

@@ -84,7 +84,7 @@ const char *et_compiled_arch(void);
  * mutable configuration is this table of measurement aids / test levers (csrc/et_options.hip): every setting selects
  * between forms that are tested to give the same bits, the defaults are the shipped configuration, and a switch is read
  * once at the start of the call it affects (set it before the call, from one thread).  Keys (value as text):
- *   kmeans_packed_min      >= 1024: shards with at least this many points iterate on the packed f16 copy (default 1310720 = 1.25 * 2^20)
+ *   kmeans_packed_min      >= 1024: shards with at least this many points iterate on the packed f16 copy (default 131072 = 2^17)
  *   kmeans_packed          0: trace-less fits keep the fp32 filter body              (default 1)
  *   kmeans_pack_fused      0: the packed copy is written by a pass of its own         (default 1: inside iteration 0)
  *   kmeans_argmax          f: matrix-core filter + exact certification (default) | v: the exact scan only
@@ -253,7 +253,7 @@ int et_euc_sim_batch(const float *a, const float *b, int64_t batch, int d, int64
 /* number of int64 in a partials block: d*K sums (d-major), K counts, sim_sum, nan_count */
 size_t et_kmeans_partials_len(int d, int K);
 /* scratch of every k-means call on a shard of N points: ~5 B per point (labels, running best similarity) + O(d K); for
- * d = 6, 3 <= K <= 32, N >= 1310720 (1.25 * 2^20) and N % 4 == 0 another 46 B per point: the packed copy of the points that the trace-less
+ * d = 6, 3 <= K <= 32, N >= 131072 (2^17) and N % 4 == 0 another 46 B per point: the packed copy of the points that the trace-less
  * Lloyd iterations of et_kmeans_fit / et_kmeans_fit_sharded read instead of X (csrc/et_kmeans.hip: kmeans_pack_kernel) */
 size_t et_kmeans_workspace_bytes(int64_t N, int d, int K);
 

@@ -876,7 +876,7 @@ def test_kmeans_packed_copy_equals_fp32_filter(ops, oracle, dev, tag, et_option)
     from eigentrajectory_amd import _lib as L
     fits = L.lib().et_internal_kmeans_packed_fits
     fits.restype = C.c_longlong
-    et_option("kmeans_packed_min", 262144)  # (the library's own threshold is 1.25 * 2^20 points: where the copy pays)
+    et_option("kmeans_packed_min", 262144)  # (the library's own threshold is 2^17 points: where the copy pays)
     x, K, *rest = packed_case(tag, oracle)
     tol = rest[0] if rest else 1e-4
     x_dev = T(x, dev)
