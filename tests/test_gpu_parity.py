@@ -964,6 +964,27 @@ def test_kmeans_packed_copy_shard_tails(ops, oracle, dev, et_option, extra):
     assert torch.equal(plain["labels"], res["labels"])
 
 
+@pytest.mark.parametrize("copies", [1, 4, 8])
+@pytest.mark.parametrize("K", [3, 20, 32])
+def test_kmeans_chain_delta_table_copies(ops, oracle, dev, et_option, copies, K):
+    """The chained loop of a single-GPU fit adds its per-iteration deltas onto several compact copies of the delta table
+    (option kmeans_chain_copies, default 2; the host lowers the number until the copies fit the table: K = 3 has room for
+    few).  Integer sums: every setting gives the bits of the oracle -- packed body and fp32 filter body, traced and not."""
+    from eigentrajectory_amd.synth import gaussian_points_np
+    et_option("kmeans_loop", "chain")
+    et_option("kmeans_packed_min", 1024)
+    et_option("kmeans_chain_copies", copies)
+    n = 256 * 45 + 36
+    x = gaussian_points_np(6, n, seed=300 + K, n_blobs=7)
+    c0, _ = oracle.kmeans_init_farthest(x, K, 11)
+    ref = oracle.kmeans_fit(x, c0, 12, 1e-4)
+    for trace in (False, True):
+        res = ops.kmeans_fit(T(x, dev), T(c0, dev), 12, 1e-4, trace=trace)
+        assert res["n_iter"] == ref["n_iter"]
+        assert np.array_equal(N_(res["labels"]), ref["labels"])
+        assert np.array_equal(N_(res["centroids"]), ref["centroids"], equal_nan=True)
+
+
 def test_kmeans_packed_copy_vs_oracle(ops, oracle, dev, et_option):
     """the packed path against the CPU oracle itself (one case: the oracle needs ~1 s per iteration at this size)"""
     import ctypes as C
