@@ -31,6 +31,8 @@ passes, wait, total, drain, nd, _, waves = [int(v) for v in buf[:7]]
 print(f"N = {n}: {res['n_iter']} iterations, avg launch {res['assign_ms'] / max(res['assign_launches'], 1) * 1e3:.1f} us "
       f"(with the stamps' own overhead)")
 print(f"passes {passes} over {waves} wavefront-launches ({passes / max(waves, 1):.1f} per wavefront and launch)")
+passes = max(passes, 1)  # (shards below the packed path's threshold: no packed passes, only the launch phases below)
+total = max(total, 1)
 print(f"per pass: whole {total / passes:.0f} cycles, exposed load wait {wait / passes:.0f} ({100 * wait / total:.1f} %), "
       f"queue drains {drain / passes:.0f} ({100 * drain / total:.1f} %; {nd} drains, {drain / max(nd, 1):.0f} cycles each)")
 # where a launch goes (thread 0 of every workgroup)
