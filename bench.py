@@ -87,8 +87,10 @@ class Stage:
         return [a.elapsed_time(b) for a, b in self.t.get(name, [])]
 
 
-def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None, comm=None):
-    """The hot path once.  Returns (n_iter of the Lloyd loop)."""
+def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None, comm=None, reference_order=False):
+    """The hot path once.  Returns (n_iter of the Lloyd loop).  `reference_order`: the k-means (farthest-first and Lloyd
+    loop) in ATen's own fp32 summation orders (BatchKMeans(sums="reference-order"): the reference's labels bit for bit)
+    instead of the exact partition-independent sums."""
     n = obs.shape[0]
     mode = ops.MODE_MOVING
     sw.start("fit")
@@ -106,7 +108,14 @@ def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None,
     rec = ops.anchor_reconstruct(c_pred.view(6, n, 1), None, None, U_pred, None, mode, nrm=nrm)
     sw.stop("reconstruct")
     del rec, c_obs
-    if km is None:
+    if km is None and reference_order:
+        sw.start("kmeans_init")
+        c0 = ops.kmeans_init_farthest_reference_order(c_pred, K, first_index)
+        sw.stop("kmeans_init")
+        sw.start("kmeans_lloyd")
+        res = ops.kmeans_fit_reference_order(c_pred, c0, max_iter, 1e-4, trace=False)
+        sw.stop("kmeans_lloyd")
+    elif km is None:
         sw.start("kmeans_init")
         c0 = ops.kmeans_init_farthest(c_pred, K, first_index)
         sw.stop("kmeans_init")
@@ -132,11 +141,12 @@ def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None,
 # the dominant kernel of the step: one launch per Lloyd iteration for shards above 32768 points (the chained kernel),
 # ONE persistent launch for all iterations of a fit below that (csrc/et_kmeans.hip: km_persist_wanted; ET_OPT_KMEANS_LOOP
 # forces a form).  Which one ran is read off the timing record (iterations per launch).
-CHAIN_KERNEL = "et::kmeans_lloyd_chain_kernel<10, false>"
-PERSIST_KERNEL = "et::kmeans_lloyd_persist_kernel<10, false>"
-# trace-less fits of shards >= 2^17 points iterate on a packed f16 copy of the points (14 B per point instead of 24,
-# csrc/et_kmeans.hip: kPackedMinPoints)
-PACKED_KERNEL = CHAIN_KERNEL  # (the same kernel: the packed body is a branch of it)
+# Kernels are matched by PREFIX against the names rocprofv3 prints (the template argument list has grown over the rounds:
+# <10, false> -> <10, false, false>); of several instantiations with the prefix the one with the most calls is the
+# per-iteration launch.  Trace-less fits of shards >= 2^17 points iterate on a packed f16 copy of the points (14 B per
+# point instead of 24): the same kernel, the packed body is a branch of it.
+CHAIN_KERNEL = "et::kmeans_lloyd_chain_kernel<10, false"
+PERSIST_KERNEL = "et::kmeans_lloyd_persist_kernel<10, false"
 
 
 def packed_fits():
@@ -148,21 +158,28 @@ def packed_fits():
     return int(fn())
 
 
-def pmc_traffic(n, kernel):
-    """HBM bytes per launch of the dominant kernel as measured by rocprofv3 PMC passes (FETCH_SIZE doubled
-    as the gfx950 guide prescribes, + WRITE_SIZE); taken from the committed profile of the same workload
-    size (profiles/*_pmc_hbm_traffic.json, made by tools/pmc_summary.py), else null."""
+def pmc_traffic(n, prefix):
+    """HBM bytes per launch of the dominant kernel as measured by rocprofv3 PMC passes (FETCH_SIZE doubled as the gfx950
+    guide prescribes, + WRITE_SIZE), from the NEWEST committed profile of the same workload size
+    (profiles/*_pmc_hbm_traffic.json, made by tools/pmc_summary.py).  The kernel is matched by prefix; when the newest
+    profile of this size does not hold it, that is an error to report (no silent fallback to an older profile).
+    -> (bytes | None, source | None, kernel name as rocprof prints it | None, error | None)"""
     import glob
+    tag = f"N={n:.0e}".replace("+0", "")
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")), reverse=True):
+        rel = os.path.relpath(path, ROOT)
         try:
             js = json.load(open(path))
-            if f"N={n:.0e}".replace("+0", "") not in js.get("note", "").replace("+0", ""):
-                continue
-            k = js["kernels"][kernel]
-            return round(k["read_bytes_corrected"] + k["write_bytes"]), os.path.relpath(path, ROOT)
-        except Exception:
+        except (OSError, ValueError) as exc:
+            return None, rel, None, f"unreadable: {exc!r}"
+        if tag not in js.get("note", "").replace("+0", ""):
             continue
-    return None, None
+        hits = {k: v for k, v in js.get("kernels", {}).items() if k.startswith(prefix)}
+        if not hits:
+            return None, rel, None, f"no kernel with prefix {prefix!r} among {sorted(js.get('kernels', {}))}"
+        name = max(hits, key=lambda k: hits[k].get("calls", 0))
+        return round(hits[name]["read_bytes_corrected"] + hits[name]["write_bytes"]), rel, name, None
+    return None, None, None, f"no profiles/*_pmc_hbm_traffic.json for {tag}"
 
 
 def _cpu_model():
@@ -714,16 +731,24 @@ def main():
         #  x the iterations that launch runs
         alg_bytes = BYTES["kmeans_iter"] * n * its_per_launch
         achieved = alg_bytes / avg_ms / 1e6
-        dominant = PERSIST_KERNEL if its_per_launch > 1.5 else (PACKED_KERNEL if packed_fits() > packed_before else CHAIN_KERNEL)
-        traffic, traffic_source = pmc_traffic(n, dominant)
+        dominant = PERSIST_KERNEL if its_per_launch > 1.5 else CHAIN_KERNEL
+        traffic, traffic_source, rocprof_name, traffic_error = pmc_traffic(n, dominant)
+        packed = its_per_launch <= 1.5 and packed_fits() > packed_before
         # `traffic` is NOT measured in this run: it is the PMC figure of the committed rocprofv3 passes of the same
-        # workload (`traffic_source`); everything else on the line is measured live
-        roofline = dict(bound="hbm", kernel=dominant.replace("et::", ""), achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+        # workload (`traffic_source`); everything else on the line is measured live.  `bound`: the roof the fraction is
+        # priced against (24 algorithmic bytes per point and iteration against the HBM peak); `limited_by`:
+        # what the counters say holds the kernel (profiles/*_sq_breakdown.txt, DESIGN 3: at N = 1e7 the 150 MB an
+        # iteration touches stay Infinity-Cache resident and the pass is bound by vector-instruction issue)
+        roofline = dict(bound="hbm", kernel=(rocprof_name or dominant + ", ...>").replace("et::", ""),
+                        limited_by=("vector-issue (packed rows Infinity-Cache resident)" if packed and n <= 12_000_000
+                                    else "hbm"),
+                        achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
                         avg_launch_ms=round(avg_ms, 5), lloyd_iterations_per_launch=round(its_per_launch, 2),
                         algorithmic_bytes_per_launch=alg_bytes,
-                        points_read_as=("packed f16 rows, 14 B per point" if its_per_launch <= 1.5 and packed_fits() > packed_before
-                                        else "fp32 rows, 24 B per point"))
+                        points_read_as=("packed f16 rows, 14 B per point" if packed else "fp32 rows, 24 B per point"))
+        if traffic_error:
+            roofline["traffic_error"] = traffic_error
         out = dict(metric="trajectories/sec fit+project+reconstruct+kmeans", value=total_traj / (elapsed / args.steps),
                    unit="trajectories/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(ms_per_step, 3),
@@ -740,6 +765,22 @@ def main():
                                            (dist.get_world_size() if dist.is_initialized() else 0)), dist_path=dist_path),
                    roofline=roofline, stages=stages)
         if world == 1 and not force_dist and not args.no_extras:
+            # the same step with the k-means in the REFERENCE's summation orders (the mode that ends with the imported
+            # reference's labels bit for bit: tests/golden g7, g7c, g7d) -- `value` times the exact-sum default
+            sw_ro = Stage()
+            one_step(ops, obs, pred, K, args.max_iter, first_index, sw_ro, reference_order=True)
+            torch.cuda.synchronize()
+            sw_ro = Stage()
+            t_ro = time.perf_counter()
+            its_ro = [one_step(ops, obs, pred, K, args.max_iter, first_index, sw_ro, reference_order=True) for _ in range(3)]
+            torch.cuda.synchronize()
+            ms_ro = (time.perf_counter() - t_ro) / 3 * 1e3
+            out["value_reference_order"] = round(n / ms_ro * 1e3, 1)
+            out["reference_order_step"] = dict(
+                ms_per_step=round(ms_ro, 3), lloyd_iterations_per_step=[int(i) for i in its_ro],
+                stages_ms={k: round(float(np.mean(sw_ro.ms(k))), 4) for k in ("fit", "project", "reconstruct", "kmeans_init", "kmeans_lloyd")},
+                note="fit + project + reconstruct as in `value`; farthest-first and the Lloyd loop through "
+                     "et_kmeans_*_reforder (ATen's fp32 cascade order, kmeans.py:180-182)")
             more, sizes = extra_stages(ops, obs, pred, n, K, args.max_iter, first_index, dev)
             stages.update(more)
             stages["kmeans_lloyd_reference_order"] = reference_order_lloyd(ops, dev, n, K, args.max_iter, first_index)

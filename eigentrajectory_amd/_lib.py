@@ -87,9 +87,16 @@ def lib():
         l.et_kmeans_reforder_shard_block.restype = C.c_int64
         _lib = l
         # the library reads nothing from the environment; ET_OPT_<KEY>=value is forwarded once, here (A/B scripts under tools/)
-        for name, value in os.environ.items():
-            if name.startswith("ET_OPT_"):
-                set_option(name[len("ET_OPT_"):].lower(), value)
+        # every variable is applied; the ones the library rejects are named in ONE warning (never an exception out of
+        # whichever unrelated call happened to load the library)
+        rejected = []
+        for name, value in sorted(os.environ.items()):
+            if name.startswith("ET_OPT_") and l.et_set_option(name[len("ET_OPT_"):].lower().encode(), value.encode()) != ET_OK:
+                rejected.append(f"{name}={value}")
+        if rejected:
+            import warnings
+            warnings.warn("eigentrajectory_amd: et_set_option rejected " + ", ".join(rejected) +
+                          " (unknown key or value; the other ET_OPT_ variables were applied)", RuntimeWarning, stacklevel=2)
     return _lib
 
 

@@ -1075,21 +1075,6 @@ __device__ __forceinline__ void cascade_levels(Load load, const unsigned *sLab, 
 #ifdef ET_EXP_RF_CHECK
 __device__ unsigned g_rf_check[64];
 #endif
-// split_f16 (et_mfma_filter.h) as plain expressions: (a, b) * sg -> packed {hi(a), hi(b)}, {lo(a), lo(b)}, round to nearest
-// (a sg is exact, sg being a power of two; the residual a sg - hi has at most 13 significant bits: exact as well).  The
-// inline-assembly form writes registers the hazard recogniser cannot see: in this kernel the register allocator handed it
-// the B operands of the previous point's matrix instructions while those were still being read, and the second point of
-// every quad was certified on garbage -- wrong labels in 0.5 % of the points, found by the oracle; a variant build with
-// more code in between happened to be right.  Ten instructions per pair instead of four.
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_f16_visible(float a, float b, float sg, unsigned &hi, unsigned &lo) {
-    const float as = a * sg, bs = b * sg;
-    const f16x2_t h = {(_Float16)as, (_Float16)bs};
-    const f16x2_t l = {(_Float16)(as - (float)h.x), (_Float16)(bs - (float)h.y)};
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
-}
-
 template <int NREGS>
 __device__ __forceinline__ double assign_group_filter(const float4 *__restrict__ x4, int L2, const float *sC, int K, float sg,
                                                       unsigned *sLab, unsigned *__restrict__ LTg, unsigned short *sQ, int q_cap,
@@ -1107,7 +1092,7 @@ __device__ __forceinline__ double assign_group_filter(const float4 *__restrict__
         float nb = -60000.0f;
         if (j < K) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) split_f16_visible(sC[j * 8 + 2 * p], sC[j * 8 + 2 * p + 1], 2.0f * sg, ch[p], cl[p]);
+            for (int p = 0; p < 3; ++p) split_f16(sC[j * 8 + 2 * p], sC[j * 8 + 2 * p + 1], 2.0f * sg, ch[p], cl[p]);
             nb = -sC[j * 8 + 6] * sg2;
         }
         const auto nh = __builtin_amdgcn_cvt_pkrtz(nb, 0.f);
@@ -1146,7 +1131,7 @@ __device__ __forceinline__ double assign_group_filter(const float4 *__restrict__
                 const float rs = fmaf(__builtin_amdgcn_sqrtf(an) * sg, kUp, kTiny);  // >= sg ||x||
                 unsigned w[7];  // {xh01, xh23, xh45, xl01, xl23, xl45, (r, 1)}
 #pragma unroll
-                for (int p = 0; p < 3; ++p) split_f16_visible(x[2 * p], x[2 * p + 1], sg, w[p], w[3 + p]);
+                for (int p = 0; p < 3; ++p) split_f16(x[2 * p], x[2 * p + 1], sg, w[p], w[3 + p]);
                 w[6] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(fmaf(rs, kUp, kTiny), 1.0f));
                 const unsigned ones = 0x14003c00u;  // {1, 2^-10}: partners of {hi, lo * 2^10} of -|c|^2
                 u32x4 bLo, bUp;
@@ -2044,7 +2029,12 @@ __global__ __launch_bounds__(kThreads) void reforder_fast_prepare_kernel(const A
     if (threadIdx.x == 0) {  // (max_abs_x / bad_input stay as the scan left them)
         st->n_total = a.geo.N;
         st->iter = 0;
-        st->done = st->bad_input ? 1 : 0;
+        // non-finite input in ANY problem of the batch stops all of them before the first iteration (the batch iterates and
+        // stops jointly: a problem that sat out would leave the others waiting for its arrival); the host reads the
+        // bad_input flags after the loop and returns ET_ERR_BAD_DATA
+        int bad = 0;
+        for (int b = 0; b < a.batch; ++b) bad |= at<et_kmeans_state>(a.ws + (int64_t)b * a.ws_stride, a.lay.state)->bad_input;
+        st->done = bad ? 1 : 0;
         st->error = 0.0;
         st->inertia = 0.0;
     }

@@ -22,18 +22,22 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // (a, b) * sg (a power of two) -> packed f16 {hi(a), hi(b)} and {lo(a), lo(b)} with sg a ~ hi + lo, round to nearest:
 // |sg a - hi - lo| <= 2^-22 |sg a| + 2^-25 (inside the 2^-20 relative + 2^-24 absolute the bounds below are derived
-// with).  Four instructions per pair: v_fma_mixlo/mixhi_f16 scale and round in one step (a sg is exact in fp32, sg
-// being a power of two) and evaluate the residual a sg - hi exactly (it has at most 13 significant bits) before
-// rounding it to f16 -- no separate scaling multiplies and no pack instructions.  (Inline asm: from the C expression the
-// compiler rounds the second hi twice, five instructions; none of the operands is an MFMA result.)
+// with).  Written as fused multiply-adds rounded to f16, which the compiler selects as v_fma_mixlo/mixhi_f16: they scale
+// and round in one step (a sg is exact in fp32, sg being a power of two) and evaluate the residual a sg - hi exactly (it
+// has at most 13 significant bits) before rounding it to f16 -- five instructions per pair, no separate scaling
+// multiplies, no pack instructions.  NOT inline assembly (the four-instruction form rounds of 2-5 used): the hazard
+// recogniser cannot see registers an asm statement writes, and next to matrix instructions the allocator handed the asm
+// the B operands of MFMAs that were still reading them (round 5, reference-order kernel: 0.5 % wrong labels in one
+// build, none in another).  Every site uses this form, whether or not an MFMA is in flight.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_f16(float a, float b, float sg, unsigned &hi, unsigned &lo) {
-    unsigned h, l;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=&v"(h) : "v"(a), "v"(sg));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+&v"(h) : "v"(b), "v"(sg));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=&v"(l) : "v"(a), "v"(sg), "v"(h));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+&v"(l) : "v"(b), "v"(sg), "v"(h));
-    hi = h;
-    lo = l;
+    f16x2_t h, l;
+    h.x = (_Float16)__builtin_fmaf(a, sg, 0.0f);
+    h.y = (_Float16)__builtin_fmaf(b, sg, 0.0f);
+    l.x = (_Float16)__builtin_fmaf(a, sg, -(float)h.x);
+    l.y = (_Float16)__builtin_fmaf(b, sg, -(float)h.y);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
 }
 
 // max(|a|, |b|, |c|) in one instruction (from fmaxf(fmaxf(fabsf ...)) the compiler canonicalises two of the operands

@@ -203,7 +203,9 @@ class ShardedKMeans:
             if self.world > 1 and self.comm is None:
                 raise NotImplementedError("sums='reference-order' over several ranks runs as one native call: pass comm=Communicator(...)")
             res = ops.kmeans_fit_reference_order_sharded(sh.X, centroids, self.counts, self.rank, self.comm, max_iter, tol,
-                                                         trace=False)
+                                                         trace=trace is not None)
+            if trace is not None:  # (the caller's (max_iter, 2) tensor, like the exact path: rows [0, n_iter) are written)
+                trace[:res["n_iter"]].copy_(res["trace"])
             centroids.copy_(res["centroids"])
             res["centroids"] = centroids
             return res

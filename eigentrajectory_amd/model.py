@@ -253,19 +253,38 @@ class EigenTrajectory(nn.Module):
     _PREDICTOR_STAMP_EVERY = 64
 
     def _predictor_stamp(self):
-        """Addresses of the predictor's parameters and buffers -- walking them costs more host time than the ~21 us replay
-        they protect once a predictor has hundreds of tensors, so the walk is redone when this wrapper saw something that
-        can move them (``_apply``: .to() / .cuda() / .half(); ``load_state_dict``; ``train()`` / ``eval()``) and otherwise only
-        every 64th call.  Blind spots, by construction of a pointer-keyed cache: a predictor moved or re-allocated behind the
-        wrapper's back is noticed up to 63 replays late; an in-place ``.data`` swap that keeps the storage is not noticed at
-        all (neither was it before)."""
+        """Addresses of the predictor's parameters and buffers.  Walking hundreds of tensors costs more host time than the
+        ~21 us replay it protects, so the FULL walk is redone when something that can move them was seen -- this wrapper's
+        ``_apply`` (.to() / .cuda() / .half()), ``load_state_dict``, ``train()`` / ``eval()``, ``baseline_model`` re-assigned
+        or deleted -- and every 64th call; EVERY call compares a cheap probe: the identity of the predictor module, the
+        number of its direct parameter / buffer / sub-module slots and the addresses of its first, middle and last parameter (a
+        ``.to()`` / ``.half()`` / ``.cuda()`` on the sub-module behind the wrapper's back moves all of them).  A cache entry also
+        keeps the tensors it captured alive (``_graph_for``: ``keep``), so a replay that slipped through reads live memory.
+        Not noticed: an in-place ``.data`` swap that keeps the storage (never was)."""
         d = self.__dict__
+        bm = self.baseline_model
+        first = next(bm.parameters(), None)  # (stops at the first one: no walk of the module tree)
+        sampled = d.get("_pstamp_sampled", ())  # the middle and the last parameter OBJECTS of the last full walk
+        probe = (id(bm), len(bm._parameters), len(bm._buffers), len(bm._modules),
+                 0 if first is None else first.data_ptr()) + tuple(t.data_ptr() for t in sampled)
         n = d.get("_pstamp_calls", 0)
         d["_pstamp_calls"] = n + 1
-        if d.get("_pstamp") is None or n % self._PREDICTOR_STAMP_EVERY == 0:
-            d["_pstamp"] = (tuple(p.data_ptr() for p in self.baseline_model.parameters()),
-                            tuple(b.data_ptr() for b in self.baseline_model.buffers()))
+        if d.get("_pstamp") is None or d.get("_pstamp_probe") != probe or n % self._PREDICTOR_STAMP_EVERY == 0:
+            ps = list(bm.parameters())
+            d["_pstamp_sampled"] = sampled = tuple(ps[i] for i in sorted({len(ps) // 2, len(ps) - 1})) if ps else ()
+            d["_pstamp_probe"] = probe[:5] + tuple(t.data_ptr() for t in sampled)
+            d["_pstamp"] = (tuple(p.data_ptr() for p in ps), tuple(b.data_ptr() for b in bm.buffers()))
         return d["_pstamp"]
+
+    def __setattr__(self, name, value):
+        if name == "baseline_model":
+            self.__dict__["_pstamp"] = None
+        super().__setattr__(name, value)
+
+    def __delattr__(self, name):
+        if name == "baseline_model":
+            self.__dict__["_pstamp"] = None
+        super().__delattr__(name)
 
     def _apply(self, fn, *args, **kwargs):
         self.__dict__["_pstamp"] = None
@@ -306,7 +325,9 @@ class EigenTrajectory(nn.Module):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             outs = run(obs_traj, pred_traj)
-        entry = cache[key] = dict(stamp=stamp, graph=graph, ins=(obs_traj, pred_traj), outs=outs)
+        # `keep`: the tensors whose addresses the graph holds stay alive as long as the capture does
+        keep = params + tuple(self.baseline_model.parameters()) + tuple(self.baseline_model.buffers())
+        entry = cache[key] = dict(stamp=stamp, graph=graph, ins=(obs_traj, pred_traj), outs=outs, keep=keep)
         return entry
 
     @torch.no_grad()

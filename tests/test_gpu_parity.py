@@ -730,10 +730,12 @@ def _nccl_world1_worker(rank, port, out_dir):
         assert torch.equal(resn["centroids"], res["centroids"]) and torch.equal(resn["labels"], res["labels"])
         assert resn["inertia"] == res["inertia"] and resn["error"] == res["error"]
         # sums="reference-order" over shards: per iteration one ncclAllGather of the rank's record (world 1: from itself)
-        rf = kn.fit(c0n.clone(), max_iter=30, tol=1e-4, sums="reference-order")
-        one = ops.kmeans_fit_reference_order(torch.from_numpy(x).to(dev), c0n, 30, 1e-4, trace=False)
+        tr = torch.zeros((30, 2), device=dev)
+        rf = kn.fit(c0n.clone(), max_iter=30, tol=1e-4, sums="reference-order", trace=tr)
+        one = ops.kmeans_fit_reference_order(torch.from_numpy(x).to(dev), c0n, 30, 1e-4, trace=True)
         assert torch.equal(rf["centroids"], one["centroids"]) and torch.equal(rf["labels"], one["labels"])
         assert rf["n_iter"] == one["n_iter"] and rf["error"] == one["error"]
+        assert torch.equal(tr[:rf["n_iter"]], one["trace"]) and float(tr[rf["n_iter"]:].abs().sum()) == 0.0  # the caller's trace
         comm.close()
         np.savez(os.path.join(out_dir, "rank0.npz"), U_pred=U_pred.cpu().numpy(), count=count, c0=c0.cpu().numpy(),
                  centroids=res["centroids"].cpu().numpy(), labels=res["labels"].cpu().numpy(), n_iter=res["n_iter"])
@@ -1471,6 +1473,59 @@ def test_full_size_properties(ops, dev, n):
     assert abs(res2["inertia"] - float((-ms.double()).mean())) < 1e-5 * abs(res2["inertia"])
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n,iters", [(1_000_000, 12), (10_000_000, 5)])
+def test_headline_sizes_vs_oracle(ops, oracle, dev, n, iters):
+    """BASELINE.json's own sizes (configs 2 and 4) against the oracle itself, on bench.py's data and with the library's
+    default options: the Gram over all rows; projection and reconstruction (S = 1) on every 64th row and the last 1000
+    (rows are independent); the 20 farthest-first picks; and the exact-sum fit as the bench runs it -- trace-less, i.e.
+    on the packed f16 copy with the certification of csrc/et_kmeans_packed.hip -- labels, centroids, iteration count bit
+    for bit against the scalar restatement of kmeans.py:143-259 after `iters` iterations."""
+    import ctypes as C
+    from eigentrajectory_amd import _lib as L
+    from eigentrajectory_amd.synth import synthetic_trajectories_torch
+    obs, pred = synthetic_trajectories_torch(n, dev, seed=0, min_disp=1e-3)
+    mode = ops.MODE_MOVING
+    g_obs, g_pred, cnt = ops.fit_gram(obs, pred, mode, 0.0, 1)
+    obs_np, pred_np = N_(obs), N_(pred)
+    r_obs, r_pred, r_cnt = oracle.fit_gram(obs_np, pred_np, 1, 0.0, 1)
+    assert int(cnt.item()) == r_cnt == n
+    # (the fp32 normalised rows differ from the oracle's in the last ulp -- sincosf / atan2f of the device library vs
+    # glibc --; over 1e6 .. 1e7 rows those differences average out to ~1e-9 of the largest entry: bar 2e-8.  Exact
+    # summation itself: test_fit_gram_summation_exact)
+    for g, r in ((g_obs, r_obs), (g_pred, r_pred)):
+        close(N_(g), r, tol=2e-8)
+    (U_obs, _), (U_pred, _) = ops.eigh_topk_batch([g_obs, g_pred], 6)
+    for U, g in ((U_obs, g_obs), (U_pred, g_pred)):
+        np.testing.assert_allclose(N_(U), oracle.eigh_topk(N_(g), 6)[0], atol=1e-6)
+    c_obs, c_pred, nrm, _ = ops.norm_project(obs, pred, U_obs, U_pred, None, None, mode, want_flag=False)
+    rec = ops.anchor_reconstruct(c_pred.view(6, n, 1), None, None, U_pred, None, mode, nrm=nrm)
+    rows = np.unique(np.concatenate([np.arange(0, n, 64), np.arange(n - 1000, n)]))
+    ro, rp, rn, _ = oracle.norm_project(obs_np[rows], pred_np[rows], N_(U_obs), N_(U_pred), None, None, 1)
+    x_np = N_(c_pred)
+    assert np.array_equal(N_(nrm)[:, rows], rn)
+    close(N_(c_obs)[:, rows], ro)
+    close(x_np[:, rows], rp)
+    r_rec = oracle.anchor_reconstruct(np.ascontiguousarray(x_np[:, rows, None]), obs_np[rows], None, None, N_(U_pred), None, 1)
+    close(N_(rec)[:, rows], r_rec)
+    del rec, c_obs, obs, pred, obs_np, pred_np
+    # k-means on the GPU's own coefficients (the same bits go to the oracle)
+    first = 12345
+    c0 = ops.kmeans_init_farthest(c_pred, 20, first)
+    r_c0, _ = oracle.kmeans_init_farthest(x_np, 20, first)
+    assert np.array_equal(N_(c0), r_c0)
+    fits = L.lib().et_internal_kmeans_packed_fits
+    fits.restype = C.c_longlong
+    before = fits()
+    res = ops.kmeans_fit(c_pred, c0, iters, 1e-4, trace=False)
+    assert fits() == before + 1, "the bench's fit iterates on the packed copy: this test must too"
+    ref = oracle.kmeans_fit(x_np, r_c0, iters, 1e-4)
+    assert res["n_iter"] == ref["n_iter"] == iters
+    assert np.array_equal(N_(res["labels"]), ref["labels"])
+    assert np.array_equal(N_(res["centroids"]), ref["centroids"])
+    assert np.float32(res["error"]) == np.float32(ref["error"]) and np.float32(res["inertia"]) == np.float32(ref["inertia"])
+
+
 # ------------------------------------------------------------------ training harness (SURVEY §8f-2)
 class TinyPredictor(torch.nn.Module):
     """(k+2, N) -> (k, N, S): a per-pedestrian MLP, standing in for the reference's predictor networks."""
@@ -2184,6 +2239,23 @@ def test_scene_calls_replayed_from_a_graph(dev):
             obs_fit2, pred_fit2 = synthetic_trajectories_torch(3000, dev, seed=2)
             model.calculate_parameters(obs_fit2, pred_fit2)  # new parameter tensors
     assert len(model._scene_graphs) == 6  # three scenes x two kinds
+    # the predictor changed BEHIND the wrapper's back must be noticed on the very next replay: re-assigned, its weights
+    # re-allocated through the sub-module (.double().float() gives new storage), a parameter re-registered
+    obs, pred = scenes[1]
+    for change in ("reassign", "realloc", "reregister"):
+        if change == "reassign":
+            torch.manual_seed(1)
+            model.baseline_model = Lin().to(dev)
+        elif change == "realloc":
+            model.baseline_model.double().float()
+            with torch.no_grad():
+                model.baseline_model.w.mul_(-0.5)
+        else:
+            model.baseline_model.w = torch.nn.Parameter(torch.randn(6 * 20, 8, device=dev) * 0.05)
+        ade, fde = model.evaluate(obs, pred)
+        ade_r, fde_r = model.evaluate_replayed(obs, pred)
+        assert torch.equal(ade, ade_r) and torch.equal(fde, fde_r), change
+        assert torch.equal(model(obs)["recon_traj"], model.forward_replayed(obs)["recon_traj"]), change
 
 
 @pytest.mark.parametrize("scene,n_max", [("eth", 60), ("univ", 300)])
@@ -2505,3 +2577,22 @@ def test_kmeans_fit_batch_reports_bad_data(ops, dev, n):
         ops.kmeans_fit(T(x, dev), T(c0[0], dev), 10, 1e-4)
 
 
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("bad_problem", [0, 1])
+def test_reference_order_batch_reports_bad_data_promptly(ops, dev, bad_problem):
+    """NaN in ONE problem of a reference-order batch: every problem stops before the first iteration (the batch iterates
+    jointly) and the call returns ValueError after one launch pair, not after max_iter of them."""
+    import time
+    from eigentrajectory_amd.synth import gaussian_points_np
+    n = 20000
+    x = np.stack([gaussian_points_np(6, n, seed=3 + b, n_blobs=4) for b in range(2)])
+    c0 = np.ascontiguousarray(x[:, :, :20])
+    ops.kmeans_fit_reference_order_batch(T(x, dev), T(c0, dev), 5, 1e-4, trace=False)  # (clean: warms the path up)
+    x[bad_problem, 2, n // 2] = np.nan
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with pytest.raises(ValueError):
+        ops.kmeans_fit_reference_order_batch(T(x, dev), T(c0, dev), 100000, 1e-4, trace=False)
+    assert time.perf_counter() - t0 < 5.0
