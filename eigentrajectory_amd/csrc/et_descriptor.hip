@@ -56,8 +56,41 @@ __device__ __forceinline__ int64_t tile_of_block() {
 // ------------------------------------------------------------------------------------------
 // (round 5: staging the rows memory -> LDS directly, `buffer_load_dwordx4 ... lds`, default and non-temporal policy, measured
 // no faster: profiles/r05d_project_dma_ab.txt; source: tools/lost_forms/project_lds_dma.hip.txt)
-template <int TO, int TP, int K>
-__global__ __launch_bounds__(kTile) void project_tile_kernel(
+// Cache policy of the two HBM-bound kernels on BIG launches (round 6, profiles/r06b_project_recon_ab.txt: same-box A/B, five
+// alternating rounds per form at N = 1e7).  STREAM = the launch moves more than the 256 MB memory-side cache holds:
+//   projection      row loads non-temporal (each row is read once) and C_obs stores non-temporal (nobody re-reads them soon);
+//                   C_pred and nrm keep the default policy -- the reconstruction and the k-means read them next.
+//                   0.384 -> 0.357 ms (-7 %): the 1.6 GB of rows no longer push C_pred / nrm out of the memory-side cache.
+//   reconstruction  96-byte row stores non-temporal and the tiles walked from the END (what the projection wrote last is
+//                   what the cache still holds): +0.011 ms for itself, -0.026 ms for the farthest-first pass behind it
+//                   (C_pred stays cached).  project + reconstruct 0.619 -> 0.603 ms.
+// Small launches (scenes, dataset-sized fits) keep the default policy everywhere: their consumers read the results from
+// L2 / the memory-side cache.  Measured and NOT adopted: 128-row projection tiles (6 workgroups per CU instead of 3):
+// +2.5 % time; non-temporal C_pred / nrm stores: +1 %.
+constexpr int64_t kStreamBytes = 256ll << 20;
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ void st_f32(float *p, float v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <bool NT>
+__device__ __forceinline__ float4 ld_f32x4(const float4 *p) {
+    if constexpr (NT) {
+        const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return *p;
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void st_f32x4(float4 *p, const float4 &v) {
+    if constexpr (NT) __builtin_nontemporal_store((f32x4_nt){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_nt *>(p));
+    else *p = v;
+}
+
+template <int TO, int TP, int K, int TILE, bool STREAM>
+__global__ __launch_bounds__(TILE) void project_tile_kernel(
     const float *__restrict__ obs, const float *__restrict__ pred, int64_t N,
     const float *__restrict__ U_obs_m, const float *__restrict__ U_pred_m,
     const float *__restrict__ U_obs_s, const float *__restrict__ U_pred_s,
@@ -70,14 +103,14 @@ __global__ __launch_bounds__(kTile) void project_tile_kernel(
     static_assert(DO % 4 == 0 && DP % 4 == 0, "rows must be float4 multiples");
     static_assert(PO % 2 == 1 && PP % 2 == 1, "padded pitch must be odd in float4 units");
 
-    __shared__ float4 sObs[kTile * PO];
-    __shared__ float4 sPred[kTile * PP];
+    __shared__ float4 sObs[TILE * PO];
+    __shared__ float4 sPred[TILE * PP];
     __shared__ float sU[2 * UN];  // [descriptor: 0 static, 1 moving][obs rows | pred rows][K]
 
     const int tid = threadIdx.x;
-    const int64_t n0 = tile_of_block<true>() * kTile;
+    const int64_t n0 = tile_of_block<true>() * TILE;
     if (n0 >= N) return;
-    const int rows = (int)min((int64_t)kTile, N - n0);
+    const int rows = (int)min((int64_t)TILE, N - n0);
     const bool has_pred = pred != nullptr && C_pred != nullptr;
 
     // ---- phase 1: stage rows (all loads issued before the first LDS write)
@@ -86,19 +119,19 @@ __global__ __launch_bounds__(kTile) void project_tile_kernel(
         float4 v[QO];
 #pragma unroll
         for (int j = 0; j < QO; ++j) {
-            const int q = tid + j * kTile;
-            v[j] = (q < rows * QO) ? g[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int q = tid + j * TILE;
+            v[j] = (q < rows * QO) ? ld_f32x4<STREAM>(g + q) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         float4 w[QP];
         if (has_pred) {
             const float4 *gp = reinterpret_cast<const float4 *>(pred + n0 * DP);
 #pragma unroll
             for (int j = 0; j < QP; ++j) {
-                const int q = tid + j * kTile;
-                w[j] = (q < rows * QP) ? gp[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int q = tid + j * TILE;
+                w[j] = (q < rows * QP) ? ld_f32x4<STREAM>(gp + q) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        for (int i = tid; i < 2 * UN; i += kTile) {
+        for (int i = tid; i < 2 * UN; i += TILE) {
             const int desc = i / UN, r = i - desc * UN;
             const float *src;
             int off;
@@ -114,13 +147,13 @@ __global__ __launch_bounds__(kTile) void project_tile_kernel(
         }
 #pragma unroll
         for (int j = 0; j < QO; ++j) {
-            const int q = tid + j * kTile;
+            const int q = tid + j * TILE;
             sObs[(q / QO) * PO + (q % QO)] = v[j];
         }
         if (has_pred) {
 #pragma unroll
             for (int j = 0; j < QP; ++j) {
-                const int q = tid + j * kTile;
+                const int q = tid + j * TILE;
                 sPred[(q / QP) * PP + (q % QP)] = w[j];
             }
         }
@@ -143,10 +176,10 @@ __global__ __launch_bounds__(kTile) void project_tile_kernel(
     const float dx = ox - xo[DO - 6], dy = oy - xo[DO - 5];
     const RowNorm p = row_norm(ox, oy, dx, dy, mode, static_dist);
     if (nrm) {
-        nrm[n] = ox;
-        nrm[N + n] = oy;
-        nrm[2 * N + n] = dx;
-        nrm[3 * N + n] = dy;
+        st_f32<false>(nrm + n, ox);
+        st_f32<false>(nrm + N + n, oy);
+        st_f32<false>(nrm + 2 * N + n, dx);
+        st_f32<false>(nrm + 3 * N + n, dy);
     }
     if (flag) flag[n] = (uint8_t)p.mv;
 
@@ -165,7 +198,7 @@ __global__ __launch_bounds__(kTile) void project_tile_kernel(
             for (int j = 0; j < K; ++j) acc[j] = fmaf(u[(2 * t + 1) * K + j], b, acc[j]);
         }
 #pragma unroll
-        for (int j = 0; j < K; ++j) C_obs[(int64_t)j * N + n] = acc[j];
+        for (int j = 0; j < K; ++j) st_f32<STREAM>(C_obs + (int64_t)j * N + n, acc[j]);
     }
     if (has_pred) {
         const float *up = u + DO * K;
@@ -188,7 +221,7 @@ __global__ __launch_bounds__(kTile) void project_tile_kernel(
             for (int j = 0; j < K; ++j) acc[j] = fmaf(up[(4 * q + 3) * K + j], b, acc[j]);
         }
 #pragma unroll
-        for (int j = 0; j < K; ++j) C_pred[(int64_t)j * N + n] = acc[j];
+        for (int j = 0; j < K; ++j) st_f32<false>(C_pred + (int64_t)j * N + n, acc[j]);
     }
 }
 
@@ -359,7 +392,7 @@ __device__ __forceinline__ RowNorm fetch_row_norm(const float *s) {
 #endif
 constexpr int kReconTiles = ET_RECON_TILES;  // consecutive tiles per workgroup when S > 1 (U / anchors staged once)
 
-template <int TP, int K>
+template <int TP, int K, bool STREAM>
 __global__ __launch_bounds__(kTile) void reconstruct_tile_kernel(
     const float *__restrict__ C, int64_t N, int S, int TN, int T_obs,
     const float *__restrict__ obs, const float *__restrict__ nrm,
@@ -376,7 +409,7 @@ __global__ __launch_bounds__(kTile) void reconstruct_tile_kernel(
     const int tid = threadIdx.x;
     const int tiles = S == 1 ? 1 : kReconTiles;
     const int nl = tid / S, s = tid - nl * S;
-    int64_t n0 = tile_of_block() * tiles * TN;
+    int64_t n0 = (STREAM ? (int64_t)gridDim.x - 1 - blockIdx.x : tile_of_block()) * tiles * TN;
     if (n0 >= N) return;
     int rows = (int)min((int64_t)TN, N - n0);
 
@@ -452,7 +485,7 @@ __global__ __launch_bounds__(kTile) void reconstruct_tile_kernel(
         const int total = S * per_plane;
         for (int q = tid; q < total; q += kTile) {
             const int sp = q / per_plane, r = q - sp * per_plane;
-            out4[((int64_t)sp * N + n0) * QP + r] = src4[q];
+            st_f32x4<STREAM>(out4 + ((int64_t)sp * N + n0) * QP + r, src4[q]);
         }
         if (tid < rows_next) p = p_next;
         n0 = n0_next;
@@ -1221,8 +1254,10 @@ extern "C" int et_norm_project(const float *obs, const float *pred, int64_t N, i
     const unsigned grid = (unsigned)ceil_div(N, kTile);
     const bool fast = T_obs == 8 && (!pred || T_pred == 12) && k == 6 && aligned16(obs) && (!pred || aligned16(pred));
     if (fast) {
-        hipLaunchKernelGGL((project_tile_kernel<8, 12, 6>), dim3(grid), dim3(kTile), 0, st, obs, pred, N, U_obs_m,
-                           U_pred_m, U_obs_s, U_pred_s, mode, static_dist, C_obs, C_pred, nrm, flag);
+        const bool stream = N * (int64_t)(pred ? 224 : 104) > kStreamBytes;
+        auto kern = stream ? project_tile_kernel<8, 12, 6, kTile, true> : project_tile_kernel<8, 12, 6, kTile, false>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kTile), 0, st, obs, pred, N, U_obs_m, U_pred_m, U_obs_s, U_pred_s, mode,
+                           static_dist, C_obs, C_pred, nrm, flag);
     } else {
         hipLaunchKernelGGL(project_generic_kernel, dim3(grid), dim3(kTile), 0, st, obs, pred, N, T_obs, T_pred, k,
                            U_obs_m, U_pred_m, U_obs_s, U_pred_s, mode, static_dist, C_obs, C_pred, nrm, flag);
@@ -1258,8 +1293,10 @@ extern "C" int et_anchor_reconstruct_fwd(const float *C, int64_t N, int S, int k
         const int TN = kTile / S;
         const size_t lds = sizeof(float) * ((size_t)TN * S * 24 + (size_t)TN * kNormStride + 2 * 24 * 6 + 2 * 6 * (size_t)S);
         const int64_t per_wg = (int64_t)TN * (S == 1 ? 1 : kReconTiles);
-        hipLaunchKernelGGL((reconstruct_tile_kernel<12, 6>), dim3((unsigned)ceil_div(N, per_wg)), dim3(kTile), lds, st, C, N,
-                           S, TN, T_obs, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, mode, static_dist, out);
+        const bool stream = N * S * (int64_t)96 > kStreamBytes;
+        auto kern = stream ? reconstruct_tile_kernel<12, 6, true> : reconstruct_tile_kernel<12, 6, false>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(N, per_wg)), dim3(kTile), lds, st, C, N, S, TN, T_obs, obs, nrm, A_m,
+                           A_s, U_pred_m, U_pred_s, mode, static_dist, out);
     } else {
         const int64_t pairs = N * S;
         hipLaunchKernelGGL(reconstruct_generic_kernel, dim3((unsigned)ceil_div(pairs, kTile)), dim3(kTile), 0, st, C, N,

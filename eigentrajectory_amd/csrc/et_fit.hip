@@ -43,6 +43,40 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // 484-490 us, 11 VALU instructions per row; this form: 457-464 us.)
 constexpr int kWaveGramThreads = 256;
 
+// normalize_point (et_common.h) on two points at once with the packed fp32 instructions (v_pk_add / v_pk_mul_f32: two
+// results per lane and issue slot): (tx c, ty c) + (ty s, tx (-s)), then * sca -- the same products and the same single
+// additions as normalize_point, hence the same bits (sca = 1 for the static descriptor: x * 1 is x).  Five instructions
+// per point instead of ten.
+#ifndef ET_EXP_GRAM_NT
+#define ET_EXP_GRAM_NT 0
+#endif
+#ifndef ET_EXP_GRAM
+#define ET_EXP_GRAM 0
+#endif
+typedef float f32x4_ld __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_rows(const float4 *p) {
+#if ET_EXP_GRAM_NT
+    const f32x4_ld v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_ld *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+struct NormPk {
+    f32x2_t o, cc, sn, sc;
+    __device__ __forceinline__ explicit NormPk(const RowNorm &p)
+        : o{p.ox, p.oy}, cc{p.c, p.c}, sn{p.s, -p.s}, sc{p.mv ? p.sca : 1.0f, p.mv ? p.sca : 1.0f} {}
+    __device__ __forceinline__ f32x2_t point(f32x2_t xy) const {
+        const f32x2_t t = xy - o;
+        return (t * cc + __builtin_shufflevector(t, t, 1, 0) * sn) * sc;
+    }
+    __device__ __forceinline__ float4 quad(float x0, float y0, float x1, float y1) const {
+        const f32x2_t a = point((f32x2_t){x0, y0}), b = point((f32x2_t){x1, y1});
+        return make_float4(a.x, a.y, b.x, b.y);
+    }
+};
+
 template <int TO, int TP>
 __global__ __launch_bounds__(kWaveGramThreads) void gram_wave_kernel(
     const float *__restrict__ obs, const float *__restrict__ pred, int64_t N, int mode, float static_dist, int which,
@@ -78,14 +112,14 @@ __global__ __launch_bounds__(kWaveGramThreads) void gram_wave_kernel(
         const float4 *gp = reinterpret_cast<const float4 *>(pred + n0 * DP);
         if (rows == 64) {
 #pragma unroll
-            for (int j = 0; j < QO; ++j) ro[j] = go[lane + j * 64];
+            for (int j = 0; j < QO; ++j) ro[j] = ld_rows(go + lane + j * 64);
 #pragma unroll
-            for (int j = 0; j < QP; ++j) rp[j] = gp[lane + j * 64];
+            for (int j = 0; j < QP; ++j) rp[j] = ld_rows(gp + lane + j * 64);
         } else {
 #pragma unroll
-            for (int j = 0; j < QO; ++j) ro[j] = lane + j * 64 < rows * QO ? go[lane + j * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < QO; ++j) ro[j] = lane + j * 64 < rows * QO ? ld_rows(go + lane + j * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int j = 0; j < QP; ++j) rp[j] = lane + j * 64 < rows * QP ? gp[lane + j * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < QP; ++j) rp[j] = lane + j * 64 < rows * QP ? ld_rows(gp + lane + j * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto wave_sync = [&]() {  // LDS hand-over between the lanes of this wavefront
@@ -105,10 +139,14 @@ __global__ __launch_bounds__(kWaveGramThreads) void gram_wave_kernel(
 #pragma unroll
         for (int j = 0; j < QP; ++j) {
             const int q = lane + j * 64;
-            sPred[(q / QP) * PP + (q % QP)] = rp[j];
+            const int f4 = q % QP;  // float4 of the row: features [4 f4, 4 f4 + 4)
+            sPred[(q / QP) * PP + (f4 < 2 ? f4 : (f4 < 4 ? f4 + 2 : f4 - 2))] = rp[j];  // stored as [0:8 | 16:24 | 8:16]
         }
         if (tile + stride < n_tiles) fetch(tile + stride);  // in flight during the rest of this pass
         wave_sync();
+#if ET_EXP_GRAM >= 2  // measurement aid: loads + stage-in only
+        if (0)
+#endif
         {
             float4 *orow = sObs + lane * PO, *prow = sPred + lane * PP;
             bool use = false;
@@ -126,20 +164,13 @@ __global__ __launch_bounds__(kWaveGramThreads) void gram_wave_kernel(
                 const RowNorm p = row_norm(ox, oy, ox - xo[DO - 6], oy - xo[DO - 5], mode, static_dist);
                 use = p.mv == which;
                 if (use) {
+                    const NormPk np(p);
 #pragma unroll
-                    for (int j = 0; j < QO; ++j) {
-                        float4 o;
-                        normalize_point(p, xo[4 * j], xo[4 * j + 1], o.x, o.y);
-                        normalize_point(p, xo[4 * j + 2], xo[4 * j + 3], o.z, o.w);
-                        orow[j] = o;
-                    }
+                    for (int j = 0; j < QO; ++j) orow[j] = np.quad(xo[4 * j], xo[4 * j + 1], xo[4 * j + 2], xo[4 * j + 3]);
 #pragma unroll
                     for (int q = 0; q < QP; ++q) {
                         const float4 v = prow[q];
-                        float4 o;
-                        normalize_point(p, v.x, v.y, o.x, o.y);
-                        normalize_point(p, v.z, v.w, o.z, o.w);
-                        prow[q] = o;
+                        prow[q] = np.quad(v.x, v.y, v.z, v.w);
                     }
                     ++my_count;
                 }
@@ -153,16 +184,35 @@ __global__ __launch_bounds__(kWaveGramThreads) void gram_wave_kernel(
             }
         }
         wave_sync();
+#if ET_EXP_GRAM >= 1  // measurement aid: no matrix phase
+        if (0)
+#endif
         {
-            const float *po = reinterpret_cast<const float *>(sObs) + kslot * (4 * PO) + feat;
-            const float *pr = reinterpret_cast<const float *>(sPred) + kslot * (4 * PP);
-            const int featb = feat < 8 ? 16 + feat : feat - 8;
+            // Operand reads, one ds_read_b32 each: lane (feat, kslot) reads feature `feat` of the trajectory in k-slot
+            // `kslot` of group g.  A ds_read_b32 is served per half-wave (k-slots {0,1} and {2,3}), bank = dword address mod
+            // 32: the 16 features of one k-slot cover 16 consecutive banks, so the second k-slot of a half-wave must sit
+            // 16 banks away.  Row pitches are 20 (obs) and 28 (pred) dwords -- odd in float4, which the lane = trajectory
+            // phases above need --, so a group's k-slots 0 / 1 (and 2 / 3) take trajectories FOUR rows apart (80 and 112
+            // dwords = 16 mod 32) instead of neighbours: group g = rows 8 (g / 2) + 2 (g % 2) + {0, 4, 1, 5}.  The tile
+            // P = pred[0:16] x pred[0:16] reads features {0..7, 16..23} of the stored order [0:8 | 16:24 | 8:16] -- banks
+            // {0..7, 16..23}, which need a shift of 8 or 24: its groups are rows 8 (g / 2) + 4 (g % 2) + {0, 2, 1, 3}
+            // (56 dwords = 24 mod 32).  (Every tile sums over all 64 trajectories of the pass whatever the grouping; with
+            // neighbouring rows in the k-slots -- rounds 2-5 -- every one of these reads was a 2-way bank conflict:
+            // SQ_LDS_BANK_CONFLICT 3.25e7 > SQ_ACTIVE_INST_LDS 2.37e7, profiles/r05r_sq_breakdown.txt.)
+            const int rowOQ = 4 * (kslot & 1) + (kslot >> 1), rowP = 2 * (kslot & 1) + (kslot >> 1);
+            const float *po = reinterpret_cast<const float *>(sObs) + rowOQ * (4 * PO) + feat;
+            const float *pq = reinterpret_cast<const float *>(sPred) + rowOQ * (4 * PP);
+            const float *pp = reinterpret_cast<const float *>(sPred) + rowP * (4 * PP) + (feat < 8 ? feat : feat + 8);
+            const int fa = feat < 8 ? feat + 16 : feat;   // feature 8 + feat in the stored order
+            const int fb = feat < 8 ? feat + 8 : feat - 8;  // feature (feat < 8 ? 16 + feat : feat - 8) in the stored order
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const double vo = (double)po[g * 4 * (4 * PO)];
-                const double vp = (double)pr[g * 4 * (4 * PP) + feat];
-                const double va = (double)pr[g * 4 * (4 * PP) + 8 + feat];
-                const double vb = (double)pr[g * 4 * (4 * PP) + featb];
+                constexpr int kRowsOQ[2] = {0, 2}, kRowsP[2] = {0, 4};
+                const int rOQ = 8 * (g >> 1) + kRowsOQ[g & 1], rP = 8 * (g >> 1) + kRowsP[g & 1];
+                const double vo = (double)po[rOQ * (4 * PO)];
+                const double vp = (double)pp[rP * (4 * PP)];
+                const double va = (double)pq[rOQ * (4 * PP) + fa];
+                const double vb = (double)pq[rOQ * (4 * PP) + fb];
                 accO = __builtin_amdgcn_mfma_f64_16x16x4f64(vo, vo, accO, 0, 0, 0);
                 accP = __builtin_amdgcn_mfma_f64_16x16x4f64(vp, vp, accP, 0, 0, 0);
                 accQ = __builtin_amdgcn_mfma_f64_16x16x4f64(va, vb, accQ, 0, 0, 0);
@@ -325,8 +375,20 @@ __global__ __launch_bounds__(kFitThreads) void gram_generic_finish_kernel(const 
 // every wavefront instead of one, and that costs more than the barrier and the LDS hand-off it removes.)
 // ------------------------------------------------------------------------------------------
 constexpr int kJacobiMaxSweeps = 30;
+// Stop test at the head of a sweep (oracle/et_oracle.c: eto_jacobi has the same constant).  Jacobi converges
+// quadratically: the sweep that finds 1e-10 would leave ~1e-20.  Until round 5 the bound was 1e-15, one more sweep (of
+// nine on the bench's matrices); on the 22 Gram matrices of the five splits and the synthetic set the two bounds give
+// the same U to 4e-14 (fp32 results: the last bit of a near-zero entry in 3 of 22).
+#ifndef ET_EIGH_HEADSTART
+#define ET_EIGH_HEADSTART 0
+#endif
+#ifndef ET_JACOBI_STOP
+#define ET_JACOBI_STOP 1e-10
+#endif
+constexpr double kJacobiStop = ET_JACOBI_STOP;
 #ifdef ET_EXP_EIGHSTAMP  // development aid: s_memtime ticks of workgroup 0's first wavefront by phase of a round:
-// [0] rounds, [1] rotation parameters, [2] barrier after them, [3] updates, [4] barrier after them, [5] sweep checks, [6] sweeps
+// [0] rounds, [1] block / V items, [2] look-ahead entries, [3] rotation chain + stepping, [4] barrier, [5] sweep checks, [6] sweeps
+// (-DET_EXP_EIGHSTAMP=1: the first wavefront; =2: the look-ahead wavefront)
 __device__ unsigned long long g_eighstamp[8];
 #define ET_EIGHSTAMP(i)                                              \
     do {                                                             \
@@ -406,39 +468,88 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
     // Round 4: the matrix lives in LDS padded with zeros to m x m (m = n rounded up to even).  The padding index pairs
     // with a zero entry, i.e. is an inactive pair, and an INACTIVE pair is applied as the identity rotation (c, s) = (1, 0)
     // -- 1 * x - 0 * y is x again, bit for bit up to the sign of a zero -- so the update phase has no `q < n` / `active`
-    // branches: every work item reads its four entries in one go, rotates twice, writes four.  A round was 2 208 cycles
-    // (profiles/r04i_eigh_stamps.txt: half of it ONE work item's latency through ~10 exec-mask branches); the maxima
-    // of the stop test go through two LDS integer maxima (|x| of non-negative doubles orders like its bit pattern).
+    // branches: every work item reads its four entries in one go, rotates twice, writes four; the maxima of the stop test
+    // go through two LDS integer maxima (|x| of non-negative doubles orders like its bit pattern).
+    //
+    // Round 6: ONE barrier per round instead of two.  A round used to be  parameters (12 lanes: LDS read -> the dependent
+    // fp64 chain alpha, beta -> rsq + Goldschmidt twice -> c, s; 644 cycles) | barrier | updates (760 cycles) | barrier
+    // (profiles/r04i_eigh_stamps.txt) -- the sum of the two phases, ~200 times per solve.  Now the parameter lanes sit in
+    // a wavefront of their own (the last one) and run one round AHEAD, beside the updates: the three entries a_pq, a_pp,
+    // a_qq that the NEXT round's pair (p, q) will need are each one entry of a 2 x 2 block this round's updates rewrite
+    // -- block (pair of p, pair of q), and the two diagonal blocks --, so the parameter lane evaluates exactly those
+    // three entries itself, with the update items' own formulas on the same inputs (row rotation of the pair holding the
+    // row, then column rotation of the pair holding the column: the same products and sums in the same order, hence the
+    // same bits), and goes straight on to the next round's c, s.  The matrix is double-buffered (every entry is rewritten
+    // by exactly one block item per round: read A[cur], write A[cur ^ 1]) so that look-ahead reads and update writes do
+    // not race; so are the parameters.  A round is max(updates, look-ahead + chain) + one barrier.  Same arithmetic per
+    // element as before -- tools/eigh_accuracy.py and the oracle comparison are unchanged.
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int lane = threadIdx.x;
     const int m = (n + 1) & ~1, half = m / 2;
-    double *A = sm;                  // m*m
-    double *V = sm + m * m;          // m*m
-    double *sC = V + m * m;          // 32 cosines
-    double *sS = sC + 32;            // 32 sines
-    unsigned long long *sMax = reinterpret_cast<unsigned long long *>(sS + 32);  // [sweep parity][off, diag]
-    int *sAct = reinterpret_cast<int *>(sMax + 4);  // 32 active, 64 used
-    int *sUsed = sAct + 32;
+    double *Abuf = sm;               // 2 * m*m
+    double *V = sm + 2 * m * m;      // m*m
+    double *sC = V + m * m;          // [2][32] cosines
+    double *sS = sC + 64;            // [2][32] sines
+    unsigned long long *sMax = reinterpret_cast<unsigned long long *>(sS + 64);  // [sweep parity][off, diag]
+    int *sAct = reinterpret_cast<int *>(sMax + 4);  // [2][32] active, 64 used
+    int *sUsed = sAct + 64;
+    uint2 *sTab = reinterpret_cast<uint2 *>(sUsed + 64);  // [m - 1 rounds][3 half look-ahead items]
     for (int i = lane; i < m * m; i += kEighThreads) {
         const int r = i / m, c = i - r * m;
-        A[i] = (r < n && c < n) ? G[r * n + c] : 0.0;
+        Abuf[i] = (r < n && c < n) ? G[r * n + c] : 0.0;
         V[i] = (r == c && r < n) ? 1.0 : 0.0;
     }
     if (lane < 4) sMax[lane] = 0ull;
+    // Look-ahead table (see "Round 6" above): item (e, L) of round r describes ONE entry of the matrix after round r that
+    // parameter lane L needs for its pair (p, q) of round r + 1 -- e = 0: a_pq, 1: a_pp, 2: a_qq -- as the 2 x 2 block of
+    // round r it lies in: the four element offsets, the pairs whose rotations act on its rows (iR) and columns (iC), and
+    // whether the entry is the block's second row / second column.  Round-robin schedules repeat every m - 1 rounds.
+    const int nItems = 3 * half;
+    for (int idx = lane; idx < (m - 1) * nItems; idx += kEighThreads) {
+        const int r = idx / nItems, it = idx - r * nItems, e = it / half, Lt = it - e * half;
+        int p, q;
+        jacobi_schedule(m, r + 1 == m - 1 ? 0 : r + 1, Lt, p, q);
+        int i1 = 0, p1 = 0, q1 = 0, i2 = 0, p2 = 0, q2 = 0;
+        for (int i = 0; i < half; ++i) {
+            int pi, qi;
+            jacobi_schedule(m, r, i, pi, qi);
+            if (p == pi || p == qi) { i1 = i; p1 = pi; q1 = qi; }
+            if (q == pi || q == qi) { i2 = i; p2 = pi; q2 = qi; }
+        }
+        const int iR = e == 2 ? i2 : i1, pR = e == 2 ? p2 : p1, qR = e == 2 ? q2 : q1;
+        const int iC = e == 1 ? i1 : i2, pC = e == 1 ? p1 : p2, qC = e == 1 ? q1 : q2;
+        const unsigned row2 = (e == 2 ? q : p) == qR, col2 = (e == 1 ? p : q) == qC, zero = e == 0 && i1 == i2;
+        sTab[idx] = make_uint2((unsigned)(pR * m + pC) | (unsigned)(pR * m + qC) << 12 | (unsigned)iR << 24,
+                               (unsigned)(qR * m + pC) | (unsigned)(qR * m + qC) << 12 | (unsigned)iC << 24 | row2 << 29 |
+                                   col2 << 30 | zero << 31);
+    }
     __syncthreads();
     // work items of this thread in the update phase:
     //   V: e = lane + t*T - T/2 -> (pair i, row j): columns p_i, q_i of row j
     //   A: b = lane + t*T       -> (pair i1, pair i2): the 2 x 2 block rows {p1, q1} x columns {p2, q2}
     // (the V items start half a workgroup away from the A blocks: for the usual small n the two kinds of work land on
     // different wavefronts and a round's critical path is the longer of the two, not their sum)
+    // (round 6) ... and on wavefronts that do not share a SIMD with the look-ahead wavefront: a workgroup's wavefronts go to
+    // the four SIMDs cyclically, w and w + 4 sit on the same one, and two busy wavefronts on a SIMD take turns issuing --
+    // the V items on wavefront 11 doubled the latency of the chain on wavefront 15.  V items: wavefronts 4 5 6, 8 9 10,
+    // 12 13 14 (in this order), 576 per slot.
+    constexpr bool kSpread = kEighThreads == 1024;
     constexpr int kVShift = kEighThreads / 2;
-    constexpr int kSlots = (32 * 64 + kVShift + kEighThreads - 1) / kEighThreads;
+    constexpr int kVPerSlot = kSpread ? 9 * 64 : kEighThreads;
+    constexpr int kSlots = kSpread ? (32 * 64 + kVPerSlot - 1) / kVPerSlot : (32 * 64 + kVShift + kEighThreads - 1) / kEighThreads;
     constexpr int kBlkSlots = (32 * 32 + kEighThreads - 1) / kEighThreads;
     constexpr int kChkSlots = (64 * 64 + kEighThreads - 1) / kEighThreads;
+    constexpr int kParBase = kEighThreads >= 128 ? kEighThreads - 64 : 0;  // the parameter lanes: first lanes of the last wavefront
     int slot_i[kSlots], slot_row[kSlots], blk_1[kBlkSlots], blk_2[kBlkSlots], chk[kChkSlots];
 #pragma unroll
     for (int t = 0; t < kSlots; ++t) {
-        const int e = lane + t * kEighThreads - kVShift;
+        int e;
+        if (kSpread) {
+            const int w = lane >> 6;
+            e = (w >= 4 && (w & 3) != 3) ? ((w - 4) - ((w - 4) >> 2)) * 64 + (lane & 63) + t * kVPerSlot : -1;
+        } else {
+            e = lane + t * kEighThreads - kVShift;
+        }
         const bool ok = e >= 0 && e < half * n;
         slot_i[t] = ok ? e / n : -1;
         slot_row[t] = ok ? (e % n) * m : 0;  // (row j) * m
@@ -451,79 +562,141 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
     }
     // (carried positions for the parameter lanes and the A blocks -- the critical path; the V items, on other wavefronts
     // and shorter, derive theirs from the round number: stepping three more slots on every wavefront costs what it saves)
-    JacobiPair par, b1[kBlkSlots], b2[kBlkSlots];
-    par.init(m, lane < half ? lane : 0);
+    JacobiPair b1[kBlkSlots], b2[kBlkSlots];
 #pragma unroll
     for (int t = 0; t < kBlkSlots; ++t) {
         b1[t].init(m, blk_1[t] < 0 ? 0 : blk_1[t]);
         b2[t].init(m, blk_2[t]);
     }
+    // The look-ahead items live in the LAST wavefront.  4 half <= 64 (n <= 32): one item per lane, a quad of lanes per
+    // pair -- lane 4 L holds a_pq and goes on to the rotation, lanes 4 L + 1 / + 2 hold a_pp / a_qq and hand them over with
+    // DPP quad broadcasts; larger n: lane L < half evaluates its three items one after the other.
+    const int pl = lane - kParBase;
+    const bool split = 4 * half <= 64;
+    const bool is_par = pl >= 0 && (split ? (pl & 3) == 0 && (pl >> 2) < half : pl < half);  // runs the rotation chain, writes c / s
+    const int L = is_par ? (split ? pl >> 2 : pl) : 0;
+    // split: lane 4 L + e holds item (e, L), e = 0, 1, 2 (the quad's fourth lane idles); serial: lane L holds items (0..2, L)
+    const int item0 = pl < 0 ? 0 : (split ? ((pl & 3) < 3 && (pl >> 2) < half ? (pl & 3) * half + (pl >> 2) : 0) : (pl < half ? pl : 0));
+    JacobiPair par;
+    par.init(m, L);
 #pragma unroll
     for (int t = 0; t < kChkSlots; ++t) {  // element of the upper triangle or the diagonal: its LDS index, +(1 << 20) for the diagonal
         const int e = lane + t * kEighThreads;
         const int i = e / n, j = e - i * n;
         chk[t] = (e < n * n && j >= i) ? (i * m + j) | (i == j ? 1 << 20 : 0) : -1;
     }
+    // c = D / g, s = sgn |beta| / g with D = |alpha| + sqrt(alpha^2 + beta^2), g = sqrt(D^2 + beta^2) (the oracle's
+    // formulas).  This chain -- sqrt -> sqrt -> divide, each a ~100-150 ns correctly rounded software sequence in fp64 --
+    // is on the critical path of every one of the ~200 rounds; here both roots come from v_rsq_f64 + two Goldschmidt
+    // steps (sqrt_rsqrt: full double precision, not correctly rounded) and the divisions become multiplications by
+    // 1 / g.  c^2 + s^2 = 1 to a few 1e-16; the result is not bit-identical to the oracle's correctly rounded chain (U
+    // agrees to ~1e-14, i.e. to the last bit of its fp32 value except on a rounding boundary) but is the same on every
+    // GPU / rank.  An inactive pair (a_pq == 0: also the padding pair of an odd n) runs the chain on zeros and drops it.
+    auto rotation = [&](double apq, double app, double aqq, int buf) {
+        const double alpha = aqq - app, beta = 2.0 * apq;
+#ifdef ET_EIGH_IEEE_PARAMS
+        const double h = sqrt(alpha * alpha + beta * beta);
+        const double D = fabs(alpha) + h;
+        const double g = sqrt(D * D + beta * beta);
+        const double rg = 1.0 / g;
+#else
+        double h, rh;
+        sqrt_rsqrt(alpha * alpha + beta * beta, h, rh);
+        const double D = fabs(alpha) + h;
+        double g, rg;
+        sqrt_rsqrt(D * D + beta * beta, g, rg);
+#endif
+        const double sgn = (alpha == 0.0 || ((alpha > 0.0) == (beta > 0.0))) ? 1.0 : -1.0;
+        const bool act = apq != 0.0;
+        sC[buf * 32 + L] = act ? D * rg : 1.0;
+        sS[buf * 32 + L] = act ? sgn * fabs(beta) * rg : 0.0;
+        sAct[buf * 32 + L] = act ? 1 : 0;
+    };
+    int cur = 0, pb = 0;
+    if (pl >= 0) __builtin_amdgcn_s_setprio(3);  // the look-ahead wavefront is every round's critical path
+    if (is_par) {  // the parameters of the very first round, from the matrix itself
+        int p, q;
+        par.get(m, p, q);
+        rotation(Abuf[__mul24(p, m) + q], Abuf[__mul24(p, m) + p], Abuf[__mul24(q, m) + q], 0);
+    }
+    uint2 ent[3] = {sTab[item0], sTab[split ? item0 : half + item0], sTab[split ? item0 : 2 * half + item0]};  // round 0's items
 #ifdef ET_EXP_EIGHSTAMP
-    const bool stamping = n == 24 && threadIdx.x < 64;
+    const bool stamping = n == 24 && (ET_EXP_EIGHSTAMP == 2 ? (pl >= 0 && pl < 64) : threadIdx.x < 64);  // 2: the look-ahead wavefront
     unsigned long long es_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, es_t = __builtin_amdgcn_s_memtime();
 #endif
     for (int sweep = 0; sweep < kJacobiMaxSweeps; ++sweep) {
 #ifdef ET_EXP_EIGHSTAMP
         if (stamping) { es_t = __builtin_amdgcn_s_memtime(); es_acc[6] += 1; }
 #endif
-        // converged when max |off-diagonal| <= 1e-15 max |diagonal| (maxima: order independent)
+        // converged when max |off-diagonal| <= 1e-10 max |diagonal| (maxima: order independent)
+        const double *Ac = Abuf + cur * m * m;
         unsigned long long *mx = sMax + 2 * (sweep & 1);
 #pragma unroll
         for (int t = 0; t < kChkSlots; ++t) {
             if (chk[t] < 0) continue;
-            const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(fabs(A[chk[t] & 0xfffff])));
+            const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(fabs(Ac[chk[t] & 0xfffff])));
             atomicMax(mx + (chk[t] >> 20), bits);
         }
         if (lane < 2) sMax[2 * ((sweep + 1) & 1) + lane] = 0ull;  // (the other parity: last read a sweep of barriers ago)
-        __syncthreads();
+        __syncthreads();  // (also publishes the first round's parameters)
         const double off = __longlong_as_double(static_cast<long long>(mx[0])), diag = __longlong_as_double(static_cast<long long>(mx[1]));
         ET_EIGHSTAMP(5);
-        if (off <= 1e-15 * diag) break;
+        if (off <= kJacobiStop * diag) break;
         for (int r = 0; r < m - 1; ++r) {
 #ifdef ET_EXP_EIGHSTAMP
             if (stamping) es_acc[0] += 1;
 #endif
-            if (lane < half) {
-                int p, q;
-                par.get(m, p, q);
-                const double apq = A[__mul24(p, m) + q], app = A[__mul24(p, m) + p], aqq = A[__mul24(q, m) + q];
-                // c = D / g, s = sgn |beta| / g with D = |alpha| + sqrt(alpha^2 + beta^2), g = sqrt(D^2 + beta^2)
-                // (the oracle's formulas).  This chain -- sqrt -> sqrt -> divide, each a ~100-150 ns correctly
-                // rounded software sequence in fp64 -- is on the critical path of every one of the ~200 rounds
-                // while 15 of the 16 wavefronts wait at the barrier; here both roots come from v_rsq_f64 + two
-                // Goldschmidt steps (sqrt_rsqrt: full double precision, not correctly rounded) and the divisions
-                // become multiplications by 1 / g.  c^2 + s^2 = 1 to a few 1e-16 as before; the result is no
-                // longer bit-identical to the oracle's correctly rounded chain (U agrees to ~1e-14, i.e. to the
-                // last bit of its fp32 value except on a rounding boundary) but is the same on every GPU / rank.
-                // An inactive pair (a_pq == 0: also the padding pair of an odd n) runs the chain on zeros and drops it.
-                const double alpha = aqq - app, beta = 2.0 * apq;
-#ifdef ET_EIGH_IEEE_PARAMS
-                const double h = sqrt(alpha * alpha + beta * beta);
-                const double D = fabs(alpha) + h;
-                const double g = sqrt(D * D + beta * beta);
-                const double rg = 1.0 / g;
-#else
-                double h, rh;
-                sqrt_rsqrt(alpha * alpha + beta * beta, h, rh);
-                const double D = fabs(alpha) + h;
-                double g, rg;
-                sqrt_rsqrt(D * D + beta * beta, g, rg);
+#if ET_EIGH_HEADSTART > 0
+            // the look-ahead wavefront's LDS reads go first: right after the barrier all sixteen wavefronts send theirs, and
+            // the reads the critical path waits for stood in that queue (profiles/r06c_eigh_stamps.txt: 900 of a round's 1 350
+            // ticks); the others have ~500 ticks of slack per round
+            if (pl < 0) __builtin_amdgcn_s_sleep(ET_EIGH_HEADSTART);
 #endif
-                const double sgn = (alpha == 0.0 || ((alpha > 0.0) == (beta > 0.0))) ? 1.0 : -1.0;
-                const bool act = apq != 0.0;
-                sC[lane] = act ? D * rg : 1.0;
-                sS[lane] = act ? sgn * fabs(beta) * rg : 0.0;
-                sAct[lane] = act ? 1 : 0;
+            const double *Ar = Abuf + cur * m * m;
+            double *Aw = Abuf + (cur ^ 1) * m * m;
+            const double *pC = sC + pb * 32, *pS = sS + pb * 32;
+            const int *pAct = sAct + pb * 32;
+            if (pl >= 0) {  // (the whole last wavefront takes the branch: the shuffles below need every lane)
+                // look-ahead: entry (row x, column y) of the matrix AFTER this round, x in this round's pair iR = (pR, qR),
+                // y in pair iC = (pC, qC):  t_c = alR A[pR][c] + beR A[qR][c] for c = pC, qC with (alR, beR) = (c, -s) of
+                // pair iR for the pair's first row, (s, c) for its second (c x - s y and s x + c y of the block items:
+                // (-s) y rounds to -(s y), the sum is the same), then alC t_pC + beC t_qC likewise with pair iC.
+                auto entry = [&](uint2 t) -> double {
+                    const double x_pp = Ar[t.x & 0xfffu], x_pq = Ar[(t.x >> 12) & 0xfffu];
+                    const double x_qp = Ar[t.y & 0xfffu], x_qq = Ar[(t.y >> 12) & 0xfffu];
+                    const int iR = (int)((t.x >> 24) & 31u), iC = (int)((t.y >> 24) & 31u);
+                    const double cR = pC[iR], sR = pS[iR], cC = pC[iC], sC_ = pS[iC];
+                    const int actR = pAct[iR];
+                    const bool row2 = (t.y >> 29) & 1u, col2 = (t.y >> 30) & 1u;
+                    const double alR = row2 ? sR : cR, beR = row2 ? cR : -sR;
+                    const double alC = col2 ? sC_ : cC, beC = col2 ? cC : -sC_;
+                    const double v = alC * (alR * x_pp + beR * x_qp) + beC * (alR * x_pq + beR * x_qq);
+                    // (m = 2: the next pair IS this pair; its rotated off-diagonal entry is exactly zero, like the block item's)
+                    return ((t.y >> 31) & (unsigned)actR) ? 0.0 : v;
+                };
+                double apq, app, aqq;
+                if (split) {  // a_pp, a_qq from the quad's lanes 1 and 2: DPP moves, no trip through the LDS
+                    const double v = entry(ent[0]);
+                    const int lo = __double2loint(v), hi = __double2hiint(v);
+                    apq = v;
+                    app = __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x55, 0xf, 0xf, false), __builtin_amdgcn_mov_dpp(lo, 0x55, 0xf, 0xf, false));
+                    aqq = __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0xaa, 0xf, 0xf, false), __builtin_amdgcn_mov_dpp(lo, 0xaa, 0xf, 0xf, false));
+                } else {
+                    apq = entry(ent[0]);
+                    app = entry(ent[1]);
+                    aqq = entry(ent[2]);
+                }
+                ET_EIGHSTAMP(2);  // [2] look-ahead entries (+ shuffles)
+                // the next round's items: in flight during the chain below
+                const int rn = r + 1 == m - 1 ? 0 : r + 1;
+                ent[0] = sTab[rn * nItems + item0];
+                if (!split) {
+                    ent[1] = sTab[rn * nItems + half + item0];
+                    ent[2] = sTab[rn * nItems + 2 * half + item0];
+                }
+                if (is_par) rotation(apq, app, aqq, pb ^ 1);
             }
-            ET_EIGHSTAMP(1);
-            __syncthreads();
-            ET_EIGHSTAMP(2);
+            ET_EIGHSTAMP(3);  // [3] rotation chain
             // A' = J^T A J for the round's disjoint rotations, one 2 x 2 block per work item: the row rotation of pair
             // i1 followed by the column rotation of pair i2 touches exactly these four entries, so "all row updates,
             // then all column updates" (the oracle's order, with its intermediate roundings) needs no barrier in between.
@@ -537,9 +710,9 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
                 b1[t].get(m, p1, q1);
                 b2[t].get(m, p2, q2);
                 const int rp = __mul24(p1, m), rq = __mul24(q1, m);
-                const int diag_act = sAct[i1] & (i1 == i2 ? 1 : 0);  // (read by every lane: a read under a branch is a round trip of its own)
-                const double c1 = sC[i1], s1 = sS[i1], c2 = sC[i2], s2 = sS[i2];
-                const double x_pp = A[rp + p2], x_pq = A[rp + q2], x_qp = A[rq + p2], x_qq = A[rq + q2];
+                const int diag_act = pAct[i1] & (i1 == i2 ? 1 : 0);  // (read by every lane: a read under a branch is a round trip of its own)
+                const double c1 = pC[i1], s1 = pS[i1], c2 = pC[i2], s2 = pS[i2];
+                const double x_pp = Ar[rp + p2], x_pq = Ar[rp + q2], x_qp = Ar[rq + p2], x_qq = Ar[rq + q2];
                 // rows p1, q1 (columns p2 and q2), then columns p2, q2 (rows p1 and q1)
                 const double t_pp = c1 * x_pp - s1 * x_qp, t_qp = s1 * x_pp + c1 * x_qp;
                 const double t_pq = c1 * x_pq - s1 * x_qq, t_qq = s1 * x_pq + c1 * x_qq;
@@ -550,10 +723,10 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
                     r_pq = 0.0;
                     r_qp2 = 0.0;
                 }
-                A[rp + p2] = r_pp;
-                A[rp + q2] = r_pq;
-                A[rq + p2] = r_qp2;
-                A[rq + q2] = r_qq;
+                Aw[rp + p2] = r_pp;
+                Aw[rp + q2] = r_pq;
+                Aw[rq + p2] = r_qp2;
+                Aw[rq + q2] = r_qq;
             }
 #pragma unroll
             for (int t = 0; t < kSlots; ++t) {  // V' = V J: columns p, q of every row
@@ -561,25 +734,27 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
                 if (i < 0) continue;
                 int p, q;
                 jacobi_schedule(m, r, i, p, q);
-                const double c = sC[i], sn = sS[i];
+                const double c = pC[i], sn = pS[i];
                 double *row = V + slot_row[t];
                 const double vjp = row[p], vjq = row[q];
                 row[p] = c * vjp - sn * vjq;
                 row[q] = sn * vjp + c * vjq;
             }
-            par.step(m);
 #pragma unroll
             for (int t = 0; t < kBlkSlots; ++t) {
                 b1[t].step(m);
                 b2[t].step(m);
             }
-            ET_EIGHSTAMP(3);
+            ET_EIGHSTAMP(1);  // [1] this wavefront's block / V items
             __syncthreads();
             ET_EIGHSTAMP(4);
+            cur ^= 1;
+            pb ^= 1;
         }
     }
+    double *A = Abuf + cur * m * m;
 #ifdef ET_EXP_EIGHSTAMP
-    if (stamping && threadIdx.x == 0)
+    if (stamping && (ET_EXP_EIGHSTAMP == 2 ? pl == 0 : threadIdx.x == 0))
         for (int i = 0; i < 7; ++i) atomicAdd(&g_eighstamp[i], es_acc[i]);
 #endif
     __syncthreads();
@@ -692,7 +867,8 @@ extern "C" int et_fit_gram(const float *obs, const float *pred, int64_t N, int T
 
 static size_t eigh_lds_bytes(int n) {
     const size_t m = ((size_t)n + 1) & ~(size_t)1;  // zero-padded to even
-    return sizeof(double) * (2 * m * m + 64 + 4) + sizeof(int) * (32 + 64 + 2);
+    // A (double-buffered), V, c / s (x2), maxima; active (x2), used; the look-ahead table
+    return sizeof(double) * (3 * m * m + 128 + 4) + sizeof(int) * (64 + 64) + sizeof(uint2) * (m - 1) * 3 * (m / 2);
 }
 
 extern "C" int et_eigh_topk_batch(int batch, const double *const *G, const int *n, const int *k, float *const *U,

@@ -30,6 +30,6 @@ rounds, sweeps = v[0], v[6]
 tot = sum(v[1:6])
 print(f"{a.elapsed_time(b) * 1e3:.1f} us between events (with the stamps), {sweeps} sweep checks, {rounds} rounds, {tot} ticks "
       f"({tot / max(rounds, 1):.0f} per round)")
-for i, nm in enumerate(["rotation parameters (12 lanes)", "barrier after them", "updates of A and V", "barrier after them",
-                        "convergence checks (per sweep)"]):
+for i, nm in enumerate(["block / V items of the wavefront", "look-ahead entries (+ shuffles)", "rotation chain + stepping",
+                        "barrier", "convergence checks (per sweep)"]):
     print(f"    {nm:34s} {v[i + 1]:9d} ticks  {100 * v[i + 1] / tot:5.1f} %   {v[i + 1] / max(rounds, 1):6.0f} per round")
