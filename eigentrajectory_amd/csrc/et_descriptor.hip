@@ -55,7 +55,7 @@ __device__ __forceinline__ int64_t tile_of_block() {
 //   phase 2  lane = trajectory: normaliser state, normalise, U^T x (U from LDS), k-major stores
 // ------------------------------------------------------------------------------------------
 // (round 5: staging the rows memory -> LDS directly, `buffer_load_dwordx4 ... lds`, default and non-temporal policy, measured
-// no faster: profiles/r05d_project_dma_ab.txt; source: tools/lost_forms/project_lds_dma.hip.txt)
+// no faster: profiles/r05d_project_dma_ab.txt; source: tools/archive/lost_forms/project_lds_dma.hip.txt)
 // Cache policy of the two HBM-bound kernels on BIG launches (round 6, profiles/r06b_project_recon_ab.txt: same-box A/B, five
 // alternating rounds per form at N = 1e7).  STREAM = the launch moves more than the 256 MB memory-side cache holds:
 //   projection      row loads non-temporal (each row is read once) and C_obs stores non-temporal (nobody re-reads them soon);
@@ -782,7 +782,7 @@ __host__ __device__ constexpr size_t metrics_mfma_lds_floats(int S, int n_desc) 
     return (size_t)kMetWaves * kMetSlice + (((size_t)n_desc * 6 * S + 3) & ~(size_t)3) + (size_t)kMetWaves * kMetStages * kMetStage;
 }
 
-#ifdef ET_EXP_METSTAMP  // development aid (tools/metstamp.py): shader cycles (s_memtime) a wavefront spends in the phases of
+#ifdef ET_EXP_METSTAMP  // development aid (tools/archive/metstamp.py): shader cycles (s_memtime) a wavefront spends in the phases of
 // a pass, summed over all wavefronts: [0] passes, [1] slice hand-over + stores + requests, [2] wait for this pass's
 // inputs, [3] LDS reads + ground-truth normalisation + operands, [4] matrix instructions + hand-over, [5] distances,
 // [6] best-of-S, [7] wavefronts
@@ -1224,7 +1224,7 @@ static bool need_s(int mode) { return mode != ET_MODE_MOVING; }
 
 // (persistent, barrier-free STREAMING forms of the one-descriptor projection / S = 1 reconstruction were built in round 4 and lost
 // to the workgroup-tile kernels -- project 0.414 against 0.386 ms, reconstruct 0.253 against 0.228 ms at N = 1e7, same box,
-// profiles/r04a_stream_ab.txt; their source: tools/lost_forms/project_reconstruct_stream.hip.txt)
+// profiles/r04a_stream_ab.txt; their source: tools/archive/lost_forms/project_reconstruct_stream.hip.txt)
 static int cu_count() {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) != hipSuccess ||

@@ -36,2523 +36,9 @@
 #include "et_mfma_filter.h"
 #include "et_options.h"
 
-namespace et {
-namespace reforder {
-
-constexpr int kThreads = 256;
-constexpr int kMaxD = ET_KMEANS_MAX_D;
-
-__host__ __device__ inline int ceil_log2_aten(int64_t x) {  // c10::utils::CeilLog2
-    if (x <= 2) return 1;
-    int l = 0;
-    for (int64_t v = x - 1; v > 0; v >>= 1) ++l;
-    return l;
-}
-__host__ __device__ inline int level_power(int64_t size) {
-    const int lp = ceil_log2_aten(size) / 4;
-    return lp > 4 ? lp : 4;
-}
-
-// ATen multi_row_sum over `size` values v[0], v[stride], ...
-__device__ inline float cascade_f32(const float *v, int stride, int size) {
-    const int lp = level_power(size);
-    const int step = 1 << lp, lmask = step - 1;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    int i = 0;
-    while (i + step <= size) {
-        for (int q = 0; q < step; ++q, ++i) acc[0] = acc[0] + v[i * stride];
-        for (int lv = 1; lv < 4; ++lv) {
-            acc[lv] = acc[lv] + acc[lv - 1];
-            acc[lv - 1] = 0.f;
-            if ((i & (lmask << (lv * lp))) != 0) break;
-        }
-    }
-    for (; i < size; ++i) acc[0] = acc[0] + v[i * stride];
-    for (int lv = 1; lv < 4; ++lv) acc[0] = acc[0] + acc[lv];
-    return acc[0];
-}
-// ATen row_sum: 4 interleaved lanes, leftovers onto lane 0, lanes combined in order
-__device__ inline float row_sum_f32(const float *v, int size) {
-    const int s4 = size / 4;
-    float lane[4];
-    for (int k = 0; k < 4; ++k) lane[k] = cascade_f32(v + k, 4, s4);
-    for (int i = s4 * 4; i < size; ++i) lane[0] = lane[0] + v[i];
-    for (int k = 1; k < 4; ++k) lane[0] = lane[0] + lane[k];
-    return lane[0];
-}
-// which order column `pos` of `count` gets in x.pow(2).sum(dim=-2)
-__host__ __device__ inline bool column_is_sequential(int64_t pos, int64_t count) {
-    return count < 8 ? pos < count / 4 * 4 : pos < count / 32 * 32;
-}
-// ATen vectorized_inner_sum over a contiguous array (kmeans.py:50)
-__device__ inline float inner_sum_f32(const float *v, int size) {
-    if (size < 8) return row_sum_f32(v, size);  // less than one vector: the scalar kernel's row_sum
-    const int nv = size / 8;
-    float lanes[8];
-    for (int l = 0; l < 8; ++l) {
-        const int s4 = nv / 4;
-        float slot[4];
-        for (int k = 0; k < 4; ++k) slot[k] = cascade_f32(v + 8 * k + l, 32, s4);
-        for (int i = s4 * 4; i < nv; ++i) slot[0] = slot[0] + v[8 * i + l];
-        for (int k = 1; k < 4; ++k) slot[0] = slot[0] + slot[k];
-        lanes[l] = slot[0];
-    }
-    float acc = 0.f;
-    for (int i = nv * 8; i < size; ++i) acc = acc + v[i];
-    for (int l = 0; l < 8; ++l) acc = acc + lanes[l];
-    return acc;
-}
-
-__device__ inline float sqnorm_at(const float *sq, int d, int64_t pos, int64_t count) {
-    if (count == 1 && d >= 8) return inner_sum_f32(sq, d);  // one column of >= 8 rows: a contiguous reduction for ATen
-    return column_is_sequential(pos, count) ? cascade_f32(sq, 1, d) : row_sum_f32(sq, d);
-}
-
-// torch.max (kmeans.py:156): NaN beats everything, first index wins
-__device__ inline bool gt_nanmax(float cand, float best) { return (cand > best) || (isnan(cand) && !isnan(best)); }
-// torch.argmin (kmeans.py:97): NaN is the smallest, first index wins.  Is (v1, i1) ahead of (v2, i2)?
-__device__ inline bool argmin_ahead(float v1, long long i1, float v2, long long i2) {
-    const bool n1 = isnan(v1), n2 = isnan(v2);
-    if (n1 != n2) return n1;
-    if (!n1 && v1 != v2) return v1 < v2;
-    return i1 < i2;
-}
-
-// |c_j|^2 of the `count` centroid columns currently in play, into LDS
-__device__ inline void stage_centroid_norms(const float *cen, int d, int K, int count, float *sC, float *sBn) {
-    for (int e = threadIdx.x; e < d * count; e += blockDim.x) sC[e] = cen[(e / count) * K + (e % count)];
-    __syncthreads();
-    for (int j = threadIdx.x; j < count; j += blockDim.x) {
-        float sq[kMaxD];
-        for (int i = 0; i < d; ++i) {
-            const float v = sC[i * count + j];
-            sq[i] = v * v;
-        }
-        sBn[j] = sqnorm_at(sq, d, j, count);
-    }
-    __syncthreads();
-}
-
-// max_j euc_sim(x_n, c_j) over `count` centroids and its arg-max
-__device__ inline void best_of(const float *X, int64_t N, int d, int64_t n, const float *sC, const float *sBn, int count,
-                               float &best, int &lb) {
-    float x[kMaxD], sq[kMaxD];
-    for (int i = 0; i < d; ++i) {
-        x[i] = X[(int64_t)i * N + n];
-        sq[i] = x[i] * x[i];
-    }
-    const float an = sqnorm_at(sq, d, n, N);
-    best = 0.f;
-    lb = 0;
-    for (int j = 0; j < count; ++j) {
-        float y = 0.f;
-        for (int i = 0; i < d; ++i) y = fmaf(x[i], sC[i * count + j], y);
-        y = y * 2.0f;
-        y = y - an;
-        y = y - sBn[j];
-        if (j == 0 || gt_nanmax(y, best)) {
-            best = y;
-            lb = j;
-        }
-    }
-}
-
-// ---- kmeans.py:143-158: labels, maxsims, per-cluster counts ----
-__global__ __launch_bounds__(kThreads) void reforder_assign_kernel(const float *__restrict__ X, int64_t N, int d, int K,
-                                                                   const float *__restrict__ cen, uint8_t *__restrict__ labels,
-                                                                   float *__restrict__ maxsims,
-                                                                   unsigned long long *__restrict__ counts) {
-    extern __shared__ float smem[];
-    float *sC = smem, *sBn = smem + d * K;
-    __shared__ unsigned sCnt[256];
-    for (int j = threadIdx.x; j < 256; j += blockDim.x) sCnt[j] = 0u;
-    stage_centroid_norms(cen, d, K, K, sC, sBn);
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
-        float best;
-        int lb;
-        best_of(X, N, d, n, sC, sBn, K, best, lb);
-        labels[n] = (uint8_t)lb;
-        maxsims[n] = best;
-        atomicAdd(&sCnt[lb], 1u);
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < K; j += blockDim.x)
-        if (sCnt[j]) atomicAdd(&counts[j], (unsigned long long)sCnt[j]);
-}
-
-// ---- kmeans.py:180-182, inner two cascade levels ----
-// work item (g, lane, column): group g = L consecutive level-0 chunks of L lane terms each (the last group may hold
-// fewer full chunks); S1[g][lane][column] = the level-1 accumulator after those chunks
-__global__ __launch_bounds__(kThreads) void reforder_group_kernel(const float *__restrict__ X, int64_t N, int d, int K,
-                                                                  const uint8_t *__restrict__ labels, int lp, int64_t n_groups,
-                                                                  int64_t full_chunks, float *__restrict__ S1) {
-    const int dk = d * K;
-    const int64_t total = n_groups * 4 * dk;
-    const int64_t L = (int64_t)1 << lp;
-    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (int64_t)gridDim.x * blockDim.x) {
-        const int e = (int)(w % dk);
-        const int lane = (int)((w / dk) % 4);
-        const int64_t g = w / (4 * dk);
-        const int j = e % K;
-        const float *x = X + (int64_t)(e / K) * N;
-        float acc1 = 0.f;
-        for (int64_t c = g * L; c < (g + 1) * L && c < full_chunks; ++c) {
-            float acc0 = 0.f;
-            for (int64_t r = c * L; r < (c + 1) * L; ++r) {
-                const int64_t n = 4 * r + lane;
-                if (labels[n] == j) acc0 = acc0 + x[n];
-            }
-            acc1 = acc1 + acc0;
-        }
-        S1[w] = acc1;
-    }
-}
-
-// outer two levels, leftovers, lane combination -> sums (d, K)
-__global__ __launch_bounds__(kThreads) void reforder_finish_kernel(const float *__restrict__ X, int64_t N, int d, int K,
-                                                                   const uint8_t *__restrict__ labels, int lp,
-                                                                   int64_t full_chunks, const float *__restrict__ S1,
-                                                                   float *__restrict__ lanes, float *__restrict__ sums) {
-    const int dk = d * K;
-    const int64_t L = (int64_t)1 << lp;
-    const int64_t size = N / 4, full_groups = full_chunks / L;
-    for (int w = threadIdx.x; w < 4 * dk; w += blockDim.x) {
-        const int e = w % dk, lane = w / dk;
-        const int j = e % K;
-        const float *x = X + (int64_t)(e / K) * N;
-        float acc2 = 0.f, acc3 = 0.f;
-        for (int64_t g = 0; g < full_groups; ++g) {
-            acc2 = acc2 + S1[(g * 4 + lane) * dk + e];
-            if ((g + 1) % L == 0) {
-                acc3 = acc3 + acc2;
-                acc2 = 0.f;
-            }
-        }
-        const float acc1 = full_chunks % L ? S1[(full_groups * 4 + lane) * dk + e] : 0.f;
-        float acc0 = 0.f;
-        for (int64_t r = full_chunks * L; r < size; ++r) {
-            const int64_t n = 4 * r + lane;
-            if (labels[n] == j) acc0 = acc0 + x[n];
-        }
-        lanes[w] = ((acc0 + acc1) + acc2) + acc3;
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < dk; e += blockDim.x) {
-        const int j = e % K;
-        const float *x = X + (int64_t)(e / K) * N;
-        float p = lanes[e];
-        for (int64_t n = size * 4; n < N; ++n)
-            if (labels[n] == j) p = p + x[n];
-        for (int lane = 1; lane < 4; ++lane) p = p + lanes[lane * dk + e];
-        sums[e] = p;
-    }
-}
-
-// deterministic fp64 partial sums of the maxsims (the inertia is only printed by the reference, kmeans.py:236)
-__global__ __launch_bounds__(kThreads) void reforder_inertia_kernel(const float *__restrict__ maxsims, int64_t N,
-                                                                    double *__restrict__ partial) {
-    __shared__ double sW[kThreads];
-    double s = 0.0;
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x)
-        s = s + (double)maxsims[n];
-    sW[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = kThreads / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) sW[threadIdx.x] = sW[threadIdx.x] + sW[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) partial[blockIdx.x] = sW[0];
-}
-
-// kmeans.py:231-239: centroids = sums / counts, error, inertia, stop flag.  One workgroup.
-__global__ __launch_bounds__(kThreads) void reforder_update_kernel(et_kmeans_state *state, const float *__restrict__ sums,
-                                                                   unsigned long long *__restrict__ counts,
-                                                                   const double *__restrict__ partial, int n_partial,
-                                                                   int64_t N, int d, int K, float tol, float *__restrict__ cen,
-                                                                   float *__restrict__ trace) {
-    extern __shared__ float smem[];
-    float *sSq = smem;
-    const int dk = d * K;
-    for (int e = threadIdx.x; e < dk; e += blockDim.x) {
-        const float c = sums[e] / (float)(long long)counts[e % K];  // 0/0 = NaN for an empty cluster (kmeans.py:182)
-        const float diff = cen[e] - c;
-        sSq[e] = diff * diff;
-        cen[e] = c;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float error = inner_sum_f32(sSq, dk);
-        double s = 0.0;
-        for (int b = 0; b < n_partial; ++b) s = s + partial[b];
-        const float inertia = (float)(-(s / (double)N));
-        const int64_t it = state->iter;
-        if (trace) {
-            trace[2 * it] = error;
-            trace[2 * it + 1] = inertia;
-        }
-        state->error = (double)error;
-        state->inertia = (double)inertia;
-        state->iter = it + 1;
-        state->done = (error <= tol) ? 1 : 0;
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < K; j += blockDim.x) counts[j] = 0ull;  // for the next assignment
-}
-
-// ---- kmeans.py:88-112 farthest-first: step with `count` centroids known ----
-struct Cand {
-    float v;
-    int pad;
-    long long idx;
-};
-__global__ __launch_bounds__(kThreads) void reforder_init_step_kernel(const float *__restrict__ X, int64_t N, int d, int K,
-                                                                      int count, const float *__restrict__ C0,
-                                                                      Cand *__restrict__ cands) {
-    extern __shared__ float smem[];
-    float *sC = smem, *sBn = smem + d * count;
-    stage_centroid_norms(C0, d, K, count, sC, sBn);
-    float bv = 0.f;
-    long long bi = -1;
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
-        float best;
-        int lb;
-        best_of(X, N, d, n, sC, sBn, count, best, lb);
-        if (bi < 0 || argmin_ahead(best, n, bv, bi)) {
-            bv = best;
-            bi = n;
-        }
-    }
-    __shared__ float sV[kThreads];
-    __shared__ long long sI[kThreads];
-    sV[threadIdx.x] = bv;
-    sI[threadIdx.x] = bi;
-    __syncthreads();
-    for (int o = kThreads / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            const float v2 = sV[threadIdx.x + o];
-            const long long i2 = sI[threadIdx.x + o];
-            if (i2 >= 0 && (sI[threadIdx.x] < 0 || argmin_ahead(v2, i2, sV[threadIdx.x], sI[threadIdx.x]))) {
-                sV[threadIdx.x] = v2;
-                sI[threadIdx.x] = i2;
-            }
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        cands[blockIdx.x].v = sV[0];
-        cands[blockIdx.x].idx = sI[0];
-    }
-}
-// ---- the same step, incrementally (d < 8, K <= 32): the reference re-evaluates euc_sim against ALL `count` current
-// centroids, but which of the two norm orders a centroid's |b|^2 takes depends on (column, count) in a way that leaves only two
-// regimes for count <= 31: every column in the 4-lane order ("R"), except count = 4 .. 7, where columns 0 .. 3 are summed in
-// sequence ("S") (column_is_sequential).  So a running maximum over the R-order similarities (bestR: all centroids; bestR4:
-// centroids >= 4) is exact -- max is order independent, NaN sticky -- and a step evaluates ONE new centroid per point (plus,
-// in the four steps count = 4 .. 7, the S-order similarities of centroids 0 .. 3) instead of `count`:
-//   count in 1..3, 8..31:  value = bestR;      count in 4..7:  value = max(max_{j<4} sim_S(x, c_j), bestR4)
-// 9.0 -> ~1.5 ms for the 19 steps at 1e7 points; the same picks bit for bit (tests: every G7c / G7d case, odd shapes).
-template <int D>  // D = 6: the coordinates in registers; 0: any d < 8 (run-time loops)
-__global__ __launch_bounds__(kThreads) void reforder_init_step_inc_kernel(const float *__restrict__ X, int64_t N, int d_rt, int K,
-                                                                          int count, const float *__restrict__ C0,
-                                                                          float *__restrict__ bestR, float *__restrict__ bestR4,
-                                                                          uint8_t *__restrict__ nearest, unsigned *__restrict__ max_abs_bits,
-                                                                          int skip_ok, Cand *__restrict__ cands,
-                                                                          const Cand *__restrict__ prev_cands, int n_prev,
-                                                                          float *__restrict__ C0_rw) {
-    constexpr int DM = D ? D : 8;
-    const int d = D ? D : d_rt;
-    __shared__ float sV[kThreads];
-    __shared__ long long sI[kThreads];
-    __shared__ float sNew[DM + 1];      // the newest centroid (column count - 1) and its R-order norm
-    __shared__ float sS[4 * (DM + 1)];  // count in 4..7: centroids 0..3 and their S-order norms
-    __shared__ float sDelta[ET_KMEANS_MAX_CLUSTERS];  // lower bounds of ||c_new - c_j||^2, j < count - 1
-    __shared__ unsigned sMabs;
-    const bool window = count >= 4 && count <= 7;
-    // Outside the window the step's value IS bestR, and a point whose nearest centroid c_l (the arg-max behind bestR) is
-    // closer than half the distance from c_l to the new centroid cannot get a larger similarity from the new one -- the test
-    // of csrc/et_kmeans.hip's farthest-first (init_step_body: ||c_new - c_l||^2 >= 4 (E - b), E >= twice the rounding error
-    // of the similarity formula in ANY summation order of the norms), on the reference-order values: such a point costs
-    // 5 bytes (bestR, nearest) instead of 28, and its value is bit for bit what the full evaluation would leave.
-    // (skip_ok: only for big shards -- below ~2e6 points a step is two dependent round trips instead of one and nothing else)
-    const bool can_skip = count >= 2 && !window && skip_ok != 0;
-    if (threadIdx.x == 0) sMabs = 0u;
-    // Centroid count - 1 is the winner of the PREVIOUS step's workgroup candidates: every workgroup derives it itself (the same
-    // reduction everywhere; workgroup 0 also stores it into C0) -- two short round trips in the prologue instead of a pick
-    // launch between two steps (19 launches and their boundaries per seeding).  prev_cands == nullptr: it is in C0 already.
-    if (prev_cands) {
-        float pv = 0.f;
-        long long pi = -1;
-        for (int b = threadIdx.x; b < n_prev; b += kThreads) {
-            const float v = prev_cands[b].v;
-            const long long i = prev_cands[b].idx;
-            if (i >= 0 && (pi < 0 || argmin_ahead(v, i, pv, pi))) {
-                pv = v;
-                pi = i;
-            }
-        }
-        sV[threadIdx.x] = pv;
-        sI[threadIdx.x] = pi;
-        __syncthreads();
-        for (int o = kThreads / 2; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) {
-                const float v2 = sV[threadIdx.x + o];
-                const long long i2 = sI[threadIdx.x + o];
-                if (i2 >= 0 && (sI[threadIdx.x] < 0 || argmin_ahead(v2, i2, sV[threadIdx.x], sI[threadIdx.x]))) {
-                    sV[threadIdx.x] = v2;
-                    sI[threadIdx.x] = i2;
-                }
-            }
-            __syncthreads();
-        }
-        if ((int)threadIdx.x < d) {
-            const float v = X[(int64_t)threadIdx.x * N + sI[0]];
-            sNew[threadIdx.x] = v;
-            if (blockIdx.x == 0) C0_rw[threadIdx.x * K + (count - 1)] = v;
-        }
-        __syncthreads();
-    } else if ((int)threadIdx.x < d) {
-        sNew[threadIdx.x] = C0[threadIdx.x * K + (count - 1)];
-    }
-    if (!prev_cands) __syncthreads();
-    if (can_skip && (int)threadIdx.x >= 128 && (int)threadIdx.x < 128 + count - 1) {
-        const int j = (int)threadIdx.x - 128;
-        double s2 = 0.0;
-        for (int i = 0; i < d; ++i) {
-            const double t = (double)sNew[i] - (double)C0[i * K + j];
-            s2 += t * t;
-        }
-        sDelta[j] = (float)(s2 * (1.0 - 4e-6)) * (1.0f - 1e-6f);
-    }
-    if (threadIdx.x == 0) {
-        float sq[kMaxD];
-        for (int i = 0; i < d; ++i) sq[i] = sNew[i] * sNew[i];
-        sNew[DM] = row_sum_f32(sq, d);
-    }
-    if (window && threadIdx.x >= 64 && threadIdx.x < 68) {
-        const int j = threadIdx.x - 64;
-        float sq[kMaxD];
-        for (int i = 0; i < d; ++i) {
-            const float v = j == count - 1 ? sNew[i] : C0[i * K + j];  // (count = 4: column 3 is being stored by workgroup 0 right now)
-            sS[j * (DM + 1) + i] = v;
-            sq[i] = v * v;
-        }
-        sS[j * (DM + 1) + DM] = cascade_f32(sq, 1, d);
-    }
-    __syncthreads();
-    float bv = 0.f;
-    long long bi = -1;
-    float E = __int_as_float(0x7f800000);  // (unknown: nothing is skipped)
-    if (can_skip) {
-        const float R = 2.0f * sqrtf((float)d) * __uint_as_float(*max_abs_bits) * 1.0001f;  // every centroid is a point
-        E = R * R * 1.9073486328125e-6f;                                                   // 2^-19 (|x| + |c|)^2
-        if (!(E <= 3.0e38f)) E = __int_as_float(0x7f800000);
-    }
-    float mabs = 0.f;
-    const int64_t seq_cols = N < 8 ? N / 4 * 4 : N / 32 * 32;  // column_is_sequential(n, N)
-    // one point: `known` = its bestR is in b already and the skip test has been made (passed: skip)
-    auto visit = [&](int64_t n, bool known, float b, bool skip) {
-        if (skip) {
-            if (bi < 0 || argmin_ahead(b, n, bv, bi)) {
-                bv = b;
-                bi = n;
-            }
-            return;
-        }
-        float x[DM];
-#pragma unroll
-        for (int i = 0; i < DM; ++i) x[i] = i < d ? X[(int64_t)i * N + n] : 0.f;
-        if (count == 1) {
-#pragma unroll
-            for (int i = 0; i < DM; ++i) mabs = fmaxf(mabs, fabsf(x[i]));  // (a NaN is ignored here and never skipped later)
-        }
-        float an;
-        if (n < seq_cols) {  // rows in sequence (0 + s0 = s0)
-            an = x[0] * x[0];
-#pragma unroll
-            for (int i = 1; i < DM; ++i)
-                if (i < d) an = an + x[i] * x[i];
-        } else {
-            float sq[kMaxD];
-            for (int i = 0; i < d; ++i) sq[i] = x[i] * x[i];
-            an = sqnorm_at(sq, d, n, N);
-        }
-        auto sim = [&](const float *c) {
-            float y = 0.f;
-#pragma unroll
-            for (int i = 0; i < DM; ++i)
-                if (i < d) y = fmaf(x[i], c[i], y);
-            y = y * 2.0f;
-            y = y - an;
-            y = y - c[DM];
-            return y;
-        };
-        const float yn = sim(sNew);
-        float r = count == 1 ? yn : (known ? b : bestR[n]);
-        const bool took = count == 1 || gt_nanmax(yn, r);
-        if (took) {
-            r = yn;
-            bestR[n] = r;
-            nearest[n] = (uint8_t)(count - 1);
-        }
-        float value = r;
-        if (count >= 5 && count <= 7) {  // (bestR4 is only ever read inside the window)
-            float r4 = count == 5 ? yn : bestR4[n];
-            if (count > 5 && gt_nanmax(yn, r4)) r4 = yn;
-            bestR4[n] = r4;
-            value = r4;
-        }
-        if (window) {
-            float v = sim(sS);
-            for (int j = 1; j < 4; ++j) {
-                const float y = sim(sS + j * (DM + 1));
-                if (gt_nanmax(y, v)) v = y;
-            }
-            if (count >= 5 && gt_nanmax(value, v)) v = value;
-            value = v;
-        }
-        if (bi < 0 || argmin_ahead(value, n, bv, bi)) {
-            bv = value;
-            bi = n;
-        }
-    };
-    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gstride = (int64_t)gridDim.x * blockDim.x;
-    if (can_skip) {
-        // four points per lane through one 16-byte load of bestR and one 4-byte load of nearest (one point per lane and trip
-        // was a chain of ~38 dependent round trips per thread at 1e7 points: 48 us per step whatever it skipped)
-        const int64_t n4 = N / 4;
-        for (int64_t g = gtid; g < n4; g += gstride) {
-            const float4 b4 = reinterpret_cast<const float4 *>(bestR)[g];
-            const unsigned l4 = reinterpret_cast<const unsigned *>(nearest)[g];
-            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float w = E - bb[v];  // (a NaN or +inf anywhere makes a comparison false: full evaluation)
-                const bool skip = w >= 0.0f && sDelta[(l4 >> (8 * v)) & 0xffu] >= 4.0001f * w;
-                visit(4 * g + v, true, bb[v], skip);
-            }
-        }
-        for (int64_t n = 4 * n4 + gtid; n < N; n += gstride) {
-            const float b = bestR[n];
-            const float w = E - b;
-            visit(n, true, b, w >= 0.0f && sDelta[nearest[n]] >= 4.0001f * w);
-        }
-    } else {
-        for (int64_t n = gtid; n < N; n += gstride) visit(n, false, 0.f, false);
-    }
-    sV[threadIdx.x] = bv;
-    sI[threadIdx.x] = bi;
-    if (count == 1 && mabs > 0.f) atomicMax(&sMabs, __float_as_uint(mabs));  // (non-negative floats order like their bits)
-    __syncthreads();
-    for (int o = kThreads / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            const float v2 = sV[threadIdx.x + o];
-            const long long i2 = sI[threadIdx.x + o];
-            if (i2 >= 0 && (sI[threadIdx.x] < 0 || argmin_ahead(v2, i2, sV[threadIdx.x], sI[threadIdx.x]))) {
-                sV[threadIdx.x] = v2;
-                sI[threadIdx.x] = i2;
-            }
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        cands[blockIdx.x].v = sV[0];
-        cands[blockIdx.x].idx = sI[0];
-        if (count == 1 && sMabs) atomicMax(max_abs_bits, sMabs);
-    }
-}
-// the winner of the blocks' candidates becomes column `col`; col = 0: the given first index
-__global__ __launch_bounds__(kThreads) void reforder_init_pick_kernel(const float *__restrict__ X, int64_t N, int d, int K, int col,
-                                                                      const Cand *__restrict__ cands, int n_cands,
-                                                                      int64_t first_index, float *__restrict__ C0) {
-    __shared__ float sV[kThreads];
-    __shared__ long long sI[kThreads];
-    // (all candidates requested side by side: one thread walking up to 1024 of them was ~200 us of every step)
-    float bv = 0.f;
-    long long bi = col > 0 ? -1 : first_index;
-    if (col > 0)
-        for (int b = threadIdx.x; b < n_cands; b += kThreads) {
-            const float v = cands[b].v;
-            const long long i = cands[b].idx;
-            if (i >= 0 && (bi < 0 || argmin_ahead(v, i, bv, bi))) {
-                bv = v;
-                bi = i;
-            }
-        }
-    sV[threadIdx.x] = bv;
-    sI[threadIdx.x] = bi;
-    __syncthreads();
-    for (int o = kThreads / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            const float v2 = sV[threadIdx.x + o];
-            const long long i2 = sI[threadIdx.x + o];
-            if (i2 >= 0 && (sI[threadIdx.x] < 0 || argmin_ahead(v2, i2, sV[threadIdx.x], sI[threadIdx.x]))) {
-                sV[threadIdx.x] = v2;
-                sI[threadIdx.x] = i2;
-            }
-        }
-        __syncthreads();
-    }
-    const long long idx = sI[0];
-    for (int i = threadIdx.x; i < d; i += kThreads) C0[i * K + col] = X[(int64_t)i * N + idx];
-}
-
-// kmeans.py:59-76 with both norms in torch's order: a (d,m), b (d,n) -> y (m,n)
-__global__ __launch_bounds__(kThreads) void reforder_euc_sim_kernel(const float *__restrict__ a, const float *__restrict__ b,
-                                                                    int d, int64_t m, int64_t n, float *__restrict__ y) {
-    const int64_t total = m * n;
-    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = w / n, j = w % n;
-        float sa[kMaxD], sb[kMaxD];
-        float dot = 0.f;
-        for (int t = 0; t < d; ++t) {
-            const float av = a[(int64_t)t * m + i], bv = b[(int64_t)t * n + j];
-            sa[t] = av * av;
-            sb[t] = bv * bv;
-            dot = fmaf(av, bv, dot);
-        }
-        float v = dot * 2.0f;
-        v = v - sqnorm_at(sa, d, i, m);
-        v = v - sqnorm_at(sb, d, j, n);
-        y[w] = v;
-    }
-}
-
-struct Workspace {
-    et_kmeans_state *state;
-    uint8_t *labels_u8;
-    float *maxsims;
-    float *best4;  // farthest-first, incremental form: running maximum over centroids >= 4
-    unsigned long long *counts;
-    float *sums;
-    float *lanes;
-    double *partial;
-    Cand *cands;
-    float *S1;
-    size_t bytes;
-};
-constexpr int kMaxBlocks = 1024;
-static size_t up(size_t v) { return (v + 255) / 256 * 256; }
-static Workspace carve(void *base, int64_t N, int d, int K) {
-    Workspace w;
-    unsigned char *p = (unsigned char *)base;
-    size_t off = 0;
-    const size_t dk = (size_t)d * K;
-    w.state = (et_kmeans_state *)(p + off);
-    off = up(off + sizeof(et_kmeans_state));
-    w.labels_u8 = p + off;
-    off = up(off + (size_t)N + 4);
-    w.maxsims = (float *)(p + off);
-    off = up(off + sizeof(float) * (size_t)N);
-    w.best4 = (float *)(p + off);
-    off = up(off + sizeof(float) * (size_t)N);
-    w.counts = (unsigned long long *)(p + off);
-    off = up(off + sizeof(unsigned long long) * 256);
-    w.sums = (float *)(p + off);
-    off = up(off + sizeof(float) * dk);
-    w.lanes = (float *)(p + off);
-    off = up(off + sizeof(float) * 4 * dk);
-    w.partial = (double *)(p + off);
-    off = up(off + sizeof(double) * kMaxBlocks);
-    w.cands = (Cand *)(p + off);  // (two buffers: the incremental farthest-first reads one step's while it writes the next's)
-    off = up(off + sizeof(Cand) * 2 * kMaxBlocks);
-    const int lp = level_power(N / 4);
-    const int64_t L = (int64_t)1 << lp;
-    const int64_t groups = (N / 4 / L + L - 1) / L + 1;
-    w.S1 = (float *)(p + off);
-    off = up(off + sizeof(float) * (size_t)groups * 4 * dk);
-    w.bytes = off;
-    return w;
-}
-static bool dims_ok(int d, int K) { return d >= 1 && d <= ET_KMEANS_MAX_D && K >= 1 && K <= ET_KMEANS_MAX_CLUSTERS; }
-static int grid_for(int64_t items) {
-    const int64_t b = (items + kThreads - 1) / kThreads;
-    return (int)(b < 1 ? 1 : (b > kMaxBlocks ? kMaxBlocks : b));
-}
-
-
-// =====================================================================================================================
-// The FAST form of the reference-order Lloyd iteration (d = 6, K <= 32, 1024 <= N < 2^29): one launch per iteration.
-//
-// ATen's cascade (kmeans.py:180-182) is a fixed tree over INDEX RANGES, so it parallelises without changing a single
-// addition: with L = level step, lane k in 0..3 and lane-term r <-> point n = 4 r + k,
-//   level 0   a "chain" = the L consecutive lane terms of one (chunk, lane): sequential adds into the chunk's per-cluster
-//             accumulators -- one work item per (chain, coordinate), the K accumulators in LDS ([cluster][chain]: the
-//             lanes of a wavefront never share a bank), L read-add-write steps;
-//   level 1   a "group" = L consecutive chunks (4 L^2 points): per (lane, coordinate, cluster) the chunk results are
-//             added in chunk order -- one workgroup owns a group, so this never leaves LDS;
-//   level 2   a "block" = L consecutive groups: folded, in group order, by whichever workgroup of the block arrives last;
-//   level 3 + the leftovers (partial block / group / chunk, the N mod 4 terms), the lane combination, the division by the
-//             count, the error in ATen's inner-sum order and the stop flag: by the workgroup that arrives last of all.
-// Everything that crosses workgroups inside a launch travels through device-scope stores / loads / atomics (served by the
-// memory side: no cache fence), arrivals are one relaxed atomic after s_waitcnt + barrier (the idiom of
-// kmeans_lloyd_persist_kernel).  The same workgroup first ASSIGNS its group's points (exact arg-max, kmeans.py:143-158,
-// norms in ATen's orders), so an iteration reads the coordinates once from memory.
-//
-// Layout: the points of the full groups are kept in a permuted copy XT made once per fit (reforder_permute_kernel): per
-// group and coordinate the 4 L^2 values as [tile][r / 4][chain][r % 4] (tile = 16 chunks = 64 chains), so that a lane's
-// 16-byte load is four consecutive steps of its own chain and a wavefront's load is 1 KB contiguous; labels live in the
-// same order (LT) and are un-permuted once, when the fit hands them out.  The points after the last full group (< 4 L^2 +
-// 4 L + 4: the "tail") stay where they are and belong to one extra workgroup.
-//
-// Several problems (blockIdx.y) iterate in ONE loop and stop TOGETHER on the error summed over the whole batch in ATen's
-// inner-sum order over the contiguous (l, d, K) tensor -- kmeans.py:228-240.
-// =====================================================================================================================
-namespace fast {
-
-constexpr int kD = 6;
-constexpr int kFThreads = 384;  // six wavefronts: one per coordinate in the level-0 phase
-constexpr int kFMaxK = 32;
-constexpr int kFMaxBatch = 64;
-constexpr int kFMaxLp = 6;  // L <= 64 (N < 2^29)
-constexpr int kUThreads = 256;  // reforder_update_kernel2
-constexpr size_t kUMaxLds = 128 * 1024;
-
-struct Geo {
-    int64_t N;
-    int lp;               // L = 1 << lp
-    int64_t G;            // full level-1 groups
-    int64_t tail0;        // first point of the tail = G * 4 L^2
-    int64_t full_chunks;  // (N / 4) / L
-    int n_blk, full_blk;  // level-2 blocks (a partial last one included) / complete ones
-};
-static Geo make_geo(int64_t N, int lp_forced = 0) {  // lp_forced: a shard takes the level step of the WHOLE array
-    Geo g;
-    g.N = N;
-    g.lp = lp_forced ? lp_forced : level_power(N / 4);
-    const int64_t L = (int64_t)1 << g.lp;
-    g.full_chunks = N / 4 / L;
-    g.G = g.full_chunks / L;
-    g.tail0 = g.G * 4 * L * L;
-    g.full_blk = (int)(g.G / L);
-    g.n_blk = (int)((g.G + L - 1) / L);
-    return g;
-}
-
-// LDS of the groups kernel: [level-0 accumulators (K rows + a dummy one per coordinate and tile) | a group's label words];
-// the tail's label bytes (4 L^2 + 4 L + 16) alias the accumulators until level 0 clears them
-__host__ __device__ inline size_t acc_region_bytes(int K, int L, int TR) {
-    const size_t acc = sizeof(float) * (size_t)TR * kD * (K + 1) * 64, tail = ((size_t)(4 * L * L + 4 * L + 16) + 15) / 16 * 16;
-    return acc > tail ? acc : tail;
-}
-
-// byte offsets inside one problem's block of the workspace.  S1 / S2 / T hold one float4 = the four lanes k of a (group |
-// block | tail part, coordinate, cluster) entry.
-struct Layout {
-    size_t state, cen, arrive, cnt, S1, S2, T, Sin, XT, LT, tail, bytes;
-};
-static Layout make_layout(const Geo &g, int K) {
-    Layout l;
-    const size_t dk = (size_t)kD * K;
-    size_t off = 0;
-    l.state = off;
-    off = up(off + sizeof(et_kmeans_state));
-    l.cen = off;
-    off = up(off + sizeof(float) * dk);
-    l.arrive = off;
-    off = up(off + sizeof(unsigned) * 4);
-    l.cnt = off;  // per workgroup of the groups kernel: its points per cluster
-    off = up(off + sizeof(unsigned) * (size_t)(g.G + 1) * kFMaxK);
-    l.S1 = off;
-    off = up(off + sizeof(float4) * (size_t)g.G * dk);
-    l.S2 = off;
-    off = up(off + sizeof(float4) * (size_t)(g.n_blk + 1) * (dk + kFMaxK / 4));  // a row: d K sums, then the block's counts
-    l.T = off;
-    off = up(off + sizeof(float4) * (2 * dk + 1));
-    l.Sin = off;
-    off = up(off + sizeof(double) * (size_t)(g.G + 1));
-    l.XT = off;
-    off = up(off + sizeof(float) * (size_t)g.tail0 * kD);
-    l.LT = off;
-    off = up(off + (size_t)g.tail0 + 4);
-    l.tail = off;
-    off = up(off + (size_t)(g.N - g.tail0) + 4);
-    l.bytes = off;
-    return l;
-}
-// in front of the problems' blocks: the batch-wide arrival counter and the batch's squared centroid differences
-static size_t shared_bytes(int K, int64_t batch) { return up(256 + sizeof(float) * (size_t)batch * kD * K); }
-
-struct Args {
-    const float *X;     // problem 0's points (d, N); problem b: X + b * x_stride
-    int64_t x_stride;
-    unsigned char *ws;  // problem 0's block; problem b: ws + b * ws_stride
-    int64_t ws_stride;
-    unsigned *batch_arrive;
-    float *sq_all;      // (batch, d K) squared centroid differences of this iteration
-    Layout lay;
-    Geo geo;
-    int K, batch;
-    float tol;
-    float *trace;       // (batch, max_iter, 2) or nullptr
-    int max_iter;
-    int tiles_per_round;  // level-0 tiles in LDS at a time (1 or 2)
-    unsigned long long *mail;  // host-visible progress word or nullptr
-};
-
-template <typename T>
-__device__ __forceinline__ T *at(unsigned char *ws, size_t off) { return reinterpret_cast<T *>(ws + off); }
-__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// 16-byte device-scope (sc1: served by the memory side, write-through) accesses through buffer instructions
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void *base, int64_t bytes) {
-    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-    const int nb = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffffll ? 0x7fffffffll : bytes));
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, nb, 0x00020000);
-}
-constexpr int kAuxSc1 = 1 << 4;  // gfx940+ cache-policy immediate: bit 0 sc0, bit 1 nt, bit 4 sc1
-__device__ __forceinline__ float4 ld16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, kAuxSc1);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-__device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 f) {
-    const u32x4_t v = {__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w)};
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, kAuxSc1);
-}
-
-// X (d, N) -> XT: one work item per (group, tile, r / 4, chain): four strided reads per coordinate, one 16-byte store
-__global__ __launch_bounds__(kThreads) void reforder_permute_kernel(const float *__restrict__ X, int64_t x_stride,
-                                                                    unsigned char *ws, int64_t ws_stride, size_t off_XT,
-                                                                    Geo geo) {
-    X += (int64_t)blockIdx.y * x_stride;
-    float4 *XT4 = reinterpret_cast<float4 *>(ws + (int64_t)blockIdx.y * ws_stride + off_XT);
-    const int lp = geo.lp;
-    const int64_t L = (int64_t)1 << lp, L2 = L * L;
-    const int64_t total = geo.G * L2;  // quads
-    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t g = w >> (2 * lp), qi = w & (L2 - 1);
-        const int t = (int)(qi & 63);
-        const int64_t qrb = qi >> 6;                 // tile * (L / 4) + rb
-        const int64_t q = qrb / (L / 4), rb = qrb % (L / 4);
-        const int64_t c = q * 16 + (t >> 2);         // chunk inside the group
-        const int64_t n0 = g * 4 * L2 + 4 * (c * L + 4 * rb) + (t & 3);
-#pragma unroll
-        for (int i = 0; i < kD; ++i) {
-            const float *x = X + (int64_t)i * geo.N + n0;
-            XT4[(g * kD + i) * L2 + qi] = make_float4(x[0], x[4], x[8], x[12]);
-        }
-    }
-}
-
-// arg-max over the K centroid rows in LDS (row j = c[0..5], |c_j|^2, -) for NP points; NANS: torch.max's rule (a NaN beats
-// everything, the first one stays), else plain `>` (no similarity can be NaN).  The next row is requested while this one
-// is evaluated.
-template <bool NANS, int NP>
-__device__ __forceinline__ void points_best(const float (&x)[NP][kD], const float (&an)[NP], const float *sC, int K, int (&lb)[NP],
-                                            float (&bv)[NP]) {
-    const float4 *s4 = reinterpret_cast<const float4 *>(sC);
-    float4 n0 = s4[0], n1 = s4[1];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        lb[p] = 0;
-        bv[p] = 0.f;
-    }
-    for (int j = 0; j < K; ++j) {
-        const float4 c0 = n0, c1 = n1;
-        if (j + 1 < K) {
-            n0 = s4[2 * j + 2];
-            n1 = s4[2 * j + 3];
-        }
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            float y = fmaf(x[p][0], c0.x, 0.f);  // kmeans.py:71
-            y = fmaf(x[p][1], c0.y, y);
-            y = fmaf(x[p][2], c0.z, y);
-            y = fmaf(x[p][3], c0.w, y);
-            y = fmaf(x[p][4], c1.x, y);
-            y = fmaf(x[p][5], c1.y, y);
-            y = y * 2.0f;   // :72
-            y = y - an[p];  // :73
-            y = y - c1.z;   // :74
-            const bool take = NANS ? (j == 0 || gt_nanmax(y, bv[p])) : (j == 0 || y > bv[p]);
-            bv[p] = take ? y : bv[p];
-            lb[p] = take ? j : lb[p];
-        }
-    }
-}
-
-// points_best<false> for the four points of a quad as two packed pairs (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: the
-// same IEEE operations, two points per instruction).  No similarity can be NaN or infinite here (the caller checked the
-// magnitudes), so "the first row always wins" is `y > -inf`.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void quad_best(const float4 (&xv)[kD], const float *sC, int K, int (&lb)[4], float (&bv)[4]) {
-    f32x2 xa[kD], xb[kD];
-#pragma unroll
-    for (int i = 0; i < kD; ++i) {
-        xa[i] = f32x2{xv[i].x, xv[i].y};
-        xb[i] = f32x2{xv[i].z, xv[i].w};
-    }
-    f32x2 ana = xa[0] * xa[0], anb = xb[0] * xb[0];  // kmeans.py:73, a full block's column: rows in sequence (0 + s0 = s0)
-#pragma unroll
-    for (int i = 1; i < kD; ++i) {
-        ana = ana + xa[i] * xa[i];
-        anb = anb + xb[i] * xb[i];
-    }
-    int opaque = 0;  // (keeps the first rows' loads and their splats inside the caller's loop: hoisted, they cost 20 registers)
-    asm volatile("" : "+v"(opaque));
-    const float4 *s4 = reinterpret_cast<const float4 *>(sC) + opaque;
-    float4 n0 = s4[0], n1 = s4[1];
-    lb[0] = lb[1] = lb[2] = lb[3] = 0;
-    bv[0] = bv[1] = bv[2] = bv[3] = -__builtin_inff();
-    const f32x2 zero = {0.f, 0.f};
-#pragma clang loop unroll(disable)
-    for (int j = 0; j < K; ++j) {
-        const float4 c0 = n0, c1 = n1;
-        n0 = s4[2 * j + 2];  // (row K: the table has kFMaxK + 1 rows)
-        n1 = s4[2 * j + 3];
-        const float cc[kD] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
-        f32x2 ya = zero, yb = zero;
-#pragma unroll
-        for (int i = 0; i < kD; ++i) {
-            const f32x2 c = {cc[i], cc[i]};
-            ya = __builtin_elementwise_fma(xa[i], c, ya);  // kmeans.py:71
-            yb = __builtin_elementwise_fma(xb[i], c, yb);
-        }
-        ya = ya * 2.0f;  // :72
-        yb = yb * 2.0f;
-        ya = ya - ana;   // :73
-        yb = yb - anb;
-        const f32x2 bn = {c1.z, c1.z};
-        ya = ya - bn;    // :74
-        yb = yb - bn;
-        const float y[4] = {ya.x, ya.y, yb.x, yb.y};
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const bool take = y[p] > bv[p];
-            bv[p] = take ? y[p] : bv[p];
-            lb[p] = take ? j : lb[p];
-        }
-    }
-}
-
-__device__ __forceinline__ double wave_sum_f64(double v) {  // fixed tree: the same bits for the same inputs
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = v + __shfl_xor(v, o);
-    return v;
-}
-
-#ifdef ET_EXP_RFSTAMP  // measurement build (tools/rfstamp.py): s_memrealtime at the phase boundaries of four workgroups
-__device__ unsigned long long g_rf_stamps[4 * 16];
-#define RF_STAMP(who, i)                                                                                           \
-    do {                                                                                                           \
-        if ((who) < 4 && threadIdx.x == 0 && blockIdx.y == 0) g_rf_stamps[(who) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
-// slot `i` of row `who`: the latest time any workgroup passed here
-#define RF_STAMP_MAX(who, i)                                                                               \
-    do {                                                                                                   \
-        if (threadIdx.x == 0 && blockIdx.y == 0) atomicMax(&g_rf_stamps[(who) * 16 + (i)], __builtin_amdgcn_s_memrealtime()); \
-    } while (0)
-// slot `i` of row 3 += ticks since *t (thread 0 of workgroup 0 only), *t = now
-#define RF_ACC(i, t)                                                                  \
-    do {                                                                              \
-        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {                 \
-            const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();         \
-            g_rf_stamps[3 * 16 + 8 + (i)] += now_ - (t);                              \
-            (t) = now_;                                                               \
-        }                                                                             \
-    } while (0)
-#else
-#define RF_ACC(i, t) \
-    do {             \
-    } while (0)
-#define RF_STAMP_MAX(who, i) \
-    do {                     \
-    } while (0)
-#define RF_STAMP(who, i) \
-    do {                 \
-    } while (0)
-#endif
-
-// Levels 0 and 1 of the cascade for the chunks 0 .. n_all-1 of one group (n_all <= L), TR tiles (of 16 chunks) at a time:
-//   level 0  wavefront = coordinate, lane = chain (chunk, lane k); the chain's K (+ one dummy) accumulators are the LDS
-//            words [row][chain]; a step = read, add, write of the row its label names;
-//   level 1  work item (coordinate, cluster): adds the results of the chunks < n_l1 in chunk order (four lanes k side by
-//            side in one 16-byte read, four reads in flight); the result of chunk n_l1 (if n_all > n_l1: the lane terms after the last full chunk) is
-//            handed back untouched in acc0.
-// load(tile, rb, lane, coordinate) -> the four values of steps 4 rb .. 4 rb + 3 of chain `lane` of `tile`; sLab: the same
-// steps' labels, one word per (tile, rb, chain); a label = K routes a term that does not exist to the dummy row.
-template <class Load>
-__device__ __forceinline__ void cascade_levels(Load load, const unsigned *sLab, float *sAcc, int K, int L, int TR, int n_all,
-                                               int n_l1, float4 &acc1, float4 &acc0) {
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int RB = L / 4, rows = K + 1, dk = kD * K;
-    const int tiles = (n_all + 15) >> 4;
-    const int ci = tid / K, cj = tid % K;
-    // Accumulator word of (row, chain): column chain ^ (4 (row & 7)) of the row's 64 words.  Level 0 (lane = chain, row =
-    // label) stays inside bank  lane mod 4 + a scrambled multiple of 4; level 1 (lane = (coordinate, cluster), a 16-byte
-    // read of the four lanes k of chunk c) finds the rows of eight consecutive clusters in eight different bank groups --
-    // without the swizzle every lane of a wavefront reads the same four banks.
-    [[maybe_unused]] unsigned long long tacc = __builtin_amdgcn_s_memrealtime();
-    for (int q0 = 0; q0 < tiles; q0 += TR) {
-        const int tr = tiles - q0 < TR ? tiles - q0 : TR;
-        for (int ql = 0; ql < tr; ++ql) {
-            float *blk = sAcc + ((size_t)(ql * kD + wave) * rows) * 64;  // this wavefront's (tile, coordinate) block
-            {
-                float4 *z = reinterpret_cast<float4 *>(blk);
-                for (int e = lane; e < rows * 16; e += 64) z[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            RF_ACC(0, tacc);
-            const unsigned *lr = sLab + (q0 + ql) * RB * 64 + lane;
-            // the chain's values, four 16-byte loads (= 16 steps) in flight at a time: with one load per four steps the loop ran
-            // at the latency of its loads, not of its LDS updates (eight in flight cost the registers of a seventh wavefront)
-            for (int rb0 = 0; rb0 < RB; rb0 += 4) {
-                float4 xc[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) xc[u] = load(q0 + ql, rb0 + u, lane, wave);
-#ifdef ET_EXP_RFSTAMP
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-                RF_ACC(1, tacc);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    // four steps: their accumulators are requested together and the additions chained in registers -- a
-                    // later step whose label repeats an earlier one takes that step's result instead of the (stale) word
-                    // it read, and writes in order, so the row ends with the same sequential sum as read-add-write per
-                    // step, at one LDS round trip per four steps instead of four
-                    const float4 xv = xc[u];
-                    const unsigned l4 = lr[(rb0 + u) * 64];
-                    const unsigned j0 = l4 & 255u, j1 = (l4 >> 8) & 255u, j2 = (l4 >> 16) & 255u, j3 = l4 >> 24;
-                    float *p0 = blk + j0 * 64 + (lane ^ ((j0 & 7u) << 2)), *p1 = blk + j1 * 64 + (lane ^ ((j1 & 7u) << 2));
-                    float *p2 = blk + j2 * 64 + (lane ^ ((j2 & 7u) << 2)), *p3 = blk + j3 * 64 + (lane ^ ((j3 & 7u) << 2));
-                    const float r0 = *p0, r1 = *p1, r2 = *p2, r3 = *p3;
-                    const float n0 = r0 + xv.x;
-                    const float n1 = (j1 == j0 ? n0 : r1) + xv.y;
-                    const float n2 = (j2 == j1 ? n1 : (j2 == j0 ? n0 : r2)) + xv.z;
-                    const float n3 = (j3 == j2 ? n2 : (j3 == j1 ? n1 : (j3 == j0 ? n0 : r3))) + xv.w;
-                    *p0 = n0;
-                    *p1 = n1;
-                    *p2 = n2;
-                    *p3 = n3;
-                }
-#ifdef ET_EXP_RFSTAMP
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-                RF_ACC(2, tacc);
-            }
-        }
-        __syncthreads();
-        RF_ACC(3, tacc);
-        if (tid < dk) {
-            for (int ql = 0; ql < tr; ++ql) {
-                const float *row = sAcc + ((size_t)(ql * kD + ci) * rows + cj) * 64;
-                const int sw = (cj & 7) << 2;
-#pragma clang loop unroll(disable)
-                for (int h = 0; h < 4; ++h) {  // four chunks' results requested together, added in chunk order
-                    float4 v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(row + (((4 * h + u) << 2) ^ sw));
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int cg = (q0 + ql) * 16 + 4 * h + u;
-                        if (cg < n_l1) {
-                            acc1.x = acc1.x + v[u].x;
-                            acc1.y = acc1.y + v[u].y;
-                            acc1.z = acc1.z + v[u].z;
-                            acc1.w = acc1.w + v[u].w;
-                        } else if (cg == n_l1) {
-                            acc0 = v[u];
-                        }
-                    }
-                }
-            }
-        }
-        RF_ACC(4, tacc);
-        __syncthreads();
-        RF_ACC(5, tacc);
-    }
-}
-
-// ---- the assignment of a group by CERTIFICATION (iterations >= 1, no NaN possible): csrc/et_kmeans.hip's matrix-core filter
-//      ("Lloyd half-step for iterations >= 1": that is where the bounds are derived) on the quads of the permuted copy.  Per
-//      point the second largest of the f16-MFMA upper bounds u_j >= Y_j + |x|^2 is compared with the exact Y_l + |x|^2 of the
-//      point's OLD label l (one fmaf chain, kmeans.py:71-74 with the norms in ATen's orders -- the bound E1 on the chain's
-//      rounding holds for any order of the six-term norm sums): if it exceeds every other cluster's bound the reference's
-//      arg-max is l, strictly, and Y_l is its maximum similarity.  Every other point (1-3 % per iteration) goes on a
-//      workgroup queue and gets the exact scan afterwards, four threads per point.  The same labels as the exact scan of
-//      every point, by construction; what it saves is the scan: ~300 vector + 16 matrix instructions per 256 points
-//      instead of ~720 vector instructions. ----
-#ifdef ET_EXP_RF_CHECK
-__device__ unsigned g_rf_check[64];
-#endif
-template <int NREGS>
-__device__ __forceinline__ double assign_group_filter(const float4 *__restrict__ x4, int L2, const float *sC, int K, float sg,
-                                                      unsigned *sLab, unsigned *__restrict__ LTg, unsigned short *sQ, int q_cap,
-                                                      int *sQn, bool &ok) {
-    const int tid = (int)threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
-    constexpr float kUp = 1.001953125f, kTiny = 1.1920928955078125e-7f;  // (1 + 2^-9) v + 2^-23 survives the rtz to f16
-    const float sg2 = sg * sg;
-    const float4 *s4 = reinterpret_cast<const float4 *>(sC);
-    // A operands (loop invariant): this lane feeds accumulator row m = col, k-half = half; cluster j sits in register j >> 1
-    // of half j & 1 (rows of clusters >= K: -60000) -- csrc/et_kmeans.hip, filter_assign_body
-    u32x4 a1 = {0u, 0u, 0u, 0u}, a2 = {0u, 0u, 0u, 0u};
-    {
-        const int j = 2 * (4 * (col >> 3) + (col & 3)) + ((col >> 2) & 1);
-        unsigned ch[3] = {0u, 0u, 0u}, cl[3] = {0u, 0u, 0u};
-        float nb = -60000.0f;
-        if (j < K) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p) split_f16(sC[j * 8 + 2 * p], sC[j * 8 + 2 * p + 1], 2.0f * sg, ch[p], cl[p]);
-            nb = -sC[j * 8 + 6] * sg2;
-        }
-        const auto nh = __builtin_amdgcn_cvt_pkrtz(nb, 0.f);
-        const unsigned bnd = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(nb, (nb - (float)nh[0]) * 1024.0f));
-        unsigned ebd = 0u;
-        if (j < K) {
-            const float cj = sqrtf(sC[j * 8 + 6]) * sg * 1.001f;
-            ebd = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(fmaf(3.0517578125e-5f * cj, kUp, kTiny),
-                                                                           fmaf(fmaf(cj, 1.52587890625e-5f, 9.5367431640625e-7f) * cj, kUp, kTiny)));
-        }
-        a1 = u32x4{ch[0], ch[1], ch[2], half == 0 ? bnd : ebd};
-        a2 = u32x4{cl[0], cl[1], cl[2], 0u};
-    }
-    const f16x8 A1 = __builtin_bit_cast(f16x8, a1), A2 = __builtin_bit_cast(f16x8, a2);
-    double sim = 0.0;
-    for (int qi = tid; qi < L2; qi += kFThreads) {  // (L2 mod 384 = 256: whole wavefronts run the last round)
-        const unsigned old_packed = LTg[qi];
-        unsigned undecided = 0u;
-        // Register-lean on purpose (the first form held the quad's 24 coordinates and both tiles' 32 accumulators: 122
-        // registers = two workgroups per CU, and lost to the exact scan): two points at a time from 8-byte loads (the lines
-        // are in the L1 after the first), the two 32-point tiles of a step one after the other.
-#pragma unroll
-        for (int hq = 0; hq < 2; ++hq) {
-            float2 v[kD];
-#pragma unroll
-            for (int i = 0; i < kD; ++i) v[i] = reinterpret_cast<const float2 *>(x4 + i * L2 + qi)[hq];
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                const int q = 2 * hq + qq;
-                float x[kD];
-#pragma unroll
-                for (int i = 0; i < kD; ++i) x[i] = qq == 0 ? v[i].x : v[i].y;
-                float an = x[0] * x[0];  // kmeans.py:73, a full block's column: rows in sequence
-#pragma unroll
-                for (int i = 1; i < kD; ++i) an = an + x[i] * x[i];
-                const float rs = fmaf(__builtin_amdgcn_sqrtf(an) * sg, kUp, kTiny);  // >= sg ||x||
-                unsigned w[7];  // {xh01, xh23, xh45, xl01, xl23, xl45, (r, 1)}
-#pragma unroll
-                for (int p = 0; p < 3; ++p) split_f16(x[2 * p], x[2 * p + 1], sg, w[p], w[3 + p]);
-                w[6] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(fmaf(rs, kUp, kTiny), 1.0f));
-                const unsigned ones = 0x14003c00u;  // {1, 2^-10}: partners of {hi, lo * 2^10} of -|c|^2
-                u32x4 bLo, bUp;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const auto r = p < 3 ? __builtin_amdgcn_permlane32_swap(w[p], w[3 + p], false, false)
-                                         : __builtin_amdgcn_permlane32_swap(ones, w[6], false, false);
-                    bLo[p] = r[0];
-                    bUp[p] = r[1];
-                }
-                float bL, sL, bU, sU;
-                {
-                    f32x16 acc;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, __builtin_bit_cast(f16x8, bLo), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, __builtin_bit_cast(f16x8, bLo), acc, 0, 0, 0);
-                    top2<NREGS>(acc, bL, sL);
-                }
-                {
-                    f32x16 acc;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, __builtin_bit_cast(f16x8, bUp), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2, __builtin_bit_cast(f16x8, bUp), acc, 0, 0, 0);
-                    top2<NREGS>(acc, bU, sU);
-                }
-                const auto rb = __builtin_amdgcn_permlane32_swap(__float_as_uint(bL), __float_as_uint(bU), false, false);
-                const auto rq = __builtin_amdgcn_permlane32_swap(__float_as_uint(sL), __float_as_uint(sU), false, false);
-                const float b0 = __uint_as_float(rb[0]), b1 = __uint_as_float(rb[1]);
-                const float s0 = __uint_as_float(rq[0]), s1 = __uint_as_float(rq[1]);
-                const float second = vmed3(b0, b1, vmax(s0, s1));  // second largest upper bound u_j
-                // exact similarity to the old label's centroid, kmeans.py:71-74
-                const int ol = (int)((old_packed >> (8 * q)) & 0xffu);
-                const float4 r0 = s4[2 * ol], r1 = s4[2 * ol + 1];
-                float y = fmaf(x[0], r0.x, 0.f);
-                y = fmaf(x[1], r0.y, y);
-                y = fmaf(x[2], r0.z, y);
-                y = fmaf(x[3], r0.w, y);
-                y = fmaf(x[4], r1.x, y);
-                y = fmaf(x[5], r1.y, y);
-                y = y * 2.0f;
-                y = y - an;
-                y = y - r1.z;
-                // keep <=> (Y_l + |x|^2) sg^2 exceeds every other cluster's upper bound: w - second > eps(r) + rounding of w
-                const float wv = (y + an) * sg2;
-                const float th = fmaf(fabsf(wv), 2.384185791015625e-7f,
-                                      fmaf(rs, fmaf(rs, 1.52587890625e-5f, 9.5367431640625e-7f), 2.3283064365386963e-10f));
-#ifdef ET_EXP_RF_ALL_UNDECIDED
-                const bool keep = false;
-#else
-                const bool keep = wv - second > th;
-#endif
-                sim = sim + (keep ? (double)y : 0.0);
-                undecided |= keep ? 0u : (1u << q);
-            }
-        }
-        sLab[qi] = old_packed;  // (the bytes of undecided points are replaced below)
-        if (undecided) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if ((undecided >> q) & 1u) {
-                    const int slot = atomicAdd(sQn, 1);
-                    if (slot < q_cap) sQ[slot] = (unsigned short)(qi * 4 + q);
-                }
-        }
-    }
-    __syncthreads();
-    // ---- the undecided points: exact arg-max, four threads per point (clusters sub, sub + 4, ...; first maximum wins) ----
-    const int nq = *sQn, sub = tid & 3;
-    ok = nq <= q_cap;  // (more undecided points than the queue holds: the caller runs the exact scan of the whole group)
-    if (!ok) return 0.0;
-    for (int base = 0; base < nq; base += kFThreads / 4) {
-        const int e = base + (tid >> 2);
-        const bool act = e < nq;
-        const int pid = sQ[act ? e : 0], qi = pid >> 2, q = pid & 3;
-        float x[kD];
-#pragma unroll
-        for (int i = 0; i < kD; ++i) x[i] = reinterpret_cast<const float *>(x4 + i * L2 + qi)[q];
-        float an = x[0] * x[0];
-#pragma unroll
-        for (int i = 1; i < kD; ++i) an = an + x[i] * x[i];
-        float best = -__builtin_inff();
-        int lb = 0x7fffffff;
-        for (int j = sub; j < K; j += 4) {
-            const float4 r0 = s4[2 * j], r1 = s4[2 * j + 1];
-            float y = fmaf(x[0], r0.x, 0.f);
-            y = fmaf(x[1], r0.y, y);
-            y = fmaf(x[2], r0.z, y);
-            y = fmaf(x[3], r0.w, y);
-            y = fmaf(x[4], r1.x, y);
-            y = fmaf(x[5], r1.y, y);
-            y = y * 2.0f;
-            y = y - an;
-            y = y - r1.z;
-            if (y > best) {
-                best = y;
-                lb = j;
-            }
-        }
-#pragma unroll
-        for (int o = 1; o < 4; o <<= 1) {
-            const float ob = __shfl_xor(best, o);
-            const int ol = __shfl_xor(lb, o);
-            if (ob > best || (ob == best && ol < lb)) {
-                best = ob;
-                lb = ol;
-            }
-        }
-        if (act && sub == 0) {
-            reinterpret_cast<uint8_t *>(sLab)[pid] = (uint8_t)lb;
-            reinterpret_cast<uint8_t *>(LTg)[pid] = (uint8_t)lb;
-            sim = sim + (double)best;
-        }
-    }
-    __syncthreads();
-    return sim;
-}
-
-// ---- one Lloyd iteration, first half: assignment + levels 0 and 1.  Workgroup g < G: group g; workgroup G: the tail ----
-// NREGS = 0: the exact scan of every point (L = 16: four workgroups per CU); 10 / 16 (K <= 20 / 32): iterations >= 1 certify
-// the labels with the matrix-core filter (L >= 32; more registers: fewer wavefronts per CU, far fewer instructions)
-template <int NREGS>
-__global__ __launch_bounds__(kFThreads, NREGS ? 6 : 7) void reforder_groups_kernel(const Args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int K = a.K, dk = kD * K;
-    unsigned char *ws = a.ws + (int64_t)blockIdx.y * a.ws_stride;
-    const et_kmeans_state *state = at<et_kmeans_state>(ws, a.lay.state);
-    // (the centroids are requested together with the flag: one round trip to memory, not two)
-    float cpre[kD];
-    {
-        const float *cen0 = at<float>(ws, a.lay.cen);
-#pragma unroll
-        for (int i = 0; i < kD; ++i) cpre[i] = cen0[i * K + (tid < K ? tid : 0)];
-    }
-    const int64_t done0 = state->done, iter0 = state->iter;
-    const double max_abs_x = state->max_abs_x;
-    if (done0) return;  // the whole batch stopped in an earlier launch (kmeans.py:239), or bad input was flagged
-    const float *X = a.X + (int64_t)blockIdx.y * a.x_stride;
-    const Geo &geo = a.geo;
-    const int lp = geo.lp;
-    const int L = 1 << lp, L2 = L * L, RB = L / 4;
-    const int64_t N = geo.N;
-    unsigned *cnt = at<unsigned>(ws, a.lay.cnt);
-    float4 *S1 = at<float4>(ws, a.lay.S1);
-    float4 *T = at<float4>(ws, a.lay.T);
-    double *Sin = at<double>(ws, a.lay.Sin);
-    const float4 *XT4 = at<const float4>(ws, a.lay.XT);
-    unsigned *LT32 = at<unsigned>(ws, a.lay.LT);
-    uint8_t *tail_lab = at<uint8_t>(ws, a.lay.tail);
-
-    __shared__ __attribute__((aligned(16))) float sC[(kFMaxK + 1) * 8];  // (+ a row the arg-max loop's last prefetch may read)
-    __shared__ unsigned sCnt[kFMaxK];
-    __shared__ double sWsum[8];
-    const int TR = a.tiles_per_round;
-    float *sAcc = reinterpret_cast<float *>(smem);                                          // [tile in round][coordinate][row][64 chains]
-    unsigned *sLab = reinterpret_cast<unsigned *>(smem + acc_region_bytes(K, 1 << a.geo.lp, TR));  // a group's labels, one word per quad
-    // the tail's workgroup is dispatched FIRST: it is as long as any other and at the highest index it used to start when the
-    // last slot freed up, alone on the chip for its whole 20 us (N = 1e7: the launch ended 113 us after it began, the groups 93)
-    const int64_t gidx = blockIdx.x == 0 ? geo.G : (int64_t)blockIdx.x - 1;
-    const bool is_tail = gidx == geo.G;
-    [[maybe_unused]] const int who = is_tail ? 1 : (gidx == 0 ? 0 : 9);
-    RF_STAMP(who, 0);
-
-    // ---- prologue: centroid rows with |c_j|^2 in ATen's order for column j of K (kmeans.py:74), NaN / overflow test ----
-    int bad = 0;
-    if (tid < K) {
-        float sq[kMaxD];
-#pragma unroll
-        for (int i = 0; i < kD; ++i) {
-            const float v = cpre[i];
-            sC[tid * 8 + i] = v;
-            sq[i] = v * v;
-            bad |= !(fabsf(v) < 1e18f);
-        }
-        sC[tid * 8 + 6] = sqnorm_at(sq, kD, tid, K);
-        sC[tid * 8 + 7] = 0.f;
-    }
-    __shared__ unsigned sMaxC;
-    __shared__ int sQn;
-    if (tid < kFMaxK) sCnt[tid] = 0u;
-    if (tid == 0) {
-        sMaxC = 0u;
-        sQn = 0;
-    }
-    __syncthreads();
-    if (tid < K) {
-        float m = 0.f;
-#pragma unroll
-        for (int i = 0; i < kD; ++i) m = fmaxf(m, fabsf(cpre[i]));
-        atomicMax(&sMaxC, __float_as_uint(m));  // (non-negative floats order like their bit patterns; a NaN sets `bad`)
-    }
-    const bool nans = __syncthreads_or(bad) != 0 || !(max_abs_x < 1e18);
-    double sim = 0.0;
-    float4 acc1 = make_float4(0.f, 0.f, 0.f, 0.f), acc0 = acc1;
-    RF_STAMP(who, 1);
-
-    if (!is_tail) {
-        // ---- assignment of the group's 4 L^2 points (kmeans.py:143-158): a quad = four consecutive steps of one chain ----
-        const float4 *x4 = XT4 + gidx * kD * L2;
-        bool filtered = false;
-        if constexpr (NREGS > 0) {
-            // power-of-two scale: every |x| sg, |c| sg < 32 (csrc/et_kmeans.hip, filter_assign_body); the first iteration (no
-            // labels yet), a possible NaN or a scale whose square leaves the fp32 range: the exact scan decides
-            const int e_max = exponent_above(fmax(max_abs_x, (double)__uint_as_float(sMaxC)));
-            if (iter0 > 0 && !nans && K >= 3 && e_max >= -40 && e_max <= 60) {
-                const int q_cap = min(4 * L2, (int)((size_t)TR * kD * (K + 1) * 64 * sizeof(float) / sizeof(unsigned short)));
-                sim = assign_group_filter<NREGS>(x4, L2, sC, K, ldexpf(1.0f, 5 - e_max), sLab, LT32 + gidx * L2,
-                                                 reinterpret_cast<unsigned short *>(sAcc), q_cap, &sQn, filtered);
-                if (!filtered) sim = 0.0;
-            }
-        }
-        for (int qi = tid; qi < L2 && !filtered; qi += kFThreads) {
-            float4 xv[kD];
-#pragma unroll
-            for (int i = 0; i < kD; ++i) xv[i] = x4[i * L2 + qi];
-            int lb[4];
-            float bv[4];
-            if (!nans) {
-                quad_best(xv, sC, K, lb, bv);
-            } else {  // (an empty cluster's NaN centroid, or magnitudes near the fp32 range: torch.max's NaN rule, point by point)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    float x[1][kD], an[1], b1[1];
-                    int l1[1];
-#pragma unroll
-                    for (int i = 0; i < kD; ++i) x[0][i] = p == 0 ? xv[i].x : (p == 1 ? xv[i].y : (p == 2 ? xv[i].z : xv[i].w));
-                    float sacc = x[0][0] * x[0][0];
-#pragma unroll
-                    for (int i = 1; i < kD; ++i) sacc = sacc + x[0][i] * x[0][i];
-                    an[0] = sacc;
-                    points_best<true, 1>(x, an, sC, K, l1, b1);
-                    lb[p] = l1[0];
-                    bv[p] = b1[0];
-                }
-            }
-            const unsigned packed = (unsigned)lb[0] | ((unsigned)lb[1] << 8) | ((unsigned)lb[2] << 16) | ((unsigned)lb[3] << 24);
-            sLab[qi] = packed;
-            LT32[gidx * L2 + qi] = packed;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) sim = sim + (double)bv[p];
-        }
-        __syncthreads();
-        for (int qi = tid; qi < L2; qi += kFThreads) {  // points per cluster, from the final labels
-            const unsigned l4 = sLab[qi];
-            atomicAdd(&sCnt[l4 & 255u], 1u);
-            atomicAdd(&sCnt[(l4 >> 8) & 255u], 1u);
-            atomicAdd(&sCnt[(l4 >> 16) & 255u], 1u);
-            atomicAdd(&sCnt[l4 >> 24], 1u);
-        }
-        RF_STAMP(who, 2);
-        RF_STAMP_MAX(0, 8);
-        cascade_levels([&](int q, int rb, int ln, int i) { return x4[i * L2 + (q * RB + rb) * 64 + ln]; }, sLab, sAcc, K, L, TR, L, L,
-                       acc1, acc0);
-        if (tid < dk) S1[gidx * dk + tid] = acc1;
-        RF_STAMP(who, 3);
-        RF_STAMP_MAX(0, 9);
-    } else {
-        // ---- the tail: the points tail0 .. N-1 where they lie in X -- the chunks of the partial group (level 1 of their
-        //      level-0 sums -> T[0 .. d K)), the lane terms after the last full chunk (level 0 -> T[d K ..)), and the
-        //      N mod 4 points after the lanes' ranges (their labels -> T[2 d K]) ----
-        const int64_t tail0 = geo.tail0, size = N / 4;
-        const int nt = (int)(N - tail0);
-        const int pc = (int)(geo.full_chunks - geo.G * L);    // full chunks of the partial group (< L)
-        const int rem = (int)(size - geo.full_chunks * L);    // lane terms after them (< L)
-        const int n_all = pc + (rem > 0 ? 1 : 0);
-        // (the tail's label bytes live in the accumulators' space until level 0 clears it: a region of their own made the
-        // launch's LDS 41.9 KB at L = 32 -- three workgroups per CU instead of four)
-        uint8_t *sTail = reinterpret_cast<uint8_t *>(sAcc);
-        for (int m0 = 2 * tid; m0 < nt; m0 += 2 * kFThreads) {  // two points per thread side by side
-            float x[2][kD], an[2];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int64_t n = tail0 + (m0 + p < nt ? m0 + p : m0);
-                float sq[kMaxD];
-#pragma unroll
-                for (int i = 0; i < kD; ++i) {
-                    x[p][i] = X[(int64_t)i * N + n];
-                    sq[i] = x[p][i] * x[p][i];
-                }
-                an[p] = sqnorm_at(sq, kD, n, N);  // the last N mod 32 columns take the 4-lane order
-            }
-            int lb[2];
-            float bv[2];
-            if (nans) points_best<true, 2>(x, an, sC, K, lb, bv);
-            else points_best<false, 2>(x, an, sC, K, lb, bv);
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-                if (m0 + p < nt) {
-                    sTail[m0 + p] = (uint8_t)lb[p];
-                    tail_lab[m0 + p] = (uint8_t)lb[p];
-                    atomicAdd(&sCnt[lb[p]], 1u);
-                    sim = sim + (double)bv[p];
-                }
-        }
-        __syncthreads();
-        RF_STAMP(who, 2);
-        // the label words of the chains' steps; a step past the lane's range gets the dummy row
-        const int tiles = (n_all + 15) >> 4;
-        for (int w = tid; w < tiles * RB * 64; w += kFThreads) {
-            const int t = w & 63, rb = (w >> 6) % RB, q = (w >> 6) / RB;
-            const int c = q * 16 + (t >> 2), k = t & 3;
-            unsigned word = 0u;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = 4 * rb + u;
-                const bool real = c < pc || (c == pc && r < rem);
-                const unsigned lb = real ? (unsigned)sTail[4 * (c * L + r) + k] : (unsigned)K;
-                word |= lb << (8 * u);
-            }
-            sLab[w] = word;
-        }
-        unsigned lw = 0u;  // labels of the N mod 4 leftover points, for the workgroup that combines the lanes
-        if (tid == 0)
-            for (int64_t n = size * 4; n < N; ++n) lw |= (unsigned)sTail[n - tail0] << (8 * (int)(n & 3));
-        __syncthreads();
-        const int64_t lim = N - tail0;
-        cascade_levels(
-            [&](int q, int rb, int ln, int i) {
-                const float *x = X + (int64_t)i * N + tail0;
-                const int64_t m0 = 4 * ((int64_t)(q * 16 + (ln >> 2)) * L + 4 * rb) + (ln & 3);
-                float4 v;
-                v.x = m0 < lim ? x[m0] : 0.f;
-                v.y = m0 + 4 < lim ? x[m0 + 4] : 0.f;
-                v.z = m0 + 8 < lim ? x[m0 + 8] : 0.f;
-                v.w = m0 + 12 < lim ? x[m0 + 12] : 0.f;
-                return v;
-            },
-            sLab, sAcc, K, L, TR, n_all, pc, acc1, acc0);
-        if (tid < dk) {
-            T[tid] = acc1;
-            T[dk + tid] = acc0;
-        }
-        if (tid == 0) T[2 * dk] = make_float4(__uint_as_float(lw), 0.f, 0.f, 0.f);
-        RF_STAMP(who, 3);
-    }
-    // ---- this workgroup's counts and similarity sum (read by the next kernel) ----
-    sim = wave_sum_f64(sim);
-    if (lane == 0) sWsum[wave] = sim;
-    __syncthreads();
-    if (tid < kFMaxK) cnt[gidx * kFMaxK + tid] = sCnt[tid];
-    if (tid == 0) {
-        double s = sWsum[0];
-        for (int w = 1; w < kFThreads / 64; ++w) s = s + sWsum[w];
-        Sin[gidx] = s;
-    }
-    RF_STAMP(who, 4);
-    RF_STAMP_MAX(0, 10);
-}
-
-// ATen's inner (contiguous) sum (inner_sum_f32) of v[0..size) in LDS, its 32 (vector lane, slot) cascades side by side;
-// scratch: 40 floats of LDS.  Called by a whole workgroup (>= 64 threads); the result is returned to every thread.
-__device__ __forceinline__ float inner_sum_parallel(const float *v, int size, float *scratch) {
-    const int tid = (int)threadIdx.x;
-    if (size < 8) {
-        if (tid == 0) scratch[0] = row_sum_f32(v, size);
-        __syncthreads();
-        const float r = scratch[0];
-        __syncthreads();
-        return r;
-    }
-    const int nv = size / 8, s4 = nv / 4;
-    if (tid < 32) scratch[tid] = cascade_f32(v + 8 * (tid >> 3) + (tid & 7), 32, s4);  // slot k = tid / 8 of lane l = tid % 8
-    __syncthreads();
-    if (tid < 8) {
-        float s = scratch[tid];
-        for (int i = s4 * 4; i < nv; ++i) s = s + v[8 * i + tid];
-        for (int k = 1; k < 4; ++k) s = s + scratch[8 * k + tid];
-        scratch[32 + tid] = s;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float acc = 0.f;
-        for (int i = nv * 8; i < size; ++i) acc = acc + v[i];
-        for (int l = 0; l < 8; ++l) acc = acc + scratch[32 + l];
-        scratch[0] = acc;
-    }
-    __syncthreads();
-    const float r = scratch[0];
-    __syncthreads();
-    return r;
-}
-
-// ---- second half: level 2 (workgroup b: block b, its groups' results in group order); the workgroup that arrives last:
-//      level 3, the leftovers, the lane combination, the new centroids (kmeans.py:180-182); the last one of the batch: the
-//      error over the whole (l, d, K) tensor in ATen's order (kmeans.py:45-51, 232), the stop flag, the next launch's
-//      counters.  Rows travel memory -> LDS with every load of a pass in flight at once. ----
-// SINGLE (TT = 1024 threads, one workgroup per problem): shards of at most `1024 / slot` blocks (N <= 131 072 at K <= 20) --
-// thread group b folds block b straight from memory into LDS and the same workgroup goes on with level 3: no arrival, no
-// rows through memory, one small workgroup instead of a grid (-1.5 us per iteration where an iteration is 20 us).
-template <int TT, bool SINGLE>
-__global__ __launch_bounds__(TT) void reforder_update_kernel2(const Args a, int rows_cap, int slot) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int K = a.K, dk = kD * K;
-    unsigned char *ws = a.ws + (int64_t)blockIdx.y * a.ws_stride;
-    et_kmeans_state *state = at<et_kmeans_state>(ws, a.lay.state);
-    if (state->done) {
-        if (a.mail && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)  // (the host stops launching when it reads this)
-            __hip_atomic_store(a.mail, (1ull << 63) | (unsigned long long)state->iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
-    }
-    const float *X = a.X + (int64_t)blockIdx.y * a.x_stride;
-    const Geo &geo = a.geo;
-    const int lp = geo.lp, L = 1 << lp;
-    const int64_t N = geo.N;
-    float *cen = at<float>(ws, a.lay.cen);
-    unsigned *arrive = at<unsigned>(ws, a.lay.arrive);
-    const float4 *S1 = at<const float4>(ws, a.lay.S1);
-    float4 *S2 = at<float4>(ws, a.lay.S2);
-    const float4 *T = at<const float4>(ws, a.lay.T);
-    const double *Sin = at<const double>(ws, a.lay.Sin);
-    __shared__ double sWsum[16];
-    __shared__ int sFlag[2];
-    __shared__ float sScr[40];
-    float4 *sRows = reinterpret_cast<float4 *>(smem);
-    [[maybe_unused]] const int who = blockIdx.x == 0 ? 2 : 9;
-    RF_STAMP(who, 0);
-
-    // ---- level 2 ----
-    const int blk = SINGLE ? tid / slot : (int)blockIdx.x;
-    [[maybe_unused]] const int ltid = SINGLE ? tid % slot : tid;  // column of the row this thread folds
-    const int64_t g0 = (int64_t)blk << lp;
-    const int ng = (int)((geo.G - g0) < L ? (geo.G - g0) : L);
-    float4 a2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int rowlen = dk + kFMaxK / 4;  // float4 per row of S2: the sums, then the block's points per cluster (bit patterns)
-    uint4 c2 = make_uint4(0u, 0u, 0u, 0u);
-    const uint4 *cnt4 = at<const uint4>(ws, a.lay.cnt);  // rows of kFMaxK counts = kFMaxK / 4 words of 16 bytes
-    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rS2 = rsrc_of(S2, (int64_t)sizeof(float4) * (geo.n_blk + 1) * rowlen);
-    if constexpr (SINGLE) {
-        // thread group `blk` (slot threads, ltid = column): its block's rows straight from memory, sixteen in flight, added in
-        // row order; the result is row `blk` of the LDS table level 3 reads below
-        if (blk < geo.n_blk && ltid < rowlen) {
-            const float4 *src = S1 + g0 * dk;
-            const uint4 *csrc = cnt4 + g0 * (kFMaxK / 4);
-            for (int r8 = 0; r8 < ng; r8 += 16) {
-                float4 v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int r = r8 + u < ng ? r8 + u : r8;
-                    v[u] = ltid < dk ? src[r * dk + ltid] : __builtin_bit_cast(float4, csrc[r * (kFMaxK / 4) + (ltid - dk)]);
-                }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    if (r8 + u < ng) {
-                        if (ltid < dk) {
-                            a2.x = a2.x + v[u].x;
-                            a2.y = a2.y + v[u].y;
-                            a2.z = a2.z + v[u].z;
-                            a2.w = a2.w + v[u].w;
-                        } else {
-                            const uint4 c = __builtin_bit_cast(uint4, v[u]);
-                            c2.x += c.x;
-                            c2.y += c.y;
-                            c2.z += c.z;
-                            c2.w += c.w;
-                        }
-                    }
-                }
-            }
-            if (ltid >= dk && blk == 0) {  // block 0 takes the tail's counts along
-                const uint4 v = cnt4[geo.G * (kFMaxK / 4) + (ltid - dk)];
-                c2.x += v.x;
-                c2.y += v.y;
-                c2.z += v.z;
-                c2.w += v.w;
-            }
-            sRows[blk * rowlen + ltid] = ltid < dk ? a2 : __builtin_bit_cast(float4, c2);
-        }
-        __syncthreads();
-    } else {
-        for (int r0 = 0; r0 < ng; r0 += rows_cap) {
-            const int nr = ng - r0 < rows_cap ? ng - r0 : rows_cap;
-            const float4 *src = S1 + (g0 + r0) * dk;
-            const uint4 *csrc = cnt4 + (g0 + r0) * (kFMaxK / 4);
-            for (int r8 = 0; r8 < nr; r8 += 16) {  // sixteen rows' loads in flight per thread: thread = column, rows in sequence
-                if (tid < rowlen) {
-                    float4 v[16];
-    #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int r = r8 + u < nr ? r8 + u : r8;
-                        v[u] = tid < dk ? src[r * dk + tid] : __builtin_bit_cast(float4, csrc[r * (kFMaxK / 4) + (tid - dk)]);
-                    }
-    #pragma unroll
-                    for (int u = 0; u < 16; ++u)
-                        if (r8 + u < nr) sRows[(r8 + u) * rowlen + tid] = v[u];
-                }
-            }
-            __syncthreads();
-            if (tid < dk) {
-                for (int g = 0; g < nr; ++g) {
-                    const float4 v = sRows[g * rowlen + tid];
-                    a2.x = a2.x + v.x;
-                    a2.y = a2.y + v.y;
-                    a2.z = a2.z + v.z;
-                    a2.w = a2.w + v.w;
-                }
-            } else if (tid < rowlen) {  // (integers: any order)
-                for (int g = 0; g < nr; ++g) {
-                    const uint4 v = __builtin_bit_cast(uint4, sRows[g * rowlen + tid]);
-                    c2.x += v.x;
-                    c2.y += v.y;
-                    c2.z += v.z;
-                    c2.w += v.w;
-                }
-            }
-            __syncthreads();
-        }
-        if (tid < dk) st16_sc1(rS2, (unsigned)(((int64_t)blk * rowlen + tid) * sizeof(float4)), a2);
-        if (tid >= dk && tid < rowlen) {
-            if (blk == 0) {  // block 0 takes the tail's counts along
-                const uint4 v = cnt4[geo.G * (kFMaxK / 4) + (tid - dk)];
-                c2.x += v.x;
-                c2.y += v.y;
-                c2.z += v.z;
-                c2.w += v.w;
-            }
-            st16_sc1(rS2, (unsigned)(((int64_t)blk * rowlen + tid) * sizeof(float4)), __builtin_bit_cast(float4, c2));
-        }
-        RF_STAMP(who, 1);
-        // ---- arrival: the stores have been performed at the memory side ----
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        if (tid == 0) sFlag[0] = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)geo.n_blk - 1u;
-        __syncthreads();
-        RF_STAMP(who, 2);
-        if (!sFlag[0]) return;
-    }
-
-    // ---- last workgroup of this problem: level 3 over the complete blocks, in block order ----
-    RF_STAMP(3, 0);
-    float4 a3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned ctot[4] = {0u, 0u, 0u, 0u};
-    __shared__ unsigned sCntTot[kFMaxK];
-    for (int r0 = 0; r0 < geo.full_blk; r0 += rows_cap) {
-        const int nr = geo.full_blk - r0 < rows_cap ? geo.full_blk - r0 : rows_cap;
-        const unsigned base = (unsigned)((int64_t)r0 * rowlen * sizeof(float4));
-        if constexpr (!SINGLE) {
-            for (int e0 = 0; e0 < nr * rowlen; e0 += 16 * TT) {  // sixteen 16-byte loads per lane in flight
-                float4 v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int e = e0 + u * TT + tid;
-                    v[u] = ld16_sc1(rS2, base + (unsigned)((e < nr * rowlen ? e : 0) * sizeof(float4)));
-                }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int e = e0 + u * TT + tid;
-                    if (e < nr * rowlen) sRows[e] = v[u];
-                }
-            }
-            __syncthreads();
-        }  // (SINGLE: the rows are in the table already, all of them: rows_cap >= n_blk)
-        if (tid < dk) {
-            for (int b = 0; b < nr; ++b) {
-                const float4 v = sRows[b * rowlen + tid];
-                a3.x = a3.x + v.x;
-                a3.y = a3.y + v.y;
-                a3.z = a3.z + v.z;
-                a3.w = a3.w + v.w;
-            }
-        } else if (tid < rowlen) {
-            for (int b = 0; b < nr; ++b) {
-                const float4 v = sRows[b * rowlen + tid];
-                ctot[0] += __float_as_uint(v.x);
-                ctot[1] += __float_as_uint(v.y);
-                ctot[2] += __float_as_uint(v.z);
-                ctot[3] += __float_as_uint(v.w);
-            }
-        }
-        __syncthreads();
-    }
-    float4 part_row = make_float4(0.f, 0.f, 0.f, 0.f);  // the partial block's row, this thread's column
-    if (geo.n_blk > geo.full_blk && tid < rowlen)
-        part_row = SINGLE ? sRows[geo.full_blk * rowlen + tid]
-                          : ld16_sc1(rS2, (unsigned)(((int64_t)geo.full_blk * rowlen + tid) * sizeof(float4)));
-    if (tid >= dk && tid < rowlen) {
-        if (geo.n_blk > geo.full_blk) {
-            const float4 v = part_row;
-            ctot[0] += __float_as_uint(v.x);
-            ctot[1] += __float_as_uint(v.y);
-            ctot[2] += __float_as_uint(v.z);
-            ctot[3] += __float_as_uint(v.w);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) sCntTot[4 * (tid - dk) + u] = ctot[u];
-    }
-    // the inertia of this assignment (kmeans.py:234; only printed by the reference): fp64, a fixed order
-    // (always as kUThreads = 256 threads would do it -- four wavefronts' partial sums --, so that both forms give the same bits)
-    double part = 0.0;
-    if (tid < kUThreads) {
-        for (int64_t gb = 0; gb <= geo.G; gb += 8 * kUThreads) {  // eight loads in flight; a fixed order per thread
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int64_t g = gb + (int64_t)u * kUThreads + tid;
-                v[u] = Sin[g <= geo.G ? g : 0];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (gb + (int64_t)u * kUThreads + tid <= geo.G) part = part + v[u];
-        }
-    }
-    part = wave_sum_f64(part);
-    if (lane == 0) sWsum[wave] = part;
-    float *sq_mine = a.sq_all + (int64_t)blockIdx.y * dk;
-    float *sSq = reinterpret_cast<float *>(smem);
-    __syncthreads();  // sCntTot, sWsum
-    if (tid < dk) {
-        const int j = tid % K;
-        const float *x = X + (int64_t)(tid / K) * N;
-        const float4 p2 = part_row;
-        const float4 p1 = T[tid], p0 = T[dk + tid];
-        const unsigned lw = __float_as_uint(T[2 * dk].x);
-        float p = ((p0.x + p1.x) + p2.x) + a3.x;
-        // the N mod 4 terms after the lanes' ranges go onto lane 0 (their labels: one word from the tail's workgroup)
-        for (int64_t n = N / 4 * 4; n < N; ++n)
-            if (((lw >> (8 * (int)(n & 3))) & 255u) == (unsigned)j) p = p + x[n];
-        p = p + (((p0.y + p1.y) + p2.y) + a3.y);
-        p = p + (((p0.z + p1.z) + p2.z) + a3.z);
-        p = p + (((p0.w + p1.w) + p2.w) + a3.w);
-        const float c = p / (float)sCntTot[j];  // 0/0 = NaN for an empty cluster (kmeans.py:182)
-        const float diff = cen[tid] - c;
-        cen[tid] = c;
-        if (a.batch > 1) __hip_atomic_store(&sq_mine[tid], diff * diff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else sSq[tid] = diff * diff;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double s = sWsum[0];
-        for (int w = 1; w < kUThreads / 64; ++w) s = s + sWsum[w];
-        __hip_atomic_store(&state->inertia, (double)(float)(-(s / (double)N)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    RF_STAMP(3, 1);
-    if (a.batch > 1) {
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        if (tid == 0)
-            sFlag[1] = __hip_atomic_fetch_add(a.batch_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)a.batch - 1u;
-        __syncthreads();
-        if (!sFlag[1]) return;
-        const int tot = a.batch * dk;
-        for (int e = tid; e < tot; e += TT) sSq[e] = __hip_atomic_load(&a.sq_all[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-    }
-    RF_STAMP(3, 2);
-    const float error = inner_sum_parallel(sSq, a.batch * dk, sScr);
-    const int done = (error <= a.tol) ? 1 : 0;
-    RF_STAMP(3, 3);
-    for (int b = tid; b < a.batch; b += TT) {
-        et_kmeans_state *st = at<et_kmeans_state>(a.ws + (int64_t)b * a.ws_stride, a.lay.state);
-        const int64_t it = st->iter;
-        const double ine = __hip_atomic_load(&st->inertia, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (a.trace) {
-            float *tr = a.trace + ((int64_t)b * a.max_iter + it) * 2;
-            tr[0] = error;
-            tr[1] = (float)ine;
-        }
-        st->error = (double)error;
-        st->iter = it + 1;
-        st->done = done;
-        if (b == 0 && a.mail)
-            __hip_atomic_store(a.mail, ((unsigned long long)(done != 0) << 63) | (unsigned long long)(it + 1), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    for (int b = 0; b < a.batch; ++b) {
-        unsigned char *wb = a.ws + (int64_t)b * a.ws_stride;
-        if (tid == 0) at<unsigned>(wb, a.lay.arrive)[0] = 0u;
-    }
-    if (tid == 0) *a.batch_arrive = 0u;
-    RF_STAMP(3, 4);
-}
-
-// =====================================================================================================================
-// The reference-order iteration over SHARDS (one process per GPU; not in the reference).  The order of a cascade sum is a
-// property of the whole array, but its tree is made of index ranges: with every shard boundary on a multiple of a level-2
-// block (4 L^3 points, L from the TOTAL number of points) a rank owns whole blocks, runs levels 0 .. 2 of its own rows
-// exactly as above, and what has to travel is one row of d K sums (+ K counts) per block -- 2 KB per 16 384 points at
-// L = 16, per 1 048 576 at L = 64 -- plus the last rank's leftovers: ONE all-gather per iteration; then every rank runs
-// the same sequential level 3 over the ranks' rows in rank order (= global block order), the lane combination, the update
-// and the stop flag: identical centroids everywhere without a broadcast, and the same bits as the single-GPU fit.
-// Record of a rank (16-byte words): rows[max_rows][d K + 8] | T1[d K] | T0[d K] | leftover labels | leftover coordinates
-// (3 points x 6, 5 words) | tail counts (8) | similarity sum (fp64 in one word).
-// =====================================================================================================================
-struct ShardRec {
-    int max_rows, rowlen, dk;
-    __host__ __device__ int t1() const { return max_rows * rowlen; }
-    __host__ __device__ int t0() const { return t1() + dk; }
-    __host__ __device__ int lab() const { return t0() + dk; }
-    __host__ __device__ int coords() const { return lab() + 1; }
-    __host__ __device__ int tailcnt() const { return coords() + 5; }
-    __host__ __device__ int sin() const { return tailcnt() + kFMaxK / 4; }
-    __host__ __device__ int words() const { return sin() + 1; }
-};
-
-// levels 2 of this rank's blocks -> its record (plain stores: the all-gather follows the kernel); workgroup 0 adds the
-// tail's rows, the leftover points, the tail's counts and the rank's similarity sum
-__global__ __launch_bounds__(kUThreads) void reforder_level2_sharded_kernel(const Args a, ShardRec rec, int rows_local,
-                                                                           float4 *__restrict__ send, int rows_cap) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int K = a.K, dk = kD * K;
-    unsigned char *ws = a.ws;
-    const et_kmeans_state *state = at<et_kmeans_state>(ws, a.lay.state);
-    if (state->done) return;
-    const Geo &geo = a.geo;
-    const int lp = geo.lp, L = 1 << lp;
-    const float4 *S1 = at<const float4>(ws, a.lay.S1);
-    const uint4 *cnt4 = at<const uint4>(ws, a.lay.cnt);
-    float4 *sRows = reinterpret_cast<float4 *>(smem);
-    const int blk = (int)blockIdx.x, rowlen = rec.rowlen;
-    if (blk < rows_local) {
-        const int64_t g0 = (int64_t)blk << lp;
-        const int ng = (int)((geo.G - g0) < L ? (geo.G - g0) : L);
-        float4 a2 = make_float4(0.f, 0.f, 0.f, 0.f);
-        uint4 c2 = make_uint4(0u, 0u, 0u, 0u);
-        for (int r0 = 0; r0 < ng; r0 += rows_cap) {
-            const int nr = ng - r0 < rows_cap ? ng - r0 : rows_cap;
-            const float4 *src = S1 + (g0 + r0) * dk;
-            const uint4 *csrc = cnt4 + (g0 + r0) * (kFMaxK / 4);
-            for (int r8 = 0; r8 < nr; r8 += 16) {
-                if (tid < rowlen) {
-                    float4 v[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int r = r8 + u < nr ? r8 + u : r8;
-                        v[u] = tid < dk ? src[r * dk + tid] : __builtin_bit_cast(float4, csrc[r * (kFMaxK / 4) + (tid - dk)]);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 16; ++u)
-                        if (r8 + u < nr) sRows[(r8 + u) * rowlen + tid] = v[u];
-                }
-            }
-            __syncthreads();
-            if (tid < dk) {
-                for (int g = 0; g < nr; ++g) {
-                    const float4 v = sRows[g * rowlen + tid];
-                    a2.x = a2.x + v.x;
-                    a2.y = a2.y + v.y;
-                    a2.z = a2.z + v.z;
-                    a2.w = a2.w + v.w;
-                }
-            } else if (tid < rowlen) {
-                for (int g = 0; g < nr; ++g) {
-                    const uint4 v = __builtin_bit_cast(uint4, sRows[g * rowlen + tid]);
-                    c2.x += v.x;
-                    c2.y += v.y;
-                    c2.z += v.z;
-                    c2.w += v.w;
-                }
-            }
-            __syncthreads();
-        }
-        if (tid < dk) send[(int64_t)blk * rowlen + tid] = a2;
-        else if (tid < rowlen) send[(int64_t)blk * rowlen + tid] = __builtin_bit_cast(float4, c2);
-    }
-    if (blk != 0) return;
-    const float4 *T = at<const float4>(ws, a.lay.T);
-    const double *Sin = at<const double>(ws, a.lay.Sin);
-    if (tid < dk) {
-        send[rec.t1() + tid] = T[tid];
-        send[rec.t0() + tid] = T[dk + tid];
-    }
-    if (tid == 0) send[rec.lab()] = T[2 * dk];
-    if (tid < 5) {  // the N mod 4 points after the lanes' ranges: their coordinates travel with the record
-        const int64_t N = geo.N, n0 = N / 4 * 4;
-        float v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = 4 * tid + u, pnt = e / kD, i = e % kD;
-            v[u] = (e < 3 * kD && n0 + pnt < N) ? a.X[(int64_t)i * N + n0 + pnt] : 0.f;
-        }
-        send[rec.coords() + tid] = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    if (tid >= 64 && tid < 64 + kFMaxK / 4) send[rec.tailcnt() + (tid - 64)] = __builtin_bit_cast(float4, cnt4[geo.G * (kFMaxK / 4) + (tid - 64)]);
-    __shared__ double sWsum[8];
-    double part = 0.0;
-    for (int64_t g = tid; g <= geo.G; g += kUThreads) part = part + Sin[g];
-    part = wave_sum_f64(part);
-    if (lane == 0) sWsum[wave] = part;
-    __syncthreads();
-    if (tid == 0) {
-        double sum = sWsum[0];
-        for (int w = 1; w < kUThreads / 64; ++w) sum = sum + sWsum[w];
-        const unsigned long long b = (unsigned long long)__double_as_longlong(sum);
-        send[rec.sin()] = make_float4(__uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)), 0.f, 0.f);
-    }
-}
-
-// every rank, identically: level 3 over the ranks' complete blocks in rank order, the tail rank's partial block / tail /
-// leftovers, lane combination, new centroids (kmeans.py:180-182), error (ATen's inner sum), stop flag
-__global__ __launch_bounds__(kUThreads) void reforder_finish_sharded_kernel(const Args a, ShardRec rec, int P, const int *__restrict__ rows_of,
-                                                                           int tail_rank, int tail_full_rows, int64_t N_total,
-                                                                           const float4 *__restrict__ table, int rows_cap) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = (int)threadIdx.x;
-    const int K = a.K, dk = kD * K, rowlen = rec.rowlen;
-    et_kmeans_state *state = at<et_kmeans_state>(a.ws, a.lay.state);
-    if (state->done) return;
-    float *cen = at<float>(a.ws, a.lay.cen);
-    __shared__ unsigned sCntTot[kFMaxK];
-    __shared__ float sScr[40];
-    float4 *sRows = reinterpret_cast<float4 *>(smem);
-    float4 a3 = make_float4(0.f, 0.f, 0.f, 0.f), p2 = a3;
-    unsigned ctot[4] = {0u, 0u, 0u, 0u};
-    const int words = rec.words();
-    for (int r = 0; r < P; ++r) {
-        const float4 *rr = table + (int64_t)r * words;
-        const int nrows = rows_of[r], nfull = r == tail_rank ? tail_full_rows : nrows;
-        for (int r0 = 0; r0 < nrows; r0 += rows_cap) {
-            const int nr = nrows - r0 < rows_cap ? nrows - r0 : rows_cap;
-            for (int e = tid; e < nr * rowlen; e += kUThreads) sRows[e] = rr[r0 * rowlen + e];
-            __syncthreads();
-            if (tid < dk) {
-                for (int b = 0; b < nr; ++b) {
-                    const float4 v = sRows[b * rowlen + tid];
-                    if (r0 + b < nfull) {
-                        a3.x = a3.x + v.x;
-                        a3.y = a3.y + v.y;
-                        a3.z = a3.z + v.z;
-                        a3.w = a3.w + v.w;
-                    } else {
-                        p2 = v;  // (the partial block: the tail rank's last row)
-                    }
-                }
-            } else if (tid < rowlen) {
-                for (int b = 0; b < nr; ++b) {
-                    const uint4 v = __builtin_bit_cast(uint4, sRows[b * rowlen + tid]);
-                    ctot[0] += v.x;
-                    ctot[1] += v.y;
-                    ctot[2] += v.z;
-                    ctot[3] += v.w;
-                }
-            }
-            __syncthreads();
-        }
-        if (tid >= dk && tid < rowlen) {
-            const uint4 t = __builtin_bit_cast(uint4, rr[rec.tailcnt() + (tid - dk)]);
-            ctot[0] += t.x;
-            ctot[1] += t.y;
-            ctot[2] += t.z;
-            ctot[3] += t.w;
-        }
-    }
-    if (tid >= dk && tid < rowlen) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) sCntTot[4 * (tid - dk) + u] = ctot[u];
-    }
-    __syncthreads();
-    const float4 *last = table + (int64_t)tail_rank * words;  // (the rank that owns the end of the array)
-    float *sSq = reinterpret_cast<float *>(smem);
-    if (tid < dk) {
-        const int j = tid % K, i = tid / K;
-        const float4 p1 = last[rec.t1() + tid], p0 = last[rec.t0() + tid];
-        const unsigned lw = __float_as_uint(last[rec.lab()].x);
-        const float *lc = reinterpret_cast<const float *>(last + rec.coords());
-        float p = ((p0.x + p1.x) + p2.x) + a3.x;
-        for (int pnt = 0; pnt < (int)(N_total & 3); ++pnt)  // the N mod 4 terms after the lanes' ranges go onto lane 0
-            if (((lw >> (8 * pnt)) & 255u) == (unsigned)j) p = p + lc[pnt * kD + i];
-        p = p + (((p0.y + p1.y) + p2.y) + a3.y);
-        p = p + (((p0.z + p1.z) + p2.z) + a3.z);
-        p = p + (((p0.w + p1.w) + p2.w) + a3.w);
-        const float c = p / (float)sCntTot[j];  // 0/0 = NaN for an empty cluster (kmeans.py:182)
-        const float diff = cen[tid] - c;
-        cen[tid] = c;
-        sSq[tid] = diff * diff;
-    }
-    __syncthreads();
-    const float error = inner_sum_parallel(sSq, dk, sScr);
-    if (tid == 0) {
-        double sum = 0.0;
-        for (int r = 0; r < P; ++r) {
-            const float4 w = table[(int64_t)r * words + rec.sin()];
-            sum = sum + __longlong_as_double((long long)(((unsigned long long)__float_as_uint(w.y) << 32) | __float_as_uint(w.x)));
-        }
-        const float inertia = (float)(-(sum / (double)N_total));
-        const int64_t it = state->iter;
-        if (a.trace) {
-            a.trace[2 * it] = error;
-            a.trace[2 * it + 1] = inertia;
-        }
-        state->inertia = (double)inertia;
-        state->error = (double)error;
-        state->iter = it + 1;
-        state->done = (error <= a.tol) ? 1 : 0;
-    }
-}
-
-// before the loop: state, working centroids, counters
-__global__ __launch_bounds__(kThreads) void reforder_fast_prepare_kernel(const Args a, const float *__restrict__ cen_in) {
-    unsigned char *ws = a.ws + (int64_t)blockIdx.x * a.ws_stride;
-    const int dk = kD * a.K;
-    et_kmeans_state *st = at<et_kmeans_state>(ws, a.lay.state);
-    if (threadIdx.x == 0) {  // (max_abs_x / bad_input stay as the scan left them)
-        st->n_total = a.geo.N;
-        st->iter = 0;
-        // non-finite input in ANY problem of the batch stops all of them before the first iteration (the batch iterates and
-        // stops jointly: a problem that sat out would leave the others waiting for its arrival); the host reads the
-        // bad_input flags after the loop and returns ET_ERR_BAD_DATA
-        int bad = 0;
-        for (int b = 0; b < a.batch; ++b) bad |= at<et_kmeans_state>(a.ws + (int64_t)b * a.ws_stride, a.lay.state)->bad_input;
-        st->done = bad ? 1 : 0;
-        st->error = 0.0;
-        st->inertia = 0.0;
-    }
-    for (int e = threadIdx.x; e < dk; e += blockDim.x) at<float>(ws, a.lay.cen)[e] = cen_in[(int64_t)blockIdx.x * dk + e];
-    if (threadIdx.x == 0) at<unsigned>(ws, a.lay.arrive)[0] = 0u;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *a.batch_arrive = 0u;
-}
-
-// after the loop: labels in the caller's order (int64), centroids
-__global__ __launch_bounds__(kThreads) void reforder_fast_finish_kernel(const Args a, float *__restrict__ cen_out,
-                                                                        int64_t *__restrict__ labels) {
-    unsigned char *ws = a.ws + (int64_t)blockIdx.y * a.ws_stride;
-    const int dk = kD * a.K;
-    const Geo &geo = a.geo;
-    const int lp = geo.lp;
-    const int64_t L = (int64_t)1 << lp, L2 = L * L, N = geo.N;
-    if (blockIdx.x == 0)
-        for (int e = threadIdx.x; e < dk; e += blockDim.x) cen_out[(int64_t)blockIdx.y * dk + e] = at<float>(ws, a.lay.cen)[e];
-    if (!labels) return;
-    const uint8_t *LT = at<const uint8_t>(ws, a.lay.LT), *tl = at<const uint8_t>(ws, a.lay.tail);
-    int64_t *out = labels + (int64_t)blockIdx.y * N;
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
-        uint8_t v;
-        if (n >= geo.tail0) {
-            v = tl[n - geo.tail0];
-        } else {
-            const int64_t g = n / (4 * L2), m = n % (4 * L2);
-            const int64_t k = m & 3, lt = m >> 2, c = lt >> lp, r = lt & (L - 1);
-            const int64_t q = c >> 4, t = (c & 15) * 4 + k, rb = r >> 2, u = r & 3;
-            v = LT[(g * L2 + (q * (L / 4) + rb) * 64 + t) * 4 + u];
-        }
-        out[n] = (int64_t)v;
-    }
-}
-
-static bool fast_shape(int64_t N, int d, int K) {
-    if (d != kD || K < 1 || K > kFMaxK || N < 1024 || N >= ((int64_t)1 << 29)) return false;
-    const Geo g = make_geo(N);
-    return g.lp <= kFMaxLp && g.G >= 1;
-}
-// level-0 tiles (16 chunks) whose accumulators are in LDS at a time: ONE -- at L = 32 two tiles (73 KB, two workgroups per
-// CU) took 123 us per iteration at 1e7 points against 111 us with one (38 KB, four per CU), same box
-static int fast_tiles_per_round(const Geo &) { return 1; }
-static int fast_filter_min_lp() { return options().reforder_filter_min_lp.load(std::memory_order_relaxed); }
-static size_t fast_lds_bytes(const Geo &g, int K, int TR) {
-    const int L = 1 << g.lp;
-    const size_t body = acc_region_bytes(K, L, TR) + sizeof(unsigned) * (size_t)L * L;
-    return (body + 15) / 16 * 16;
-}
-// rows of d K float4 the update kernel stages at a time, and its dynamic LDS
-static int update_rows_cap(const Geo &g, int K, int batch, size_t *lds) {
-    const size_t row = sizeof(float4) * ((size_t)kD * K + kFMaxK / 4);
-    const int L = 1 << g.lp;
-    int want = g.full_blk > L ? g.full_blk : L;
-    if ((size_t)want * row > kUMaxLds) want = (int)(kUMaxLds / row);
-    size_t bytes = (size_t)want * row;
-    const size_t sq = sizeof(float) * (size_t)batch * kD * K;
-    if (sq > bytes) bytes = sq;
-    *lds = (bytes + 15) / 16 * 16;
-    return want;
-}
-
-#ifdef ET_EXP_RF_CHECK
-extern "C" int et_debug_rfcheck(unsigned *host) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rf_check), sizeof(unsigned) * 64) == hipSuccess ? 0 : 3;
-}
-#endif
-#ifdef ET_EXP_RFSTAMP
-extern "C" int et_debug_rfstamps(unsigned long long *host) {
-    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rf_stamps), sizeof(unsigned long long) * 64) != hipSuccess) return 3;
-    static const unsigned long long zeros[64] = {};
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_rf_stamps), zeros, sizeof zeros) == hipSuccess ? 0 : 3;  // (reading resets)
-}
-#endif
-
-}  // namespace fast
-
-}  // namespace reforder
-}  // namespace et
-
-using namespace et::reforder;
-
-static size_t fast_workspace_bytes(int64_t N, int K, int64_t batch) {
-    const fast::Geo g = fast::make_geo(N);
-    return fast::shared_bytes(K, batch) + (size_t)batch * fast::make_layout(g, K).bytes;
-}
-
-extern "C" size_t et_kmeans_reforder_workspace_bytes(int64_t N, int d, int K) {
-    if (!dims_ok(d, K) || N < 0) return 0;
-    const size_t generic = carve(nullptr, N, d, K).bytes;
-    const size_t quick = fast::fast_shape(N, d, K) ? fast_workspace_bytes(N, K, 1) : 0;
-    return generic > quick ? generic : quick;
-}
-
-extern "C" size_t et_kmeans_reforder_batch_workspace_bytes(int64_t N, int d, int K, int64_t batch) {
-    if (!dims_ok(d, K) || N < 0 || batch < 1) return 0;
-    if (batch == 1) return et_kmeans_reforder_workspace_bytes(N, d, K);
-    if (!fast::fast_shape(N, d, K) || batch > fast::kFMaxBatch) return 0;
-    return fast_workspace_bytes(N, K, batch);
-}
-
-// the fast form (see namespace fast): all `batch` problems in one loop of one launch per iteration, joint stop
-static int fast_fit(const float *X, int64_t x_stride, int64_t N, int K, int64_t batch, int max_iter, float tol, float *centroids,
-                    int64_t *labels, float *trace, et_kmeans_state *states_host, et_kmeans_timing *timing_host, void *workspace,
-                    hipStream_t st) {
-    using namespace fast;
-    Args a;
-    a.geo = make_geo(N);
-    a.lay = make_layout(a.geo, K);
-    unsigned char *base = (unsigned char *)workspace;
-    a.batch_arrive = (unsigned *)base;
-    a.sq_all = (float *)(base + 256);
-    a.ws = base + shared_bytes(K, batch);
-    a.ws_stride = (int64_t)a.lay.bytes;
-    a.X = X;
-    a.x_stride = x_stride;
-    a.K = K;
-    a.batch = (int)batch;
-    a.tol = tol;
-    a.trace = trace;
-    a.max_iter = max_iter;
-    a.mail = nullptr;
-    int rc = ET_OK;
-    et::StateRing *ring = et::StateRing::get(&rc);
-    if (!ring) return rc;
-    a.mail = ring->mailbox_device();
-    if (a.mail) ring->mailbox_reset();
-    a.tiles_per_round = fast_tiles_per_round(a.geo);
-    const size_t lds = fast_lds_bytes(a.geo, K, a.tiles_per_round);
-    size_t ulds = 0;
-    const int rows_cap = update_rows_cap(a.geo, K, (int)batch, &ulds);
-    {
-        static bool lds_set[64] = {};
-        int dev_id = 0;
-        ET_HIP_TRY(hipGetDevice(&dev_id));
-        if (!lds_set[dev_id & 63]) {
-            for (const void *f : {reinterpret_cast<const void *>(reforder_groups_kernel<0>), reinterpret_cast<const void *>(reforder_groups_kernel<10>),
-                                  reinterpret_cast<const void *>(reforder_groups_kernel<16>)})
-                ET_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-            for (const void *f : {reinterpret_cast<const void *>(reforder_update_kernel2<kUThreads, false>),
-                                  reinterpret_cast<const void *>(reforder_update_kernel2<1024, true>)})
-                ET_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUMaxLds));
-            lds_set[dev_id & 63] = true;
-        }
-    }
-    for (int64_t b = 0; b < batch; ++b) {
-        rc = et_kmeans_scan(X + b * x_stride, N, kD, (et_kmeans_state *)(a.ws + b * a.ws_stride + a.lay.state), (et_stream_t)st);
-        if (rc) return rc;
-    }
-    hipLaunchKernelGGL(reforder_fast_prepare_kernel, dim3((unsigned)batch), dim3(kThreads), 0, st, a, (const float *)centroids);
-    {
-        const int64_t quads = a.geo.G << (2 * a.geo.lp);
-        const int pg = (int)std::min<int64_t>((quads + kThreads - 1) / kThreads, 2048);
-        hipLaunchKernelGGL(reforder_permute_kernel, dim3(pg, (unsigned)batch), dim3(kThreads), 0, st, X, x_stride, a.ws,
-                           a.ws_stride, a.lay.XT, a.geo);
-    }
-    ET_LAUNCH_CHECK();
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    if (timing_host) {
-        ET_HIP_TRY(hipEventCreate(&ev[0]));
-        ET_HIP_TRY(hipEventCreate(&ev[1]));
-        ET_HIP_TRY(hipEventRecord(ev[0], st));
-    }
-    // the matrix-core label filter pays where the exact scan is what a launch waits for: L >= 32 (N > 4.2e6)
-    const bool use_filter = a.geo.lp >= fast_filter_min_lp() && K >= 3;
-    constexpr int kAhead = 16, kEvery = 4;
-    et_kmeans_state *state0 = (et_kmeans_state *)(a.ws + a.lay.state);
-    int launched = 0;
-    bool done = false;
-    const dim3 grid((unsigned)(a.geo.G + 1), (unsigned)batch), ugrid((unsigned)a.geo.n_blk, (unsigned)batch);
-    // few blocks (N <= 131 072 at K <= 20): one 1024-thread workgroup per problem folds them side by side (no arrival hop)
-    const int uslot = (kD * K + kFMaxK / 4 + 63) / 64 * 64;
-    const bool single_update = a.geo.n_blk <= 1024 / uslot && et::options().reforder_single_update.load(std::memory_order_relaxed) != 0;
-    for (int it = 0; it < max_iter && !done; ++it) {
-        if (!use_filter) hipLaunchKernelGGL(reforder_groups_kernel<0>, grid, dim3(kFThreads), lds, st, a);
-        else if (K <= 20) hipLaunchKernelGGL(reforder_groups_kernel<10>, grid, dim3(kFThreads), lds, st, a);
-        else hipLaunchKernelGGL(reforder_groups_kernel<16>, grid, dim3(kFThreads), lds, st, a);
-        if (single_update)
-            hipLaunchKernelGGL((reforder_update_kernel2<1024, true>), dim3(1, (unsigned)batch), dim3(1024), ulds, st, a, rows_cap, uslot);
-        else
-            hipLaunchKernelGGL((reforder_update_kernel2<kUThreads, false>), ugrid, dim3(kUThreads), ulds, st, a, rows_cap, 0);
-        ET_LAUNCH_CHECK();
-        launched = it + 1;
-        if (a.mail) {  // stay at most kAhead launches ahead of the device's report; stop when it carries the flag
-            for (unsigned spins = 0;; ++spins) {
-                if (ring->mailbox_done()) {
-                    done = true;
-                    break;
-                }
-                if ((long long)launched - ring->mailbox_iter() <= kAhead) break;
-                if ((spins & 0xfffu) == 0xfffu && hipStreamQuery(st) == hipSuccess) break;
-                sched_yield();
-            }
-        } else {
-            if (launched % kEvery == 0) {
-                rc = ring->post(state0, st, &done);
-                if (rc) return rc;
-            }
-            ring->poll(&done);
-        }
-    }
-    if (timing_host) ET_HIP_TRY(hipEventRecord(ev[1], st));
-    const int64_t fgrid = std::min<int64_t>((N + kThreads - 1) / kThreads, 2048);
-    hipLaunchKernelGGL(reforder_fast_finish_kernel, dim3((unsigned)fgrid, (unsigned)batch), dim3(kThreads), 0, st, a, centroids,
-                       labels);
-    ET_LAUNCH_CHECK();
-    for (int64_t b = 0; b < batch; ++b)
-        ET_HIP_TRY(hipMemcpyAsync(&states_host[b], a.ws + b * a.ws_stride + a.lay.state, sizeof(et_kmeans_state),
-                                  hipMemcpyDeviceToHost, st));
-    ET_HIP_TRY(hipStreamSynchronize(st));
-    if (timing_host) {
-        float ms = 0.f;
-        ET_HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
-        timing_host->assign_ms = ms;
-        timing_host->assign_launches = launched;
-        timing_host->first_assign_ms = 0.0;
-        timing_host->iterations = states_host[0].iter;
-        (void)hipEventDestroy(ev[0]);
-        (void)hipEventDestroy(ev[1]);
-    }
-    for (int64_t b = 0; b < batch; ++b)
-        if (states_host[b].bad_input) return ET_ERR_BAD_DATA;
-    return ET_OK;
-}
-
-// ---- shards (see "The reference-order iteration over SHARDS" above) ----
-namespace {
-struct ShardPlan {
-    int P = 0, rank = 0, tail_rank = 0, tail_full = 0, max_rows = 0, lp = 0;
-    int64_t N_total = 0;
-    int rows[ET_REFORDER_MAX_RANKS] = {};
-    fast::Geo geo;
-    fast::ShardRec rec;
-    size_t off_send = 0, off_table = 0, off_rows = 0, bytes = 0;
-};
-int shard_plan(const int64_t *n_locals, int P, int rank, int K, ShardPlan *p) {
-    using namespace fast;
-    if (!n_locals || P < 1 || P > ET_REFORDER_MAX_RANKS || rank < 0 || rank >= P || K < 1 || K > kFMaxK) return ET_ERR_INVALID_ARG;
-    int64_t total = 0;
-    int tail_rank = 0;
-    for (int r = 0; r < P; ++r) {
-        if (n_locals[r] < 0) return ET_ERR_INVALID_ARG;
-        total += n_locals[r];
-        if (n_locals[r] > 0) tail_rank = r;
-    }
-    if (!fast_shape(total, kD, K)) return ET_ERR_UNSUPPORTED;
-    p->lp = level_power(total / 4);
-    const int64_t block = (int64_t)4 << (3 * p->lp);
-    p->P = P;
-    p->rank = rank;
-    p->tail_rank = tail_rank;
-    p->N_total = total;
-    p->max_rows = 1;
-    for (int r = 0; r < P; ++r) {
-        if (r != tail_rank && n_locals[r] % block != 0) return ET_ERR_INVALID_ARG;  // whole level-2 blocks before the tail rank
-        const Geo g = make_geo(n_locals[r], p->lp);
-        p->rows[r] = g.n_blk;
-        if (r == tail_rank) p->tail_full = g.full_blk;
-        if (g.n_blk > p->max_rows) p->max_rows = g.n_blk;
-    }
-    p->geo = make_geo(n_locals[rank], p->lp);
-    p->rec.max_rows = p->max_rows;
-    p->rec.dk = kD * K;
-    p->rec.rowlen = kD * K + kFMaxK / 4;
-    size_t off = shared_bytes(K, 1) + make_layout(p->geo, K).bytes;
-    p->off_send = off;
-    off = up(off + sizeof(float4) * (size_t)p->rec.words());
-    p->off_table = off;
-    off = up(off + sizeof(float4) * (size_t)p->rec.words() * P);
-    p->off_rows = off;
-    off = up(off + sizeof(int) * ET_REFORDER_MAX_RANKS);
-    p->bytes = off;
-    return ET_OK;
-}
-}  // namespace
-
-extern "C" int64_t et_kmeans_reforder_shard_block(int64_t N_total, int d, int K) {
-    if (!fast::fast_shape(N_total, d, K)) return 0;
-    return (int64_t)4 << (3 * level_power(N_total / 4));
-}
-
-extern "C" size_t et_kmeans_reforder_sharded_workspace_bytes(const int64_t *n_locals, int nranks, int rank, int d, int K) {
-    ShardPlan p;
-    if (d != fast::kD || shard_plan(n_locals, nranks, rank, K, &p) != ET_OK) return 0;
-    return p.bytes;
-}
-
-// `gather(ctx, send, recv, bytes, stream)`: every rank's `bytes` at send -> recv[rank * bytes ...] on every rank (in stream
-// order); `agree(ctx, state, stream)`: MAX over ranks of state->max_abs_x / bad_input.  Both nullptr: one rank.
-extern "C" int et_internal_kmeans_reforder_sharded_run(const float *X, const int64_t *n_locals, int nranks, int rank, int K,
-                                                       int max_iter, float tol, float *centroids, int64_t *labels, float *trace,
-                                                       et_kmeans_state *state_host, void *workspace, size_t workspace_bytes,
-                                                       int (*gather)(void *, const void *, void *, size_t, hipStream_t),
-                                                       int (*agree)(void *, et_kmeans_state *, hipStream_t), void *ctx,
-                                                       et_stream_t stream) {
-    using namespace fast;
-    ShardPlan p;
-    int rc = shard_plan(n_locals, nranks, rank, K, &p);
-    if (rc) return rc;
-    if (!centroids || !state_host || !workspace || max_iter < 1 || (p.geo.N > 0 && !X)) return ET_ERR_INVALID_ARG;
-    if (nranks > 1 && !gather) return ET_ERR_INVALID_ARG;
-    if (workspace_bytes < p.bytes) return ET_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    Args a;
-    a.geo = p.geo;
-    a.lay = make_layout(a.geo, K);
-    unsigned char *base = (unsigned char *)workspace;
-    a.batch_arrive = (unsigned *)base;
-    a.sq_all = (float *)(base + 256);
-    a.ws = base + shared_bytes(K, 1);
-    a.ws_stride = (int64_t)a.lay.bytes;
-    a.X = X;
-    a.x_stride = 0;
-    a.K = K;
-    a.batch = 1;
-    a.tol = tol;
-    a.trace = trace;
-    a.max_iter = max_iter;
-    a.mail = nullptr;
-    a.tiles_per_round = fast_tiles_per_round(a.geo);
-    float4 *send = (float4 *)(base + p.off_send), *table = (float4 *)(base + p.off_table);
-    int *rows_dev = (int *)(base + p.off_rows);
-    et::StateRing *ring = et::StateRing::get(&rc);
-    if (!ring) return rc;
-    const size_t lds = fast_lds_bytes(a.geo, K, a.tiles_per_round);
-    size_t l2lds = 0;
-    const int l2cap = update_rows_cap(a.geo, K, 1, &l2lds);
-    const size_t rowb = sizeof(float4) * (size_t)p.rec.rowlen;
-    const int fcap = (int)std::min<size_t>((size_t)p.max_rows, kUMaxLds / rowb);
-    const size_t flds = std::max<size_t>((size_t)fcap * rowb, sizeof(float) * (size_t)kD * K);
-    {
-        static bool lds_set[64] = {};
-        int dev_id = 0;
-        ET_HIP_TRY(hipGetDevice(&dev_id));
-        if (!lds_set[dev_id & 63]) {
-            for (const void *f : {reinterpret_cast<const void *>(reforder_groups_kernel<0>), reinterpret_cast<const void *>(reforder_groups_kernel<10>),
-                                  reinterpret_cast<const void *>(reforder_groups_kernel<16>)})
-                ET_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-            for (const void *f : {reinterpret_cast<const void *>(reforder_level2_sharded_kernel), reinterpret_cast<const void *>(reforder_finish_sharded_kernel)})
-                ET_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUMaxLds));
-            lds_set[dev_id & 63] = true;
-        }
-    }
-    et_kmeans_state *state = (et_kmeans_state *)(a.ws + a.lay.state);
-    rc = et_kmeans_scan(X, a.geo.N, kD, state, stream);
-    if (rc) return rc;
-    if (agree) {
-        rc = agree(ctx, state, st);
-        if (rc) return rc;
-    }
-    ET_HIP_TRY(hipMemcpyAsync(rows_dev, p.rows, sizeof(int) * (size_t)p.P, hipMemcpyHostToDevice, st));  // (p outlives the copy: this call ends with a synchronize)
-    ET_HIP_TRY(hipMemsetAsync(send, 0, sizeof(float4) * (size_t)p.rec.words(), st));
-    hipLaunchKernelGGL(reforder_fast_prepare_kernel, dim3(1), dim3(kThreads), 0, st, a, (const float *)centroids);
-    if (a.geo.G > 0) {
-        const int64_t quads = a.geo.G << (2 * a.geo.lp);
-        const int pg = (int)std::min<int64_t>((quads + kThreads - 1) / kThreads, 2048);
-        hipLaunchKernelGGL(reforder_permute_kernel, dim3(pg, 1), dim3(kThreads), 0, st, X, (int64_t)0, a.ws, a.ws_stride, a.lay.XT,
-                           a.geo);
-    }
-    ET_LAUNCH_CHECK();
-    const bool use_filter = a.geo.lp >= fast_filter_min_lp() && K >= 3;
-    constexpr int kEvery = 4;
-    bool done = false;
-    const dim3 grid((unsigned)(a.geo.G + 1), 1), l2grid((unsigned)std::max(p.rows[rank], 1), 1);
-    const size_t rec_bytes = sizeof(float4) * (size_t)p.rec.words();
-    for (int it = 0; it < max_iter && !done; ++it) {
-        if (!use_filter) hipLaunchKernelGGL(reforder_groups_kernel<0>, grid, dim3(kFThreads), lds, st, a);
-        else if (K <= 20) hipLaunchKernelGGL(reforder_groups_kernel<10>, grid, dim3(kFThreads), lds, st, a);
-        else hipLaunchKernelGGL(reforder_groups_kernel<16>, grid, dim3(kFThreads), lds, st, a);
-        hipLaunchKernelGGL(reforder_level2_sharded_kernel, l2grid, dim3(kUThreads), l2lds, st, a, p.rec, p.rows[rank], send, l2cap);
-        ET_LAUNCH_CHECK();
-        if (gather) {
-            rc = gather(ctx, send, table, rec_bytes, st);
-            if (rc) return rc;
-        } else {
-            ET_HIP_TRY(hipMemcpyAsync(table, send, rec_bytes, hipMemcpyDeviceToDevice, st));
-        }
-        hipLaunchKernelGGL(reforder_finish_sharded_kernel, dim3(1), dim3(kUThreads), flds, st, a, p.rec, p.P, (const int *)rows_dev,
-                           p.tail_rank, p.tail_full, p.N_total, (const float4 *)table, fcap);
-        ET_LAUNCH_CHECK();
-        // the stop flag is read one post late, by a blocking wait on that specific copy: which copy a rank sees must not
-        // depend on timing, or the ranks would stop enqueueing collectives at different iterations (et_sharded.hip)
-        if ((it + 1) % kEvery == 0) {
-            rc = ring->post(state, st, &done);
-            if (!rc && ring->pending() > 1) rc = ring->wait_oldest(&done);
-            if (rc) return rc;
-        }
-    }
-    const int64_t fgrid = std::max<int64_t>(1, std::min<int64_t>((a.geo.N + kThreads - 1) / kThreads, 2048));
-    hipLaunchKernelGGL(reforder_fast_finish_kernel, dim3((unsigned)fgrid, 1), dim3(kThreads), 0, st, a, centroids,
-                       a.geo.N > 0 ? labels : nullptr);
-    ET_LAUNCH_CHECK();
-    ET_HIP_TRY(hipMemcpyAsync(state_host, state, sizeof(et_kmeans_state), hipMemcpyDeviceToHost, st));
-    ET_HIP_TRY(hipStreamSynchronize(st));
-    state_host->n_total = p.N_total;
-    return state_host->bad_input ? ET_ERR_BAD_DATA : ET_OK;
-}
-
-extern "C" int et_euc_sim_reforder(const float *a, const float *b, int d, int64_t m, int64_t n, float *y,
-                                   et_stream_t stream) {
-    if (d < 1 || d > ET_KMEANS_MAX_D || m < 0 || n < 0 || ((m > 0 && n > 0) && (!a || !b || !y))) return ET_ERR_INVALID_ARG;
-    if (m == 0 || n == 0) return ET_OK;
-    hipLaunchKernelGGL(reforder_euc_sim_kernel, dim3(grid_for(m * n)), dim3(kThreads), 0, (hipStream_t)stream, a, b, d, m, n, y);
-    ET_LAUNCH_CHECK();
-    return ET_OK;
-}
-
-extern "C" int et_kmeans_init_farthest_reforder(const float *X, int64_t N, int d, int K, int64_t first_index, float *C0,
-                                                void *workspace, size_t workspace_bytes, et_stream_t stream) {
-    if (!dims_ok(d, K) || N < 1 || !X || !C0 || first_index < 0 || first_index >= N) return ET_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < et_kmeans_reforder_workspace_bytes(N, d, K)) return ET_ERR_WORKSPACE;
-    const Workspace w = carve(workspace, N, d, K);
-    hipStream_t st = (hipStream_t)stream;
-    const int grid = grid_for(N);
-    hipLaunchKernelGGL(reforder_init_pick_kernel, dim3(1), dim3(kThreads), 0, st, X, N, d, K, 0, (const Cand *)w.cands, 0,
-                       first_index, C0);
-    const bool incremental = d < 8 && K <= 32;  // (see reforder_init_step_inc_kernel)
-    unsigned *max_abs_bits = reinterpret_cast<unsigned *>(w.counts);  // (free until a fit uses the workspace)
-    const int skip_ok = N >= et::options().reforder_init_skip_min.load(std::memory_order_relaxed) ? 1 : 0;
-    if (incremental) ET_HIP_TRY(hipMemsetAsync(max_abs_bits, 0, sizeof(unsigned), st));
-    for (int i = 1; i < K; ++i) {
-        const size_t lds = sizeof(float) * ((size_t)d * i + (size_t)i);
-        // (incremental form: step i reads the candidates step i - 1 wrote -- two buffers, a late workgroup of this launch must
-        // not see this launch's records -- and picks centroid i - 1 itself; only the last centroid needs the pick launch)
-        Cand *mine = w.cands + (size_t)(i & 1) * kMaxBlocks;
-        const Cand *prev = i > 1 ? w.cands + (size_t)((i - 1) & 1) * kMaxBlocks : nullptr;
-        if (incremental && d == 6)
-            hipLaunchKernelGGL(reforder_init_step_inc_kernel<6>, dim3(grid), dim3(kThreads), 0, st, X, N, d, K, i, (const float *)C0,
-                               w.maxsims, w.best4, w.labels_u8, max_abs_bits, skip_ok, mine, prev, grid, C0);
-        else if (incremental)
-            hipLaunchKernelGGL(reforder_init_step_inc_kernel<0>, dim3(grid), dim3(kThreads), 0, st, X, N, d, K, i, (const float *)C0,
-                               w.maxsims, w.best4, w.labels_u8, max_abs_bits, skip_ok, mine, prev, grid, C0);
-        else
-            hipLaunchKernelGGL(reforder_init_step_kernel, dim3(grid), dim3(kThreads), lds, st, X, N, d, K, i, (const float *)C0,
-                               w.cands);
-        if (!incremental || i == K - 1)
-            hipLaunchKernelGGL(reforder_init_pick_kernel, dim3(1), dim3(kThreads), 0, st, X, N, d, K, i,
-                               (const Cand *)(incremental ? mine : w.cands), grid, (int64_t)0, C0);
-    }
-    ET_LAUNCH_CHECK();
-    return ET_OK;
-}
-
-extern "C" int et_kmeans_predict_reforder(const float *X, int64_t N, int d, const float *centroids, int K, int64_t *labels,
-                                          float *maxsims, void *workspace, size_t workspace_bytes, et_stream_t stream) {
-    if (!dims_ok(d, K) || N < 0 || !centroids || (N > 0 && !X)) return ET_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < et_kmeans_reforder_workspace_bytes(N, d, K)) return ET_ERR_WORKSPACE;
-    if (N == 0) return ET_OK;
-    const Workspace w = carve(workspace, N, d, K);
-    hipStream_t st = (hipStream_t)stream;
-    ET_HIP_TRY(hipMemsetAsync(w.counts, 0, sizeof(unsigned long long) * 256, st));
-    hipLaunchKernelGGL(reforder_assign_kernel, dim3(grid_for(N)), dim3(kThreads), sizeof(float) * ((size_t)d * K + (size_t)K), st,
-                       X, N, d, K, centroids, w.labels_u8, maxsims ? maxsims : w.maxsims, w.counts);
-    ET_LAUNCH_CHECK();
-    return labels ? et_kmeans_labels_i64(w.labels_u8, N, labels, stream) : ET_OK;
-}
-
-extern "C" int et_kmeans_fit_reforder(const float *X, int64_t N, int d, int K, int max_iter, float tol, float *centroids,
-                                      int64_t *labels, float *trace, et_kmeans_state *state_host, void *workspace,
-                                      size_t workspace_bytes, et_stream_t stream) {
-    if (!dims_ok(d, K) || N < 1 || !X || !centroids || !state_host || max_iter < 1) return ET_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < et_kmeans_reforder_workspace_bytes(N, d, K)) return ET_ERR_WORKSPACE;
-    if (fast::fast_shape(N, d, K))
-        return fast_fit(X, 0, N, K, 1, max_iter, tol, centroids, labels, trace, state_host, nullptr, workspace, (hipStream_t)stream);
-    const Workspace w = carve(workspace, N, d, K);
-    hipStream_t st = (hipStream_t)stream;
-    // non-finite input: reported like et_kmeans_fit does (the reference would propagate NaN)
-    int rc = et_kmeans_scan(X, N, d, w.state, stream);
-    if (rc) return rc;
-    ET_HIP_TRY(hipMemsetAsync(w.counts, 0, sizeof(unsigned long long) * 256, st));
-    ET_HIP_TRY(hipMemcpyAsync(state_host, w.state, sizeof(et_kmeans_state), hipMemcpyDeviceToHost, st));
-    ET_HIP_TRY(hipStreamSynchronize(st));
-    if (state_host->bad_input) return ET_ERR_BAD_DATA;
-    const int lp = level_power(N / 4);
-    const int64_t L = (int64_t)1 << lp;
-    const int64_t full_chunks = N / 4 / L;
-    const int64_t n_groups = (full_chunks + L - 1) / L;
-    const size_t dk = (size_t)d * K;
-    const size_t lds_assign = sizeof(float) * (dk + (size_t)K), lds_update = sizeof(float) * dk;
-    const int grid = grid_for(N);
-    for (int it = 0; it < max_iter; ++it) {
-        hipLaunchKernelGGL(reforder_assign_kernel, dim3(grid), dim3(kThreads), lds_assign, st, X, N, d, K,
-                           (const float *)centroids, w.labels_u8, w.maxsims, w.counts);
-        if (n_groups > 0)
-            hipLaunchKernelGGL(reforder_group_kernel, dim3(grid_for(n_groups * 4 * (int64_t)dk)), dim3(kThreads), 0, st, X, N, d, K,
-                               (const uint8_t *)w.labels_u8, lp, n_groups, full_chunks, w.S1);
-        hipLaunchKernelGGL(reforder_finish_kernel, dim3(1), dim3(kThreads), 0, st, X, N, d, K, (const uint8_t *)w.labels_u8, lp,
-                           full_chunks, (const float *)w.S1, w.lanes, w.sums);
-        hipLaunchKernelGGL(reforder_inertia_kernel, dim3(grid), dim3(kThreads), 0, st, (const float *)w.maxsims, N, w.partial);
-        hipLaunchKernelGGL(reforder_update_kernel, dim3(1), dim3(kThreads), lds_update, st, w.state, (const float *)w.sums,
-                           w.counts, (const double *)w.partial, grid, N, d, K, tol, centroids, trace);
-        ET_LAUNCH_CHECK();
-        // the reference tests `error <= tol` on the host every iteration (kmeans.py:239); so does this mode
-        ET_HIP_TRY(hipMemcpyAsync(state_host, w.state, sizeof(et_kmeans_state), hipMemcpyDeviceToHost, st));
-        ET_HIP_TRY(hipStreamSynchronize(st));
-        if (state_host->done) break;
-    }
-    if (labels) {
-        rc = et_kmeans_labels_i64(w.labels_u8, N, labels, stream);
-        if (rc) return rc;
-        ET_HIP_TRY(hipStreamSynchronize(st));
-    }
-    return ET_OK;
-}
-
-/* kmeans.py:228-240 for `batch` problems in ONE loop, stopped TOGETHER on the error summed over the whole (l, d, K) tensor in
- * ATen's order; d = 6, K <= 32, 1024 <= N < 2^29, batch <= 64 (batch = 1: any shape, like et_kmeans_fit_reforder). */
-extern "C" int et_kmeans_fit_reforder_batch(const float *X, int64_t x_stride, int64_t N, int d, int K, int64_t batch,
-                                            int max_iter, float tol, float *centroids, int64_t *labels, float *trace,
-                                            et_kmeans_state *states_host, et_kmeans_timing *timing_host, void *workspace,
-                                            size_t workspace_bytes, et_stream_t stream) {
-    if (!dims_ok(d, K) || N < 1 || batch < 1 || !X || !centroids || !states_host || max_iter < 1) return ET_ERR_INVALID_ARG;
-    const size_t need = et_kmeans_reforder_batch_workspace_bytes(N, d, K, batch);
-    if (need == 0) return ET_ERR_INVALID_ARG;  // a batch of a shape the fast form does not take
-    if (!workspace || workspace_bytes < need) return ET_ERR_WORKSPACE;
-    if (fast::fast_shape(N, d, K))
-        return fast_fit(X, x_stride, N, K, batch, max_iter, tol, centroids, labels, trace, states_host, timing_host, workspace,
-                        (hipStream_t)stream);
-    return et_kmeans_fit_reforder(X, N, d, K, max_iter, tol, centroids, labels, trace, states_host, workspace, workspace_bytes,
-                                  stream);
-}
+#include "et_reforder_plain.inl"
+#include "et_reforder_fast_geometry.inl"
+#include "et_reforder_fast_assign.inl"
+#include "et_reforder_fast_update.inl"
+#include "et_reforder_sharded.inl"
+#include "et_reforder_host.inl"

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 sys.path.insert(0, ".")
 from eigentrajectory_amd import ops, _lib as L
-from tests.test_gpu_parity import _reference_order_shards_native
+from tests._gpu_common import _reference_order_shards_native
 
 dev = torch.device("cuda:0")
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
