@@ -95,8 +95,7 @@ def one_step(ops, obs, pred, K, max_iter, first_index, sw, km=None, timing=None,
     mode = ops.MODE_MOVING
     sw.start("fit")
     if km is None:
-        g_obs, g_pred, _ = ops.fit_gram(obs, pred, mode, 0.0, 1)
-        (U_obs, _), (U_pred, _) = ops.eigh_topk_batch([g_obs, g_pred], 6)
+        U_obs, U_pred = ops.fit_descriptor(obs, pred, 6, mode, 0.0, 1)[:2]  # (et_fit_descriptor: Gram, reduction, one launch for both eigenproblems)
     else:
         from eigentrajectory_amd.dist import fit_descriptor_sharded
         U_obs, U_pred, _, _, _ = fit_descriptor_sharded(obs, pred, 6, mode, 0.0, 1, want_count=False, comm=comm)

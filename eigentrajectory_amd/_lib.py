@@ -30,6 +30,7 @@ SYMBOLS = [
     "et_norm_project", "et_scene_project", "et_scene_project_train", "et_wrapper_losses_fwd", "et_wrapper_losses_bwd",
     "et_anchor_reconstruct_fwd", "et_anchor_reconstruct_bwd", "et_anchor_reconstruct_metrics",
     "et_fit_gram_workspace_bytes", "et_fit_gram", "et_eigh_topk", "et_eigh_topk_batch",
+    "et_fit_descriptor_workspace_bytes", "et_fit_descriptor",
     "et_euc_sim", "et_euc_sim_batch", "et_kmeans_partials_len", "et_kmeans_workspace_bytes", "et_kmeans_scan", "et_kmeans_begin",
     "et_kmeans_init_step", "et_kmeans_init_set", "et_kmeans_init_select", "et_kmeans_gather_point", "et_kmeans_init_farthest",
     "et_kmeans_assign_accumulate", "et_kmeans_update", "et_kmeans_joint_done", "et_kmeans_labels_i64", "et_kmeans_fit", "et_kmeans_batch_workspace_bytes", "et_kmeans_fit_batch", "et_kmeans_predict", "et_kmeans_predict_batch",
@@ -79,7 +80,7 @@ def lib():
                                  "rebuild the library (make -C eigentrajectory_amd/csrc)")
         l.et_status_string.restype = C.c_char_p
         l.et_compiled_arch.restype = C.c_char_p
-        for name in ("et_fit_gram_workspace_bytes", "et_kmeans_partials_len", "et_kmeans_workspace_bytes",
+        for name in ("et_fit_gram_workspace_bytes", "et_fit_descriptor_workspace_bytes", "et_kmeans_partials_len", "et_kmeans_workspace_bytes",
                      "et_kmeanspp_workspace_bytes", "et_kmeans_sharded_workspace_bytes", "et_kmeans_batch_workspace_bytes",
                      "et_kmeanspp_batch_workspace_bytes", "et_kmeans_reforder_workspace_bytes",
                      "et_kmeans_reforder_batch_workspace_bytes", "et_kmeans_reforder_sharded_workspace_bytes"):

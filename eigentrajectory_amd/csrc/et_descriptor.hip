@@ -60,10 +60,13 @@ __device__ __forceinline__ int64_t tile_of_block() {
 // alternating rounds per form at N = 1e7).  STREAM = the launch moves more than the 256 MB memory-side cache holds:
 //   projection      row loads non-temporal (each row is read once) and C_obs stores non-temporal (nobody re-reads them soon);
 //                   C_pred and nrm keep the default policy -- the reconstruction and the k-means read them next.
-//                   0.384 -> 0.357 ms (-7 %): the 1.6 GB of rows no longer push C_pred / nrm out of the memory-side cache.
-//   reconstruction  96-byte row stores non-temporal and the tiles walked from the END (what the projection wrote last is
-//                   what the cache still holds): +0.011 ms for itself, -0.026 ms for the farthest-first pass behind it
-//                   (C_pred stays cached).  project + reconstruct 0.619 -> 0.603 ms.
+//                   0.384 -> 0.357 ms (-7 %).  The S = 1 reconstruction behind it pays 0.010 ms of that back (the dirty
+//                   C_pred / nrm lines the cache now keeps are written out while it runs): project + reconstruct
+//                   0.619 -> 0.602 ms.
+//   reconstruction  S > 1 (the model form, 1920 B written per 496 B read): 96-byte row stores non-temporal, tiles walked
+//                   from the end: 4.85 -> 4.30 ms at S = 20 (0.62 -> 0.70 of the roof).  S = 1: non-temporal row stores cost
+//                   the kernel 0.012 ms (and save the farthest-first pass behind it 0.026 ms in the bench's sequence --
+//                   not taken: the reconstruction is the stage with a target) -- default policy, identity tile order.
 // Small launches (scenes, dataset-sized fits) keep the default policy everywhere: their consumers read the results from
 // L2 / the memory-side cache.  Measured and NOT adopted: 128-row projection tiles (6 workgroups per CU instead of 3):
 // +2.5 % time; non-temporal C_pred / nrm stores: +1 %.
@@ -1293,7 +1296,7 @@ extern "C" int et_anchor_reconstruct_fwd(const float *C, int64_t N, int S, int k
         const int TN = kTile / S;
         const size_t lds = sizeof(float) * ((size_t)TN * S * 24 + (size_t)TN * kNormStride + 2 * 24 * 6 + 2 * 6 * (size_t)S);
         const int64_t per_wg = (int64_t)TN * (S == 1 ? 1 : kReconTiles);
-        const bool stream = N * S * (int64_t)96 > kStreamBytes;
+        const bool stream = S > 1 && N * S * (int64_t)96 > kStreamBytes;  // (S = 1: the default policy is faster, see kStreamBytes)
         auto kern = stream ? reconstruct_tile_kernel<12, 6, true> : reconstruct_tile_kernel<12, 6, false>;
         hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(N, per_wg)), dim3(kTile), lds, st, C, N, S, TN, T_obs, obs, nrm, A_m,
                            A_s, U_pred_m, U_pred_s, mode, static_dist, out);

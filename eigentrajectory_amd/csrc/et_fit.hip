@@ -242,8 +242,23 @@ __global__ __launch_bounds__(kWaveGramThreads) void gram_wave_kernel(
     if (tid == 0) dst[L::kBlocks * 256] = (double)*sCountPtr;
 }
 
+// G_obs (i, j) / G_pred (i, j) from the three summed 16 x 16 tiles (GramLayout): every entry of the upper triangle comes
+// from exactly one tile and is mirrored, so the matrices are exactly symmetric.
+__device__ __forceinline__ double gram_obs_entry(const double *O, int i, int j) { return i <= j ? O[i * 16 + j] : O[j * 16 + i]; }
+__device__ __forceinline__ double gram_pred_entry(const double *P, const double *Q, int i, int j) {
+    if (i > j) {
+        const int t = i;
+        i = j;
+        j = t;
+    }
+    if (j < 16) return P[i * 16 + j];                   // pred[0:16] x pred[0:16]
+    if (i >= 8) return Q[(i - 8) * 16 + (j - 16)];      // pred[8:24] x pred[16:24]
+    return Q[(j - 8) * 16 + (8 + i)];                   // transpose of pred[16:24] x pred[0:8]
+}
+
 // Sum the workgroup partials of one entry: one wavefront per entry, a fixed strided + butterfly
-// order (reproducible for a given grid).
+// order (reproducible for a given grid).  769 small workgroups on purpose: the partials are 4.7 MB, and ONE workgroup
+// pulling them through its CU (the reduction folded into the eigensolver's launch, tried in round 6) takes 80 us.
 __global__ __launch_bounds__(64) void gram_reduce_kernel(const double *__restrict__ partials, int n_partials, int stride,
                                                          double *__restrict__ sums) {
     const int e = blockIdx.x;
@@ -263,23 +278,8 @@ __global__ __launch_bounds__(kFitThreads) void gram_finish_kernel(const double *
     using L = GramLayout<TO, TP>;
     constexpr int DO = L::DO, DP = L::DP;
     const double *O = sSum, *P = sSum + 256, *Q = sSum + 512;
-    for (int e = threadIdx.x; e < DO * DO; e += kFitThreads) {
-        const int i = e / DO, j = e % DO;
-        G_obs[e] = i <= j ? O[i * 16 + j] : O[j * 16 + i];
-    }
-    for (int e = threadIdx.x; e < DP * DP; e += kFitThreads) {
-        int i = e / DP, j = e % DP;
-        if (i > j) {
-            const int t = i;
-            i = j;
-            j = t;
-        }
-        double v;
-        if (j < 16) v = P[i * 16 + j];                       // pred[0:16] x pred[0:16]
-        else if (i >= 8) v = Q[(i - 8) * 16 + (j - 16)];     // pred[8:24] x pred[16:24]
-        else v = Q[(j - 8) * 16 + (8 + i)];                  // transpose of pred[16:24] x pred[0:8]
-        G_pred[e] = v;
-    }
+    for (int e = threadIdx.x; e < DO * DO; e += kFitThreads) G_obs[e] = gram_obs_entry(O, e / DO, e % DO);
+    for (int e = threadIdx.x; e < DP * DP; e += kFitThreads) G_pred[e] = gram_pred_entry(P, Q, e / DP, e % DP);
     if (threadIdx.x == 0) *count = (int64_t)sSum[L::kBlocks * 256];
 }
 
@@ -463,8 +463,11 @@ struct JacobiPair {
     }
 };
 
-__device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int n, int k, float *__restrict__ U,
-                                               float *__restrict__ sigma) {
+// `gload(r, c)`: entry (r, c) of the matrix (from memory, or from LDS tiles in the fused fit kernel); `sm`: the body's LDS
+// (eigh_lds_bytes(n) bytes, 16-byte aligned).
+template <class GLoad>
+__device__ __forceinline__ void eigh_topk_body(GLoad gload, int n, int k, float *__restrict__ U, float *__restrict__ sigma,
+                                               double *sm) {
     // Round 4: the matrix lives in LDS padded with zeros to m x m (m = n rounded up to even).  The padding index pairs
     // with a zero entry, i.e. is an inactive pair, and an INACTIVE pair is applied as the identity rotation (c, s) = (1, 0)
     // -- 1 * x - 0 * y is x again, bit for bit up to the sign of a zero -- so the update phase has no `q < n` / `active`
@@ -483,7 +486,6 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
     // by exactly one block item per round: read A[cur], write A[cur ^ 1]) so that look-ahead reads and update writes do
     // not race; so are the parameters.  A round is max(updates, look-ahead + chain) + one barrier.  Same arithmetic per
     // element as before -- tools/eigh_accuracy.py and the oracle comparison are unchanged.
-    extern __shared__ __attribute__((aligned(16))) double sm[];
     const int lane = threadIdx.x;
     const int m = (n + 1) & ~1, half = m / 2;
     double *Abuf = sm;               // 2 * m*m
@@ -496,7 +498,7 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
     uint2 *sTab = reinterpret_cast<uint2 *>(sUsed + 64);  // [m - 1 rounds][3 half look-ahead items]
     for (int i = lane; i < m * m; i += kEighThreads) {
         const int r = i / m, c = i - r * m;
-        Abuf[i] = (r < n && c < n) ? G[r * n + c] : 0.0;
+        Abuf[i] = (r < n && c < n) ? gload(r, c) : 0.0;
         V[i] = (r == c && r < n) ? 1.0 : 0.0;
     }
     if (lane < 4) sMax[lane] = 0ull;
@@ -787,7 +789,8 @@ __device__ __forceinline__ void eigh_topk_body(const double *__restrict__ G, int
 
 __global__ __launch_bounds__(kEighThreads) void eigh_topk_kernel(const double *__restrict__ G, int n, int k,
                                                                   float *__restrict__ U, float *__restrict__ sigma) {
-    eigh_topk_body(G, n, k, U, sigma);
+    extern __shared__ __attribute__((aligned(16))) double eigh_smem[];
+    eigh_topk_body([=](int r, int c) { return G[r * n + c]; }, n, k, U, sigma, eigh_smem);
 }
 
 // several independent matrices in one launch, one workgroup each (the obs / pred, moving / static Gram
@@ -801,8 +804,41 @@ struct EighBatch {
 };
 
 __global__ __launch_bounds__(kEighThreads) void eigh_topk_batch_kernel(const EighBatch b) {
+    extern __shared__ __attribute__((aligned(16))) double eigh_smem[];
     const int i = blockIdx.x;
-    eigh_topk_body(b.G[i], b.n[i], b.k[i], b.U[i], b.sigma[i]);
+    const double *G = b.G[i];
+    const int n = b.n[i];
+    eigh_topk_body([=](int r, int c) { return G[r * n + c]; }, n, b.k[i], b.U[i], b.sigma[i], eigh_smem);
+}
+
+// The fit of ONE descriptor behind the Gram kernel and its partial reduction: workgroup 0 assembles G_obs (16 x 16) from
+// the summed obs tile and solves it, workgroup 1 G_pred (24 x 24) from the two pred tiles -- gram_finish_kernel's assembly
+// folded into the eigensolver's launch (one launch and one kernel boundary fewer: -8 us of a 0.5 ms fit).
+// G_obs / G_pred / count are optional outputs (the same bits et_fit_gram writes).
+template <int TO, int TP>
+__global__ __launch_bounds__(kEighThreads) void fit_finish_eigh_kernel(const double *__restrict__ sums, int k,
+                                                                       double *__restrict__ G_obs, double *__restrict__ G_pred,
+                                                                       int64_t *__restrict__ count, float *__restrict__ U_obs,
+                                                                       float *__restrict__ U_pred, float *__restrict__ sigma_obs,
+                                                                       float *__restrict__ sigma_pred) {
+    using L = GramLayout<TO, TP>;
+    constexpr int DO = L::DO, DP = L::DP;
+    extern __shared__ __attribute__((aligned(16))) double eigh_smem[];
+    double *sT = eigh_smem;  // this workgroup's summed tiles: O (256) | P, Q (512)
+    const bool is_pred = blockIdx.x == 1;
+    const int base = is_pred ? 256 : 0, cnt = is_pred ? 512 : 256;
+    for (int e = threadIdx.x; e < cnt; e += kEighThreads) sT[e] = sums[base + e];
+    if (!is_pred && count && threadIdx.x == 0) *count = (int64_t)sums[L::kBlocks * 256];
+    __syncthreads();
+    if (!is_pred) {
+        if (G_obs)
+            for (int e = threadIdx.x; e < DO * DO; e += kEighThreads) G_obs[e] = gram_obs_entry(sT, e / DO, e % DO);
+        eigh_topk_body([=](int r, int c) { return gram_obs_entry(sT, r, c); }, DO, k, U_obs, sigma_obs, eigh_smem + 512);
+    } else {
+        if (G_pred)
+            for (int e = threadIdx.x; e < DP * DP; e += kEighThreads) G_pred[e] = gram_pred_entry(sT, sT + 256, e / DP, e % DP);
+        eigh_topk_body([=](int r, int c) { return gram_pred_entry(sT, sT + 256, r, c); }, DP, k, U_pred, sigma_pred, eigh_smem + 512);
+    }
 }
 
 static int fit_grid(int64_t N) {
@@ -820,6 +856,11 @@ extern "C" size_t et_fit_gram_workspace_bytes(int64_t N, int T_obs, int T_pred) 
     const size_t DO = 2 * (size_t)T_obs, DP = 2 * (size_t)T_pred;
     const size_t per = DO * DO + DP * DP + 1;  // the generic layout is the larger one
     return sizeof(double) * per * ((size_t)fit_grid(N) + 1);  // workgroup partials + their sums
+}
+
+extern "C" size_t et_fit_descriptor_workspace_bytes(int64_t N, int T_obs, int T_pred) {
+    const size_t DO = 2 * (size_t)T_obs, DP = 2 * (size_t)T_pred;
+    return et_fit_gram_workspace_bytes(N, T_obs, T_pred) + sizeof(double) * (DO * DO + DP * DP + 2);  // + G_obs, G_pred, count
 }
 
 extern "C" int et_fit_gram(const float *obs, const float *pred, int64_t N, int T_obs, int T_pred, int mode,
@@ -902,6 +943,50 @@ extern "C" int et_eigh_topk(const double *G, int n, int k, float *U, float *sigm
         ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(eigh_topk_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(eigh_topk_kernel, dim3(1), dim3(kEighThreads), lds, (hipStream_t)stream, G, n, k, U, sigma);
+    ET_LAUNCH_CHECK();
+    return ET_OK;
+}
+
+extern "C" int et_fit_descriptor(const float *obs, const float *pred, int64_t N, int T_obs, int T_pred, int k, int mode,
+                                 float static_dist, int which, float *U_obs, float *U_pred, float *sigma_obs,
+                                 float *sigma_pred, double *G_obs, double *G_pred, int64_t *count, void *workspace,
+                                 size_t workspace_bytes, et_stream_t stream) {
+    if (!U_obs || !U_pred || !sigma_obs || !sigma_pred || k < 1 || T_obs < 3 || T_obs > ET_MAX_T || T_pred < 1 || T_pred > ET_MAX_T ||
+        k > 2 * T_obs || k > 2 * T_pred)
+        return ET_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const bool fused = N > 0 && T_obs == 8 && T_pred == 12 && obs && pred && aligned16(obs) && aligned16(pred) && mode >= 0 &&
+                       mode <= 3 && (which == 0 || which == 1);
+    if (!fused) {  // any other shape (and N = 0): the two calls one after the other; G goes through the workspace's tail
+        const size_t gram_ws = et_fit_gram_workspace_bytes(N, T_obs, T_pred);
+        const size_t DO = 2 * (size_t)T_obs, DP = 2 * (size_t)T_pred;
+        if (!workspace || workspace_bytes < et_fit_descriptor_workspace_bytes(N, T_obs, T_pred)) return ET_ERR_WORKSPACE;
+        double *tail = reinterpret_cast<double *>(static_cast<char *>(workspace) + gram_ws);
+        double *go = G_obs ? G_obs : tail, *gp = G_pred ? G_pred : tail + DO * DO;
+        int64_t *cn = count ? count : reinterpret_cast<int64_t *>(tail + DO * DO + DP * DP);
+        const int rc = et_fit_gram(obs, pred, N, T_obs, T_pred, mode, static_dist, which, go, gp, cn, workspace, gram_ws, stream);
+        if (rc) return rc;
+        const double *Gs[2] = {go, gp};
+        const int ns[2] = {(int)DO, (int)DP}, ks[2] = {k, k};
+        float *Us[2] = {U_obs, U_pred}, *ss[2] = {sigma_obs, sigma_pred};
+        return et_eigh_topk_batch(2, Gs, ns, ks, Us, ss, stream);
+    }
+    if (!workspace || workspace_bytes < et_fit_descriptor_workspace_bytes(N, T_obs, T_pred)) return ET_ERR_WORKSPACE;
+    const int grid = fit_grid(N);
+    double *partials = (double *)workspace;
+    hipLaunchKernelGGL((gram_wave_kernel<8, 12>), dim3(grid), dim3(kWaveGramThreads), 0, st, obs, pred, N, mode, static_dist, which,
+                       partials);
+    ET_LAUNCH_CHECK();
+    constexpr int per = GramLayout<8, 12>::kPartial;
+    double *sums = partials + (size_t)grid * per;
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(per), dim3(64), 0, st, partials, grid, per, sums);
+    ET_LAUNCH_CHECK();
+    const size_t lds = sizeof(double) * 512 + eigh_lds_bytes(24);
+    if (lds > 48 * 1024)
+        ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fit_finish_eigh_kernel<8, 12>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((fit_finish_eigh_kernel<8, 12>), dim3(2), dim3(kEighThreads), lds, st, sums, k, G_obs, G_pred, count, U_obs,
+                       U_pred, sigma_obs, sigma_pred);
     ET_LAUNCH_CHECK();
     return ET_OK;
 }

@@ -95,8 +95,7 @@ class ETDescriptor(nn.Module):
     def parameter_initialization(self, obs_traj, pred_traj):
         r"""Initialize the ET descriptor parameters (descriptor.py:116-142; call once before training)"""
         if self._fused:
-            g_obs, g_pred, _ = ops.fit_gram(obs_traj, pred_traj, self._mode, which=self._mode)
-            (U_obs_trunc, _), (U_pred_trunc, _) = ops.eigh_topk_batch([g_obs, g_pred], self.k)  # one launch
+            U_obs_trunc, U_pred_trunc = ops.fit_descriptor(obs_traj, pred_traj, self.k, self._mode, which=self._mode)[:2]  # two launches
             self.traj_normalizer.calculate_params(obs_traj)
             pred_traj_norm = self.traj_normalizer.normalize(pred_traj)
         else:  # any other flag combination: stand-alone normalise, then one Gram + eigh per half

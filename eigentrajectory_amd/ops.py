@@ -213,6 +213,29 @@ def fit_gram(obs, pred, mode, static_dist=0.0, which=1):
     return g_obs, g_pred, count
 
 
+def fit_descriptor(obs, pred, k, mode, static_dist=0.0, which=1, want_gram=False):
+    """descriptor.py:116-142 for one descriptor in ONE call (et_fit_descriptor: the Gram kernel, its partial reduction, and
+    one launch that assembles and solves both eigenproblems).  -> (U_obs (2T_obs,k), U_pred (2T_pred,k), sigma_obs (k), sigma_pred (k),
+    count (int64 device tensor)) and, with ``want_gram``, + (G_obs, G_pred) -- the same bits as :func:`fit_gram` +
+    :func:`eigh_topk_batch`."""
+    dev = L.require_device(obs)
+    obs, pred = _dev_args(dev, obs, pred)
+    n, t_obs, _ = obs.shape
+    t_pred = pred.shape[1]
+    k = int(k)
+    U_obs, U_pred = torch.empty((2 * t_obs, k), device=dev), torch.empty((2 * t_pred, k), device=dev)
+    s_obs, s_pred = torch.empty((k,), device=dev), torch.empty((k,), device=dev)
+    count = torch.empty((1,), device=dev, dtype=torch.int64)
+    g_obs = torch.empty((2 * t_obs, 2 * t_obs), device=dev, dtype=torch.float64) if want_gram else None
+    g_pred = torch.empty((2 * t_pred, 2 * t_pred), device=dev, dtype=torch.float64) if want_gram else None
+    ws = torch.empty((max(L.lib().et_fit_descriptor_workspace_bytes(L.i64(n), t_obs, t_pred), 8),), device=dev, dtype=torch.uint8)
+    L.check(L.lib().et_fit_descriptor(L.ptr(obs), L.ptr(pred), L.i64(n), t_obs, t_pred, k, int(mode), L.f32(static_dist),
+                                      int(which), L.ptr(U_obs), L.ptr(U_pred), L.ptr(s_obs), L.ptr(s_pred), L.ptr(g_obs),
+                                      L.ptr(g_pred), L.ptr(count), L.ptr(ws), C.c_size_t(ws.numel()), L.stream(dev)),
+            "et_fit_descriptor")
+    return (U_obs, U_pred, s_obs, s_pred, count) + ((g_obs, g_pred) if want_gram else ())
+
+
 def eigh_topk(G, k):
     """Top-k eigenvectors (n,k) fp32 and sigma (k,) = sqrt(eigenvalues) of a symmetric fp64 matrix."""
     dev = L.require_device(G)

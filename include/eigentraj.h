@@ -208,6 +208,18 @@ int et_fit_gram(const float *obs, const float *pred, int64_t N, int T_obs, int T
                 double *G_obs, double *G_pred, int64_t *count,
                 void *workspace, size_t workspace_bytes, et_stream_t stream);
 
+/* The fit of ONE descriptor in a single call (descriptor.py:116-142 parameter_initialization = normalise -> SVD of the obs
+ * rows + SVD of the pred rows): et_fit_gram followed by the eigensolve of both matrices, the matrix assembly folded into
+ * the eigensolver's launch (three launches in all).  U_obs (2T_obs,k), U_pred (2T_pred,k),
+ * sigma_obs / sigma_pred (k) as et_eigh_topk writes them; G_obs, G_pred, count: optional outputs (may be NULL), the same
+ * bits et_fit_gram returns.  Any (T_obs, T_pred) and N = 0 are accepted (they run the two calls one after the other). */
+size_t et_fit_descriptor_workspace_bytes(int64_t N, int T_obs, int T_pred);
+int et_fit_descriptor(const float *obs, const float *pred, int64_t N, int T_obs, int T_pred, int k,
+                      int mode, float static_dist, int which,
+                      float *U_obs, float *U_pred, float *sigma_obs, float *sigma_pred,
+                      double *G_obs, double *G_pred, int64_t *count,
+                      void *workspace, size_t workspace_bytes, et_stream_t stream);
+
 /* Top-k eigenpairs of a symmetric n x n fp64 matrix (n <= 64), parallel-order (round-robin) Jacobi in one
  * workgroup: U (n,k) fp32 = eigenvectors by descending eigenvalue, each signed so its
  * largest-|.| component is positive; sigma[k] = sqrt(max(lambda,0)) -- U[:, :k], S[:k]

@@ -542,3 +542,22 @@ def test_agentformer_tenth_of_univ_replay_g15(dev):
     for got in (N_(torch.cat(fused, dim=1)), N_(torch.cat(plain, dim=1))):
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5)
         np.testing.assert_allclose(got.mean(axis=1, dtype=np.float64), z["ade_fde_mean"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,t_obs,t_pred,mode", [(70001, 8, 12, 2), (257, 8, 12, 1), (1, 8, 12, 0), (5000, 5, 7, 1), (3000, 8, 12, 3)])
+def test_fit_descriptor_one_call_equals_gram_plus_eigh(ops, dev, n, t_obs, t_pred, mode):
+    """et_fit_descriptor (descriptor.py:116-142 in one call: the Gram kernel, its partial reduction and ONE launch that assembles and
+    solves both eigenproblems) returns the bits of et_fit_gram followed by et_eigh_topk_batch -- G, count, U, sigma --, for the
+    (8, 12) fast path and for any other shape (which runs the two calls one after the other)."""
+    rng = np.random.default_rng(n)
+    obs = (rng.standard_normal((n, t_obs, 2)).cumsum(1) * 0.3).astype(np.float32)
+    pred = (obs[:, -1:, :] + rng.standard_normal((n, t_pred, 2)).cumsum(1) * 0.3).astype(np.float32)
+    k = min(6, 2 * t_obs)
+    for which in (1, 0):
+        g_obs, g_pred, cnt = ops.fit_gram(T(obs, dev), T(pred, dev), mode, 0.3, which)
+        (U_obs, s_obs), (U_pred, s_pred) = ops.eigh_topk_batch([g_obs, g_pred], k)
+        got = ops.fit_descriptor(T(obs, dev), T(pred, dev), k, mode, 0.3, which, want_gram=True)
+        for a, b in zip(got, (U_obs, U_pred, s_obs, s_pred, cnt, g_obs, g_pred)):
+            assert np.array_equal(N_(a), N_(b), equal_nan=True)
+        lean = ops.fit_descriptor(T(obs, dev), T(pred, dev), k, mode, 0.3, which)  # (no G outputs requested)
+        assert torch.equal(lean[0], U_obs) and torch.equal(lean[1], U_pred) and torch.equal(lean[4], cnt)

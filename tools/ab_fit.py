@@ -14,7 +14,7 @@ sys.path.insert(0, R)
 def worker():
     import numpy as np
     import torch
-    from eigentrajectory_amd import ops
+    from eigentrajectory_amd import _lib as L, ops
     from eigentrajectory_amd.synth import synthetic_trajectories_torch
     dev = torch.device("cuda:0")
     n = int(float(os.environ.get("AB_N", "1e7")))
@@ -37,6 +37,8 @@ def worker():
     out = dict(gram_ms=med(lambda: ops.fit_gram(obs, pred, ops.MODE_MOVING, 0.0, 1)),
                eigh_ms=med(lambda: ops.eigh_topk_batch([g_obs, g_pred], 6)),
                fit_ms=med(lambda: ops.eigh_topk_batch(list(ops.fit_gram(obs, pred, ops.MODE_MOVING, 0.0, 1)[:2]), 6)),
+               fit_one_call_ms=(med(lambda: ops.fit_descriptor(obs, pred, 6, ops.MODE_MOVING, 0.0, 1)) if hasattr(ops, "fit_descriptor")
+                                and hasattr(L.lib(), "et_fit_descriptor") else float("nan")),
                g00=float(g_obs[0, 0].item()))
     print(json.dumps(out))
 
@@ -52,7 +54,7 @@ def main():
             res = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker"], env=env, capture_output=True, text=True)
             try:
                 d = json.loads(res.stdout.strip().splitlines()[-1])
-                print(f"round {r} {name:8s} gram {d['gram_ms']:.4f}  eigh {d['eigh_ms']:.4f}  fit {d['fit_ms']:.4f}  (G_obs[0,0] = {d['g00']!r})", flush=True)
+                print(f"round {r} {name:8s} gram {d['gram_ms']:.4f}  eigh {d['eigh_ms']:.4f}  fit {d['fit_ms']:.4f}  one call {d['fit_one_call_ms']:.4f}  (G_obs[0,0] = {d['g00']!r})", flush=True)
             except Exception:
                 print(f"round {r} {name}: FAILED\n{res.stdout[-500:]}\n{res.stderr[-1500:]}", flush=True)
 
