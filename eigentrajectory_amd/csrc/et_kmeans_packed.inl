@@ -2,7 +2,7 @@
 // compiled on its own): trace-less Lloyd iterations on the packed f16 copy of the points: PackedHeader, kmeans_pack_kernel, the per-launch tables, packed_assign_body.
 // clang-format off: the fragment starts and ends at namespace scope of whatever the including file has open.
 // The filter above reads 24 B per point and iteration to certify that a label did not change, and an iteration takes as
-// long as the memory side needs to stream them.  The certification does not need the exact coordinates:
+// long as the memory side needs to stream them (HISTORY.md 3.2).  The certification does not need the exact coordinates:
 // kmeans_pack_kernel writes, once per fit,
 //   xh   three rows of N dwords: the coordinate pairs (0,1), (2,3), (4,5) of  s (x - mu)  rounded to f16 (nearest);
 //        mu = the mean of 1024 evenly spaced points (any vector would do: arg-max_j -|x - c_j|^2 does not depend on the
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_pack_kernel(const float *__
 
 // a += f16(w.lo or w.hi) * b: the compiler folds the (exact) conversion into one v_fma_mix_f32.  Compiler-visible on
 // purpose: these instructions sit between matrix instructions, and the hazard recogniser does not look inside inline
-// assembly (an asm helper's output once landed in a register an earlier v_mfma was still reading).
+// assembly (HISTORY.md 3.8: an asm helper's output once landed in a register an earlier v_mfma was still reading).
 __device__ __forceinline__ float fma_mix_lo(unsigned w, float b, float a) {
     return fmaf((float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)), b, a);
 }

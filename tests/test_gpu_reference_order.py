@@ -241,7 +241,7 @@ def test_reference_order_fast_form_vs_oracle(ops, oracle, dev, et_option, n, K, 
     levels of ATen's cascade, permuted copy, last-arriver updates) against the oracle's literal restatement, on sizes that
     exercise every leftover of the cascade (partial chunk / group / block, N mod 4, N mod 32) and on batches: labels, centroid
     bits, per-iteration errors, iteration count; and problem 0 alone (l = 1: its own stop).  filter_lp = 4 switches the
-    matrix-core label certification on (built, tested equal, off by default: DESIGN 3.8): the same bits; -1: the update kernel's grid
+    matrix-core label certification on (built, tested equal, off by default: HISTORY.md 3.8): the same bits; -1: the update kernel's grid
     form on the small shards that take the single-workgroup form by default."""
     from eigentrajectory_amd.synth import gaussian_points_np
     if filter_lp < 0:  # (-1: the update as a grid of block workgroups + last arriver also where one workgroup would do)
