@@ -64,7 +64,7 @@ __device__ __forceinline__ int64_t tile_of_block() {
 //                   C_pred / nrm lines the cache now keeps are written out while it runs): project + reconstruct
 //                   0.619 -> 0.602 ms.
 //   reconstruction  S > 1 (the model form, 1920 B written per 496 B read): 96-byte row stores non-temporal, tiles walked
-//                   from the end: 4.85 -> 4.30 ms at S = 20 (0.62 -> 0.70 of the roof).  S = 1: non-temporal row stores cost
+//                   from the end: 4.78 -> 4.68 ms at S = 20 (-2 %, four alternating rounds, tools/ab_recon.py).  S = 1: non-temporal row stores cost
 //                   the kernel 0.012 ms (and save the farthest-first pass behind it 0.026 ms in the bench's sequence --
 //                   not taken: the reconstruction is the stage with a target) -- default policy, identity tile order.
 // Small launches (scenes, dataset-sized fits) keep the default policy everywhere: their consumers read the results from
@@ -1296,7 +1296,11 @@ extern "C" int et_anchor_reconstruct_fwd(const float *C, int64_t N, int S, int k
         const int TN = kTile / S;
         const size_t lds = sizeof(float) * ((size_t)TN * S * 24 + (size_t)TN * kNormStride + 2 * 24 * 6 + 2 * 6 * (size_t)S);
         const int64_t per_wg = (int64_t)TN * (S == 1 ? 1 : kReconTiles);
+#ifdef ET_EXP_RECON_NOSTREAM  // measurement aid
+        const bool stream = false;
+#else
         const bool stream = S > 1 && N * S * (int64_t)96 > kStreamBytes;  // (S = 1: the default policy is faster, see kStreamBytes)
+#endif
         auto kern = stream ? reconstruct_tile_kernel<12, 6, true> : reconstruct_tile_kernel<12, 6, false>;
         hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(N, per_wg)), dim3(kTile), lds, st, C, N, S, TN, T_obs, obs, nrm, A_m,
                            A_s, U_pred_m, U_pred_s, mode, static_dist, out);
