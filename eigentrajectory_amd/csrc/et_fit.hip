@@ -388,7 +388,7 @@ constexpr int kJacobiMaxSweeps = 30;
 constexpr double kJacobiStop = ET_JACOBI_STOP;
 #ifdef ET_EXP_EIGHSTAMP  // development aid: s_memtime ticks of workgroup 0's first wavefront by phase of a round:
 // [0] rounds, [1] block / V items, [2] look-ahead entries, [3] rotation chain + stepping, [4] barrier, [5] sweep checks, [6] sweeps
-// (-DET_EXP_EIGHSTAMP=1: the first wavefront; =2: the look-ahead wavefront)
+// (-DET_EXP_EIGHSTAMP=w + 1: wavefront w; 16 = the look-ahead wavefront)
 __device__ unsigned long long g_eighstamp[8];
 #define ET_EIGHSTAMP(i)                                              \
     do {                                                             \
@@ -623,7 +623,7 @@ __device__ __forceinline__ void eigh_topk_body(GLoad gload, int n, int k, float 
     }
     uint2 ent[3] = {sTab[item0], sTab[split ? item0 : half + item0], sTab[split ? item0 : 2 * half + item0]};  // round 0's items
 #ifdef ET_EXP_EIGHSTAMP
-    const bool stamping = n == 24 && (ET_EXP_EIGHSTAMP == 2 ? (pl >= 0 && pl < 64) : threadIdx.x < 64);  // 2: the look-ahead wavefront
+    const bool stamping = n == 24 && (int)(threadIdx.x >> 6) == ET_EXP_EIGHSTAMP - 1;  // wavefront ET_EXP_EIGHSTAMP - 1 (16: the look-ahead one)
     unsigned long long es_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, es_t = __builtin_amdgcn_s_memtime();
 #endif
     for (int sweep = 0; sweep < kJacobiMaxSweeps; ++sweep) {
@@ -756,7 +756,7 @@ __device__ __forceinline__ void eigh_topk_body(GLoad gload, int n, int k, float 
     }
     double *A = Abuf + cur * m * m;
 #ifdef ET_EXP_EIGHSTAMP
-    if (stamping && (ET_EXP_EIGHSTAMP == 2 ? pl == 0 : threadIdx.x == 0))
+    if (stamping && (threadIdx.x & 63) == 0)
         for (int i = 0; i < 7; ++i) atomicAdd(&g_eighstamp[i], es_acc[i]);
 #endif
     __syncthreads();
