@@ -405,7 +405,9 @@ def extra_stages(ops, obs, pred, n, K, max_iter, first_index, dev):
     with torch.no_grad():
         g_obs, g_pred, _ = ops.fit_gram(obs, pred, mode, 0.0, 1)
         (U_obs, _), (U_pred, _) = ops.eigh_topk_batch([g_obs, g_pred], 6)
-        _, _, nrm, _ = ops.norm_project(obs, pred, U_obs, U_pred, None, None, mode, want_flag=False)
+        _, _, nrm, _, pose = ops.norm_project(obs, pred, U_obs, U_pred, None, None, mode, want_flag=False, want_pose=True)
+        pose_split = ops.norm_project(obs, None, U_obs, None, U_obs, None, ops.MODE_SPLIT, 0.3, want_nrm=False, want_flag=False,
+                                      want_obs=False, want_pose=True)[4]
         S = 20
         C20 = torch.randn((6, n, S), device=dev) * 0.1
         A = torch.randn((6, S), device=dev)
@@ -418,14 +420,19 @@ def extra_stages(ops, obs, pred, n, K, max_iter, first_index, dev):
               480.0 + 16.0 + 1920.0)
         stage("reconstruct_S20_bwd", _median_ms(lambda: ops._reconstruct_bwd(rec, None, nrm, U_pred, None, mode, 0.0, 8)),
               1920.0 + 16.0 + 480.0)
+        # the normaliser from the projection's optional pose record (5,N): origin, rotation x scale, 1 / scale -- 20 B per row
+        # instead of nrm's 16, and no square root / reciprocal / selects per pass in the metric kernel
         stage("reconstruct_metrics_S20",
+              _median_ms(lambda: ops.anchor_reconstruct_metrics(C20, pred, A, None, U_pred, None, mode, pose=pose)),
+              480.0 + 20.0 + 96.0 + 8.0)
+        stage("reconstruct_metrics_S20_from_nrm",
               _median_ms(lambda: ops.anchor_reconstruct_metrics(C20, pred, A, None, U_pred, None, mode, nrm=nrm)),
               480.0 + 16.0 + 96.0 + 8.0)
         # the wrapper's evaluate() form: descriptor chosen per row (model.py:46,73)
         stage("reconstruct_metrics_S20_per_row_descriptor",
-              _median_ms(lambda: ops.anchor_reconstruct_metrics(C20, pred, A, A, U_pred, U_pred, ops.MODE_SPLIT, 0.3, nrm=nrm)),
-              480.0 + 16.0 + 96.0 + 8.0)
-        del rec, C20
+              _median_ms(lambda: ops.anchor_reconstruct_metrics(C20, pred, A, A, U_pred, U_pred, ops.MODE_SPLIT, 0.3, pose=pose_split)),
+              480.0 + 20.0 + 96.0 + 8.0)
+        del rec, C20, pose, pose_split
         torch.cuda.empty_cache()
         out["scene_latency"] = scene_latency(dev, U_obs, U_pred)
         for tag, m in (("1e5", 100_000), ("1e6", 1_000_000)):

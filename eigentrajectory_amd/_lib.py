@@ -27,8 +27,9 @@ SCENE_MAX_N = 16384  # ET_SCENE_MAX_N
 SYMBOLS = [
     "et_abi_version", "et_status_string", "et_compiled_arch", "et_set_option", "et_get_option",
     "et_norm_params", "et_norm_params_from_nrm", "et_normalize", "et_denormalize",
-    "et_norm_project", "et_scene_project", "et_scene_project_train", "et_wrapper_losses_fwd", "et_wrapper_losses_bwd",
+    "et_norm_project", "et_norm_project_pose", "et_scene_project", "et_scene_project_train", "et_wrapper_losses_fwd", "et_wrapper_losses_bwd",
     "et_anchor_reconstruct_fwd", "et_anchor_reconstruct_bwd", "et_anchor_reconstruct_metrics",
+    "et_anchor_reconstruct_metrics_pose",
     "et_fit_gram_workspace_bytes", "et_fit_gram", "et_eigh_topk", "et_eigh_topk_batch",
     "et_fit_descriptor_workspace_bytes", "et_fit_descriptor",
     "et_euc_sim", "et_euc_sim_batch", "et_kmeans_partials_len", "et_kmeans_workspace_bytes", "et_kmeans_scan", "et_kmeans_begin",

@@ -92,13 +92,27 @@ __device__ __forceinline__ void st_f32x4(float4 *p, const float4 &v) {
     else *p = v;
 }
 
+// pose (5,N): the normaliser in the form the fused error metric consumes (et_anchor_reconstruct_metrics_pose) -- origin,
+// the rotation already multiplied by the scale, and 1 / scale with the moving / static decision in its sign bit:
+//   normalise(g) = ((g - o) . (c', s'), (g - o) . (-s', c')),   ||denorm(w) - g|| = ||w - normalise(g)|| * |inv|
+// An optional output of the projection (20 B per row): the metric kernel then spends no square root, reciprocal or
+// selects on re-deriving them from nrm for every pass.
+__device__ __forceinline__ void store_pose(float *__restrict__ pose, int64_t N, int64_t n, const RowNorm &p) {
+    pose[n] = p.ox;
+    pose[N + n] = p.oy;
+    pose[2 * N + n] = p.c * p.sca;
+    pose[3 * N + n] = p.s * p.sca;
+    pose[4 * N + n] = __uint_as_float(__float_as_uint(p.inv) | (p.mv ? 0x80000000u : 0u));
+}
+
 template <int TO, int TP, int K, int TILE, bool STREAM>
 __global__ __launch_bounds__(TILE) void project_tile_kernel(
     const float *__restrict__ obs, const float *__restrict__ pred, int64_t N,
     const float *__restrict__ U_obs_m, const float *__restrict__ U_pred_m,
     const float *__restrict__ U_obs_s, const float *__restrict__ U_pred_s,
     int mode, float static_dist,
-    float *__restrict__ C_obs, float *__restrict__ C_pred, float *__restrict__ nrm, uint8_t *__restrict__ flag) {
+    float *__restrict__ C_obs, float *__restrict__ C_pred, float *__restrict__ nrm, uint8_t *__restrict__ flag,
+    float *__restrict__ pose) {
     constexpr int DO = 2 * TO, DP = 2 * TP;
     constexpr int QO = DO / 4, QP = DP / 4;        // float4 per row
     constexpr int PO = QO + 1, PP = QP + 1;        // padded row pitch in float4 (odd -> conflict free)
@@ -185,6 +199,7 @@ __global__ __launch_bounds__(TILE) void project_tile_kernel(
         st_f32<false>(nrm + 3 * N + n, dy);
     }
     if (flag) flag[n] = (uint8_t)p.mv;
+    if (pose) store_pose(pose, N, n, p);
 
     const float *u = sU + p.mv * UN;
     if (C_obs) {
@@ -235,7 +250,8 @@ __global__ __launch_bounds__(kTile) void project_generic_kernel(
     const float *__restrict__ U_obs_m, const float *__restrict__ U_pred_m,
     const float *__restrict__ U_obs_s, const float *__restrict__ U_pred_s,
     int mode, float static_dist,
-    float *__restrict__ C_obs, float *__restrict__ C_pred, float *__restrict__ nrm, uint8_t *__restrict__ flag) {
+    float *__restrict__ C_obs, float *__restrict__ C_pred, float *__restrict__ nrm, uint8_t *__restrict__ flag,
+    float *__restrict__ pose) {
     const int64_t n = (int64_t)blockIdx.x * kTile + threadIdx.x;
     if (n >= N) return;
     const float *row = obs + n * 2 * T_obs;
@@ -249,6 +265,7 @@ __global__ __launch_bounds__(kTile) void project_generic_kernel(
         nrm[3 * N + n] = dy;
     }
     if (flag) flag[n] = (uint8_t)p.mv;
+    if (pose) store_pose(pose, N, n, p);
     if (C_obs) {
         const float *U = p.mv ? U_obs_m : U_obs_s;
         for (int j = 0; j < k; ++j) {
@@ -773,8 +790,10 @@ constexpr int kMetStages = 2; // ring depth = passes in flight per wavefront + 1
                               // 1.97 / 2.13 / 2.34 / 3.04 ms for 2 / 3 / 4 / 6 stages, profiles/r04g_metrics.txt)
 constexpr float kMetScaleU = 1024.f, kMetScaleC = 128.f, kMetUnscale = 1.f / (1024.f * 128.f);
 constexpr int kMetStage = 9 * 64;  // floats per ring stage: 6 coefficient slots | 2 x 64 ground truth | normaliser state
-constexpr int kMetRows = 8;        // >= 64 / S for S >= 12 (rounded up to keep the slices 16-byte aligned)
-constexpr int kMetSlice = kMetRows * 24 + 2 * 64 + kMetRows;  // floats per wavefront: normalised gt | (ADE, FDE) per pair | 1 / sca
+constexpr int kMetRows = 5;        // >= 64 / S for S >= 12
+// floats per wavefront: normalised gt | (ADE, FDE) per pair | 1 / sca (8 slots).  256 floats: with the two ring stages a
+// workgroup takes 23 008 B of LDS -- SEVEN workgroups per CU (with kMetRows = 8: 24 160 B, six)
+constexpr int kMetSlice = kMetRows * 24 + 2 * 64 + 8;
 
 // memory -> LDS without a destination register: LDS address = M0 + 4 * lane
 __device__ __forceinline__ void lds_dma_b32(unsigned __attribute__((ext_vector_type(4))) desc, unsigned lds_addr, unsigned voffset, unsigned soffset) {
@@ -801,14 +820,24 @@ __device__ unsigned long long g_metstamp[8];
 #define ET_METSTAMP(i)
 #endif
 
-template <int TP, int K, int MODE>
-__global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kernel(
+#ifndef ET_EXP_MET
+#define ET_EXP_MET 0
+#endif
+#ifndef ET_MET_WGS
+#define ET_MET_WGS 6
+#endif
+template <int TP, int K, int MODE, bool POSE>
+__global__ __launch_bounds__(kMetWaves * 64, MODE == ET_MODE_SPLIT ? 5 : ET_MET_WGS) void reconstruct_metrics_mfma_kernel(
     const float *__restrict__ C, int N, int S, int TNW, int T_obs,
-    const float *__restrict__ obs, const float *__restrict__ nrm,
+    const float *__restrict__ obs, const float *__restrict__ nrm_or_pose,
     const float *__restrict__ A_m, const float *__restrict__ A_s,
     const float *__restrict__ U_m, const float *__restrict__ U_s,
     float static_dist, const float *__restrict__ gt, float *__restrict__ ade, float *__restrict__ fde, int use_f16) {
     static_assert(TP == 12 && K == 6, "rows = 24 features in a 32-row tile, k = 6 = three k per half");
+    static_assert(!POSE || MODE != ET_MODE_IDENTITY, "the identity mode has no normaliser to precompute");
+    // POSE: the normaliser arrives as pose (5,N) = ox, oy, c sca, s sca, +-1 / sca (store_pose) instead of nrm (4,N)
+    const float *nrm = nrm_or_pose;
+    constexpr int kPlanes = POSE ? 5 : 4;
     constexpr int DP = 2 * TP, D = kMetStages;
     constexpr bool SPLIT = MODE == ET_MODE_SPLIT;
     constexpr int ND = SPLIT ? 2 : 1;  // descriptors in play: SPLIT 0 static / 1 moving, else the mode's own
@@ -825,7 +854,11 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
     float *sRing = sA + ((ND * K * S + 3) & ~3) + wave * (D * kMetStage);
     const int col_in_tile = lane & 31, h = lane >> 5;
 
-    // A operands of lane (f, h): U[f][2 j + h] * 2^10, j = 0..2 (f = the lane's feature row; rows 24..31 are padding)
+    // A operands of lane (f, h): U[phi(f)][2 j + h] * 2^10, j = 0..2 (f = the lane's tile row; rows 24..31 are padding).
+    // Tile row 4 m + i holds feature phi = 4 m + (x_A, x_B, y_A, y_B)[i] of the step pair (A, B) = (2 m, 2 m + 1) -- rows 1
+    // and 2 of every group of four swapped against the feature order (x_A, y_A, x_B, y_B) --, so a lane's accumulator pairs are
+    // (x_A, x_B) and (y_A, y_B): the epilogue squares and adds two steps per packed instruction.
+    const int feat_of_row = (col_in_tile & ~3) + ((col_in_tile & 1) << 1) + ((col_in_tile >> 1) & 1);
     float aU[ND][3];
     f16x8_t aHi[ND], aLo[ND];  // (Uh0 Uh1 Uh2 Uh0 Uh1 Uh2 0 0), (Ul0 Ul1 Ul2 Ul0 Ul1 Ul2 0 0)
     bool u_small = true;
@@ -835,7 +868,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
         _Float16 uh[3], ul[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const float u = (U && col_in_tile < DP) ? U[col_in_tile * K + 2 * j + h] * kMetScaleU : 0.f;
+            const float u = (U && col_in_tile < DP) ? U[feat_of_row * K + 2 * j + h] * kMetScaleU : 0.f;
             aU[d][j] = u;
             u_small = u_small && fabsf(u) < 32768.f;
             uh[j] = (_Float16)u;
@@ -908,7 +941,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
         return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, nb, 0x00020000);
     };
     const u32x4_t dc0 = desc_of(C, 2 * plane * 4), dc1 = desc_of(C + 2 * plane, 2 * plane * 4), dc2 = desc_of(C + 4 * plane, 2 * plane * 4);
-    const u32x4_t dg = desc_of(gt, (int64_t)N * DP * 4), dn = nrm ? desc_of(nrm, (int64_t)4 * N * 4) : dg;  // (without nrm: a readable dummy)
+    const u32x4_t dg = desc_of(gt, (int64_t)N * DP * 4), dn = nrm ? desc_of(nrm, (int64_t)kPlanes * N * 4) : dg;  // (without nrm: a readable dummy)
     const __amdgpu_buffer_rsrc_t ra = rsrc_of(ade, (int64_t)N * 4), rf = rsrc_of(fde, (int64_t)N * 4);
     unsigned oc[2];  // tile t's coefficient loads: (h * plane + column) * 4
 #pragma unroll
@@ -916,12 +949,15 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
     // ground truth: the pass's TNW rows are TNW * 24 contiguous floats -> two loads, lane = float index
     const unsigned og0 = 4u * (unsigned)(lane < TNW * DP ? lane : 0), og1 = 4u * (unsigned)(64 + lane < TNW * DP ? 64 + lane : 0);
     // normaliser state [4][N]: lane j * TNW + r loads plane j, row r
-    const unsigned onr = (nrm && lane < 4 * TNW) ? 4u * (unsigned)((int64_t)(lane / TNW) * N + lane % TNW) : 0u;
+    const unsigned onr = (nrm && lane < kPlanes * TNW) ? 4u * (unsigned)((int64_t)(lane / TNW) * N + lane % TNW) : 0u;
     const bool use_nrm = nrm != nullptr && MODE != ET_MODE_IDENTITY;
     const unsigned ring_addr = __builtin_amdgcn_readfirstlane(
         (unsigned)reinterpret_cast<unsigned long long>((__attribute__((address_space(3))) float *)sRing));
     auto first_row = [&](int ps) { return min(ps * TNW, N - TNW); };
     auto issue = [&](int ps, int stage) {  // (passes beyond the last re-request the last one: same count every time)
+#if ET_EXP_MET == 3  // measurement aid: every pass re-requests pass 0's inputs (cache resident: no memory traffic)
+        ps = 0;
+#endif
         const int n0 = __builtin_amdgcn_readfirstlane(first_row(min(ps, n_pass - 1)));
         const unsigned base = ring_addr + (unsigned)stage * (unsigned)(kMetStage * 4);
         const unsigned so_c = (unsigned)n0 * (unsigned)(S * 4), so_g = (unsigned)n0 * (unsigned)(DP * 4), so_n = (unsigned)n0 * 4u;
@@ -990,42 +1026,57 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
         int mv_lane = 0;
         if (g_ok) {
             const float2 gp = *reinterpret_cast<const float2 *>(sIn + 6 * 64 + gr * DP + 2 * gs);
-            float ox = sIn[8 * 64 + gr], oy = sIn[8 * 64 + TNW + gr], dx = sIn[8 * 64 + 2 * TNW + gr], dy = sIn[8 * 64 + 3 * TNW + gr];
-            if (!use_nrm && MODE != ET_MODE_IDENTITY) {  // (no cached state: from the observed row)
-                const float *row = obs + (int64_t)(n0 + gr) * 2 * T_obs;
-                ox = row[2 * (T_obs - 1)];
-                oy = row[2 * (T_obs - 1) + 1];
-                dx = ox - row[2 * (T_obs - 3)];
-                dy = oy - row[2 * (T_obs - 3) + 1];
-            }
-            // normaliser state as row_norm() forms it, with the hardware's 1-ulp square root and reciprocal in place of
-            // the correctly rounded sequences (~40 instructions per pass on every lane): the metric is compared at
-            // 1e-5 m, these differ by 1e-7 relative.  The moving / static decision (model.py:46) keeps row_norm's exact test.
-            int mv = MODE == ET_MODE_MOVING;
-            if (SPLIT) {
-                const float hx = dx * 0.5f, hy = dy * 0.5f;
-                mv = sqrtf(hx * hx + hy * hy) > static_dist ? 1 : 0;
-            }
-            mv_lane = mv;
-            float c = 1.f, sn = 0.f, sca = 1.f, back = 1.f;
-            if (MODE != ET_MODE_IDENTITY) {
-                const float r2 = dx * dx + dy * dy;
-                const float r = __builtin_amdgcn_sqrtf(r2), ir = __builtin_amdgcn_rcpf(r);
-                const bool still = !(r > 0.0f);
-                c = still ? (isnan(r) ? r : 1.0f) : dx * ir;
-                sn = still ? (isnan(r) ? r : 0.0f) : dy * ir;
-                sca = mv ? ir * 2.0f : 1.0f;
-                back = mv ? r * 0.5f : 1.0f;
-            } else {
-                ox = 0.f;
-                oy = 0.f;
-            }
-            // normalizer.py:42-51: ((p - ori) @ R) * sca;  ||denorm(w) - gt|| = ||w - normalise(gt)|| / sca
-            const float tx = gp.x - ox, ty = gp.y - oy;
             float2 o;  // (stored NEGATED: the epilogue's fused multiply-add then takes it as it is)
-            o.x = (tx * c + ty * sn) * -sca;
-            o.y = (tx * (-sn) + ty * c) * -sca;
-            *reinterpret_cast<float2 *>(sGn + gr * DP + 2 * gs) = o;
+            float back;
+            if constexpr (POSE) {
+                // normalizer.py:42-51 with the rotation and the scale in one pair: ((p - ori) @ R) * sca = (t . (c', s'), t . (-s', c'))
+                const float ox = sIn[8 * 64 + gr], oy = sIn[8 * 64 + TNW + gr], cs = sIn[8 * 64 + 2 * TNW + gr], ss = sIn[8 * 64 + 3 * TNW + gr];
+                const float bk = sIn[8 * 64 + 4 * TNW + gr];
+                mv_lane = (int)(__float_as_uint(bk) >> 31);  // (SPLIT: the row takes the moving descriptor)
+                back = fabsf(bk);
+                const float tx = gp.x - ox, ty = gp.y - oy;
+                o.x = -(tx * cs + ty * ss);
+                o.y = tx * ss - ty * cs;
+            } else {
+                float ox = sIn[8 * 64 + gr], oy = sIn[8 * 64 + TNW + gr], dx = sIn[8 * 64 + 2 * TNW + gr], dy = sIn[8 * 64 + 3 * TNW + gr];
+                if (!use_nrm && MODE != ET_MODE_IDENTITY) {  // (no cached state: from the observed row)
+                    const float *row = obs + (int64_t)(n0 + gr) * 2 * T_obs;
+                    ox = row[2 * (T_obs - 1)];
+                    oy = row[2 * (T_obs - 1) + 1];
+                    dx = ox - row[2 * (T_obs - 3)];
+                    dy = oy - row[2 * (T_obs - 3) + 1];
+                }
+                // normaliser state as row_norm() forms it, with the hardware's 1-ulp square root and reciprocal in place of
+                // the correctly rounded sequences (~40 instructions per pass on every lane): the metric is compared at
+                // 1e-5 m, these differ by 1e-7 relative.  The moving / static decision (model.py:46) keeps row_norm's exact test.
+                int mv = MODE == ET_MODE_MOVING;
+                if (SPLIT) {
+                    const float hx = dx * 0.5f, hy = dy * 0.5f;
+                    mv = sqrtf(hx * hx + hy * hy) > static_dist ? 1 : 0;
+                }
+                mv_lane = mv;
+                float c = 1.f, sn = 0.f, sca = 1.f;
+                back = 1.f;
+                if (MODE != ET_MODE_IDENTITY) {
+                    const float r2 = dx * dx + dy * dy;
+                    const float r = __builtin_amdgcn_sqrtf(r2), ir = __builtin_amdgcn_rcpf(r);
+                    const bool still = !(r > 0.0f);
+                    c = still ? (isnan(r) ? r : 1.0f) : dx * ir;
+                    sn = still ? (isnan(r) ? r : 0.0f) : dy * ir;
+                    sca = mv ? ir * 2.0f : 1.0f;
+                    back = mv ? r * 0.5f : 1.0f;
+                } else {
+                    ox = 0.f;
+                    oy = 0.f;
+                }
+                // normalizer.py:42-51: ((p - ori) @ R) * sca;  ||denorm(w) - gt|| = ||w - normalise(gt)|| / sca
+                const float tx = gp.x - ox, ty = gp.y - oy;
+                o.x = (tx * c + ty * sn) * -sca;
+                o.y = (tx * (-sn) + ty * c) * -sca;
+            }
+            float *og = sGn + gr * DP + 4 * (gs >> 1) + (gs & 1);  // (x_A, x_B, y_A, y_B) per step pair, like the tile rows
+            og[0] = o.x;
+            og[2] = o.y;
             if (gs == 0) sBack[gr] = back;
         }
         // bit 12 r (+ step): row r of the pass takes the moving descriptor.  (Every lane asks: a ballot inside the branch
@@ -1048,6 +1099,14 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
                                 fmaxf(fmaxf(fabsf(b[1][0]), fabsf(b[1][1])), fabsf(b[1][2])));
         f32x16_t acc[2];
         ET_METSTAMP(3);
+#if ET_EXP_MET == 2  // measurement aid: no operand split, no matrix instructions
+        if (1) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] = b[t][i % 3] * aU[0][i % 3] + big;
+        } else
+#endif
         if (f16_ok && __ballot(!(big < 32768.f)) == 0ull) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -1102,14 +1161,17 @@ __global__ __launch_bounds__(kMetWaves * 64) void reconstruct_metrics_mfma_kerne
             float last = 0.f;
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                const float4 gn = g4[2 * g];  // = -(normalised ground truth)
-                // (two fp32 per instruction: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on adjacent registers)
-                f32x2_t e = __builtin_elementwise_fma((f32x2_t){acc[t][4 * g], acc[t][4 * g + 1]}, un, (f32x2_t){gn.x, gn.y});
-                f32x2_t f = __builtin_elementwise_fma((f32x2_t){acc[t][4 * g + 2], acc[t][4 * g + 3]}, un, (f32x2_t){gn.z, gn.w});
-                e = e * e;
-                f = f * f;
+                const float4 gn = g4[2 * g];  // = -(normalised ground truth): (x_A, x_B, y_A, y_B)
+                // (two steps per instruction: v_pk_fma_f32 / v_pk_mul_f32 on adjacent registers)
+                const f32x2_t ex = __builtin_elementwise_fma((f32x2_t){acc[t][4 * g], acc[t][4 * g + 1]}, un, (f32x2_t){gn.x, gn.y});
+                const f32x2_t ey = __builtin_elementwise_fma((f32x2_t){acc[t][4 * g + 2], acc[t][4 * g + 3]}, un, (f32x2_t){gn.z, gn.w});
+                const f32x2_t d2 = __builtin_elementwise_fma(ey, ey, ex * ex);
                 // v_sqrt_f32 (1 ulp): the metric is compared at 1e-5 m
-                const f32x2_t d = {__builtin_amdgcn_sqrtf(e.x + e.y), __builtin_amdgcn_sqrtf(f.x + f.y)};
+#if ET_EXP_MET == 1  // measurement aid: no square roots
+                const f32x2_t d = d2;
+#else
+                const f32x2_t d = {__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
+#endif
                 sum2 = sum2 + d;
                 last = d.y;  // h = 1, g = 2: step 11
             }
@@ -1248,6 +1310,14 @@ extern "C" int et_norm_project(const float *obs, const float *pred, int64_t N, i
                                const float *U_obs_m, const float *U_pred_m, const float *U_obs_s,
                                const float *U_pred_s, int mode, float static_dist, float *C_obs, float *C_pred,
                                float *nrm, uint8_t *flag, et_stream_t stream) {
+    return et_norm_project_pose(obs, pred, N, T_obs, T_pred, k, U_obs_m, U_pred_m, U_obs_s, U_pred_s, mode, static_dist, C_obs,
+                                C_pred, nrm, flag, nullptr, stream);
+}
+
+extern "C" int et_norm_project_pose(const float *obs, const float *pred, int64_t N, int T_obs, int T_pred, int k,
+                                    const float *U_obs_m, const float *U_pred_m, const float *U_obs_s,
+                                    const float *U_pred_s, int mode, float static_dist, float *C_obs, float *C_pred,
+                                    float *nrm, uint8_t *flag, float *pose, et_stream_t stream) {
     if (N < 0 || !dims_ok(T_obs, T_pred, k) || mode < 0 || mode > 3) return ET_ERR_INVALID_ARG;
     if (N == 0) return ET_OK;
     if (!obs) return ET_ERR_INVALID_ARG;
@@ -1260,10 +1330,10 @@ extern "C" int et_norm_project(const float *obs, const float *pred, int64_t N, i
         const bool stream = N * (int64_t)(pred ? 224 : 104) > kStreamBytes;
         auto kern = stream ? project_tile_kernel<8, 12, 6, kTile, true> : project_tile_kernel<8, 12, 6, kTile, false>;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kTile), 0, st, obs, pred, N, U_obs_m, U_pred_m, U_obs_s, U_pred_s, mode,
-                           static_dist, C_obs, C_pred, nrm, flag);
+                           static_dist, C_obs, C_pred, nrm, flag, pose);
     } else {
         hipLaunchKernelGGL(project_generic_kernel, dim3(grid), dim3(kTile), 0, st, obs, pred, N, T_obs, T_pred, k,
-                           U_obs_m, U_pred_m, U_obs_s, U_pred_s, mode, static_dist, C_obs, C_pred, nrm, flag);
+                           U_obs_m, U_pred_m, U_obs_s, U_pred_s, mode, static_dist, C_obs, C_pred, nrm, flag, pose);
     }
     ET_LAUNCH_CHECK();
     return ET_OK;
@@ -1318,9 +1388,28 @@ extern "C" int et_anchor_reconstruct_metrics(const float *C, int64_t N, int S, i
                                              const float *U_pred_m, const float *U_pred_s, int mode,
                                              float static_dist, const float *gt, float *ade, float *fde,
                                              et_stream_t stream) {
+    return et_anchor_reconstruct_metrics_pose(C, N, S, k, T_obs, T_pred, obs, nrm, nullptr, A_m, A_s, U_pred_m, U_pred_s, mode,
+                                              static_dist, gt, ade, fde, stream);
+}
+
+// the shapes reconstruct_metrics_mfma_kernel takes: a wavefront takes 64 / S trajectories per pass and normalises one
+// ground-truth point per lane, so S <= 64 and (64 / S) * 12 <= 64, i.e. 12 <= S <= 64 (the model form is S = 20)
+static bool metrics_mfma_shape(int64_t N, int S, int k, int T_pred, const float *gt) {
+    return T_pred == 12 && k == 6 && aligned16(gt) && S >= 12 && S <= 64 && N >= 64 / S && N * S < ((int64_t)1 << 29) &&
+           N * 24 < ((int64_t)1 << 30);
+}
+
+extern "C" int et_anchor_reconstruct_metrics_pose(const float *C, int64_t N, int S, int k, int T_obs, int T_pred,
+                                                  const float *obs, const float *nrm, const float *pose, const float *A_m,
+                                                  const float *A_s, const float *U_pred_m, const float *U_pred_s, int mode,
+                                                  float static_dist, const float *gt, float *ade, float *fde,
+                                                  et_stream_t stream) {
     if (N < 0 || S < 1 || !dims_ok(T_obs, T_pred, k) || mode < 0 || mode > 3) return ET_ERR_INVALID_ARG;
     if (N == 0) return ET_OK;
-    if (!C || !gt || !ade || !fde || (!obs && !nrm && mode != ET_MODE_IDENTITY)) return ET_ERR_INVALID_ARG;
+    // pose is consumed by the matrix-core kernel only: any other shape (or metrics_form = t) needs nrm or obs
+    const bool pose_usable = pose && mode != ET_MODE_IDENTITY && metrics_mfma_shape(N, S, k, T_pred, gt) &&
+                             options().metrics_form.load(std::memory_order_relaxed) != 't';
+    if (!C || !gt || !ade || !fde || (!obs && !nrm && !pose_usable && mode != ET_MODE_IDENTITY)) return ET_ERR_INVALID_ARG;
     if ((need_m(mode) && !U_pred_m) || (need_s(mode) && !U_pred_s)) return ET_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     const bool fast = T_pred == 12 && k == 6 && S <= kTile && aligned16(gt);
@@ -1329,15 +1418,13 @@ extern "C" int et_anchor_reconstruct_metrics(const float *C, int64_t N, int S, i
         // option metrics_form (et_set_option; A/B runs, tests): t = the vector-ALU workgroup-tile kernel, f = fp32 matrix instructions only
         const int form = options().metrics_form.load(std::memory_order_relaxed);
         const int use_f16 = form != 'f';
-        // the matrix-core kernel: a wavefront takes 64 / S trajectories per pass and normalises one ground-truth point
-        // per lane, so S <= 64 and (64 / S) * 12 <= 64, i.e. 12 <= S <= 64 (the model form is S = 20)
-        if (form != 't' && aligned16(gt) && S >= 12 && S <= 64 && N >= 64 / S && N * S < ((int64_t)1 << 29) && N * 24 < ((int64_t)1 << 30)) {
+        if (form != 't' && metrics_mfma_shape(N, S, k, T_pred, gt)) {
             const int TNW = 64 / S;
             const int64_t passes = ceil_div(N, TNW);
             const size_t lds = sizeof(float) * metrics_mfma_lds_floats(S, mode == ET_MODE_SPLIT ? 2 : 1);
             // a persistent grid: exactly the workgroups that are resident together (a surplus workgroup would start when
             // the others are done and double the run time of its CU)
-#define ET_METRICS_LAUNCH(MODE)                                                                                           \
+#define ET_METRICS_LAUNCH(MODE, POSE)                                                                                     \
     do {                                                                                                                  \
         /* (asked once per mode and LDS size: the query is a few microseconds of host time, as much as a scene call's   \
            whole kernel) */                                                                                               \
@@ -1346,20 +1433,24 @@ extern "C" int et_anchor_reconstruct_metrics(const float *C, int64_t N, int S, i
         const unsigned long long c = cached.load(std::memory_order_relaxed);                                             \
         if ((c >> 32) == (unsigned long long)lds + 1) per_cu = (int)(c & 0xffffffffull);                                  \
         else {                                                                                                            \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reconstruct_metrics_mfma_kernel<12, 6, MODE>,       \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reconstruct_metrics_mfma_kernel<12, 6, MODE, POSE>, \
                                                              kMetWaves * 64, lds) != hipSuccess || per_cu < 1)           \
                 per_cu = 2;                                                                                               \
             cached.store((((unsigned long long)lds + 1) << 32) | (unsigned)per_cu, std::memory_order_relaxed);            \
         }                                                                                                                 \
         const unsigned g = (unsigned)min((int64_t)cu_count() * per_cu, ceil_div(passes, kMetWaves));                      \
-        hipLaunchKernelGGL((reconstruct_metrics_mfma_kernel<12, 6, MODE>), dim3(g), dim3(kMetWaves * 64), lds, st, C,     \
-                           (int)N, S, TNW, T_obs, obs, nrm, A_m, A_s, U_pred_m, U_pred_s, static_dist, gt, ade, fde,      \
-                           use_f16);                                                                                      \
+        hipLaunchKernelGGL((reconstruct_metrics_mfma_kernel<12, 6, MODE, POSE>), dim3(g), dim3(kMetWaves * 64), lds, st,  \
+                           C, (int)N, S, TNW, T_obs, obs, POSE ? pose : nrm, A_m, A_s, U_pred_m, U_pred_s, static_dist,   \
+                           gt, ade, fde, use_f16);                                                                        \
     } while (0)
-            if (mode == ET_MODE_SPLIT) ET_METRICS_LAUNCH(ET_MODE_SPLIT);
-            else if (mode == ET_MODE_MOVING) ET_METRICS_LAUNCH(ET_MODE_MOVING);
-            else if (mode == ET_MODE_STATIC) ET_METRICS_LAUNCH(ET_MODE_STATIC);
-            else ET_METRICS_LAUNCH(ET_MODE_IDENTITY);
+            if (pose_usable) {
+                if (mode == ET_MODE_SPLIT) ET_METRICS_LAUNCH(ET_MODE_SPLIT, true);
+                else if (mode == ET_MODE_MOVING) ET_METRICS_LAUNCH(ET_MODE_MOVING, true);
+                else ET_METRICS_LAUNCH(ET_MODE_STATIC, true);
+            } else if (mode == ET_MODE_SPLIT) ET_METRICS_LAUNCH(ET_MODE_SPLIT, false);
+            else if (mode == ET_MODE_MOVING) ET_METRICS_LAUNCH(ET_MODE_MOVING, false);
+            else if (mode == ET_MODE_STATIC) ET_METRICS_LAUNCH(ET_MODE_STATIC, false);
+            else ET_METRICS_LAUNCH(ET_MODE_IDENTITY, false);
 #undef ET_METRICS_LAUNCH
         } else {
             const size_t lds = sizeof(float) * ((size_t)TN * 24 + (size_t)TN * S * 2 + (size_t)TN * kNormStride + 2 * 24 * 6 +

@@ -97,10 +97,12 @@ def denormalize(traj, ori=None, rot=None, sca=None):
 
 # ---------------------------------------------------------------------------- projection
 def norm_project(obs, pred, U_obs_m, U_pred_m, U_obs_s, U_pred_s, mode, static_dist=0.0,
-                 want_nrm=True, want_flag=True, want_obs=True):
+                 want_nrm=True, want_flag=True, want_obs=True, want_pose=False):
     """descriptor.py:144-160 fused with model.py:73-90.
 
-    Returns (C_obs (k,N) | None, C_pred (k,N) | None, nrm (4,N) | None, flag (N,) uint8 | None).
+    Returns (C_obs (k,N) | None, C_pred (k,N) | None, nrm (4,N) | None, flag (N,) uint8 | None) and, with ``want_pose``, a
+    fifth element pose (5,N): the normaliser as :func:`anchor_reconstruct_metrics` consumes it (origin, rotation x scale,
+    1 / scale with the moving / static decision in its sign).
     """
     dev = L.require_device(obs)
     obs, pred, U_obs_m, U_pred_m, U_obs_s, U_pred_s = _dev_args(dev, obs, pred, U_obs_m, U_pred_m, U_obs_s, U_pred_s)
@@ -113,6 +115,13 @@ def norm_project(obs, pred, U_obs_m, U_pred_m, U_obs_s, U_pred_s, mode, static_d
     c_pred = torch.empty((k, n), device=dev) if pred is not None else None
     nrm = torch.empty((4, n), device=dev) if want_nrm else None
     flag = torch.empty((n,), device=dev, dtype=torch.uint8) if want_flag else None
+    if want_pose:
+        pose = torch.empty((5, n), device=dev)
+        L.check(L.lib().et_norm_project_pose(L.ptr(obs), L.ptr(pred), L.i64(n), t_obs, t_pred, k, L.ptr(U_obs_m),
+                                             L.ptr(U_pred_m), L.ptr(U_obs_s), L.ptr(U_pred_s), int(mode), L.f32(static_dist),
+                                             L.ptr(c_obs), L.ptr(c_pred), L.ptr(nrm), L.ptr(flag), L.ptr(pose), L.stream(dev)),
+                "et_norm_project_pose")
+        return c_obs, c_pred, nrm, flag, pose
     L.check(L.lib().et_norm_project(L.ptr(obs), L.ptr(pred), L.i64(n), t_obs, t_pred, k, L.ptr(U_obs_m),
                                     L.ptr(U_pred_m), L.ptr(U_obs_s), L.ptr(U_pred_s), int(mode), L.f32(static_dist),
                                     L.ptr(c_obs), L.ptr(c_pred), L.ptr(nrm), L.ptr(flag), L.stream(dev)),
@@ -177,21 +186,24 @@ def anchor_reconstruct(Cc, A_m, A_s, U_m, U_s, mode, static_dist=0.0, *, obs=Non
     return _AnchorReconstruct.apply(Cc, obs, nrm, A_m, A_s, U_m, U_s, int(mode), float(static_dist), int(t_obs))
 
 
-def anchor_reconstruct_metrics(Cc, gt, A_m, A_s, U_m, U_s, mode, static_dist=0.0, *, obs=None, nrm=None, t_obs=8):
+def anchor_reconstruct_metrics(Cc, gt, A_m, A_s, U_m, U_s, mode, static_dist=0.0, *, obs=None, nrm=None, pose=None, t_obs=8):
     """Best-of-S ADE / FDE per pedestrian (utils/metrics.py:73-102) fused into the reconstruction:
-    C (k,N,S), gt (N,T_pred,2) -> ade (N,), fde (N,).  No autograd (evaluation form)."""
+    C (k,N,S), gt (N,T_pred,2) -> ade (N,), fde (N,).  No autograd (evaluation form).
+
+    ``pose`` (5,N) from ``norm_project(..., want_pose=True)`` (same mode and static_dist): the matrix-core kernel
+    (T_pred = 12, k = 6, 12 <= S <= 64) takes the normaliser from it; any other shape needs ``nrm`` or ``obs`` as well."""
     dev = L.require_device(Cc)
-    Cc, gt, obs, nrm, A_m, A_s, U_m, U_s = _dev_args(dev, Cc, gt, obs, nrm, A_m, A_s, U_m, U_s)
+    Cc, gt, obs, nrm, A_m, A_s, U_m, U_s, pose = _dev_args(dev, Cc, gt, obs, nrm, A_m, A_s, U_m, U_s, pose)
     k, n, s = Cc.shape
     if obs is not None:
         t_obs = obs.shape[1]
     t_pred = gt.shape[1]
     ade = torch.empty((n,), device=dev)
     fde = torch.empty((n,), device=dev)
-    L.check(L.lib().et_anchor_reconstruct_metrics(L.ptr(Cc), L.i64(n), s, k, int(t_obs), t_pred, L.ptr(obs), L.ptr(nrm),
-                                                  L.ptr(A_m), L.ptr(A_s), L.ptr(U_m), L.ptr(U_s), int(mode),
-                                                  L.f32(static_dist), L.ptr(gt), L.ptr(ade), L.ptr(fde), L.stream(dev)),
-            "et_anchor_reconstruct_metrics")
+    L.check(L.lib().et_anchor_reconstruct_metrics_pose(L.ptr(Cc), L.i64(n), s, k, int(t_obs), t_pred, L.ptr(obs), L.ptr(nrm),
+                                                       L.ptr(pose), L.ptr(A_m), L.ptr(A_s), L.ptr(U_m), L.ptr(U_s), int(mode),
+                                                       L.f32(static_dist), L.ptr(gt), L.ptr(ade), L.ptr(fde), L.stream(dev)),
+            "et_anchor_reconstruct_metrics_pose")
     return ade, fde
 
 

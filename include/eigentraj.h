@@ -134,6 +134,14 @@ int et_norm_project(const float *obs, const float *pred, int64_t N, int T_obs, i
                     const float *U_obs_m, const float *U_pred_m, const float *U_obs_s, const float *U_pred_s,
                     int mode, float static_dist,
                     float *C_obs, float *C_pred, float *nrm, uint8_t *flag, et_stream_t stream);
+/* ... with one more optional output, pose (5,N) = ox, oy, c sca, s sca, +-1/sca: the normaliser of a row in the form the
+ * fused error metric consumes (et_anchor_reconstruct_metrics_pose) -- origin, the heading rotation (normalizer.py:24-26)
+ * already multiplied by the scale (:28), and 1 / scale with the row's moving (sign bit set) / static decision
+ * (model.py:46,73).  20 B per row on top of the projection's 224; pose == NULL is et_norm_project. */
+int et_norm_project_pose(const float *obs, const float *pred, int64_t N, int T_obs, int T_pred, int k,
+                         const float *U_obs_m, const float *U_pred_m, const float *U_obs_s, const float *U_pred_s,
+                         int mode, float static_dist,
+                         float *C_obs, float *C_pred, float *nrm, uint8_t *flag, float *pose, et_stream_t stream);
 
 /* Scene form of the projection (one scene batch of model.py:73-90, obs only, N <= ET_SCENE_MAX_N): ONE single-workgroup
  * launch that also produces obs_ori (2,N) = last observed positions minus their mean over the scene (model.py:86-89) --
@@ -190,6 +198,15 @@ int et_anchor_reconstruct_metrics(const float *C, int64_t N, int S, int k, int T
                                   const float *A_m, const float *A_s, const float *U_pred_m, const float *U_pred_s,
                                   int mode, float static_dist, const float *gt, float *ade, float *fde,
                                   et_stream_t stream);
+/* ... with the normaliser from `pose` (5,N) as written by et_norm_project_pose under the same mode and static_dist: the
+ * matrix-core kernel (T_pred = 12, k = 6, 12 <= S <= 64) then re-derives nothing per pass (no square root, reciprocal or
+ * selects for the rotation and the scale: ~11 % of its vector instructions).  Shapes that kernel does not take fall back to
+ * nrm / obs exactly as et_anchor_reconstruct_metrics (so pass them too unless the shape is known); pose == NULL is that call. */
+int et_anchor_reconstruct_metrics_pose(const float *C, int64_t N, int S, int k, int T_obs, int T_pred,
+                                       const float *obs, const float *nrm, const float *pose,
+                                       const float *A_m, const float *A_s, const float *U_pred_m, const float *U_pred_s,
+                                       int mode, float static_dist, const float *gt, float *ade, float *fde,
+                                       et_stream_t stream);
 
 /* dC[j][n][s] = sum_f U_pred[f][j] * ((dtraj[s][n] @ R_n) / sca_n)[f]          (k,N,S) */
 int et_anchor_reconstruct_bwd(const float *dtraj, int64_t N, int S, int k, int T_obs, int T_pred,

@@ -319,6 +319,39 @@ def test_fused_metrics_matrix_kernel_few_rows_and_tail_passes(ops, oracle, dev, 
     close(N_(fde), W.batch_fde(rec, gt), tol=2e-6)
 
 
+@pytest.mark.parametrize("n,s,mode", [(1003, 20, 2), (1003, 20, 1), (1003, 20, 0), (7, 20, 2), (500, 12, 2), (333, 64, 1), (50, 5, 2)])
+def test_fused_metrics_with_the_projections_pose_record(ops, oracle, dev, n, s, mode):
+    """pose (5,N) -- the optional sixth output of the projection: origin, rotation x scale, 1 / scale with the moving / static
+    decision in its sign -- against the oracle's normaliser, and the matrix-core metrics kernel fed from it (no nrm, no obs)
+    against the oracle's reconstruction + compute_batch_ade / fde; a shape that kernel does not take (S = 5) falls back to nrm."""
+    from oracle import wrapper_ref as W
+    from eigentrajectory_amd.synth import synthetic_trajectories_np
+    rng = np.random.default_rng(n + s + mode)
+    obs, gt = synthetic_trajectories_np(n, seed=12)
+    obs[::7, -3] = obs[::7, -1] + 1e-3 * rng.standard_normal((len(obs[::7]), 2)).astype(np.float32)  # (rows under static_dist)
+    uo = rng.standard_normal((16, 6)).astype(np.float32) * 0.3
+    um, us_ = (rng.standard_normal((24, 6)).astype(np.float32) * 0.3 for _ in range(2))
+    a_m, a_s = (rng.standard_normal((6, s)).astype(np.float32) for _ in range(2))
+    c = rng.standard_normal((6, n, s)).astype(np.float32)
+    _, _, nrm, flag, pose = ops.norm_project(T(obs, dev), None, T(uo, dev), None, T(uo, dev), None, mode, 0.3, want_pose=True)
+    ox, oy, dx, dy = N_(nrm).astype(np.float64)
+    r = np.hypot(dx, dy)
+    mv = N_(flag).astype(bool)
+    sca = np.where(mv, 2.0 / r, 1.0)
+    want = np.stack([ox, oy, dx / r * sca, dy / r * sca, np.where(mv, -1.0, 1.0) / sca])
+    np.testing.assert_allclose(N_(pose), want, rtol=3e-6, atol=1e-30)
+    assert np.array_equal(np.signbit(N_(pose)[4]), mv)
+    kw = dict(pose=pose) if s >= 12 else dict(pose=pose, nrm=nrm)
+    ade, fde = ops.anchor_reconstruct_metrics(T(c, dev), T(gt, dev), T(a_m, dev), T(a_s, dev), T(um, dev), T(us_, dev), mode,
+                                              0.3, **kw)
+    rec = oracle.anchor_reconstruct(c, obs, a_m, a_s, um, us_, mode, 0.3)
+    close(N_(ade), W.batch_ade(rec, gt), tol=2e-6)
+    close(N_(fde), W.batch_fde(rec, gt), tol=2e-6)
+    if s < 12:  # the pose alone is not enough for a shape the matrix-core kernel does not take
+        with pytest.raises(Exception):
+            ops.anchor_reconstruct_metrics(T(c, dev), T(gt, dev), T(a_m, dev), T(a_s, dev), T(um, dev), T(us_, dev), mode, 0.3, pose=pose)
+
+
 @pytest.mark.parametrize("what", ["coefficients", "U", "nan"])
 def test_fused_metrics_values_beyond_f16_take_the_fp32_instructions(ops, oracle, dev, what):
     """|coefficient + anchor| >= 256 or |U| >= 32 would overflow the scaled f16 operands: those tiles (or the whole launch)
