@@ -28,6 +28,9 @@ def med(fn, reps=12):
         a.record(); fn(); b.record(); ev.append((a, b))
     torch.cuda.synchronize()
     return float(np.median([a.elapsed_time(b) for a, b in ev]))
+from eigentrajectory_amd import _lib as L
+import os
+if os.environ.get("ET_AB_FORM"): L.set_option("metrics_form", os.environ["ET_AB_FORM"])
 t_mov = med(lambda: ops.anchor_reconstruct_metrics(C20, pred, A, None, Up, None, ops.MODE_MOVING, nrm=nrm))
 t_spl = med(lambda: ops.anchor_reconstruct_metrics(C20, pred, A, A, Up, Up, ops.MODE_SPLIT, 0.3, nrm=nrm))
 p_mov = med(lambda: ops.anchor_reconstruct_metrics(C20, pred, A, None, Up, None, ops.MODE_MOVING, pose=pose))
@@ -41,7 +44,9 @@ rounds = int([a for a in sys.argv[1:] if a.isdigit()][0]) if any(a.isdigit() for
 for r in range(rounds):
     for name in names:
         env = dict(os.environ)
-        if name != "base":
+        if name.startswith("form="):  # the shipped library under option metrics_form = <letter>
+            env["ET_AB_FORM"] = name[5:]
+        elif name != "base":
             env["ET_LIBETAMD"] = os.path.join(R, "eigentrajectory_amd", "variants", f"libetamd_{name}.so")
         out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
         line = [l for l in out.stdout.strip().splitlines() if l.startswith("MOVING")]
