@@ -17,30 +17,42 @@ constexpr int kFitThreads = 256;
 template <int TO, int TP>
 struct GramLayout {
     static constexpr int DO = 2 * TO, DP = 2 * TP, D = DO + DP;
-    // three 16x16 fp64 MFMA tiles cover G_obs (16x16) and the upper triangle of G_pred (24x24):
-    //   O = obs x obs,  P = pred[0:16] x pred[0:16],  Q = pred[8:24] x (pred[16:24] | pred[0:8])
-    static constexpr int kBlocks = 3;
-    static constexpr int kPartial = kBlocks * 256 + 1;               // doubles per partial (+ row count)
+    // ten v_mfma_f64_4x4x4_4b per four rows: an instruction is four independent 4 x 4 x 4 products ("slots"), slot s working
+    // on FOUR blocks of four features (gram4_block) and instruction t on the pair (qa <= qb) of them -- every slot computes
+    // the upper triangle of its 16 x 16 sub-Gram.  Slot 0: the observation's blocks 0..3; slots 1..3: the prediction's
+    // {0,1,2,3}, {4,5,0,1}, {2,3,4,5} -- three 4-subsets that cover every pair of its six blocks.  40 block products per four
+    // rows against the 48 of three 16 x 16 tiles, at the same rate per product (tools/exp/mfma_f64_rate.hip: 16 against
+    // 64 cycles), the same four operand conversions per lane.
+    static constexpr int kPairs = 10;
+    static constexpr int kSums = kPairs * 64;  // [pair t][lane]: lane = j + 4 slot + 16 i (i: row of the A block, j: row of the B block)
+    static constexpr int kPartial = kSums + 1;  // doubles per partial (+ row count)
 };
+// unified feature block (0..3 observation, 4..9 prediction) at position q of slot s
+__host__ __device__ constexpr int gram4_block(int s, int q) { return s == 0 ? q : 4 + (s == 1 ? q : (s == 2 ? (q < 2 ? 4 + q : q - 2) : 2 + q)); }
+__host__ __device__ constexpr int gram4_pair(int qa, int qb) { return qa * 4 - qa * (qa - 1) / 2 + (qb - qa); }  // qa <= qb
 
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-
-// Gram kernel, (T_obs, T_pred) = (8, 12).  A wavefront takes 64 trajectories per pass, in its own 12 KB LDS slice:
-//  1. coalesced float4 loads (prefetched one pass ahead into registers) -> LDS rows (pitch + 16 B)
+// Gram kernel, (T_obs, T_pred) = (8, 12).  A wavefront takes 64 trajectories per pass, in its own 11 KB LDS slice:
+//  1. coalesced float4 loads (prefetched one pass ahead into registers) -> one LDS row per trajectory, [obs 16 | pred 24]
+//     + 16 B (pitch 11 float4: odd)
 //  2. lane = trajectory: normaliser state, normalise the row IN PLACE (fp32; rows that do not belong
 //     to descriptor `which` become zeros)
-//  3. fp64 matrix cores: per group of 4 trajectories three v_mfma_f64_16x16x4_f64 add the outer
-//     products to three 16x16 tiles (A[i][k] = feature i of trajectory k).  Products of fp32 values
-//     are exact in fp64 and every tile entry is one k-ordered fma chain.  The loop over the wavefront's 16 groups
+//  3. fp64 matrix instructions: per group of 4 trajectories ten v_mfma_f64_4x4x4_4b_f64 add the outer products of
+//     4-feature blocks to ten accumulators (GramLayout; operand lane = i + 4 slot + 16 k: feature i of the slot's block, of
+//     trajectory k; result lane = j + 4 slot + 16 i -- found by experiment, tools/exp/mfma_f64_4x4x4_layout.hip).  Products
+//     of fp32 values are exact in fp64 and every entry is one k-ordered fma chain.  The loop over the wavefront's 16 groups
 //     is unrolled: the LDS operand reads use immediate offsets.
 //  4. waves are summed through LDS in a fixed order; every workgroup writes one partial.
-// On this chip VALU and MFMA issue do not overlap (profiles/r02e_mfma_valu_issue.txt: a SIMD's time is matrix time
-// PLUS vector time), so the kernel is built for the fewest vector instructions per row -- lane = trajectory
-// normalisation, 5.7 VALU instructions per row -- and, the slices being wavefront-private, there is no workgroup
-// barrier inside the loop: the three resident wavefronts of a SIMD drift apart and fill each other's waits.
+// On this chip fp64 matrix instructions and vector instructions do not overlap, not even from different wavefronts of a
+// SIMD (tools/exp/mfma_f64_rate.hip: 2 x 16x16x4 beside 32 v_fma_f32 of a second wavefront take the SUM of their times;
+// the fp64 matrix rate equals the fp64 vector rate), so the kernel is built for the fewest vector instructions per row --
+// lane = trajectory normalisation, 5.7 VALU instructions per row, four v_cvt_f64_f32 (6 ns each, as much as 256 fp64
+// multiply-adds) per lane and group -- and, the slices being wavefront-private, there is no workgroup barrier inside the
+// loop: the three resident wavefronts of a SIMD drift apart and fill each other's waits.
 // (Round 2 A/B at N = 1e7, gram + reduce + finish: 256-row workgroup tiles with three barriers per pass 496-506 us;
 // operands loaded straight into the MFMA layout and normalised there with DPP, no LDS staging, 6 wavefronts per SIMD:
-// 484-490 us, 11 VALU instructions per row; this form: 457-464 us.)
+// 484-490 us, 11 VALU instructions per row; wavefront slices + three v_mfma_f64_16x16x4 per group -- 48 block products for
+// the 31 distinct ones, rounds 2-6: 457-464 -> 412-423 us; ten 4x4x4_4b per group -- 40 block products: 408-416 us, the
+// fit stage inside the bench step 0.497-0.501 against 0.511-0.533 ms, profiles/r06p_gram4_ab.txt.)
 constexpr int kWaveGramThreads = 256;
 
 // normalize_point (et_common.h) on two points at once with the packed fp32 instructions (v_pk_add / v_pk_mul_f32: two
@@ -85,10 +97,11 @@ __global__ __launch_bounds__(kWaveGramThreads) void gram_wave_kernel(
     static_assert(TO == 8 && TP == 12, "the MFMA tiling below is laid out for 16 + 24 features");
     constexpr int DO = L::DO, DP = L::DP;
     constexpr int QO = DO / 4, QP = DP / 4;
-    constexpr int PO = QO + 1, PP = QP + 1;
     constexpr int kWaves = kWaveGramThreads / 64;
-    constexpr int kSliceF4 = 64 * (PO + PP);  // float4 per wavefront slice
-    constexpr int kRedDoubles = kWaves * L::kBlocks * 256;
+    constexpr int PR = QO + QP + 1;  // ONE row per trajectory: [obs 16 | pred 24] + 4 floats of padding = 11 float4 (odd: conflict free)
+    static_assert(PR % 2 == 1, "the row pitch must be odd in float4 units");
+    constexpr int kSliceF4 = 64 * PR;
+    constexpr int kRedDoubles = kWaves * L::kSums;
     constexpr int kLdsDoubles = (2 * kWaves * kSliceF4 > kRedDoubles ? 2 * kWaves * kSliceF4 : kRedDoubles) + 2;
     __shared__ __attribute__((aligned(16))) double sMem[kLdsDoubles];
     double *sRed = sMem;  // reused after the loop
@@ -96,11 +109,23 @@ __global__ __launch_bounds__(kWaveGramThreads) void gram_wave_kernel(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int feat = lane & 15, kslot = lane >> 4;
-    float4 *sObs = reinterpret_cast<float4 *>(sMem) + wave * kSliceF4;
-    float4 *sPred = sObs + 64 * PO;
-
-    f64x4 accO = {0.0, 0.0, 0.0, 0.0}, accP = accO, accQ = accO;
+    const int kslot = lane >> 4;
+    float4 *sRow = reinterpret_cast<float4 *>(sMem) + wave * kSliceF4;
+    double acc[L::kPairs];
+#pragma unroll
+    for (int t = 0; t < L::kPairs; ++t) acc[t] = 0.0;
+    // operand lane (i, slot, k) = lane (& 3, >> 2 & 3, >> 4): feature 4 block + i of the trajectory in k-slot k.  The four
+    // k-slots of a group take rows {0,3,6,1} / {4,7,2,5} of an 8-row window (dword offsets 44 row + 4 block + i: with the
+    // 11-float4 pitch half of a half-wave's ds_read_b32 are 2-way bank conflicted whatever the rows -- an exhaustive search
+    // over row assignments and block orders found no conflict-free one, HISTORY.md --, the other half conflict free)
+    const int opi = lane & 3, opslot = (lane >> 2) & 3;
+    const int rowA = kslot == 0 ? 0 : (kslot == 1 ? 3 : (kslot == 2 ? 6 : 1)), rowB = rowA ^ 4;
+    int offA[4], offB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        offA[q] = rowA * (4 * PR) + 4 * gram4_block(opslot, q) + opi;
+        offB[q] = rowB * (4 * PR) + 4 * gram4_block(opslot, q) + opi;
+    }
     int my_count = 0;
     const int64_t n_tiles = ceil_div(N, (int64_t)64);
     const int64_t first = (int64_t)blockIdx.x * kWaves + wave, stride = (int64_t)gridDim.x * kWaves;
@@ -134,13 +159,12 @@ __global__ __launch_bounds__(kWaveGramThreads) void gram_wave_kernel(
 #pragma unroll
         for (int j = 0; j < QO; ++j) {
             const int q = lane + j * 64;
-            sObs[(q / QO) * PO + (q % QO)] = ro[j];
+            sRow[(q / QO) * PR + (q % QO)] = ro[j];
         }
 #pragma unroll
         for (int j = 0; j < QP; ++j) {
             const int q = lane + j * 64;
-            const int f4 = q % QP;  // float4 of the row: features [4 f4, 4 f4 + 4)
-            sPred[(q / QP) * PP + (f4 < 2 ? f4 : (f4 < 4 ? f4 + 2 : f4 - 2))] = rp[j];  // stored as [0:8 | 16:24 | 8:16]
+            sRow[(q / QP) * PR + QO + (q % QP)] = rp[j];
         }
         if (tile + stride < n_tiles) fetch(tile + stride);  // in flight during the rest of this pass
         wave_sync();
@@ -148,7 +172,7 @@ __global__ __launch_bounds__(kWaveGramThreads) void gram_wave_kernel(
         if (0)
 #endif
         {
-            float4 *orow = sObs + lane * PO, *prow = sPred + lane * PP;
+            float4 *orow = sRow + lane * PR, *prow = orow + QO;
             bool use = false;
             if (lane < rows) {
                 float xo[DO];
@@ -188,34 +212,18 @@ __global__ __launch_bounds__(kWaveGramThreads) void gram_wave_kernel(
         if (0)
 #endif
         {
-            // Operand reads, one ds_read_b32 each: lane (feat, kslot) reads feature `feat` of the trajectory in k-slot
-            // `kslot` of group g.  A ds_read_b32 is served per half-wave (k-slots {0,1} and {2,3}), bank = dword address mod
-            // 32: the 16 features of one k-slot cover 16 consecutive banks, so the second k-slot of a half-wave must sit
-            // 16 banks away.  Row pitches are 20 (obs) and 28 (pred) dwords -- odd in float4, which the lane = trajectory
-            // phases above need --, so a group's k-slots 0 / 1 (and 2 / 3) take trajectories FOUR rows apart (80 and 112
-            // dwords = 16 mod 32) instead of neighbours: group g = rows 8 (g / 2) + 2 (g % 2) + {0, 4, 1, 5}.  The tile
-            // P = pred[0:16] x pred[0:16] reads features {0..7, 16..23} of the stored order [0:8 | 16:24 | 8:16] -- banks
-            // {0..7, 16..23}, which need a shift of 8 or 24: its groups are rows 8 (g / 2) + 4 (g % 2) + {0, 2, 1, 3}
-            // (56 dwords = 24 mod 32).  (Every tile sums over all 64 trajectories of the pass whatever the grouping; with
-            // neighbouring rows in the k-slots -- rounds 2-5 -- every one of these reads was a 2-way bank conflict:
-            // SQ_LDS_BANK_CONFLICT 3.25e7 > SQ_ACTIVE_INST_LDS 2.37e7, profiles/r05r_sq_breakdown.txt.)
-            const int rowOQ = 4 * (kslot & 1) + (kslot >> 1), rowP = 2 * (kslot & 1) + (kslot >> 1);
-            const float *po = reinterpret_cast<const float *>(sObs) + rowOQ * (4 * PO) + feat;
-            const float *pq = reinterpret_cast<const float *>(sPred) + rowOQ * (4 * PP);
-            const float *pp = reinterpret_cast<const float *>(sPred) + rowP * (4 * PP) + (feat < 8 ? feat : feat + 8);
-            const int fa = feat < 8 ? feat + 16 : feat;   // feature 8 + feat in the stored order
-            const int fb = feat < 8 ? feat + 8 : feat - 8;  // feature (feat < 8 ? 16 + feat : feat - 8) in the stored order
+            const float *fb = reinterpret_cast<const float *>(sRow);
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                constexpr int kRowsOQ[2] = {0, 2}, kRowsP[2] = {0, 4};
-                const int rOQ = 8 * (g >> 1) + kRowsOQ[g & 1], rP = 8 * (g >> 1) + kRowsP[g & 1];
-                const double vo = (double)po[rOQ * (4 * PO)];
-                const double vp = (double)pp[rP * (4 * PP)];
-                const double va = (double)pq[rOQ * (4 * PP) + fa];
-                const double vb = (double)pq[rOQ * (4 * PP) + fb];
-                accO = __builtin_amdgcn_mfma_f64_16x16x4f64(vo, vo, accO, 0, 0, 0);
-                accP = __builtin_amdgcn_mfma_f64_16x16x4f64(vp, vp, accP, 0, 0, 0);
-                accQ = __builtin_amdgcn_mfma_f64_16x16x4f64(va, vb, accQ, 0, 0, 0);
+            for (int g = 0; g < 16; ++g) {  // group g: window g / 2, rows {0,3,6,1} or {4,7,2,5} of it
+                const int wo = (g >> 1) * (8 * 4 * PR);
+                double v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (double)fb[((g & 1) ? offB[q] : offA[q]) + wo];
+#pragma unroll
+                for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+                    for (int qb = qa; qb < 4; ++qb)
+                        acc[gram4_pair(qa, qb)] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[qa], v[qb], acc[gram4_pair(qa, qb)], 0, 0, 0);
             }
         }
     }
@@ -225,35 +233,49 @@ __global__ __launch_bounds__(kWaveGramThreads) void gram_wave_kernel(
     if (tid == 0) *sCountPtr = 0;
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int e = ((kslot + 4 * r) * 16 + feat);
-        sRed[(wave * L::kBlocks + 0) * 256 + e] = accO[r];
-        sRed[(wave * L::kBlocks + 1) * 256 + e] = accP[r];
-        sRed[(wave * L::kBlocks + 2) * 256 + e] = accQ[r];
-    }
+    for (int t = 0; t < L::kPairs; ++t) sRed[wave * L::kSums + t * 64 + lane] = acc[t];
     if (my_count) atomicAdd(sCountPtr, my_count);
     __syncthreads();
     double *dst = partials + (size_t)blockIdx.x * L::kPartial;
-    for (int i = tid; i < L::kBlocks * 256; i += kWaveGramThreads) {
+    for (int i = tid; i < L::kSums; i += kWaveGramThreads) {
         double sum = 0.0;
-        for (int w = 0; w < kWaves; ++w) sum += sRed[w * L::kBlocks * 256 + i];
+        for (int w = 0; w < kWaves; ++w) sum += sRed[w * L::kSums + i];
         dst[i] = sum;
     }
-    if (tid == 0) dst[L::kBlocks * 256] = (double)*sCountPtr;
+    if (tid == 0) dst[L::kSums] = (double)*sCountPtr;
 }
 
-// G_obs (i, j) / G_pred (i, j) from the three summed 16 x 16 tiles (GramLayout): every entry of the upper triangle comes
-// from exactly one tile and is mirrored, so the matrices are exactly symmetric.
-__device__ __forceinline__ double gram_obs_entry(const double *O, int i, int j) { return i <= j ? O[i * 16 + j] : O[j * 16 + i]; }
-__device__ __forceinline__ double gram_pred_entry(const double *P, const double *Q, int i, int j) {
-    if (i > j) {
+// G (i, j) of the 16 x 16 sub-Gram of slot `s` from the summed accumulators S[pair][lane] (GramLayout): the entry of
+// features (4 qa + ia, 4 qb + jb) of the slot's blocks, qa <= qb, sits in pair (qa, qb), lane jb + 4 s + 16 ia.  Every
+// entry of the upper triangle is taken from ONE accumulator and mirrored: the matrices are exactly symmetric.
+__device__ __forceinline__ double gram4_slot_entry(const double *S, int s, int pa, int ia, int pb, int jb) {
+    if (pa > pb || (pa == pb && ia > jb)) {  // the transposed entry
+        int t = pa;
+        pa = pb;
+        pb = t;
+        t = ia;
+        ia = jb;
+        jb = t;
+    }
+    return S[gram4_pair(pa, pb) * 64 + jb + 4 * s + 16 * ia];
+}
+__device__ __forceinline__ double gram_obs_entry(const double *S, int i, int j) { return gram4_slot_entry(S, 0, i >> 2, i & 3, j >> 2, j & 3); }
+__device__ __forceinline__ double gram_pred_entry(const double *S, int i, int j) {
+    if (i > j) {  // (one canonical accumulator per unordered pair: blocks {0,1}, {2,3}, {4,5} are computed by two slots)
         const int t = i;
         i = j;
         j = t;
     }
-    if (j < 16) return P[i * 16 + j];                   // pred[0:16] x pred[0:16]
-    if (i >= 8) return Q[(i - 8) * 16 + (j - 16)];      // pred[8:24] x pred[16:24]
-    return Q[(j - 8) * 16 + (8 + i)];                   // transpose of pred[16:24] x pred[0:8]
+    const int ba = i >> 2, bb = j >> 2;
+    for (int s = 1; s < 4; ++s) {
+        int pa = -1, pb = -1;
+        for (int q = 0; q < 4; ++q) {
+            if (gram4_block(s, q) == 4 + ba) pa = q;
+            if (gram4_block(s, q) == 4 + bb) pb = q;
+        }
+        if (pa >= 0 && pb >= 0) return gram4_slot_entry(S, s, pa, i & 3, pb, j & 3);
+    }
+    return 0.0;  // (unreachable: the three slots cover every pair of the six blocks)
 }
 
 // Sum the workgroup partials of one entry: one wavefront per entry, a fixed strided + butterfly
@@ -277,10 +299,9 @@ __global__ __launch_bounds__(kFitThreads) void gram_finish_kernel(const double *
                                                                   int64_t *__restrict__ count) {
     using L = GramLayout<TO, TP>;
     constexpr int DO = L::DO, DP = L::DP;
-    const double *O = sSum, *P = sSum + 256, *Q = sSum + 512;
-    for (int e = threadIdx.x; e < DO * DO; e += kFitThreads) G_obs[e] = gram_obs_entry(O, e / DO, e % DO);
-    for (int e = threadIdx.x; e < DP * DP; e += kFitThreads) G_pred[e] = gram_pred_entry(P, Q, e / DP, e % DP);
-    if (threadIdx.x == 0) *count = (int64_t)sSum[L::kBlocks * 256];
+    for (int e = threadIdx.x; e < DO * DO; e += kFitThreads) G_obs[e] = gram_obs_entry(sSum, e / DO, e % DO);
+    for (int e = threadIdx.x; e < DP * DP; e += kFitThreads) G_pred[e] = gram_pred_entry(sSum, e / DP, e % DP);
+    if (threadIdx.x == 0) *count = (int64_t)sSum[L::kSums];
 }
 
 // Any-shape Gram: one workgroup per chunk of trajectories, thread = matrix entries.
@@ -824,20 +845,19 @@ __global__ __launch_bounds__(kEighThreads) void fit_finish_eigh_kernel(const dou
     using L = GramLayout<TO, TP>;
     constexpr int DO = L::DO, DP = L::DP;
     extern __shared__ __attribute__((aligned(16))) double eigh_smem[];
-    double *sT = eigh_smem;  // this workgroup's summed tiles: O (256) | P, Q (512)
+    double *sT = eigh_smem;  // the summed accumulators (GramLayout::kSums <= 768 doubles)
     const bool is_pred = blockIdx.x == 1;
-    const int base = is_pred ? 256 : 0, cnt = is_pred ? 512 : 256;
-    for (int e = threadIdx.x; e < cnt; e += kEighThreads) sT[e] = sums[base + e];
-    if (!is_pred && count && threadIdx.x == 0) *count = (int64_t)sums[L::kBlocks * 256];
+    for (int e = threadIdx.x; e < L::kSums; e += kEighThreads) sT[e] = sums[e];
+    if (!is_pred && count && threadIdx.x == 0) *count = (int64_t)sums[L::kSums];
     __syncthreads();
     if (!is_pred) {
         if (G_obs)
             for (int e = threadIdx.x; e < DO * DO; e += kEighThreads) G_obs[e] = gram_obs_entry(sT, e / DO, e % DO);
-        eigh_topk_body([=](int r, int c) { return gram_obs_entry(sT, r, c); }, DO, k, U_obs, sigma_obs, eigh_smem + 512);
+        eigh_topk_body([=](int r, int c) { return gram_obs_entry(sT, r, c); }, DO, k, U_obs, sigma_obs, eigh_smem + 768);
     } else {
         if (G_pred)
-            for (int e = threadIdx.x; e < DP * DP; e += kEighThreads) G_pred[e] = gram_pred_entry(sT, sT + 256, e / DP, e % DP);
-        eigh_topk_body([=](int r, int c) { return gram_pred_entry(sT, sT + 256, r, c); }, DP, k, U_pred, sigma_pred, eigh_smem + 512);
+            for (int e = threadIdx.x; e < DP * DP; e += kEighThreads) G_pred[e] = gram_pred_entry(sT, e / DP, e % DP);
+        eigh_topk_body([=](int r, int c) { return gram_pred_entry(sT, r, c); }, DP, k, U_pred, sigma_pred, eigh_smem + 768);
     }
 }
 
@@ -981,7 +1001,7 @@ extern "C" int et_fit_descriptor(const float *obs, const float *pred, int64_t N,
     double *sums = partials + (size_t)grid * per;
     hipLaunchKernelGGL(gram_reduce_kernel, dim3(per), dim3(64), 0, st, partials, grid, per, sums);
     ET_LAUNCH_CHECK();
-    const size_t lds = sizeof(double) * 512 + eigh_lds_bytes(24);
+    const size_t lds = sizeof(double) * 768 + eigh_lds_bytes(24);
     if (lds > 48 * 1024)
         ET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fit_finish_eigh_kernel<8, 12>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
