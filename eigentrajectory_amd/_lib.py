@@ -188,6 +188,7 @@ _FAST_SIGNATURES = {
     "et_scene_project_train": [_P, _P, _I64, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P],
     "et_wrapper_losses_fwd": [_P, _I64, _I, _I, _I, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P],
     "et_wrapper_losses_bwd": [_P, _P, _P, _P, _I64, _I, _I, _I, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P],
+    "et_fit_descriptor": [_P, _P, _I64, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P],
 }
 _fast = {}
 
