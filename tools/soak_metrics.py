@@ -31,10 +31,13 @@ for it in range(cases):
     if rng.random() < 0.2:
         c[int(rng.integers(6)), int(rng.integers(n)), int(rng.integers(S))] = float("nan")
     kw = {}
-    if mode != ops.MODE_IDENTITY and rng.random() < 0.5:  # cached normaliser state instead of the observed rows
+    src = rng.random()
+    if mode != ops.MODE_IDENTITY and src < 0.66:  # cached normaliser state instead of the observed rows: nrm, or the pose record
         z = torch.zeros((8 * 2, 6), device=dev)
-        _, _, nrm, _ = ops.norm_project(obs, None, z, None, z, None, mode if mode != 2 else 2, 0.3, want_flag=False)
-        kw["nrm"] = nrm
+        _, _, nrm, _, pose = ops.norm_project(obs, None, z, None, z, None, mode, 0.3, want_flag=False, want_pose=True)
+        kw["nrm"] = nrm  # (the tile kernel reads nrm; the matrix-core kernel the pose when it is given)
+        if src < 0.33:
+            kw["pose"] = pose
     else:
         kw["obs"] = obs
     out = {}
