@@ -152,14 +152,16 @@ def test_sgcn_end_to_end_replay_through_the_oracle_g13(oracle, scene):
         np.testing.assert_allclose(losses, z[f"{tag}.losses"], rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("scene", G.SCENES)
+@pytest.mark.parametrize("scene", G.SCENES + ["univ-all"])
 def test_sgcn_full_splits_replay_through_the_oracle_g14(oracle, scene):
     """Config 3 at full extent on CPU (tests/golden/g14: every test scene of eth / hotel / zara1 / zara2, every tenth of
     univ's): oracle projection -> THIS build's sgcn bridge -> the recorded output of the reference's SGCN -> oracle
     reconstruction: per-pedestrian best-of-20 ADE / FDE and the split-level means within 1e-5 of the reference's."""
     from eigentrajectory_amd.bridges import get_hook_func
     from oracle import wrapper_ref as W
-    z = G.load("g14_sgcn_full_splits.npz")
+    # "univ-all" (G14b): ALL 947 test scenes of univ, 24 334 pedestrians
+    z = G.load("g14b_sgcn_univ_all.npz" if scene == "univ-all" else "g14_sgcn_full_splits.npz")
+    scene = "univ" if scene == "univ-all" else scene
     g2 = G.load("g2_fit_all_scenes.npz")
     params = {k[len(scene) + 1:]: g2[k] for k in g2.files if k.startswith(f"{scene}.ET_")}
     obs, pred, sse = G.dataset(scene, "test")
@@ -189,14 +191,16 @@ def test_sgcn_full_splits_replay_through_the_oracle_g14(oracle, scene):
     np.testing.assert_allclose([ade.mean(dtype=np.float64), fde.mean(dtype=np.float64)], z[f"{scene}.ade_fde_mean"], rtol=0, atol=1e-5)
 
 
-def test_agentformer_tenth_of_univ_replay_through_the_oracle_g15(oracle):
+@pytest.mark.parametrize("extent", ["tenth", "all"])
+def test_agentformer_tenth_of_univ_replay_through_the_oracle_g15(oracle, extent):
     """Config 5's data path at G14's extent on CPU (tests/golden/g15: every tenth test scene of univ, 2 471 pedestrians;
     tools/make_golden_agentformer_full.py): oracle projection -> THIS build's agentformer bridge -> the recorded output of
     the reference's AgentFormerLight -> oracle reconstruction: per-pedestrian best-of-20 ADE / FDE and their means within
     1e-5 of the reference's."""
     from eigentrajectory_amd.bridges import get_hook_func
     from oracle import wrapper_ref as W
-    z = G.load("g15_agentformer_univ_tenth.npz")
+    # extent = "all" (G15b): ALL 947 test scenes of univ, 24 334 pedestrians
+    z = G.load("g15b_agentformer_univ_all.npz" if extent == "all" else "g15_agentformer_univ_tenth.npz")
     g2 = G.load("g2_fit_all_scenes.npz")
     params = {k[len("univ."):]: g2[k] for k in g2.files if k.startswith("univ.ET_")}
     obs, pred, sse = G.dataset("univ", "test")

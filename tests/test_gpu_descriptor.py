@@ -482,7 +482,7 @@ def test_headline_sizes_vs_oracle(ops, oracle, dev, n, iters):
     assert np.float32(res["error"]) == np.float32(ref["error"]) and np.float32(res["inertia"]) == np.float32(ref["inertia"])
 
 
-@pytest.mark.parametrize("scene", G.SCENES)
+@pytest.mark.parametrize("scene", G.SCENES + ["univ-all"])
 def test_sgcn_full_splits_replay_g14(dev, scene):
     """Config 3 at full extent (BASELINE.json: EigenTrajectory-SGCN inference, 20 samples, all five ETH/UCY splits, ADE/FDE
     vs the reference): EVERY test scene of eth / hotel / zara1 / zara2 and every tenth of univ's (tools/
@@ -495,7 +495,10 @@ def test_sgcn_full_splits_replay_g14(dev, scene):
     from eigentrajectory_amd.bridges import get_hook_func
     from eigentrajectory_amd.utils import default_hyper_params
     from .test_bridges import ReplaySGCN
-    z = G.load("g14_sgcn_full_splits.npz")
+    # "univ-all" (G14b): ALL 947 test scenes of univ, 24 334 pedestrians -- the whole of the reference's test loop on that split
+    z = G.load("g14b_sgcn_univ_all.npz" if scene == "univ-all" else "g14_sgcn_full_splits.npz")
+    every_scene = scene != "univ"
+    scene = "univ" if scene == "univ-all" else scene
     g2 = G.load("g2_fit_all_scenes.npz")
     obs, pred, sse = G.dataset(scene, "test")
     net = ReplaySGCN(None, None, None, 2e-5)
@@ -508,7 +511,7 @@ def test_sgcn_full_splits_replay_g14(dev, scene):
     model = model.to(dev).eval()
     v_all, out_all = torch.from_numpy(z[f"{scene}.v"]), torch.from_numpy(z[f"{scene}.net_out"]).to(dev)
     sizes = z[f"{scene}.scene_size"]
-    assert scene == "univ" or len(sizes) == len(sse)  # every scene of the split (univ: index % 10 == 0)
+    assert len(sizes) == (len(sse) if every_scene else len(range(0, len(sse), 10)))  # every scene of the split (G14's univ: index % 10 == 0)
     fused, plain, at = [], [], 0
     with torch.no_grad():
         for i, n in zip(z[f"{scene}.scene_index"], sizes):
@@ -532,18 +535,20 @@ def test_sgcn_full_splits_replay_g14(dev, scene):
         np.testing.assert_allclose(got.mean(axis=1, dtype=np.float64), z[f"{scene}.ade_fde_mean"], rtol=0, atol=1e-5)
 
 
-def test_agentformer_tenth_of_univ_replay_g15(dev):
+@pytest.mark.parametrize("extent", ["tenth", "all"])
+def test_agentformer_tenth_of_univ_replay_g15(dev, extent):
     """Config 5's data path (BASELINE.json: EigenTrajectory-AgentFormer, univ) at G14's extent through the PRODUCT: every tenth
     test scene of univ (95 scenes, 2 471 pedestrians; tools/make_golden_agentformer_full.py: the imported reference's wrapper
     + agentformer bridge + its seeded AgentFormerLight) -- wrapper (HIP projection) -> agentformer bridge contract (the
     predictor's recorded input is checked, its recorded output answered) -> HIP reconstruction: best-of-20 ADE / FDE per
     pedestrian and their means within 1e-5 of the reference's, for the fused metrics epilogue and for the materialised
-    trajectories of the test loop's own call `model(obs)`."""
+    trajectories of the test loop's own call `model(obs)`.  extent = "all" (G15b): ALL 947 test scenes of univ, 24 334
+    pedestrians -- the whole of the reference's test loop (utils/trainer.py:173-195) on config 5's split."""
     from eigentrajectory_amd import EigenTrajectory
     from eigentrajectory_amd.bridges import get_hook_func
     from eigentrajectory_amd.utils import default_hyper_params
     from .test_bridges import ReplayAgentFormer
-    z = G.load("g15_agentformer_univ_tenth.npz")
+    z = G.load("g15b_agentformer_univ_all.npz" if extent == "all" else "g15_agentformer_univ_tenth.npz")
     g2 = G.load("g2_fit_all_scenes.npz")
     obs, pred, sse = G.dataset("univ", "test")
     net = ReplayAgentFormer(None, None, 2e-5)
@@ -555,7 +560,7 @@ def test_agentformer_tenth_of_univ_replay_g15(dev):
     model.load_state_dict(sd)
     model = model.to(dev).eval()
     pre_all, dec_all = torch.from_numpy(z["pre_motion"]), torch.from_numpy(z["dec_motion"]).to(dev)
-    assert list(z["scene_index"]) == list(range(0, len(sse), 10))
+    assert list(z["scene_index"]) == list(range(0, len(sse), 1 if extent == "all" else 10))
     fused, plain, at = [], [], 0
     with torch.no_grad():
         for i, n in zip(z["scene_index"], z["scene_size"]):
@@ -570,7 +575,7 @@ def test_agentformer_tenth_of_univ_replay_g15(dev):
             dist = (rec - p[None]).norm(p=2, dim=-1)
             plain.append(torch.stack([dist.mean(dim=-1).min(dim=0)[0], dist[..., -1].min(dim=0)[0]]))
             at += n
-    assert at == len(z["ade"]) == 2471
+    assert at == len(z["ade"]) == (24334 if extent == "all" else 2471)
     ref = np.stack([z["ade"], z["fde"]])
     for got in (N_(torch.cat(fused, dim=1)), N_(torch.cat(plain, dim=1))):
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5)

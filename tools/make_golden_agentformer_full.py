@@ -28,6 +28,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--univ-all", action="store_true",
+                    help="G15b: ALL 947 test scenes of univ (24 334 pedestrians) -> g15b_agentformer_univ_all.npz")
     args = ap.parse_args()
     from tests import _golden as G
     sys.path.insert(0, args.ref)
@@ -69,7 +71,7 @@ def main():
     model.load_state_dict(sd)
 
     obs, pred, sse = G.dataset("univ", "test")
-    picks = [i for i in range(len(sse)) if i % 10 == 0]
+    picks = [i for i in range(len(sse)) if args.univ_all or i % 10 == 0]
     pres, decs, ades, fdes, sizes = [], [], [], [], []
     t0 = time.time()
     pre_shape = dec_shape = None
@@ -101,7 +103,7 @@ def main():
            "dec_motion": np.concatenate(decs, axis=dec_axis).astype(np.float32),
            "ade": ade, "fde": fde,
            "ade_fde_mean": np.asarray([ade.mean(dtype=np.float64), fde.mean(dtype=np.float64)])}
-    path = os.path.join(args.out, "g15_agentformer_univ_tenth.npz")
+    path = os.path.join(args.out, "g15b_agentformer_univ_all.npz" if args.univ_all else "g15_agentformer_univ_tenth.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path))
 

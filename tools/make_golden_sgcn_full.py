@@ -29,6 +29,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--univ-all", action="store_true",
+                    help="G14b: ALL 947 test scenes of univ (24 334 pedestrians, utils/trainer.py:173-195's whole loop) -> "
+                         "g14b_sgcn_univ_all.npz (12 MB of network outputs), nothing else")
     args = ap.parse_args()
     from tests import _golden as G
     sys.path.insert(0, args.ref)
@@ -53,7 +56,7 @@ def main():
     g2 = G.load("g2_fit_all_scenes.npz")
     out = {}
     t0 = time.time()
-    for scene in G.SCENES:
+    for scene in (["univ"] if args.univ_all else G.SCENES):
         hp = get_exp_config(f"./config/eigentrajectory-{{baseline}}-{scene}.json")
         torch.manual_seed(1234)
         predictor = TrajectoryPredictor(number_asymmetric_conv_layer=7, embedding_dims=64, number_gcn_layers=1, dropout=0,
@@ -77,7 +80,7 @@ def main():
                 sd[key] = torch.from_numpy(g2[f"{scene}.{key}"])
         model.load_state_dict(sd)
         obs, pred, sse = G.dataset(scene, "test")
-        picks = [i for i in range(len(sse)) if scene != "univ" or i % 10 == 0]
+        picks = [i for i in range(len(sse)) if scene != "univ" or args.univ_all or i % 10 == 0]
         vs, nets, ades, fdes, sizes = [], [], [], [], []
         for i in picks:
             s, e = sse[i]
@@ -102,7 +105,7 @@ def main():
         out[f"{scene}.ade"] = np.concatenate(ades)
         out[f"{scene}.fde"] = np.concatenate(fdes)
         out[f"{scene}.ade_fde_mean"] = np.asarray([np.concatenate(ades).mean(dtype=np.float64), np.concatenate(fdes).mean(dtype=np.float64)])
-    path = os.path.join(args.out, "g14_sgcn_full_splits.npz")
+    path = os.path.join(args.out, "g14b_sgcn_univ_all.npz" if args.univ_all else "g14_sgcn_full_splits.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path))
 
