@@ -22,7 +22,6 @@ struct Options {
     std::atomic<int> kmeans_loop{'a'};            // 'a'uto, 'c'hain (one launch per iteration), 'p'ersist (one launch per fit)
     std::atomic<int> reforder_filter_min_lp{9};  // reference-order Lloyd: level power from which the matrix-core label filter is used (4: always, 9: never = default: it measured slower)
     std::atomic<int64_t> reforder_init_skip_min{(int64_t)1 << 21};  // reference-order farthest-first: shards of at least this many points test (bestR, nearest) before reading a point's coordinates
-    std::atomic<int> reforder_scalar_rows{1};    // reference-order Lloyd, single-GPU fit: 1 (default): from N > 4.2e6 on the arg-max reads the centroid rows through scalar loads (a row = eight SGPRs); 2: always; 0: never (from LDS: every lane the same 16 bytes)
     std::atomic<int> reforder_single_update{1};  // reference-order Lloyd on shards of few level-2 blocks: 1: one 1024-thread workgroup does levels 2, 3 and the update; 0: the grid of block workgroups + last arriver
     std::atomic<int> metrics_form{'a'};           // 'a'uto, 't'ile (vector-ALU workgroup-tile kernel), 'f' (fp32 matrix instructions)
 };

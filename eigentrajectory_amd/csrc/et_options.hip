@@ -36,7 +36,6 @@ const Key *keys(int *n) {
         {"reforder_filter_min_lp", Key::kInt, &o.reforder_filter_min_lp, nullptr},
         {"reforder_init_skip_min", Key::kI64, &o.reforder_init_skip_min, nullptr},
         {"reforder_single_update", Key::kInt, &o.reforder_single_update, nullptr},
-        {"reforder_scalar_rows", Key::kInt, &o.reforder_scalar_rows, nullptr},
         {"metrics_form", Key::kChar, &o.metrics_form, "atf"},
     };
     *n = (int)(sizeof(table) / sizeof(table[0]));

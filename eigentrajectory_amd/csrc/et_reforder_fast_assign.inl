@@ -191,10 +191,8 @@ __device__ __forceinline__ double assign_group_filter(const float4 *__restrict__
 // ---- one Lloyd iteration, first half: assignment + levels 0 and 1.  Workgroup g < G: group g; workgroup G: the tail ----
 // NREGS = 0: the exact scan of every point (L = 16: four workgroups per CU); 10 / 16 (K <= 20 / 32): iterations >= 1 certify
 // the labels with the matrix-core filter (L >= 32; more registers: fewer wavefronts per CU, far fewer instructions)
-// `rows_all`: problem 0's Layout::rows (written by the previous launch's update kernel, or by the prepare kernel) -- a kernel
-// argument of its own so that it is a noalias, read-only address and the rows are fetched by scalar loads (nullptr: from LDS)
 template <int NREGS>
-__global__ __launch_bounds__(kFThreads, NREGS ? 6 : 7) void reforder_groups_kernel(const Args a, const float4 *__restrict__ rows_all) {
+__global__ __launch_bounds__(kFThreads, NREGS ? 6 : 7) void reforder_groups_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, dk = kD * K;
@@ -291,8 +289,7 @@ __global__ __launch_bounds__(kFThreads, NREGS ? 6 : 7) void reforder_groups_kern
             int lb[4];
             float bv[4];
             if (!nans) {
-                if (rows_all) quad_best_rows(xv, reinterpret_cast<const float4 *>(reinterpret_cast<const unsigned char *>(rows_all) + (int64_t)blockIdx.y * a.ws_stride), K, lb, bv);
-                else quad_best(xv, sC, K, lb, bv);
+                quad_best(xv, sC, K, lb, bv);
             } else {  // (an empty cluster's NaN centroid, or magnitudes near the fp32 range: torch.max's NaN rule, point by point)
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {

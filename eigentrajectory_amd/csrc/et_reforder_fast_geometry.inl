@@ -68,7 +68,7 @@ __host__ __device__ inline size_t acc_region_bytes(int K, int L, int TR) {
 // byte offsets inside one problem's block of the workspace.  S1 / S2 / T hold one float4 = the four lanes k of a (group |
 // block | tail part, coordinate, cluster) entry.
 struct Layout {
-    size_t state, cen, arrive, cnt, S1, S2, T, Sin, XT, LT, tail, rows, bytes;
+    size_t state, cen, arrive, cnt, S1, S2, T, Sin, XT, LT, tail, bytes;
 };
 static Layout make_layout(const Geo &g, int K) {
     Layout l;
@@ -96,9 +96,6 @@ static Layout make_layout(const Geo &g, int K) {
     off = up(off + (size_t)g.tail0 + 4);
     l.tail = off;
     off = up(off + (size_t)(g.N - g.tail0) + 4);
-    l.rows = off;  // the centroid rows as the arg-max wants them: c[0..5], |c|^2 in ATen's order, 0 -- (kFMaxK + 1) x 8 floats,
-                   // written once per iteration (reforder_rows_kernel) and read through SCALAR loads by the groups kernel
-    off = up(off + sizeof(float) * 8 * (kFMaxK + 1));
     l.bytes = off;
     return l;
 }
@@ -234,70 +231,6 @@ __device__ __forceinline__ void quad_best(const float4 (&xv)[kD], const float *s
         const float4 c0 = n0, c1 = n1;
         n0 = s4[2 * j + 2];  // (row K: the table has kFMaxK + 1 rows)
         n1 = s4[2 * j + 3];
-        const float cc[kD] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
-        f32x2 ya = zero, yb = zero;
-#pragma unroll
-        for (int i = 0; i < kD; ++i) {
-            const f32x2 c = {cc[i], cc[i]};
-            ya = __builtin_elementwise_fma(xa[i], c, ya);  // kmeans.py:71
-            yb = __builtin_elementwise_fma(xb[i], c, yb);
-        }
-        ya = ya * 2.0f;  // :72
-        yb = yb * 2.0f;
-        ya = ya - ana;   // :73
-        yb = yb - anb;
-        const f32x2 bn = {c1.z, c1.z};
-        ya = ya - bn;    // :74
-        yb = yb - bn;
-        const float y[4] = {ya.x, ya.y, yb.x, yb.y};
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const bool take = y[p] > bv[p];
-            bv[p] = take ? y[p] : bv[p];
-            lb[p] = take ? j : lb[p];
-        }
-    }
-}
-
-// row j of Layout::rows from the centroid's six coordinates (column j of K: |c_j|^2 in ATen's order, kmeans.py:74)
-__device__ __forceinline__ void write_centroid_row(float *rows, int j, int K, const float (&v)[kD]) {
-    float sq[kMaxD];
-#pragma unroll
-    for (int i = 0; i < kD; ++i) {
-        sq[i] = v[i] * v[i];
-        rows[j * 8 + i] = v[i];
-    }
-    rows[j * 8 + 6] = j < K ? sqnorm_at(sq, kD, j, K) : 0.f;
-    rows[j * 8 + 7] = 0.f;
-}
-
-// quad_best with the centroid rows in SCALAR registers: `rows` is a uniform, read-only address (a __restrict__ kernel argument),
-// so a row is one s_load_dwordx8 into eight SGPRs and feeds the packed instructions as their scalar operand.  With the rows
-// in LDS every ds_read_b128 of a row moved 1 KB through the LDS pipe for 16 useful bytes (all 64 lanes read the same address):
-// 2.6 MB per group of 16 384 points and K = 20, ~10 us of a CU's LDS time per group -- what a launch at N = 1e7 waited for.
-__device__ __forceinline__ void quad_best_rows(const float4 (&xv)[kD], const float4 *__restrict__ rows, int K, int (&lb)[4],
-                                               float (&bv)[4]) {
-    f32x2 xa[kD], xb[kD];
-#pragma unroll
-    for (int i = 0; i < kD; ++i) {
-        xa[i] = f32x2{xv[i].x, xv[i].y};
-        xb[i] = f32x2{xv[i].z, xv[i].w};
-    }
-    f32x2 ana = xa[0] * xa[0], anb = xb[0] * xb[0];  // kmeans.py:73, a full block's column: rows in sequence (0 + s0 = s0)
-#pragma unroll
-    for (int i = 1; i < kD; ++i) {
-        ana = ana + xa[i] * xa[i];
-        anb = anb + xb[i] * xb[i];
-    }
-    lb[0] = lb[1] = lb[2] = lb[3] = 0;
-    bv[0] = bv[1] = bv[2] = bv[3] = -__builtin_inff();
-    const f32x2 zero = {0.f, 0.f};
-    float4 n0 = rows[0], n1 = rows[1];
-#pragma clang loop unroll(disable)
-    for (int j = 0; j < K; ++j) {
-        const float4 c0 = n0, c1 = n1;
-        n0 = rows[2 * j + 2];  // (row K: the table has kFMaxK + 1 rows) -- requested while row j is evaluated
-        n1 = rows[2 * j + 3];
         const float cc[kD] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
         f32x2 ya = zero, yb = zero;
 #pragma unroll

@@ -32,7 +32,6 @@ __global__ __launch_bounds__(TT) void reforder_update_kernel2(const Args a, int 
     __shared__ double sWsum[16];
     __shared__ int sFlag[2];
     __shared__ float sScr[40];
-    __shared__ float sNewC[kD * kFMaxK];  // the new centroids, for the rows table
     float4 *sRows = reinterpret_cast<float4 *>(smem);
     [[maybe_unused]] const int who = blockIdx.x == 0 ? 2 : 9;
     RF_STAMP(who, 0);
@@ -242,17 +241,10 @@ __global__ __launch_bounds__(TT) void reforder_update_kernel2(const Args a, int 
         const float c = p / (float)sCntTot[j];  // 0/0 = NaN for an empty cluster (kmeans.py:182)
         const float diff = cen[tid] - c;
         cen[tid] = c;
-        sNewC[tid] = c;
         if (a.batch > 1) __hip_atomic_store(&sq_mine[tid], diff * diff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else sSq[tid] = diff * diff;
     }
     __syncthreads();
-    if (tid <= kFMaxK) {  // the rows the next launch's arg-max reads through scalar loads (Layout::rows)
-        float v[kD];
-#pragma unroll
-        for (int i = 0; i < kD; ++i) v[i] = tid < K ? sNewC[i * K + tid] : 0.f;
-        write_centroid_row(at<float>(ws, a.lay.rows), tid, K, v);
-    }
     if (tid == 0) {
         double s = sWsum[0];
         for (int w = 1; w < kUThreads / 64; ++w) s = s + sWsum[w];

@@ -85,12 +85,6 @@ static int fast_fit(const float *X, int64_t x_stride, int64_t N, int K, int64_t 
     }
     // the matrix-core label filter pays where the exact scan is what a launch waits for: L >= 32 (N > 4.2e6)
     const bool use_filter = a.geo.lp >= fast_filter_min_lp() && K >= 3;
-    // the arg-max's centroid rows through scalar loads where a launch is long enough to hide their latency (L = 64: N > 4.2e6;
-    // same box, 40 iterations: 1e7 111-114 against 117 us per launch, 1e6 level, 1e5 19.5 against 17.6); option
-    // reforder_scalar_rows: 1 = that rule (default), 2 = always, 0 = never (rows from LDS)
-    const int rows_opt = et::options().reforder_scalar_rows.load(std::memory_order_relaxed);
-    const bool use_rows = rows_opt == 2 || (rows_opt == 1 && a.geo.lp >= 6);
-    const float4 *rows_arg = use_rows ? reinterpret_cast<const float4 *>(a.ws + a.lay.rows) : nullptr;
     constexpr int kAhead = 16, kEvery = 4;
     et_kmeans_state *state0 = (et_kmeans_state *)(a.ws + a.lay.state);
     int launched = 0;
@@ -100,9 +94,9 @@ static int fast_fit(const float *X, int64_t x_stride, int64_t N, int K, int64_t 
     const int uslot = (kD * K + kFMaxK / 4 + 63) / 64 * 64;
     const bool single_update = a.geo.n_blk <= 1024 / uslot && et::options().reforder_single_update.load(std::memory_order_relaxed) != 0;
     for (int it = 0; it < max_iter && !done; ++it) {
-        if (!use_filter) hipLaunchKernelGGL(reforder_groups_kernel<0>, grid, dim3(kFThreads), lds, st, a, rows_arg);
-        else if (K <= 20) hipLaunchKernelGGL(reforder_groups_kernel<10>, grid, dim3(kFThreads), lds, st, a, rows_arg);
-        else hipLaunchKernelGGL(reforder_groups_kernel<16>, grid, dim3(kFThreads), lds, st, a, rows_arg);
+        if (!use_filter) hipLaunchKernelGGL(reforder_groups_kernel<0>, grid, dim3(kFThreads), lds, st, a);
+        else if (K <= 20) hipLaunchKernelGGL(reforder_groups_kernel<10>, grid, dim3(kFThreads), lds, st, a);
+        else hipLaunchKernelGGL(reforder_groups_kernel<16>, grid, dim3(kFThreads), lds, st, a);
         if (single_update)
             hipLaunchKernelGGL((reforder_update_kernel2<1024, true>), dim3(1, (unsigned)batch), dim3(1024), ulds, st, a, rows_cap, uslot);
         else
@@ -292,9 +286,9 @@ extern "C" int et_internal_kmeans_reforder_sharded_run(const float *X, const int
     const dim3 grid((unsigned)(a.geo.G + 1), 1), l2grid((unsigned)std::max(p.rows[rank], 1), 1);
     const size_t rec_bytes = sizeof(float4) * (size_t)p.rec.words();
     for (int it = 0; it < max_iter && !done; ++it) {
-        if (!use_filter) hipLaunchKernelGGL(reforder_groups_kernel<0>, grid, dim3(kFThreads), lds, st, a, (const float4 *)nullptr);
-        else if (K <= 20) hipLaunchKernelGGL(reforder_groups_kernel<10>, grid, dim3(kFThreads), lds, st, a, (const float4 *)nullptr);
-        else hipLaunchKernelGGL(reforder_groups_kernel<16>, grid, dim3(kFThreads), lds, st, a, (const float4 *)nullptr);
+        if (!use_filter) hipLaunchKernelGGL(reforder_groups_kernel<0>, grid, dim3(kFThreads), lds, st, a);
+        else if (K <= 20) hipLaunchKernelGGL(reforder_groups_kernel<10>, grid, dim3(kFThreads), lds, st, a);
+        else hipLaunchKernelGGL(reforder_groups_kernel<16>, grid, dim3(kFThreads), lds, st, a);
         hipLaunchKernelGGL(reforder_level2_sharded_kernel, l2grid, dim3(kUThreads), l2lds, st, a, p.rec, p.rows[rank], send, l2cap);
         ET_LAUNCH_CHECK();
         if (gather) {

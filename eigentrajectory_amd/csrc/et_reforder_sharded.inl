@@ -233,13 +233,6 @@ __global__ __launch_bounds__(kThreads) void reforder_fast_prepare_kernel(const A
         st->inertia = 0.0;
     }
     for (int e = threadIdx.x; e < dk; e += blockDim.x) at<float>(ws, a.lay.cen)[e] = cen_in[(int64_t)blockIdx.x * dk + e];
-    if ((int)threadIdx.x <= kFMaxK) {  // the first launch's centroid rows (Layout::rows)
-        const int j = (int)threadIdx.x;
-        float v[kD];
-#pragma unroll
-        for (int i = 0; i < kD; ++i) v[i] = j < a.K ? cen_in[(int64_t)blockIdx.x * dk + i * a.K + j] : 0.f;
-        write_centroid_row(at<float>(ws, a.lay.rows), j, a.K, v);
-    }
     if (threadIdx.x == 0) at<unsigned>(ws, a.lay.arrive)[0] = 0u;
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.batch_arrive = 0u;
 }

@@ -101,8 +101,6 @@ const char *et_compiled_arch(void);
  *   reforder_init_skip_min points (default 2^21): from this shard size on the reference-order farthest-first tests a point's running
  *                          similarity and nearest centroid (5 bytes) before it reads its coordinates (28); same picks
  *   reforder_single_update 1 (default): reference-order fits of at most 8 level-2 blocks update in one 1024-thread workgroup | 0: grid form
- *   reforder_scalar_rows   1 (default): single-GPU reference-order fits of more than 4.2e6 points read the arg-max's centroid rows
- *                          through scalar loads | 2: every size | 0: never (the rows come from LDS)
  *   metrics_form           a: auto (default) | t: vector-ALU tile kernel for every S | f: fp32 matrix instructions only
  * et_set_option returns ET_ERR_INVALID_ARG for an unknown key or a value the key does not take; et_get_option writes the
  * current value as text.  (The Python binding forwards environment variables ET_OPT_<KEY> once, at load.) */
